@@ -1,0 +1,185 @@
+/*
+ * mappo_hip.h -- C ABI of libmappo_hip.so: the MI355X (gfx950) device side of the
+ * MAPPO rollout-buffer hot path (GAE scan, advantage moments, minibatch gathers,
+ * slab writes).
+ *
+ * The reference (marlbenchmark/on-policy) has no FFI for this path: it is numpy
+ * code inside onpolicy/utils/shared_buffer.py and onpolicy/algorithms/r_mappo/r_mappo.py.
+ * Each entry point below names the reference lines it replaces.  A maintainer binds
+ * them with ctypes; no torch / C++ types cross this boundary.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - all payload is float32, C-contiguous, time-major: element (t, n, a, d) of a
+ *     field with row width D lives at ((t*N + n)*A + a)*D + d; "C" below is the
+ *     number of columns N*A of the [T(+1), C] scalar fields;
+ *   - the library borrows pointers for the duration of the call and allocates
+ *     nothing persistent; work is enqueued on `stream` (a hipStream_t) and the call
+ *     returns without synchronising;
+ *   - return value: 0 on success, a negative MAPPO_E_* for argument errors (nothing
+ *     enqueued), or a positive hipError_t from the launch.
+ */
+#ifndef MAPPO_HIP_H
+#define MAPPO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mappo_stream_t; /* hipStream_t; NULL = the null stream */
+
+#define MAPPO_ABI_VERSION 1
+
+/* argument errors */
+#define MAPPO_E_NULL      (-1) /* a required pointer is NULL                */
+#define MAPPO_E_SHAPE     (-2) /* a size is <= 0 or inconsistent            */
+#define MAPPO_E_FLAGS     (-3) /* unsupported flag combination              */
+#define MAPPO_E_TOO_MANY  (-4) /* more fields / slabs than MAPPO_MAX_FIELDS */
+#define MAPPO_E_ALIGN     (-5) /* a pointer is not 4-byte aligned           */
+
+/* ---------------------------------------------------------------- K1: GAE ----
+ * Replaces SharedReplayBuffer.compute_returns
+ *   (onpolicy/utils/shared_buffer.py:179-262) and, when `advantages` is given, the
+ *   first line of R_MAPPO.train (onpolicy/algorithms/r_mappo/r_mappo.py:179-182).
+ *
+ * flags select the reference branch:
+ *   USE_GAE              args.use_gae                 (shared_buffer.py:186,217)
+ *   PROPER_TIME_LIMITS   args.use_proper_time_limits  (shared_buffer.py:185)
+ *   DENORM               use_popart or use_valuenorm: D(x) = x*sigma + mu with
+ *                        (sigma, mu) = denorm[0..1]    (valuenorm.py:68-79,
+ *                        popart.py:88-98); without it D is the identity.
+ * gamma and gae_lambda are the Python floats (float64) of args.gamma /
+ * args.gae_lambda: the reference multiplies gamma*gae_lambda in float64 and only then
+ * rounds to float32 (shared_buffer.py:239), and so does this call.
+ * Arithmetic is float32 in exactly the reference's operation order, with no FMA
+ * contraction, so results are bit-identical to the numpy path given the same
+ * (sigma, mu).
+ *
+ *   rewards      [T,   C]  read
+ *   value_preds  [T+1, C]  read; row T is first overwritten with next_value in the
+ *                          GAE modes (shared_buffer.py:187,218)
+ *   next_value   [C]       read
+ *   masks        [T+1, C]  read (rows 1..T)
+ *   bad_masks    [T+1, C]  read (rows 1..T); required iff PROPER_TIME_LIMITS
+ *   returns      [T+1, C]  rows 0..T-1 written; row T is written (= next_value)
+ *                          only in the non-GAE modes (shared_buffer.py:205,260)
+ *   denorm       [2]       {sigma, mu}; required iff DENORM
+ * Optional fused epilogue (all three NULL to skip):
+ *   advantages   [T, C]    advantages[t] = fl(returns[t] - D(value_preds[t]))
+ *                          (r_mappo.py:179-182: computed from the ROUNDED returns)
+ *   active_masks [T+1, C]  rows 0..T-1 select the entries that count towards the
+ *                          moments (r_mappo.py:184: active_masks[:-1] == 0 -> NaN);
+ *                          NULL = every entry counts
+ *   adv_partials [mappo_gae_partial_rows(C), 3] float64; per-workgroup partial
+ *                          {sum adv, sum adv^2, count} over counted entries; rows
+ *                          that no workgroup owns are zero-filled by this call.
+ */
+#define MAPPO_GAE_USE_GAE            1u
+#define MAPPO_GAE_PROPER_TIME_LIMITS 2u
+#define MAPPO_GAE_DENORM             4u
+
+int mappo_gae_f32(const float* rewards, float* value_preds, const float* next_value,
+                  const float* masks, const float* bad_masks, float* returns,
+                  const float* denorm, float* advantages, const float* active_masks,
+                  double* adv_partials, int T, int64_t C, double gamma, double gae_lambda,
+                  unsigned flags, mappo_stream_t stream);
+
+/* Number of [.,3] float64 rows mappo_gae_f32 / mappo_advantages_f32 need in adv_partials
+ * for C columns. */
+int64_t mappo_gae_partial_rows(int64_t C);
+
+/* Standalone form of the fused epilogue above, for callers whose returns / value_preds /
+ * normaliser changed after mappo_gae_f32 ran (r_mappo.py:179-186):
+ *   advantages[i] = fl(returns[i] - D(value_preds[i])), i < T*C, plus the same partial
+ *   moments. denorm NULL = identity, active_masks NULL = every entry counts. */
+int mappo_advantages_f32(const float* returns, const float* value_preds, const float* denorm,
+                         const float* active_masks, float* advantages, double* adv_partials,
+                         int T, int64_t C, mappo_stream_t stream);
+
+/* Tuning hook for benchmarks: selects the kernel variant used by mappo_gae_f32
+ * (0 = automatic). All variants produce bit-identical results. Returns the previous
+ * value. */
+int mappo_gae_set_variant(int variant);
+
+/* --------------------------------------------- K5: advantage moments / stats ----
+ * Replaces np.nanmean / np.nanstd over the masked advantages
+ *   (onpolicy/algorithms/r_mappo/r_mappo.py:183-186).
+ * mappo_adv_reduce:  sums[0..2] = column sums of partials[rows,3], fixed order
+ *                    (deterministic). In a multi-GPU job the caller all-reduces
+ *                    `sums` (3 float64) across ranks between the two calls.
+ * mappo_adv_stats:   stats[0] = mean = S1/n, stats[1] = population std
+ *                    = sqrt(max(S2/n - mean^2, 0)), both rounded to float32.
+ * The normalisation (adv - mean) / (std + 1e-5) (r_mappo.py:187) is applied by the
+ * gather kernels (field.normalize) so no standalone pass over [T,C] is needed.
+ */
+int mappo_adv_reduce(const double* partials, int64_t rows, double* sums, mappo_stream_t stream);
+int mappo_adv_stats(const double* sums, float* stats, mappo_stream_t stream);
+
+/* Standalone normalisation pass, for callers that want the normalised advantages
+ * materialised (out may alias adv): out = (adv - stats[0]) / (stats[1] + 1e-5f). */
+int mappo_adv_normalize(const float* adv, const float* stats, float* out, int64_t n,
+                        mappo_stream_t stream);
+
+/* ------------------------------------------------- K3 / K4: minibatch gathers ----
+ * One launch copies a minibatch of rows of up to MAPPO_MAX_FIELDS buffer fields.
+ *
+ * mappo_gather_rows replaces the per-minibatch fancy indexing of
+ *   SharedReplayBuffer.feed_forward_generator (shared_buffer.py:363-396):
+ *   dst_f[j, :] = src_f[idx[j], :],  j in [0, mb), rows in (t, n, a) order.
+ *
+ * mappo_gather_chunks replaces recurrent_generator (shared_buffer.py:499-608,
+ *   helpers _cast :11-12, _flatten :7-8) and, with L == T, naive_recurrent_generator
+ *   (:402-497), reading straight from the time-major buffer (no transposed copy):
+ *   output row (l, j) -> flat f = idx[j]*L + l of the (n, a, t)-ordered view,
+ *   n = f / (A*T), a = (f / T) % A, t = f % T, source row (t*N + n)*A + a;
+ *   dst_f[l*mb + j, :] = src_f[that row, :].  Fields with first_only != 0 (the RNN
+ *   states, shared_buffer.py:568-569,588-589) take only l = 0: dst_f[j, :].
+ *   A chunk may straddle two (n, a) trajectories when T % L != 0, exactly as the
+ *   reference does.
+ *
+ * fields is a HOST array; idx is a DEVICE int64 array; stats (device, {mean, std})
+ * is required iff some field has normalize != 0.
+ */
+#define MAPPO_MAX_FIELDS 16
+
+typedef struct mappo_field {
+    const float* src;   /* field base (row 0), rows of `width` floats          */
+    float*       dst;   /* output base, contiguous rows of `width` floats      */
+    int32_t      width; /* floats per row (> 0)                                */
+    int32_t      first_only; /* chunk gather only: copy the l = 0 row per chunk */
+    int32_t      normalize;  /* dst = (src - stats[0]) / (stats[1] + 1e-5f)     */
+    int32_t      reserved;
+} mappo_field_t;
+
+int mappo_gather_rows(const mappo_field_t* fields, int n_fields, const int64_t* idx,
+                      int64_t mb, const float* stats, mappo_stream_t stream);
+
+int mappo_gather_chunks(const mappo_field_t* fields, int n_fields, const int64_t* idx,
+                        int64_t mb, int L, int T, int64_t N, int A, const float* stats,
+                        mappo_stream_t stream);
+
+/* ------------------------------------------------------------ K2: slab writes ----
+ * Replaces the per-field `buf[step] = x.copy()` statements of insert / chooseinsert /
+ * after_update / chooseafter_update (shared_buffer.py:107-121,142-156,162-170,
+ * 174-177): one launch copies up to MAPPO_MAX_FIELDS contiguous [N, A, D] slabs
+ * (device to device).  slabs is a HOST array.
+ */
+typedef struct mappo_slab {
+    const float* src;
+    float*       dst;
+    int64_t      count; /* floats */
+} mappo_slab_t;
+
+int mappo_slab_copy(const mappo_slab_t* slabs, int n_slabs, mappo_stream_t stream);
+
+/* --------------------------------------------------------------------- misc ---- */
+int         mappo_abi_version(void);
+const char* mappo_build_info(void);        /* "gfx950 ..." static string */
+const char* mappo_error_string(int code);  /* static string for a return code */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAPPO_HIP_H */

@@ -1,0 +1,302 @@
+// K3 / K4 -- fused multi-field minibatch gathers, and K2 -- fused slab copies, for gfx950.
+//
+// K3 replaces the 12 fancy-index gathers per minibatch of
+//   SharedReplayBuffer.feed_forward_generator (reference onpolicy/utils/shared_buffer.py:379-396);
+// K4 replaces recurrent_generator's transposing copies + Python chunk loop + np.stack
+//   (:514-604) and naive_recurrent_generator (:417-493) by reading L-row chunks straight out
+//   of the time-major buffer;
+// K2 replaces the per-field slab assignments of insert / after_update (:107-121,:162-170).
+//
+// All of it is pure HBM traffic (no arithmetic except the optional advantage
+// normalisation), so the design goals are: one launch for all fields, 16-byte accesses
+// wherever the row width allows, output writes fully coalesced, many independent loads in
+// flight per lane, and a persistent grid (a few workgroups per CU walking a tile list)
+// instead of one tiny workgroup per row.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mappo_hip.h"
+#include "mappo_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kUnroll = 8;                       // independent loads per lane per pass
+constexpr unsigned kTileUnits = kThreads * kUnroll;
+
+struct GField {
+    const float* src;
+    float* dst;
+    unsigned width;          // floats per row
+    unsigned vec;            // floats per unit (1, 2, 4)
+    unsigned upr;            // units per row
+    unsigned rows_per_tile;
+    unsigned rows_out;       // output rows of this field
+    unsigned tile_begin;     // first global tile id of this field
+    unsigned first_only;
+    unsigned normalize;
+};
+
+struct GatherArgs {
+    GField f[MAPPO_MAX_FIELDS];
+    int nf;
+    unsigned total_tiles;
+    const long long* idx;
+    unsigned mb;
+    int chunked;             // 0: rows mode, 1: chunk mode
+    unsigned L, T, N, A;
+    const float* stats;
+};
+
+template <int VEC> struct VecT;
+template <> struct VecT<4> { using type = float4; };
+template <> struct VecT<2> { using type = float2; };
+template <> struct VecT<1> { using type = float; };
+
+__device__ __forceinline__ float norm1(float x, float mean, float den) { return (x - mean) / den; }
+__device__ __forceinline__ void normv(float& v, float m, float d) { v = norm1(v, m, d); }
+__device__ __forceinline__ void normv(float2& v, float m, float d) {
+    v.x = norm1(v.x, m, d);
+    v.y = norm1(v.y, m, d);
+}
+__device__ __forceinline__ void normv(float4& v, float m, float d) {
+    v.x = norm1(v.x, m, d);
+    v.y = norm1(v.y, m, d);
+    v.z = norm1(v.z, m, d);
+    v.w = norm1(v.w, m, d);
+}
+
+// Source row (in the time-major [T, N, A] row space) of output row `r` of a field.
+__device__ __forceinline__ unsigned source_row(const GatherArgs& a, const GField& fd, unsigned r) {
+    if (!a.chunked) return (unsigned)a.idx[r];  // shared_buffer.py:379-396
+    // shared_buffer.py:554-569 on the (n, a, t)-ordered view, 574-604 for the output order
+    unsigned l = 0, j = r;
+    if (!fd.first_only) {
+        l = r / a.mb;
+        j = r - l * a.mb;
+    }
+    unsigned f = (unsigned)a.idx[j] * a.L + l;
+    unsigned at = a.A * a.T;
+    unsigned n = f / at;
+    unsigned rem = f - n * at;
+    unsigned ag = rem / a.T;
+    unsigned t = rem - ag * a.T;
+    return (t * a.N + n) * a.A + ag;
+}
+
+template <int VEC>
+__device__ __forceinline__ void copy_tile(const GatherArgs& a, const GField& fd, unsigned tile_local) {
+    using V = typename VecT<VEC>::type;
+    const unsigned row0 = tile_local * fd.rows_per_tile;
+    unsigned nrows = fd.rows_out - row0;
+    if (nrows > fd.rows_per_tile) nrows = fd.rows_per_tile;
+    const unsigned nunits = nrows * fd.upr;
+    float mean = 0.f, den = 1.f;
+    if (fd.normalize) {
+        mean = a.stats[0];
+        den = a.stats[1] + 1e-5f;  // r_mappo.py:187
+    }
+    for (unsigned i0 = 0; i0 < nunits; i0 += kTileUnits) {
+        V val[kUnroll];
+        long long doff[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            unsigned i = i0 + u * kThreads + threadIdx.x;
+            doff[u] = -1;
+            if (i < nunits) {
+                unsigned r = (fd.upr == 1) ? i : i / fd.upr;
+                unsigned w = i - r * fd.upr;
+                unsigned orow = row0 + r;
+                unsigned srow = source_row(a, fd, orow);
+                val[u] = *reinterpret_cast<const V*>(fd.src + (long long)srow * fd.width + w * VEC);
+                doff[u] = (long long)orow * fd.width + w * VEC;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            if (doff[u] >= 0) {
+                V v = val[u];
+                if (fd.normalize) normv(v, mean, den);
+                *reinterpret_cast<V*>(fd.dst + doff[u]) = v;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kThreads) gather_kernel(GatherArgs a) {
+    for (unsigned tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+        int f = 0;
+#pragma unroll 1
+        for (int k = 1; k < a.nf; ++k)
+            if (tile >= a.f[k].tile_begin) f = k;
+        const GField& fd = a.f[f];
+        const unsigned tl = tile - fd.tile_begin;
+        if (fd.vec == 4) copy_tile<4>(a, fd, tl);
+        else if (fd.vec == 2) copy_tile<2>(a, fd, tl);
+        else copy_tile<1>(a, fd, tl);
+    }
+}
+
+int build_and_launch(const mappo_field_t* fields, int n_fields, const int64_t* idx, int64_t mb,
+                     int chunked, int L, int T, int64_t N, int A, const float* stats,
+                     hipStream_t stream) {
+    if (!fields || !idx) return MAPPO_E_NULL;
+    if (n_fields <= 0 || mb <= 0) return MAPPO_E_SHAPE;
+    if (n_fields > MAPPO_MAX_FIELDS) return MAPPO_E_TOO_MANY;
+    if (mb >= (1ll << 31)) return MAPPO_E_SHAPE;
+    if (chunked) {
+        if (L <= 0 || T <= 0 || N <= 0 || A <= 0) return MAPPO_E_SHAPE;
+        if ((long long)T * N * A >= (1ll << 31) || mb * (long long)L >= (1ll << 31)) return MAPPO_E_SHAPE;
+    }
+    GatherArgs a;
+    a.nf = n_fields;
+    a.idx = reinterpret_cast<const long long*>(idx);
+    a.mb = (unsigned)mb;
+    a.chunked = chunked;
+    a.L = (unsigned)L;
+    a.T = (unsigned)T;
+    a.N = (unsigned)N;
+    a.A = (unsigned)A;
+    a.stats = stats;
+    unsigned long long tiles = 0;
+    for (int k = 0; k < n_fields; ++k) {
+        const mappo_field_t& s = fields[k];
+        if (!s.src || !s.dst) return MAPPO_E_NULL;
+        if (s.width <= 0) return MAPPO_E_SHAPE;
+        if (!mappo::aligned_to(s.src, 4) || !mappo::aligned_to(s.dst, 4)) return MAPPO_E_ALIGN;
+        if (s.normalize && !stats) return MAPPO_E_NULL;
+        GField& g = a.f[k];
+        g.src = s.src;
+        g.dst = s.dst;
+        g.width = (unsigned)s.width;
+        g.vec = (unsigned)mappo::row_vec(s.src, s.dst, s.width);
+        g.upr = g.width / g.vec;
+        g.rows_per_tile = g.upr >= kTileUnits ? 1u : kTileUnits / g.upr;
+        g.first_only = (chunked && s.first_only) ? 1u : 0u;
+        g.normalize = s.normalize ? 1u : 0u;
+        long long rows_out = (chunked && !g.first_only) ? mb * (long long)L : mb;
+        g.rows_out = (unsigned)rows_out;
+        g.tile_begin = (unsigned)tiles;
+        tiles += (unsigned long long)((rows_out + g.rows_per_tile - 1) / g.rows_per_tile);
+        if (tiles >= (1ull << 32)) return MAPPO_E_SHAPE;
+    }
+    a.total_tiles = (unsigned)tiles;
+    unsigned grid = a.total_tiles < (unsigned)(mappo::kCUs * 8) ? a.total_tiles
+                                                                  : (unsigned)(mappo::kCUs * 8);
+    hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(kThreads), 0, stream, a);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------ K2: slabs ----
+struct Slab {
+    const float* src;
+    float* dst;
+    unsigned long long units;  // float4 (vec) or float units
+    unsigned vec;
+    unsigned tile_begin;
+};
+struct SlabArgs {
+    Slab s[MAPPO_MAX_FIELDS];
+    int n;
+    unsigned total_tiles;
+};
+
+__global__ void __launch_bounds__(kThreads) slab_kernel(SlabArgs a) {
+    for (unsigned tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+        int k = 0;
+#pragma unroll 1
+        for (int q = 1; q < a.n; ++q)
+            if (tile >= a.s[q].tile_begin) k = q;
+        const Slab& s = a.s[k];
+        unsigned long long base = (unsigned long long)(tile - s.tile_begin) * kTileUnits;
+        if (s.vec == 4) {
+            const float4* src = reinterpret_cast<const float4*>(s.src);
+            float4* dst = reinterpret_cast<float4*>(s.dst);
+            float4 v[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                unsigned long long i = base + u * kThreads + threadIdx.x;
+                if (i < s.units) v[u] = src[i];
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                unsigned long long i = base + u * kThreads + threadIdx.x;
+                if (i < s.units) dst[i] = v[u];
+            }
+        } else {
+            float v[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                unsigned long long i = base + u * kThreads + threadIdx.x;
+                if (i < s.units) v[u] = s.src[i];
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                unsigned long long i = base + u * kThreads + threadIdx.x;
+                if (i < s.units) s.dst[i] = v[u];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mappo_gather_rows(const mappo_field_t* fields, int n_fields, const int64_t* idx,
+                                 int64_t mb, const float* stats, mappo_stream_t stream) {
+    return build_and_launch(fields, n_fields, idx, mb, 0, 1, 1, 1, 1, stats,
+                            static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mappo_gather_chunks(const mappo_field_t* fields, int n_fields, const int64_t* idx,
+                                   int64_t mb, int L, int T, int64_t N, int A, const float* stats,
+                                   mappo_stream_t stream) {
+    return build_and_launch(fields, n_fields, idx, mb, 1, L, T, N, A, stats,
+                            static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mappo_slab_copy(const mappo_slab_t* slabs, int n_slabs, mappo_stream_t stream) {
+    if (!slabs) return MAPPO_E_NULL;
+    if (n_slabs <= 0) return MAPPO_E_SHAPE;
+    if (n_slabs > MAPPO_MAX_FIELDS) return MAPPO_E_TOO_MANY;
+    SlabArgs a;
+    a.n = n_slabs;
+    unsigned long long tiles = 0;
+    for (int k = 0; k < n_slabs; ++k) {
+        const mappo_slab_t& s = slabs[k];
+        if (!s.src || !s.dst) return MAPPO_E_NULL;
+        if (s.count <= 0) return MAPPO_E_SHAPE;
+        if (!mappo::aligned_to(s.src, 4) || !mappo::aligned_to(s.dst, 4)) return MAPPO_E_ALIGN;
+        Slab& d = a.s[k];
+        d.src = s.src;
+        d.dst = s.dst;
+        d.vec = (unsigned)(mappo::row_vec(s.src, s.dst, s.count) == 4 ? 4 : 1);
+        d.units = (unsigned long long)s.count / d.vec;
+        d.tile_begin = (unsigned)tiles;
+        tiles += (d.units + kTileUnits - 1) / kTileUnits;
+        if (tiles >= (1ull << 32)) return MAPPO_E_SHAPE;
+    }
+    a.total_tiles = (unsigned)tiles;
+    unsigned grid = a.total_tiles < (unsigned)(mappo::kCUs * 8) ? a.total_tiles
+                                                                  : (unsigned)(mappo::kCUs * 8);
+    hipLaunchKernelGGL(slab_kernel, dim3(grid), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mappo_abi_version(void) { return MAPPO_ABI_VERSION; }
+
+extern "C" const char* mappo_build_info(void) {
+    return "libmappo_hip gfx950 (CDNA4) fp-contract=off " __DATE__;
+}
+
+extern "C" const char* mappo_error_string(int code) {
+    switch (code) {
+        case 0: return "ok";
+        case MAPPO_E_NULL: return "a required pointer is NULL";
+        case MAPPO_E_SHAPE: return "a size is <= 0, inconsistent or too large";
+        case MAPPO_E_FLAGS: return "unsupported flag combination";
+        case MAPPO_E_TOO_MANY: return "too many fields / slabs (MAPPO_MAX_FIELDS)";
+        case MAPPO_E_ALIGN: return "a pointer is not 4-byte aligned";
+        default: return code > 0 ? hipGetErrorString(static_cast<hipError_t>(code)) : "unknown error";
+    }
+}

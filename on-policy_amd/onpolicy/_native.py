@@ -1,0 +1,90 @@
+"""ctypes binding of libmappo_hip.so (C ABI: include/mappo_hip.h).
+
+There is deliberately no fallback: if the library is missing or a call fails this raises.  The
+device path is the product; a CPU stand-in would silently invalidate every parity and
+performance claim (the CPU oracle lives under oracle/ and is test infrastructure only).
+"""
+import ctypes
+import os
+
+import torch  # imported first so that the HIP runtime torch ships is the one this library binds to
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("MAPPO_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libmappo_hip.so"))
+
+MAX_FIELDS = 16
+GAE_USE_GAE, GAE_PROPER_TIME_LIMITS, GAE_DENORM = 1, 2, 4
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+
+
+class Field(ctypes.Structure):
+    """struct mappo_field (include/mappo_hip.h)."""
+    _fields_ = [("src", _vp), ("dst", _vp), ("width", ctypes.c_int32), ("first_only", ctypes.c_int32),
+                ("normalize", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class Slab(ctypes.Structure):
+    """struct mappo_slab (include/mappo_hip.h)."""
+    _fields_ = [("src", _vp), ("dst", _vp), ("count", _i64)]
+
+
+# symbol -> (restype, argtypes); must list every function include/mappo_hip.h declares
+SIGNATURES = {
+    "mappo_gae_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _i64,
+                             ctypes.c_double, ctypes.c_double, ctypes.c_uint, _vp]),
+    "mappo_gae_partial_rows": (_i64, [_i64]),
+    "mappo_gae_set_variant": (_int, [_int]),
+    "mappo_advantages_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]),
+    "mappo_adv_reduce": (_int, [_vp, _i64, _vp, _vp]),
+    "mappo_adv_stats": (_int, [_vp, _vp, _vp]),
+    "mappo_adv_normalize": (_int, [_vp, _vp, _vp, _i64, _vp]),
+    "mappo_gather_rows": (_int, [ctypes.POINTER(Field), _int, _vp, _i64, _vp, _vp]),
+    "mappo_gather_chunks": (_int, [ctypes.POINTER(Field), _int, _vp, _i64, _int, _int, _i64, _int, _vp, _vp]),
+    "mappo_slab_copy": (_int, [ctypes.POINTER(Slab), _int, _vp]),
+    "mappo_abi_version": (_int, []),
+    "mappo_build_info": (ctypes.c_char_p, []),
+    "mappo_error_string": (ctypes.c_char_p, [_int]),
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the bound library; raises NativeError if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                "libmappo_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C on-policy_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here = header / library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        if L.mappo_abi_version() != 1:
+            raise NativeError("libmappo_hip.so ABI version %d, expected 1" % L.mappo_abi_version())
+        _lib = L
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().mappo_error_string(code).decode()
+        raise NativeError("%s failed: %s (code %d)" % (what, msg, code))
+
+
+def ptr(t):
+    """Device pointer of a tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_of(device):
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,56 @@
+"""Policy wrapper: one shared actor, one (centralised) critic, one Adam optimiser each.
+
+Surface of the reference's onpolicy/algorithms/r_mappo/algorithm/rMAPPOPolicy.py (R_MAPPOPolicy :6,
+lr_decay :39, get_actions :48, get_values :76, evaluate_actions :88, act :116).
+"""
+import torch
+
+from onpolicy.algorithms.r_mappo.algorithm.r_actor_critic import R_Actor, R_Critic
+from onpolicy.utils.util import update_linear_schedule
+
+
+class R_MAPPOPolicy:
+    def __init__(self, args, obs_space, cent_obs_space, act_space, device=torch.device("cpu")):
+        self.device = device
+        self.lr = args.lr
+        self.critic_lr = args.critic_lr
+        self.opti_eps = args.opti_eps
+        self.weight_decay = args.weight_decay
+        self.obs_space = obs_space
+        self.share_obs_space = cent_obs_space
+        self.act_space = act_space
+
+        self.actor = R_Actor(args, self.obs_space, self.act_space, self.device)
+        self.critic = R_Critic(args, self.share_obs_space, self.device)
+        self.actor_optimizer = self._adam(self.actor, self.lr)
+        self.critic_optimizer = self._adam(self.critic, self.critic_lr)
+
+    def _adam(self, net, lr):
+        return torch.optim.Adam(net.parameters(), lr=lr, eps=self.opti_eps, weight_decay=self.weight_decay)
+
+    def lr_decay(self, episode, episodes):
+        update_linear_schedule(self.actor_optimizer, episode, episodes, self.lr)
+        update_linear_schedule(self.critic_optimizer, episode, episodes, self.critic_lr)
+
+    def get_actions(self, cent_obs, obs, rnn_states_actor, rnn_states_critic, masks, available_actions=None,
+                    deterministic=False):
+        """-> (values, actions, action_log_probs, rnn_states_actor, rnn_states_critic)."""
+        actions, action_log_probs, rnn_states_actor = self.actor(obs, rnn_states_actor, masks,
+                                                                 available_actions, deterministic)
+        values, rnn_states_critic = self.critic(cent_obs, rnn_states_critic, masks)
+        return values, actions, action_log_probs, rnn_states_actor, rnn_states_critic
+
+    def get_values(self, cent_obs, rnn_states_critic, masks):
+        return self.critic(cent_obs, rnn_states_critic, masks)[0]
+
+    def evaluate_actions(self, cent_obs, obs, rnn_states_actor, rnn_states_critic, action, masks,
+                         available_actions=None, active_masks=None):
+        """-> (values, action_log_probs, dist_entropy)."""
+        action_log_probs, dist_entropy = self.actor.evaluate_actions(obs, rnn_states_actor, action, masks,
+                                                                     available_actions, active_masks)
+        values = self.critic(cent_obs, rnn_states_critic, masks)[0]
+        return values, action_log_probs, dist_entropy
+
+    def act(self, obs, rnn_states_actor, masks, available_actions=None, deterministic=False):
+        actions, _, rnn_states_actor = self.actor(obs, rnn_states_actor, masks, available_actions, deterministic)
+        return actions, rnn_states_actor

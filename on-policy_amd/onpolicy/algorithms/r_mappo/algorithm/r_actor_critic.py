@@ -1,0 +1,107 @@
+"""Actor and critic networks of (R)MAPPO: trunk -> [GRU] -> action head / value head.
+
+Class names, constructor signatures, forward signatures and parameter names are those of the
+reference's onpolicy/algorithms/r_mappo/algorithm/r_actor_critic.py (R_Actor :12, forward :44,
+evaluate_actions :73; R_Critic :120, forward :156).  The maths stays in PyTorch (rocBLAS / MIOpen on
+ROCm).  Inputs may be numpy arrays (reference runners) or tensors that already live in HBM (the
+device buffer and its samplers): ``_to_device`` is a no-op for the latter, so the update path does
+no host<->device traffic.
+"""
+import torch
+import torch.nn as nn
+
+from onpolicy.algorithms.utils.util import init, check
+from onpolicy.algorithms.utils.cnn import CNNBase
+from onpolicy.algorithms.utils.mlp import MLPBase
+from onpolicy.algorithms.utils.rnn import RNNLayer
+from onpolicy.algorithms.utils.act import ACTLayer
+from onpolicy.algorithms.utils.popart import PopArt
+from onpolicy.utils.util import get_shape_from_obs_space
+
+
+def _trunk(args, shape):
+    return (CNNBase if len(shape) == 3 else MLPBase)(args, shape)
+
+
+class _DeviceMixin(object):
+    def _to_device(self, *xs):
+        out = []
+        for x in xs:
+            out.append(None if x is None else check(x).to(**self.tpdv))
+        return out
+
+
+class R_Actor(nn.Module, _DeviceMixin):
+    def __init__(self, args, obs_space, action_space, device=torch.device("cpu")):
+        super(R_Actor, self).__init__()
+        self.hidden_size = args.hidden_size
+        self._gain = args.gain
+        self._use_orthogonal = args.use_orthogonal
+        self._use_policy_active_masks = args.use_policy_active_masks
+        self._use_naive_recurrent_policy = args.use_naive_recurrent_policy
+        self._use_recurrent_policy = args.use_recurrent_policy
+        self._recurrent_N = args.recurrent_N
+        self.tpdv = dict(dtype=torch.float32, device=device)
+        self.algo = args.algorithm_name
+
+        self.base = _trunk(args, get_shape_from_obs_space(obs_space))
+        if self._recurrent:
+            self.rnn = RNNLayer(self.hidden_size, self.hidden_size, self._recurrent_N, self._use_orthogonal)
+        self.act = ACTLayer(action_space, self.hidden_size, self._use_orthogonal, self._gain, args)
+        # built on the CPU, then moved: init draws come from the CPU generator on every device
+        self.to(device)
+
+    @property
+    def _recurrent(self):
+        return self._use_naive_recurrent_policy or self._use_recurrent_policy
+
+    def _features(self, obs, rnn_states, masks):
+        feats = self.base(obs)
+        if self._recurrent:
+            feats, rnn_states = self.rnn(feats, rnn_states, masks)
+        return feats, rnn_states
+
+    def forward(self, obs, rnn_states, masks, available_actions=None, deterministic=False):
+        obs, rnn_states, masks, available_actions = self._to_device(obs, rnn_states, masks, available_actions)
+        feats, rnn_states = self._features(obs, rnn_states, masks)
+        actions, action_log_probs = self.act(feats, available_actions, deterministic)
+        return actions, action_log_probs, rnn_states
+
+    def evaluate_actions(self, obs, rnn_states, action, masks, available_actions=None, active_masks=None):
+        obs, rnn_states, action, masks, available_actions, active_masks = self._to_device(
+            obs, rnn_states, action, masks, available_actions, active_masks)
+        feats, _ = self._features(obs, rnn_states, masks)
+        return self.act.evaluate_actions(
+            feats, action, available_actions,
+            active_masks=active_masks if self._use_policy_active_masks else None)
+
+
+class R_Critic(nn.Module, _DeviceMixin):
+    def __init__(self, args, cent_obs_space, device=torch.device("cpu")):
+        super(R_Critic, self).__init__()
+        self.hidden_size = args.hidden_size
+        self._use_orthogonal = args.use_orthogonal
+        self._use_naive_recurrent_policy = args.use_naive_recurrent_policy
+        self._use_recurrent_policy = args.use_recurrent_policy
+        self._recurrent_N = args.recurrent_N
+        self._use_popart = args.use_popart
+        self.tpdv = dict(dtype=torch.float32, device=device)
+        w_init = nn.init.orthogonal_ if self._use_orthogonal else nn.init.xavier_uniform_
+
+        self.base = _trunk(args, get_shape_from_obs_space(cent_obs_space))
+        if self._recurrent:
+            self.rnn = RNNLayer(self.hidden_size, self.hidden_size, self._recurrent_N, self._use_orthogonal)
+        head = PopArt(self.hidden_size, 1, device=device) if self._use_popart else nn.Linear(self.hidden_size, 1)
+        self.v_out = init(head, w_init, lambda b: nn.init.constant_(b, 0))
+        self.to(device)
+
+    @property
+    def _recurrent(self):
+        return self._use_naive_recurrent_policy or self._use_recurrent_policy
+
+    def forward(self, cent_obs, rnn_states, masks):
+        cent_obs, rnn_states, masks = self._to_device(cent_obs, rnn_states, masks)
+        feats = self.base(cent_obs)
+        if self._recurrent:
+            feats, rnn_states = self.rnn(feats, rnn_states, masks)
+        return self.v_out(feats), rnn_states

@@ -1,0 +1,242 @@
+"""MAPPO trainer: advantage normalisation, ppo_epoch x num_mini_batch clipped-surrogate updates.
+
+Drop-in for the reference's ``R_MAPPO`` (onpolicy/algorithms/r_mappo/r_mappo.py: R_MAPPO :8,
+cal_value_loss :52, ppo_update :91, train :171, prep_training :226, prep_rollout :230) with the
+same constructor, methods, return values and ``train_info`` keys.  What differs is where the data
+lives and when the host looks at it:
+
+  * minibatches arrive as device tensors from the HBM buffer's fused gather kernels, so there is no
+    ``torch.from_numpy(...).to(device)`` per field per minibatch (reference r_mappo.py:113-117);
+  * the advantage statistics come from the moments the GAE kernel already accumulated, and the
+    normalisation is folded into the gathers (reference r_mappo.py:179-187 makes ~6 full passes);
+  * the six logged scalars are accumulated on the device and read back once per ``train()``
+    instead of three ``.item()`` syncs per minibatch (reference r_mappo.py:212-214);
+  * data-parallel training (one process per GPU, rollout threads sharded over ranks): gradients of
+    actor and critic are summed with ONE RCCL all-reduce per update over a flat bucket that the
+    parameters' ``.grad`` tensors are views of, preceded by one tiny all-reduce of the batch
+    statistics that must be global (loss denominators, ValueNorm moments).  Every rank then
+    applies the identical clipped Adam step -- the result equals the single-GPU update on the
+    union of the ranks' minibatches up to float32 summation order.
+
+The forward / backward maths of the actor and critic stays in PyTorch.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from onpolicy.utils.util import get_gard_norm, huber_loss, mse_loss
+from onpolicy.utils.valuenorm import ValueNorm
+from onpolicy.algorithms.utils.util import check
+from onpolicy.utils import dist as mdist
+
+
+class R_MAPPO():
+    """
+    :param args: (argparse.Namespace) flags (onpolicy/config.py).
+    :param policy: (R_MAPPOPolicy) policy to update.
+    :param device: (torch.device) device the networks live on.
+    """
+
+    def __init__(self, args, policy, device=torch.device("cpu")):
+        self.device = device
+        self.tpdv = dict(dtype=torch.float32, device=device)
+        self.policy = policy
+
+        self.clip_param = args.clip_param
+        self.ppo_epoch = args.ppo_epoch
+        self.num_mini_batch = args.num_mini_batch
+        self.data_chunk_length = args.data_chunk_length
+        self.value_loss_coef = args.value_loss_coef
+        self.entropy_coef = args.entropy_coef
+        self.max_grad_norm = args.max_grad_norm
+        self.huber_delta = args.huber_delta
+
+        self._use_recurrent_policy = args.use_recurrent_policy
+        self._use_naive_recurrent = args.use_naive_recurrent_policy
+        self._use_max_grad_norm = args.use_max_grad_norm
+        self._use_clipped_value_loss = args.use_clipped_value_loss
+        self._use_huber_loss = args.use_huber_loss
+        self._use_popart = args.use_popart
+        self._use_valuenorm = args.use_valuenorm
+        self._use_value_active_masks = args.use_value_active_masks
+        self._use_policy_active_masks = args.use_policy_active_masks
+
+        assert (self._use_popart and self._use_valuenorm) == False, (
+            "self._use_popart and self._use_valuenorm can not be set True simultaneously")
+
+        if self._use_popart:
+            self.value_normalizer = self.policy.critic.v_out
+        elif self._use_valuenorm:
+            self.value_normalizer = ValueNorm(1, device=self.device)
+        else:
+            self.value_normalizer = None
+
+        # data parallelism over rollout threads; world size 1 unless torch.distributed is up
+        self.dp = mdist.DataParallel(self.policy.actor, self.policy.critic, device)
+
+    # ------------------------------------------------------------------ losses
+    def _normalizer_update(self, return_batch):
+        """ValueNorm / PopArt EMA update (reference r_mappo.py:65) from GLOBAL batch moments."""
+        if self.dp.world_size == 1:
+            self.value_normalizer.update(return_batch)
+            return
+        x = return_batch.detach()
+        stats = torch.stack([x.sum(0).reshape(()).double(), (x ** 2).sum(0).reshape(()).double(),
+                             torch.tensor(float(x.shape[0]), dtype=torch.float64, device=x.device)])
+        self.dp.all_reduce(stats)
+        mean = (stats[0] / stats[2]).float().reshape(1)
+        mean_sq = (stats[1] / stats[2]).float().reshape(1)
+        self.value_normalizer.update(return_batch, batch_moments=(mean, mean_sq))
+
+    def cal_value_loss(self, values, value_preds_batch, return_batch, active_masks_batch):
+        """Clipped (huber | mse) value loss against normalised returns
+        (reference r_mappo.py:52-89); updates the value normaliser as a side effect."""
+        value_pred_clipped = value_preds_batch + (values - value_preds_batch).clamp(-self.clip_param,
+                                                                                    self.clip_param)
+        if self._use_popart or self._use_valuenorm:
+            self._normalizer_update(return_batch)
+            target = self.value_normalizer.normalize(return_batch)
+        else:
+            target = return_batch
+        error_clipped = target - value_pred_clipped
+        error_original = target - values
+
+        if self._use_huber_loss:
+            value_loss_clipped = huber_loss(error_clipped, self.huber_delta)
+            value_loss_original = huber_loss(error_original, self.huber_delta)
+        else:
+            value_loss_clipped = mse_loss(error_clipped)
+            value_loss_original = mse_loss(error_original)
+
+        if self._use_clipped_value_loss:
+            value_loss = torch.max(value_loss_original, value_loss_clipped)
+        else:
+            value_loss = value_loss_original
+
+        if self._use_value_active_masks:
+            value_loss = (value_loss * active_masks_batch).sum() / active_masks_batch.sum()
+        else:
+            value_loss = value_loss.mean()
+        return value_loss
+
+    # ------------------------------------------------------------------ one minibatch
+    def ppo_update(self, sample, update_actor=True):
+        """One actor step and one critic step on a minibatch (reference r_mappo.py:91-169).
+        -> (value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights)."""
+        share_obs_batch, obs_batch, rnn_states_batch, rnn_states_critic_batch, actions_batch, \
+            value_preds_batch, return_batch, masks_batch, active_masks_batch, old_action_log_probs_batch, \
+            adv_targ, available_actions_batch = sample[:12]
+
+        old_action_log_probs_batch = check(old_action_log_probs_batch).to(**self.tpdv)
+        adv_targ = check(adv_targ).to(**self.tpdv)
+        value_preds_batch = check(value_preds_batch).to(**self.tpdv)
+        return_batch = check(return_batch).to(**self.tpdv)
+        active_masks_batch = check(active_masks_batch).to(**self.tpdv)
+
+        values, action_log_probs, dist_entropy = self.policy.evaluate_actions(
+            share_obs_batch, obs_batch, rnn_states_batch, rnn_states_critic_batch, actions_batch,
+            masks_batch, available_actions_batch, active_masks_batch)
+
+        # clipped surrogate
+        imp_weights = torch.exp(action_log_probs - old_action_log_probs_batch)
+        surr1 = imp_weights * adv_targ
+        surr2 = torch.clamp(imp_weights, 1.0 - self.clip_param, 1.0 + self.clip_param) * adv_targ
+        per_sample = -torch.sum(torch.min(surr1, surr2), dim=-1, keepdim=True)
+        if self._use_policy_active_masks:
+            policy_loss = (per_sample * active_masks_batch).sum() / active_masks_batch.sum()
+        else:
+            policy_loss = per_sample.mean()
+
+        # In a data-parallel job each rank's loss is a mean over ITS minibatch; weighting it by
+        # (local denominator / global denominator) makes the all-reduced gradient the gradient of
+        # the global-batch mean.  Weights are exactly 1 for world size 1.
+        w_actor, w_critic = self.dp.loss_weights(
+            active_masks_batch, self._use_policy_active_masks, self._use_value_active_masks)
+
+        self.dp.zero_grad(self.policy.actor_optimizer, self.policy.critic_optimizer)
+        if update_actor:
+            ((policy_loss - dist_entropy * self.entropy_coef) * w_actor).backward()
+
+        value_loss = self.cal_value_loss(values, value_preds_batch, return_batch, active_masks_batch)
+        (value_loss * self.value_loss_coef * w_critic).backward()
+
+        self.dp.all_reduce_grads()  # no-op for world size 1
+
+        if self._use_max_grad_norm:
+            actor_grad_norm = nn.utils.clip_grad_norm_(self.policy.actor.parameters(), self.max_grad_norm)
+            critic_grad_norm = nn.utils.clip_grad_norm_(self.policy.critic.parameters(), self.max_grad_norm)
+        else:
+            actor_grad_norm = get_gard_norm(self.policy.actor.parameters())
+            critic_grad_norm = get_gard_norm(self.policy.critic.parameters())
+
+        if update_actor or self.dp.world_size == 1:
+            self.policy.actor_optimizer.step()
+        self.policy.critic_optimizer.step()
+
+        return value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights
+
+    # ------------------------------------------------------------------ one update phase
+    def _advantages(self, buffer):
+        """Normalised advantages for the samplers (reference r_mappo.py:179-187)."""
+        if hasattr(buffer, "normalized_advantages"):
+            reduce_fn = self.dp.all_reduce if self.dp.world_size > 1 else None
+            return buffer.normalized_advantages(self.value_normalizer, all_reduce=reduce_fn)
+        # Foreign buffers that hold host arrays in the reference's format (e.g. the reference's own
+        # SharedReplayBuffer): same arithmetic in torch on this trainer's device.
+        returns = torch.as_tensor(np.asarray(buffer.returns[:-1]), dtype=torch.float32)
+        value_preds = torch.as_tensor(np.asarray(buffer.value_preds[:-1]), dtype=torch.float32)
+        active = torch.as_tensor(np.asarray(buffer.active_masks[:-1]), dtype=torch.float32)
+        if self._use_popart or self._use_valuenorm:
+            value_preds = self.value_normalizer.denormalize(value_preds.to(self.device)).cpu()
+        adv = returns - value_preds
+        on = active != 0.0
+        sums = torch.stack([adv[on].double().sum(), (adv[on].double() ** 2).sum(),
+                            on.sum().double()]).to(self.device)
+        if self.dp.world_size > 1:
+            self.dp.all_reduce(sums)
+        sums = sums.cpu()
+        mean = sums[0] / sums[2]
+        std = torch.sqrt(torch.clamp(sums[1] / sums[2] - mean ** 2, min=0.0))
+        return ((adv - mean.float()) / (std.float() + 1e-5)).numpy()
+
+    def train(self, buffer, update_actor=True):
+        """ppo_epoch passes over the buffer in num_mini_batch minibatches (reference r_mappo.py:171-224).
+        -> dict with value_loss, policy_loss, dist_entropy, actor_grad_norm, critic_grad_norm, ratio
+        (means over the updates; global-batch values in a data-parallel job)."""
+        advantages = self._advantages(buffer)
+
+        keys = ('value_loss', 'policy_loss', 'dist_entropy', 'actor_grad_norm', 'critic_grad_norm', 'ratio')
+        totals = torch.zeros(len(keys), dtype=torch.float32, device=self.device)
+
+        for _ in range(self.ppo_epoch):
+            if self._use_recurrent_policy:
+                data_generator = buffer.recurrent_generator(advantages, self.num_mini_batch,
+                                                            self.data_chunk_length)
+            elif self._use_naive_recurrent:
+                data_generator = buffer.naive_recurrent_generator(advantages, self.num_mini_batch)
+            else:
+                data_generator = buffer.feed_forward_generator(advantages, self.num_mini_batch)
+
+            for sample in data_generator:
+                value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights \
+                    = self.ppo_update(sample, update_actor)
+                with torch.no_grad():
+                    totals += torch.stack([
+                        value_loss.detach().reshape(()), policy_loss.detach().reshape(()),
+                        dist_entropy.detach().reshape(()),
+                        torch.as_tensor(actor_grad_norm, **self.tpdv).reshape(()),
+                        torch.as_tensor(critic_grad_norm, **self.tpdv).reshape(()),
+                        imp_weights.detach().mean().reshape(())])
+
+        num_updates = self.ppo_epoch * self.num_mini_batch
+        totals = self.dp.average_info(totals / num_updates)
+        values = totals.tolist()  # the only device->host sync of the update phase
+        return dict(zip(keys, values))
+
+    def prep_training(self):
+        self.policy.actor.train()
+        self.policy.critic.train()
+
+    def prep_rollout(self):
+        self.policy.actor.eval()
+        self.policy.critic.eval()

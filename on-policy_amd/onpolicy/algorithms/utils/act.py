@@ -1,0 +1,98 @@
+"""Action head: maps actor features to a distribution for the env's action space, samples /
+evaluates actions.  Interface of the reference's onpolicy/algorithms/utils/act.py (ACTLayer :5,
+forward :44, get_probs :91, evaluate_actions :115); the space is recognised by class name.
+"""
+import torch
+import torch.nn as nn
+
+from .distributions import Bernoulli, Categorical, DiagGaussian
+
+
+def _masked_mean(x, active_masks, squeeze=True):
+    """(x * m).sum() / m.sum() with m = active_masks ([B,1]); plain mean when m is None."""
+    if active_masks is None:
+        return x.mean()
+    m = active_masks.squeeze(-1) if squeeze else active_masks
+    return (x * m).sum() / active_masks.sum()
+
+
+class ACTLayer(nn.Module):
+    def __init__(self, action_space, inputs_dim, use_orthogonal, gain, args=None):
+        super(ACTLayer, self).__init__()
+        self.mixed_action = False
+        self.multi_discrete = False
+        self.mujoco_box = False
+        self.action_type = kind = action_space.__class__.__name__
+        if kind == "Discrete":
+            self.action_out = Categorical(inputs_dim, action_space.n, use_orthogonal, gain)
+        elif kind == "Box":
+            self.mujoco_box = True
+            self.action_out = DiagGaussian(inputs_dim, action_space.shape[0], use_orthogonal, gain)
+        elif kind == "MultiBinary":
+            self.action_out = Bernoulli(inputs_dim, action_space.shape[0], use_orthogonal, gain)
+        elif kind == "MultiDiscrete":
+            self.multi_discrete = True
+            dims = action_space.high - action_space.low + 1
+            self.action_outs = nn.ModuleList(
+                [Categorical(inputs_dim, int(d), use_orthogonal, gain) for d in dims])
+        else:  # [Box, Discrete]
+            self.mixed_action = True
+            self.action_outs = nn.ModuleList([
+                DiagGaussian(inputs_dim, action_space[0].shape[0], use_orthogonal, gain),
+                Categorical(inputs_dim, action_space[1].n, use_orthogonal, gain)])
+
+    def _single(self, x, available_actions):
+        if self.mujoco_box or self.action_type == "MultiBinary":
+            return self.action_out(x)
+        return self.action_out(x, available_actions)
+
+    def forward(self, x, available_actions=None, deterministic=False):
+        if self.mixed_action or self.multi_discrete:
+            actions, log_probs = [], []
+            for head in self.action_outs:
+                dist = head(x)
+                a = dist.mode() if deterministic else dist.sample()
+                log_probs.append(dist.log_probs(a))
+                actions.append(a.float() if self.mixed_action else a)
+            actions = torch.cat(actions, -1)
+            log_probs = torch.cat(log_probs, -1)
+            if self.mixed_action:
+                log_probs = log_probs.sum(-1, keepdim=True)
+            return actions, log_probs
+        dist = self._single(x, available_actions)
+        actions = dist.mode() if deterministic else dist.sample()
+        return actions, dist.log_probs(actions)
+
+    def get_probs(self, x, available_actions=None):
+        if self.mixed_action or self.multi_discrete:
+            return torch.cat([head(x).probs for head in self.action_outs], -1)
+        return self._single(x, available_actions).probs
+
+    def evaluate_actions(self, x, action, available_actions=None, active_masks=None):
+        if self.mixed_action:
+            cont, disc = action.split((2, 1), -1)
+            log_probs, ents = [], []
+            for head, act in zip(self.action_outs, (cont, disc.long())):
+                dist = head(x)
+                log_probs.append(dist.log_probs(act))
+                ent = dist.entropy()
+                if active_masks is not None:
+                    same_rank = ent.dim() == active_masks.dim()
+                    ents.append(_masked_mean(ent, active_masks, squeeze=not same_rank))
+                else:
+                    ents.append(ent.mean())
+            action_log_probs = torch.cat(log_probs, -1).sum(-1, keepdim=True)
+            dist_entropy = ents[0] / 2.0 + ents[1] / 0.98
+        elif self.multi_discrete:
+            log_probs, ents = [], []
+            for head, act in zip(self.action_outs, torch.transpose(action, 0, 1)):
+                dist = head(x)
+                log_probs.append(dist.log_probs(act))
+                ents.append(_masked_mean(dist.entropy(), active_masks))
+            action_log_probs = torch.cat(log_probs, -1)
+            dist_entropy = sum(ents) / len(ents)
+        else:
+            dist = self._single(x, available_actions)
+            action_log_probs = dist.log_probs(action)
+            dist_entropy = _masked_mean(dist.entropy(), active_masks)
+        return action_log_probs, dist_entropy

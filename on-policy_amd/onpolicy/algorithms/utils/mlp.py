@@ -1,0 +1,59 @@
+"""Feature trunk of actor and critic: [LayerNorm] -> (Linear -> act -> LayerNorm) x (1 + layer_N).
+
+Parameter names (``feature_norm``, ``mlp.fc1.{0,2}``, ``mlp.fc2.<i>.{0,2}``) and the order in which
+layers are constructed match the reference's onpolicy/algorithms/utils/mlp.py (MLPLayer :6,
+MLPBase :33), so reference checkpoints load and a given seed yields the same weights.
+"""
+import torch.nn as nn
+
+from .util import init
+
+
+def _weight_init(use_orthogonal):
+    return nn.init.orthogonal_ if use_orthogonal else nn.init.xavier_uniform_
+
+
+def _zero_bias(b):
+    return nn.init.constant_(b, 0)
+
+
+def _block(in_dim, out_dim, use_orthogonal, use_ReLU, act):
+    gain = nn.init.calculate_gain('relu' if use_ReLU else 'tanh')
+    linear = init(nn.Linear(in_dim, out_dim), _weight_init(use_orthogonal), _zero_bias, gain=gain)
+    return nn.Sequential(linear, act, nn.LayerNorm(out_dim))
+
+
+class MLPLayer(nn.Module):
+    def __init__(self, input_dim, hidden_size, layer_N, use_orthogonal, use_ReLU):
+        super(MLPLayer, self).__init__()
+        self._layer_N = layer_N
+        act = nn.ReLU() if use_ReLU else nn.Tanh()
+        self.fc1 = _block(input_dim, hidden_size, use_orthogonal, use_ReLU, act)
+        self.fc2 = nn.ModuleList(
+            [_block(hidden_size, hidden_size, use_orthogonal, use_ReLU, act) for _ in range(layer_N)])
+
+    def forward(self, x):
+        x = self.fc1(x)
+        for layer in self.fc2:
+            x = layer(x)
+        return x
+
+
+class MLPBase(nn.Module):
+    def __init__(self, args, obs_shape, cat_self=True, attn_internal=False):
+        super(MLPBase, self).__init__()
+        self._use_feature_normalization = args.use_feature_normalization
+        self._use_orthogonal = args.use_orthogonal
+        self._use_ReLU = args.use_ReLU
+        self._stacked_frames = args.stacked_frames
+        self._layer_N = args.layer_N
+        self.hidden_size = args.hidden_size
+        obs_dim = obs_shape[0]
+        if self._use_feature_normalization:
+            self.feature_norm = nn.LayerNorm(obs_dim)
+        self.mlp = MLPLayer(obs_dim, self.hidden_size, self._layer_N, self._use_orthogonal, self._use_ReLU)
+
+    def forward(self, x):
+        if self._use_feature_normalization:
+            x = self.feature_norm(x)
+        return self.mlp(x)

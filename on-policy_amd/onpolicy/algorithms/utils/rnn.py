@@ -1,0 +1,82 @@
+"""GRU layer with episode-boundary resets.
+
+Parameters live in an ``nn.GRU`` called ``rnn`` plus a LayerNorm ``norm`` -- the names, shapes and
+init order of the reference's onpolicy/algorithms/utils/rnn.py (RNNLayer :7) -- but the recurrence
+is evaluated here step by step from those weights:
+
+  * the reference's training branch (rnn.py:30-77) copies the mask to the host to find the time
+    steps where some trajectory restarts (rnn.py:43-47) and runs one cuDNN/MIOpen call per
+    segment.  Multiplying the state by ``masks[t]`` at EVERY step is the same function (inside a
+    segment all masks are 1) and needs no device->host sync, so the update stays asynchronous;
+  * the input projection ``x @ W_ih^T + b_ih`` does not depend on the state and is done for all
+    L steps in one GEMM; only the [mb, H] x [H, 3H] hidden GEMM and the gates are sequential.
+
+GRU cell (PyTorch convention, gates stacked r|z|n):
+    r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z), n = tanh(gi_n + r * gh_n),
+    h' = (1 - z) * n + z * h.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class RNNLayer(nn.Module):
+    def __init__(self, inputs_dim, outputs_dim, recurrent_N, use_orthogonal):
+        super(RNNLayer, self).__init__()
+        self._recurrent_N = recurrent_N
+        self._use_orthogonal = use_orthogonal
+        self.rnn = nn.GRU(inputs_dim, outputs_dim, num_layers=self._recurrent_N)
+        for name, param in self.rnn.named_parameters():
+            if 'bias' in name:
+                nn.init.constant_(param, 0)
+            elif 'weight' in name:
+                if self._use_orthogonal:
+                    nn.init.orthogonal_(param)
+                else:
+                    nn.init.xavier_uniform_(param)
+        self.norm = nn.LayerNorm(outputs_dim)
+
+    def _layer_weights(self, k):
+        g = self.rnn
+        return (getattr(g, 'weight_ih_l%d' % k), getattr(g, 'weight_hh_l%d' % k),
+                getattr(g, 'bias_ih_l%d' % k), getattr(g, 'bias_hh_l%d' % k))
+
+    @staticmethod
+    def _cell(gi, h, w_hh, b_hh):
+        gh = F.linear(h, w_hh, b_hh)
+        i_r, i_z, i_n = gi.chunk(3, -1)
+        h_r, h_z, h_n = gh.chunk(3, -1)
+        r = torch.sigmoid(i_r + h_r)
+        z = torch.sigmoid(i_z + h_z)
+        n = torch.tanh(i_n + r * h_n)
+        return (1.0 - z) * n + z * h
+
+    def _run(self, x, h0, masks):
+        """x [L, B, in], h0 [B, R, H], masks [L, B, 1] -> (y [L, B, H], h_last [B, R, H])."""
+        L = x.size(0)
+        layer_in = x
+        finals = []
+        for k in range(self._recurrent_N):
+            w_ih, w_hh, b_ih, b_hh = self._layer_weights(k)
+            gi_all = F.linear(layer_in, w_ih, b_ih)          # one GEMM for all L steps
+            h = h0[:, k]
+            outs = []
+            for t in range(L):
+                h = self._cell(gi_all[t], h * masks[t], w_hh, b_hh)
+                outs.append(h)
+            layer_in = outs[0].unsqueeze(0) if L == 1 else torch.stack(outs, 0)
+            finals.append(h)
+        return layer_in, torch.stack(finals, 1)
+
+    def forward(self, x, hxs, masks):
+        if x.size(0) == hxs.size(0):
+            # rollout: one step for every (env, agent) row
+            y, hxs = self._run(x.unsqueeze(0), hxs, masks.reshape(1, -1, 1))
+            x = y.squeeze(0)
+        else:
+            # update: x is [L*B, .] (time-major chunks from the recurrent sampler), hxs [B, R, H]
+            B = hxs.size(0)
+            L = x.size(0) // B
+            y, hxs = self._run(x.view(L, B, x.size(1)), hxs, masks.view(L, B, 1))
+            x = y.reshape(L * B, -1)
+        return self.norm(x), hxs

@@ -1,0 +1,122 @@
+"""Data parallelism over rollout threads: one process per GPU, RCCL (torch.distributed backend
+"nccl" on ROCm) over xGMI; gloo on CPU for tests.
+
+The reference is single-process / single-device (no torch.distributed call sites anywhere), so this
+layer is new.  The MAPPO update shards naturally over ``n_rollout_threads``: every rank owns
+N / world rollout threads in its own HBM buffer, runs GAE and the samplers locally, and the only
+exchange is, per ``ppo_update``:
+
+  1. a few float64 scalars that must be global before the loss is formed (masked-loss
+     denominators; ValueNorm batch moments are reduced by the trainer the same way), and
+  2. ONE sum all-reduce of the actor+critic gradients.  The gradients of both networks live in a
+     single flat float32 bucket (each ``param.grad`` is a view into it), so there is no
+     flatten / unflatten copy and exactly one collective: 151 KB for the 8-agent MPE MLP,
+     454 KB for the SMAC GRU, 9.8 MB for Hanabi.  xGMI is a full mesh of point-to-point links, so
+     buckets this small are latency-bound; a single collective per step is what matters.
+
+plus one all-reduce of three float64 advantage moments per ``train()``.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def init_from_env(device=None):
+    """Initialise the default process group from torchrun-style environment variables
+    (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).  No-op for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 or (dist.is_available() and dist.is_initialized()):
+        return world
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = "nccl" if (device is not None and torch.device(device).type == "cuda") else "gloo"
+    kwargs = {}
+    if backend == "nccl":
+        kwargs["device_id"] = torch.device(device)
+    dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world, **kwargs)
+    return world
+
+
+def shard_threads(n_rollout_threads, rank=None, world_size=None):
+    """Rollout threads [lo, hi) owned by ``rank``: contiguous, sizes differ by at most one."""
+    if world_size is None:
+        world_size = dist.get_world_size() if is_distributed() else 1
+    if rank is None:
+        rank = dist.get_rank() if is_distributed() else 0
+    base, extra = divmod(n_rollout_threads, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class DataParallel(object):
+    """Gradient / statistics exchange for one (actor, critic) pair."""
+
+    def __init__(self, actor, critic, device, group=None):
+        self.group = group
+        self.world_size = dist.get_world_size(group) if is_distributed() else 1
+        self.rank = dist.get_rank(group) if is_distributed() else 0
+        self.device = device
+        self._flat = None
+        if self.world_size > 1:
+            params = [p for net in (actor, critic) for p in net.parameters() if p.requires_grad]
+            total = sum(p.numel() for p in params)
+            self._flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+            off = 0
+            for p in params:
+                n = p.numel()
+                p.grad = self._flat[off:off + n].view_as(p)  # autograd accumulates into the view
+                off += n
+            self._params = params
+            self._check_replicas()
+
+    def _check_replicas(self):
+        """All ranks must start from identical parameters (same seed => same CPU init stream)."""
+        with torch.no_grad():
+            digest = torch.stack([p.detach().double().sum() for p in self._params]).sum().reshape(1)
+            lo, hi = digest.clone(), digest.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+            if (hi - lo).abs().item() > 1e-6 * max(1.0, hi.abs().item()):
+                raise RuntimeError("data-parallel replicas were initialised with different parameters; "
+                                   "seed every rank identically before building the policy")
+
+    def all_reduce(self, tensor):
+        """In-place sum over ranks (no-op for one process)."""
+        if self.world_size > 1:
+            dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
+        return tensor
+
+    def zero_grad(self, *optimizers):
+        if self.world_size == 1:
+            for opt in optimizers:
+                opt.zero_grad()
+        else:
+            self._flat.zero_()  # grads are views of the bucket: one memset, nothing set to None
+
+    def all_reduce_grads(self):
+        if self.world_size > 1:
+            dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    def loss_weights(self, active_masks, policy_masked, value_masked):
+        """(w_actor, w_critic): local / global denominators of the masked means
+        (reference r_mappo.py:135-139, 84-87)."""
+        if self.world_size == 1:
+            return 1.0, 1.0
+        local = torch.stack([active_masks.detach().sum().double(),
+                             torch.tensor(float(active_masks.shape[0]), dtype=torch.float64,
+                                          device=active_masks.device)])
+        total = local.clone()
+        self.all_reduce(total)
+        w = (local / total).float()
+        return (w[0] if policy_masked else w[1]), (w[0] if value_masked else w[1])
+
+    def average_info(self, totals):
+        """Logged scalars: mean over ranks of the per-rank means."""
+        if self.world_size > 1:
+            self.all_reduce(totals)
+            totals = totals / self.world_size
+        return totals

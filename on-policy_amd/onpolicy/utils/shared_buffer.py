@@ -1,0 +1,438 @@
+"""HBM-resident rollout buffer for shared-policy MAPPO.
+
+Drop-in for the reference's ``SharedReplayBuffer`` (onpolicy/utils/shared_buffer.py:21-608): same
+constructor, attributes, methods and 12-tuple minibatch protocol, but
+
+  * every field is a float32 torch tensor in device memory, in the reference's time-major layout
+    ``[episode_length(+1), n_rollout_threads, num_agents, dim]`` (element (t, n, a) is row
+    ``(t*N + n)*A + a`` of a [rows, dim] matrix), so one rollout step is one contiguous slab per
+    field and the GAE scan reads coalesced rows;
+  * ``compute_returns`` is one launch of the ``mappo_gae_f32`` HIP kernel (GAE / discounted returns
+    with ValueNorm / PopArt de-normalisation, all seven non-MAT reference branches, bit-identical
+    float32), which also emits the un-normalised advantages and their masked moments so that
+    ``R_MAPPO.train`` needs no extra passes over the buffer (reference r_mappo.py:179-187);
+  * the three samplers are one fused multi-field gather launch per minibatch
+    (``mappo_gather_rows`` / ``mappo_gather_chunks``) reading straight from the time-major
+    buffer -- no transposed copies, no Python loop over chunks, no host<->device traffic;
+  * ``insert`` / ``after_update`` are one fused slab-copy launch (``mappo_slab_copy``).
+
+There is no CPU implementation here: the constructor raises unless it gets a HIP device and
+``libmappo_hip.so`` (see onpolicy/_native.py).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from onpolicy import _native
+from onpolicy.utils.util import get_shape_from_obs_space, get_shape_from_act_space
+
+
+def _flatten(T, N, x):
+    return x.reshape(T * N, *x.shape[2:])
+
+
+class AdvantageHandle(object):
+    """Normalised advantages without materialising them: the raw ``returns - D(value_preds)`` tensor
+    plus the device scalars (mean, std).  The samplers apply ``(adv - mean) / (std + 1e-5)``
+    (reference r_mappo.py:187) while gathering.  ``materialize()`` gives the [T, N, A, 1] tensor the
+    reference's ``train`` would have built."""
+
+    def __init__(self, raw, stats, buffer):
+        self.raw = raw
+        self.stats = stats
+        self._buffer = buffer
+
+    def materialize(self):
+        out = torch.empty_like(self.raw)
+        L = _native.lib()
+        _native.check(L.mappo_adv_normalize(self.raw.data_ptr(), self.stats.data_ptr(), out.data_ptr(),
+                                            self.raw.numel(), _native.stream_of(self.raw.device)),
+                      "mappo_adv_normalize")
+        return out
+
+
+class SharedReplayBuffer(object):
+    """
+    :param args: (argparse.Namespace) the reference's flag namespace (onpolicy/config.py).
+    :param num_agents: (int) agents per environment.
+    :param obs_space / cent_obs_space / act_space: gym-style spaces, recognised by class name.
+    :param device: optional torch device; default ``args.buffer_device`` or the current HIP device.
+    """
+
+    def __init__(self, args, num_agents, obs_space, cent_obs_space, act_space, device=None):
+        self.episode_length = args.episode_length
+        self.n_rollout_threads = args.n_rollout_threads
+        self.hidden_size = args.hidden_size
+        self.recurrent_N = args.recurrent_N
+        self.gamma = args.gamma
+        self.gae_lambda = args.gae_lambda
+        self._use_gae = args.use_gae
+        self._use_popart = args.use_popart
+        self._use_valuenorm = args.use_valuenorm
+        self._use_proper_time_limits = args.use_proper_time_limits
+        self.algo = args.algorithm_name
+        self.num_agents = num_agents
+        self._recurrent = bool(getattr(args, "use_recurrent_policy", False) or
+                               getattr(args, "use_naive_recurrent_policy", False))
+        self._sampler_rng = getattr(args, "sampler_rng", "device")
+
+        self.device = dev = self._resolve_device(args, device)
+        self._lib = _native.lib()  # raises if the HIP library is not built
+
+        obs_shape = get_shape_from_obs_space(obs_space)
+        share_obs_shape = get_shape_from_obs_space(cent_obs_space)
+        if type(obs_shape[-1]) == list:
+            obs_shape = obs_shape[:1]
+        if type(share_obs_shape[-1]) == list:
+            share_obs_shape = share_obs_shape[:1]
+
+        T, N, A = self.episode_length, self.n_rollout_threads, num_agents
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.share_obs = torch.zeros((T + 1, N, A, *share_obs_shape), **f32)
+        self.obs = torch.zeros((T + 1, N, A, *obs_shape), **f32)
+
+        rnn_shape = (T + 1, N, A, self.recurrent_N, self.hidden_size)
+        if self._recurrent:
+            self.rnn_states = torch.zeros(rnn_shape, **f32)
+            self.rnn_states_critic = torch.zeros(rnn_shape, **f32)
+        else:
+            # Feed-forward policies never read or change the RNN state (it is all zeros for the
+            # whole run), so it gets no storage: a stride-0 view of one zero serves every reader.
+            # (The reference allocates 2 x [T+1, N, A, R, H] regardless: 16.8 GB at Hanabi scale.)
+            zero = torch.zeros(1, **f32)
+            self.rnn_states = zero.expand(rnn_shape)
+            self.rnn_states_critic = zero.expand(rnn_shape)
+
+        self.value_preds = torch.zeros((T + 1, N, A, 1), **f32)
+        self.returns = torch.zeros_like(self.value_preds)
+        self.advantages = torch.zeros((T, N, A, 1), **f32)
+
+        if act_space.__class__.__name__ == 'Discrete':
+            self.available_actions = torch.ones((T + 1, N, A, act_space.n), **f32)
+        else:
+            self.available_actions = None
+
+        act_shape = get_shape_from_act_space(act_space)
+        self.actions = torch.zeros((T, N, A, act_shape), **f32)
+        self.action_log_probs = torch.zeros((T, N, A, act_shape), **f32)
+        self.rewards = torch.zeros((T, N, A, 1), **f32)
+
+        self.masks = torch.ones((T + 1, N, A, 1), **f32)
+        self.bad_masks = torch.ones_like(self.masks)
+        self.active_masks = torch.ones_like(self.masks)
+
+        self.step = 0
+
+        # device workspaces of the GAE epilogue (tiny)
+        rows = int(self._lib.mappo_gae_partial_rows(N * A))
+        self._partial_rows = rows
+        self._adv_partials = torch.zeros((rows, 3), dtype=torch.float64, device=dev)
+        self._adv_sums = torch.zeros(3, dtype=torch.float64, device=dev)
+        self._adv_stats = torch.zeros(2, **f32)
+        self._adv_fresh = False   # advantages/moments match the current returns & value_preds
+        self._stats_fresh = False
+
+    # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _resolve_device(args, device):
+        cand = device if device is not None else getattr(args, "buffer_device", None)
+        if cand is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError(
+                    "SharedReplayBuffer is HBM-resident and needs a HIP device (torch.cuda.is_available() "
+                    "is False). There is no CPU implementation of this path.")
+            cand = torch.device("cuda", torch.cuda.current_device())
+        dev = torch.device(cand)
+        if dev.type != "cuda":
+            raise RuntimeError("SharedReplayBuffer needs a HIP ('cuda') device, got %r: the rollout "
+                               "buffer, GAE and samplers are HIP kernels with no CPU fallback." % (dev,))
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        return dev
+
+    def _stream(self):
+        return _native.stream_of(self.device)
+
+    def _dev(self, x):
+        """Anything array-like -> contiguous float32 tensor on the buffer's device."""
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        elif not torch.is_tensor(x):
+            x = torch.as_tensor(np.asarray(x, dtype=np.float32))
+        x = x.detach()
+        if x.device != self.device or x.dtype != torch.float32:
+            x = x.to(device=self.device, dtype=torch.float32, non_blocking=True)
+        return x.contiguous()
+
+    def _write_slabs(self, pairs):
+        """One mappo_slab_copy launch for [(dst_view, value), ...] (K2)."""
+        keep, slabs = [], []
+        for dst, value in pairs:
+            src = self._dev(value)
+            if src.numel() != dst.numel():
+                raise ValueError("cannot write %d elements into a buffer slab of %d (shape %s)"
+                                 % (src.numel(), dst.numel(), tuple(dst.shape)))
+            assert dst.is_contiguous()
+            keep.append(src)
+            slabs.append((src.data_ptr(), dst.data_ptr(), dst.numel()))
+        arr = (_native.Slab * len(slabs))(*[_native.Slab(s, d, n) for s, d, n in slabs])
+        _native.check(self._lib.mappo_slab_copy(arr, len(slabs), self._stream()), "mappo_slab_copy")
+
+    # ------------------------------------------------------------------ storage
+    def insert(self, share_obs, obs, rnn_states_actor, rnn_states_critic, actions, action_log_probs,
+               value_preds, rewards, masks, bad_masks=None, active_masks=None, available_actions=None):
+        """Write one rollout step (reference shared_buffer.py:90-123): observation-like fields land in
+        row ``step + 1``, action-like fields in row ``step``.  Values may be numpy arrays or tensors
+        on any device, shaped [N, A, ...]."""
+        s = self.step
+        pairs = [(self.share_obs[s + 1], share_obs), (self.obs[s + 1], obs),
+                 (self.actions[s], actions), (self.action_log_probs[s], action_log_probs),
+                 (self.value_preds[s], value_preds), (self.rewards[s], rewards),
+                 (self.masks[s + 1], masks)]
+        if self._recurrent:
+            pairs += [(self.rnn_states[s + 1], rnn_states_actor),
+                      (self.rnn_states_critic[s + 1], rnn_states_critic)]
+        if bad_masks is not None:
+            pairs.append((self.bad_masks[s + 1], bad_masks))
+        if active_masks is not None:
+            pairs.append((self.active_masks[s + 1], active_masks))
+        if available_actions is not None:
+            pairs.append((self.available_actions[s + 1], available_actions))
+        self._write_slabs(pairs)
+        self._adv_fresh = False
+        self.step = (s + 1) % self.episode_length
+
+    def chooseinsert(self, share_obs, obs, rnn_states, rnn_states_critic, actions, action_log_probs,
+                     value_preds, rewards, masks, bad_masks=None, active_masks=None, available_actions=None):
+        """Turn-based (Hanabi) insert (reference shared_buffer.py:125-158): observations, active masks
+        and available actions go to row ``step`` instead of ``step + 1``."""
+        s = self.step
+        pairs = [(self.share_obs[s], share_obs), (self.obs[s], obs),
+                 (self.actions[s], actions), (self.action_log_probs[s], action_log_probs),
+                 (self.value_preds[s], value_preds), (self.rewards[s], rewards),
+                 (self.masks[s + 1], masks)]
+        if self._recurrent:
+            pairs += [(self.rnn_states[s + 1], rnn_states), (self.rnn_states_critic[s + 1], rnn_states_critic)]
+        if bad_masks is not None:
+            pairs.append((self.bad_masks[s + 1], bad_masks))
+        if active_masks is not None:
+            pairs.append((self.active_masks[s], active_masks))
+        if available_actions is not None:
+            pairs.append((self.available_actions[s], available_actions))
+        self._write_slabs(pairs)
+        self._adv_fresh = False
+        self.step = (s + 1) % self.episode_length
+
+    def after_update(self):
+        """Row T becomes row 0 of the next rollout (reference shared_buffer.py:160-170)."""
+        fields = [self.share_obs, self.obs, self.masks, self.bad_masks, self.active_masks]
+        if self._recurrent:
+            fields += [self.rnn_states, self.rnn_states_critic]
+        if self.available_actions is not None:
+            fields.append(self.available_actions)
+        self._write_slabs([(f[0], f[-1]) for f in fields])
+
+    def chooseafter_update(self):
+        """Hanabi variant (reference shared_buffer.py:172-177)."""
+        fields = [self.masks, self.bad_masks]
+        if self._recurrent:
+            fields += [self.rnn_states, self.rnn_states_critic]
+        self._write_slabs([(f[0], f[-1]) for f in fields])
+
+    # ------------------------------------------------------------------ returns
+    def _denorm_scalars(self, value_normalizer):
+        """Device tensor [sigma, mu] of the value normaliser, or None (identity)."""
+        if not (self._use_popart or self._use_valuenorm):
+            return None
+        if value_normalizer is None:
+            raise ValueError("use_popart / use_valuenorm is set but compute_returns got no value_normalizer")
+        if hasattr(value_normalizer, "denorm_scalars"):
+            s = value_normalizer.denorm_scalars()
+        else:  # a foreign normaliser with the reference's attribute names
+            vn = value_normalizer
+            if hasattr(vn, "running_mean"):
+                m, sq = vn.running_mean, vn.running_mean_sq
+            else:
+                m, sq = vn.mean, vn.mean_sq
+            debias = vn.debiasing_term.clamp(min=vn.epsilon)
+            mean = m / debias
+            var = (sq / debias - mean ** 2).clamp(min=1e-2)
+            s = torch.stack([torch.sqrt(var).reshape(()), mean.reshape(())])
+        return s.detach().to(device=self.device, dtype=torch.float32).contiguous()
+
+    def _gae_flags(self, denorm):
+        flags = 0
+        if self._use_gae:
+            flags |= _native.GAE_USE_GAE
+        if self._use_proper_time_limits:
+            flags |= _native.GAE_PROPER_TIME_LIMITS
+        if denorm is not None:
+            flags |= _native.GAE_DENORM
+        return flags
+
+    def compute_returns(self, next_value, value_normalizer=None):
+        """GAE / discounted returns over the whole buffer in one kernel launch
+        (reference shared_buffer.py:179-262).  ``next_value``: [N, A, 1] (or [N*A, 1]) array / tensor."""
+        if self.algo in ("mat", "mat_dec"):
+            raise NotImplementedError("the MAT variants of compute_returns are outside this path")
+        T, N, A = self.episode_length, self.n_rollout_threads, self.num_agents
+        nv = self._dev(next_value).reshape(-1)
+        if nv.numel() != N * A:
+            raise ValueError("next_value has %d elements, expected %d" % (nv.numel(), N * A))
+        denorm = self._denorm_scalars(value_normalizer)
+        p = _native.ptr
+        code = self._lib.mappo_gae_f32(
+            p(self.rewards), p(self.value_preds), p(nv), p(self.masks),
+            p(self.bad_masks) if self._use_proper_time_limits else None, p(self.returns), p(denorm),
+            p(self.advantages), p(self.active_masks), p(self._adv_partials),
+            T, N * A, float(self.gamma), float(self.gae_lambda), self._gae_flags(denorm), self._stream())
+        _native.check(code, "mappo_gae_f32")
+        self._adv_fresh = True
+        self._stats_fresh = False
+
+    def normalized_advantages(self, value_normalizer=None, all_reduce=None):
+        """What the prologue of the reference's ``R_MAPPO.train`` computes (r_mappo.py:179-187), as an
+        ``AdvantageHandle``.  Uses the advantages / moments the GAE launch already produced; if the
+        buffer changed since, recomputes them with one ``mappo_advantages_f32`` launch.
+        ``all_reduce``: optional callable applied in place to the float64 [3] moment sums
+        (sum, sum of squares, count) -- data-parallel training passes an RCCL all-reduce here so that
+        mean / std are global-batch statistics on every rank."""
+        T, N, A = self.episode_length, self.n_rollout_threads, self.num_agents
+        p = _native.ptr
+        if not self._adv_fresh:
+            denorm = self._denorm_scalars(value_normalizer)
+            code = self._lib.mappo_advantages_f32(p(self.returns), p(self.value_preds), p(denorm),
+                                                  p(self.active_masks), p(self.advantages),
+                                                  p(self._adv_partials), T, N * A, self._stream())
+            _native.check(code, "mappo_advantages_f32")
+            self._adv_fresh = True
+            self._stats_fresh = False
+        if not self._stats_fresh or all_reduce is not None:
+            _native.check(self._lib.mappo_adv_reduce(p(self._adv_partials), self._partial_rows,
+                                                     p(self._adv_sums), self._stream()), "mappo_adv_reduce")
+            if all_reduce is not None:
+                all_reduce(self._adv_sums)
+            _native.check(self._lib.mappo_adv_stats(p(self._adv_sums), p(self._adv_stats), self._stream()),
+                          "mappo_adv_stats")
+            self._stats_fresh = True
+        return AdvantageHandle(self.advantages, self._adv_stats, self)
+
+    # ------------------------------------------------------------------ samplers
+    def _randperm(self, n):
+        if self._sampler_rng == "host":
+            # the reference's draw (shared_buffer.py:360,415,511): CPU generator, then upload
+            return torch.randperm(n).to(self.device, non_blocking=True)
+        return torch.randperm(n, device=self.device)
+
+    def _field_table(self, advantages):
+        """(name, source tensor whose rows are gathered, trailing shape, first_only, adv mode)."""
+        T = self.episode_length
+        table = [
+            ("share_obs", self.share_obs, False),
+            ("obs", self.obs, False),
+            ("rnn_states", self.rnn_states, True),
+            ("rnn_states_critic", self.rnn_states_critic, True),
+            ("actions", self.actions, False),
+            ("value_preds", self.value_preds, False),
+            ("returns", self.returns, False),
+            ("masks", self.masks, False),
+            ("active_masks", self.active_masks, False),
+            ("action_log_probs", self.action_log_probs, False),
+        ]
+        stats = None
+        if advantages is None:
+            adv = None
+        elif isinstance(advantages, AdvantageHandle):
+            adv, stats = advantages.raw, advantages.stats
+        else:
+            adv = self._dev(advantages)
+            if adv.numel() != T * self.n_rollout_threads * self.num_agents:
+                raise ValueError("advantages has the wrong number of elements")
+        table.append(("advantages", adv, False))
+        table.append(("available_actions", self.available_actions, False))
+        return table, stats
+
+    def _gather(self, table, stats, idx, mb, chunk_len=None):
+        """One fused gather launch (K3 / K4) -> the 12-tuple of fresh device tensors."""
+        T, N, A = self.episode_length, self.n_rollout_threads, self.num_agents
+        rows_out = mb if chunk_len is None else mb * chunk_len
+        outs, fields = [], []
+        for name, src, is_state in table:
+            if src is None:
+                outs.append(None)
+                continue
+            tail = tuple(src.shape[3:])
+            width = int(np.prod(tail)) if tail else 1
+            if is_state and not self._recurrent:
+                outs.append(src[0, 0, 0].expand((mb,) + tail))  # zeros, no traffic
+                continue
+            first_only = 1 if (is_state and chunk_len is not None) else 0
+            n_rows = mb if (first_only or chunk_len is None) else rows_out
+            dst = torch.empty((n_rows,) + tail, dtype=torch.float32, device=self.device)
+            normalize = 1 if (name == "advantages" and stats is not None) else 0
+            fields.append(_native.Field(src.data_ptr(), dst.data_ptr(), width, first_only, normalize, 0))
+            outs.append(dst)
+        arr = (_native.Field * len(fields))(*fields)
+        sp = None if stats is None else stats.data_ptr()
+        if chunk_len is None:
+            code = self._lib.mappo_gather_rows(arr, len(fields), idx.data_ptr(), mb, sp, self._stream())
+            _native.check(code, "mappo_gather_rows")
+        else:
+            code = self._lib.mappo_gather_chunks(arr, len(fields), idx.data_ptr(), mb, chunk_len, T, N, A,
+                                                 sp, self._stream())
+            _native.check(code, "mappo_gather_chunks")
+        return tuple(outs)
+
+    def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None):
+        """Minibatches of independent (t, n, a) samples for MLP policies
+        (reference shared_buffer.py:340-400).  Yields
+        (share_obs, obs, rnn_states, rnn_states_critic, actions, value_preds, returns, masks,
+        active_masks, old_action_log_probs, adv_targ, available_actions) as device tensors."""
+        T, N, A = self.episode_length, self.n_rollout_threads, self.num_agents
+        batch_size = N * T * A
+        if mini_batch_size is None:
+            assert batch_size >= num_mini_batch, (
+                "PPO requires the number of processes ({}) "
+                "* number of steps ({}) * number of agents ({}) = {} "
+                "to be greater than or equal to the number of PPO mini batches ({})."
+                "".format(N, T, A, batch_size, num_mini_batch))
+            mini_batch_size = batch_size // num_mini_batch
+        rand = self._randperm(batch_size)
+        table, stats = self._field_table(advantages)
+        for i in range(num_mini_batch):
+            idx = rand[i * mini_batch_size:(i + 1) * mini_batch_size]
+            yield self._gather(table, stats, idx, mini_batch_size)
+
+    def recurrent_generator(self, advantages, num_mini_batch, data_chunk_length):
+        """Minibatches of length-L chunks for truncated BPTT (reference shared_buffer.py:499-608):
+        sequence fields come out as [L*mb, dim] (row l*mb + j), RNN states as [mb, R, H] (chunk
+        start only)."""
+        T, N, A = self.episode_length, self.n_rollout_threads, self.num_agents
+        batch_size = N * T * A
+        data_chunks = batch_size // data_chunk_length
+        mini_batch_size = data_chunks // num_mini_batch
+        rand = self._randperm(data_chunks)
+        table, stats = self._field_table(advantages)
+        for i in range(num_mini_batch):
+            idx = rand[i * mini_batch_size:(i + 1) * mini_batch_size]
+            yield self._gather(table, stats, idx, mini_batch_size, chunk_len=data_chunk_length)
+
+    def naive_recurrent_generator(self, advantages, num_mini_batch):
+        """Whole-trajectory minibatches (reference shared_buffer.py:402-497): a chunk gather with
+        L = T over a permutation of the N*A trajectories."""
+        T, N, A = self.episode_length, self.n_rollout_threads, self.num_agents
+        batch_size = N * A
+        assert batch_size >= num_mini_batch, (
+            "PPO requires the number of processes ({})* number of agents ({}) "
+            "to be greater than or equal to the number of "
+            "PPO mini batches ({}).".format(N, A, num_mini_batch))
+        num_envs_per_batch = batch_size // num_mini_batch
+        perm = self._randperm(batch_size)
+        table, stats = self._field_table(advantages)
+        for start in range(0, batch_size, num_envs_per_batch):
+            idx = perm[start:start + num_envs_per_batch]
+            yield self._gather(table, stats, idx, idx.numel(), chunk_len=T)
+
+    def feed_forward_generator_transformer(self, advantages, num_mini_batch=None, mini_batch_size=None):
+        raise NotImplementedError("the MAT sampler is outside the MAPPO hot path (SURVEY.md section 8f)")

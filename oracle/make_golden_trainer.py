@@ -1,0 +1,123 @@
+"""TEST INFRASTRUCTURE.  Trainer / network fixtures generated from the REFERENCE's R_MAPPOPolicy and
+R_MAPPO (called by oracle/make_golden.py).  For each case the fixture stores: the seeded initial
+parameters, one evaluate_actions / get_actions call, the permutations the reference drew during
+train(), the six train_info scalars, the parameters and ValueNorm statistics after train().
+"""
+import json
+import os
+
+import numpy as np
+import torch
+
+CASES = {
+    # feed-forward MAPPO, flags of train_mpe_spread.sh (--use_ReLU passed => Tanh)
+    "mlp": dict(args=dict(algorithm_name="mappo", hidden_size=16, layer_N=1, use_ReLU=False, ppo_epoch=2,
+                          num_mini_batch=2, lr=7e-4, critic_lr=7e-4),
+                T=10, N=4, A=3, Do=7, Ds=11, na=5),
+    # default ReLU, one minibatch, active-mask / huber variations off
+    "mlp_relu": dict(args=dict(algorithm_name="mappo", hidden_size=16, layer_N=2, ppo_epoch=1,
+                               num_mini_batch=1, use_huber_loss=False, use_clipped_value_loss=False,
+                               use_value_active_masks=False, use_policy_active_masks=False,
+                               use_max_grad_norm=False),
+                     T=6, N=3, A=2, Do=5, Ds=9, na=4),
+    # recurrent MAPPO (GRU), chunked sampler
+    "gru": dict(args=dict(algorithm_name="rmappo", use_recurrent_policy=True, hidden_size=16, layer_N=1,
+                          ppo_epoch=2, num_mini_batch=2, data_chunk_length=5, gain=1.0),
+                T=10, N=4, A=3, Do=7, Ds=11, na=6),
+    # no value normaliser, proper time limits
+    "mlp_nonorm": dict(args=dict(algorithm_name="mappo", hidden_size=16, ppo_epoch=1, num_mini_batch=2,
+                                 use_valuenorm=False, use_proper_time_limits=True),
+                       T=8, N=2, A=3, Do=6, Ds=6, na=3),
+}
+
+
+class PermRecorder(object):
+    def __init__(self):
+        self.orig = torch.randperm
+        self.calls = []
+
+    def __enter__(self):
+        def rec(*a, **k):
+            p = self.orig(*a, **k)
+            self.calls.append(p.numpy().copy())
+            return p
+        torch.randperm = rec
+        return self
+
+    def __exit__(self, *exc):
+        torch.randperm = self.orig
+
+
+def _sd(prefix, module, out):
+    for k, v in module.state_dict().items():
+        out[prefix + k] = v.detach().cpu().numpy().copy()
+
+
+def main(ref, make_args, fill_buffer, gold_dir):
+    out, meta = {}, {}
+    for cname, spec in CASES.items():
+        T, N, A, Do, Ds, na = (spec[k] for k in ("T", "N", "A", "Do", "Ds", "na"))
+        args = make_args(episode_length=T, n_rollout_threads=N, **spec["args"])
+        obs_space, cent_space, act_space = ref.Box((Do,)), ref.Box((Ds,)), ref.Discrete(na)
+        torch.manual_seed(1)
+        np.random.seed(1)
+        policy = ref.R_MAPPOPolicy(args, obs_space, cent_space, act_space)
+        trainer = ref.R_MAPPO(args, policy)
+        key = "trn_%s_" % cname
+        _sd(key + "init_actor.", policy.actor, out)
+        _sd(key + "init_critic.", policy.critic, out)
+
+        rng = np.random.default_rng(4242)
+        buf = ref.SharedReplayBuffer(args, A, obs_space, cent_space, act_space)
+        next_value = fill_buffer(buf, rng)
+        # valid action ids under the availability mask: pick the first available action at random
+        av = buf.available_actions[:-1]
+        pick = rng.random(av.shape) * av
+        buf.actions[:] = pick.argmax(-1)[..., None].astype(np.float32)
+        for name in ("share_obs", "obs", "rnn_states", "rnn_states_critic", "actions", "value_preds",
+                     "masks", "bad_masks", "active_masks", "action_log_probs", "available_actions",
+                     "rewards"):
+            out[key + "buf_" + name] = getattr(buf, name).copy()
+        out[key + "next_value"] = next_value
+
+        # one rollout-side and one update-side forward on step 0 of the buffer
+        B = N * A
+        flat = lambda x: x.reshape(B, *x.shape[2:])
+        trainer.prep_rollout()
+        torch.manual_seed(11)
+        with torch.no_grad():
+            values, actions, logp, h_a, h_c = policy.get_actions(
+                flat(buf.share_obs[0]), flat(buf.obs[0]), flat(buf.rnn_states[0]),
+                flat(buf.rnn_states_critic[0]), flat(buf.masks[0]), flat(buf.available_actions[0]))
+            out[key + "act_values"] = values.numpy().copy()
+            out[key + "act_actions"] = actions.numpy().astype(np.int64)
+            out[key + "act_logp"] = logp.numpy().copy()
+            out[key + "act_h_actor"] = h_a.numpy().copy()
+            out[key + "act_h_critic"] = h_c.numpy().copy()
+            ev_values, ev_logp, ev_ent = policy.evaluate_actions(
+                flat(buf.share_obs[0]), flat(buf.obs[0]), flat(buf.rnn_states[0]),
+                flat(buf.rnn_states_critic[0]), flat(buf.actions[0]), flat(buf.masks[0]),
+                flat(buf.available_actions[0]), flat(buf.active_masks[0]))
+            out[key + "eval_values"] = ev_values.numpy().copy()
+            out[key + "eval_logp"] = ev_logp.numpy().copy()
+            out[key + "eval_entropy"] = np.array(float(ev_ent), dtype=np.float32)
+
+        buf.compute_returns(next_value, trainer.value_normalizer)
+        out[key + "returns"] = buf.returns.copy()
+        trainer.prep_training()
+        torch.manual_seed(21)
+        with PermRecorder() as rec:
+            info = trainer.train(buf)
+        for i, p in enumerate(rec.calls):
+            out[key + "perm%d" % i] = p.astype(np.int64)
+        info = {k: float(v) for k, v in info.items()}
+        _sd(key + "final_actor.", policy.actor, out)
+        _sd(key + "final_critic.", policy.critic, out)
+        if trainer.value_normalizer is not None:
+            vn = trainer.value_normalizer
+            out[key + "final_norm"] = np.array([float(vn.running_mean), float(vn.running_mean_sq),
+                                                float(vn.debiasing_term)], dtype=np.float64)
+        meta[cname] = dict(spec=spec, train_info=info, n_perms=len(rec.calls))
+    np.savez_compressed(os.path.join(gold_dir, "trainer_cases.npz"), **out)
+    with open(os.path.join(gold_dir, "trainer_cases.json"), "w") as f:
+        json.dump(meta, f, indent=1)

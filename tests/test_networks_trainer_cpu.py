@@ -1,0 +1,103 @@
+"""Product networks + trainer (the PyTorch part of the path, device-agnostic) against fixtures
+produced by the reference's R_MAPPOPolicy / R_MAPPO on the same seeds (oracle/make_golden_trainer.py).
+The minibatch source here is the host OracleBuffer (test infrastructure); the device buffer is
+checked in the -m gpu tests."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import Box, Discrete, make_args
+from oracle import oracle
+
+from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy
+from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO
+
+CASES = ["mlp", "mlp_relu", "gru", "mlp_nonorm"]
+
+
+def _build(gold, cname):
+    meta = gold.meta("trainer_cases")[cname]
+    spec = meta["spec"]
+    args = make_args(episode_length=spec["T"], n_rollout_threads=spec["N"], **spec["args"])
+    spaces = Box((spec["Do"],)), Box((spec["Ds"],)), Discrete(spec["na"])
+    torch.manual_seed(1)
+    np.random.seed(1)
+    policy = R_MAPPOPolicy(args, *spaces)
+    trainer = R_MAPPO(args, policy)
+    return meta, spec, args, spaces, policy, trainer
+
+
+def _check_sd(z, prefix, module, rtol=0.0, atol=0.0):
+    sd = module.state_dict()
+    keys = [k[len(prefix):] for k in z.files if k.startswith(prefix)]
+    assert sorted(keys) == sorted(sd.keys()), (sorted(keys), sorted(sd.keys()))
+    for k in keys:
+        np.testing.assert_allclose(sd[k].numpy(), z[prefix + k], rtol=rtol, atol=atol, err_msg=prefix + k)
+
+
+@pytest.mark.parametrize("cname", CASES)
+def test_init_matches_reference_seed(gold, cname):
+    """Same seed => bit-identical initial weights and identical state_dict keys (checkpoint compat)."""
+    z = gold.npz("trainer_cases")
+    _, _, _, _, policy, _ = _build(gold, cname)
+    _check_sd(z, "trn_%s_init_actor." % cname, policy.actor)
+    _check_sd(z, "trn_%s_init_critic." % cname, policy.critic)
+
+
+@pytest.mark.parametrize("cname", CASES)
+def test_forward_matches_reference(gold, cname):
+    z = gold.npz("trainer_cases")
+    key = "trn_%s_" % cname
+    _, spec, args, _, policy, trainer = _build(gold, cname)
+    B = spec["N"] * spec["A"]
+    flat = lambda name: z[key + "buf_" + name][0].reshape(B, *z[key + "buf_" + name].shape[3:])
+    trainer.prep_rollout()
+    torch.manual_seed(11)
+    with torch.no_grad():
+        values, actions, logp, h_a, h_c = policy.get_actions(
+            flat("share_obs"), flat("obs"), flat("rnn_states"), flat("rnn_states_critic"), flat("masks"),
+            flat("available_actions"))
+        # integer sampling: identical actions under the same CPU generator state
+        np.testing.assert_array_equal(actions.numpy(), z[key + "act_actions"])
+        tol = dict(rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(values.numpy(), z[key + "act_values"], **tol)
+        np.testing.assert_allclose(logp.numpy(), z[key + "act_logp"], **tol)
+        np.testing.assert_allclose(h_a.numpy(), z[key + "act_h_actor"], **tol)
+        np.testing.assert_allclose(h_c.numpy(), z[key + "act_h_critic"], **tol)
+        ev_values, ev_logp, ev_ent = policy.evaluate_actions(
+            flat("share_obs"), flat("obs"), flat("rnn_states"), flat("rnn_states_critic"), flat("actions"),
+            flat("masks"), flat("available_actions"), flat("active_masks"))
+        np.testing.assert_allclose(ev_values.numpy(), z[key + "eval_values"], **tol)
+        np.testing.assert_allclose(ev_logp.numpy(), z[key + "eval_logp"], **tol)
+        np.testing.assert_allclose(float(ev_ent), float(z[key + "eval_entropy"]), **tol)
+
+
+@pytest.mark.parametrize("cname", CASES)
+def test_train_matches_reference(gold, cname):
+    """compute_returns + R_MAPPO.train on the same seeds: same permutations, train_info and final
+    parameters as the reference within float32 tolerance."""
+    z = gold.npz("trainer_cases")
+    key = "trn_%s_" % cname
+    meta, spec, args, spaces, policy, trainer = _build(gold, cname)
+    buf = oracle.OracleBuffer(args, spec["A"], *spaces)
+    for name in ("share_obs", "obs", "rnn_states", "rnn_states_critic", "actions", "value_preds", "masks",
+                 "bad_masks", "active_masks", "action_log_probs", "available_actions", "rewards"):
+        getattr(buf, name)[...] = z[key + "buf_" + name]
+    buf.compute_returns(z[key + "next_value"], trainer.value_normalizer)
+    np.testing.assert_array_equal(buf.returns, z[key + "returns"])
+
+    trainer.prep_training()
+    torch.manual_seed(21)
+    info = trainer.train(buf)
+    ref_info = meta["train_info"]
+    assert set(info) == set(ref_info)
+    for k in ref_info:
+        assert info[k] == pytest.approx(ref_info[k], rel=2e-4, abs=2e-6), (k, info[k], ref_info[k])
+    # Adam's first steps are ~lr-sized and sign-like, so weights move by ~lr regardless of tiny
+    # gradient differences: compare with an absolute tolerance well below lr (5e-4 .. 7e-4)
+    _check_sd(z, key + "final_actor.", policy.actor, rtol=1e-4, atol=2e-5)
+    _check_sd(z, key + "final_critic.", policy.critic, rtol=1e-4, atol=2e-5)
+    if trainer.value_normalizer is not None:
+        vn = trainer.value_normalizer
+        got = np.array([float(vn.running_mean), float(vn.running_mean_sq), float(vn.debiasing_term)])
+        np.testing.assert_allclose(got, z[key + "final_norm"], rtol=1e-5, atol=1e-9)

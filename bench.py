@@ -1,0 +1,249 @@
+#!/usr/bin/env python
+"""Benchmark of the MAPPO hot path: env-steps/sec through GAE + ppo_update.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ns|cfg2|smac] [--no-cpu-baseline]
+
+One "step" = one pass of the hot path over one synthetic rollout that is already resident in HBM:
+``buffer.compute_returns`` (HIP GAE scan) + ``R_MAPPO.train`` (ppo_epoch x num_mini_batch fused
+gathers + PyTorch fwd/bwd + Adam) + ``buffer.after_update``.  Metric (BASELINE.json):
+env-steps/sec = T * N / wall-clock, N = GLOBAL number of rollout threads.
+
+Multi-GPU (launched by torch.distributed.run, one rank per GPU): the global N rollout threads are
+sharded N / world per rank (strong scaling, fixed total work); per update one RCCL all-reduce of the
+flat actor+critic gradient bucket plus two tiny statistic all-reduces.
+
+Rank 0 prints ONE JSON line.  ``roofline`` describes the GAE scan kernel (HBM-bound; algorithmic
+bytes from SURVEY.md section 8d), timed with events on the launch stream inside the timed region;
+``roofline_gather`` the same for the fused minibatch gather; ``cpu_baseline`` is the CPU port of the
+same path (oracle buffer + the same PyTorch trainer on host cores) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "on-policy_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+
+WORKLOADS = {
+    # north star: simple_spread generalised to 8 agents, flags of train_mpe_spread.sh
+    "ns": dict(T=400, N=4096, A=8, Do=48, Ds=384, na=5, cpu_sample_N=64,
+               flags=["--algorithm_name", "mappo", "--hidden_size", "64", "--layer_N", "1", "--use_ReLU",
+                      "--ppo_epoch", "10", "--num_mini_batch", "1", "--lr", "7e-4", "--critic_lr", "7e-4",
+                      "--gain", "0.01"],
+               recurrent=False,
+               label="synthetic MPE simple_spread x8 agents, T=400 N=4096 A=8, mappo MLP h64, ppo_epoch=10, 1 minibatch"),
+    # BASELINE.json configs[1]
+    "cfg2": dict(T=200, N=1024, A=5, Do=30, Ds=150, na=5, cpu_sample_N=64,
+                 flags=["--algorithm_name", "mappo", "--hidden_size", "64", "--layer_N", "1", "--use_ReLU",
+                        "--ppo_epoch", "10", "--num_mini_batch", "1", "--lr", "7e-4", "--critic_lr", "7e-4"],
+                 recurrent=False,
+                 label="synthetic T=200 N=1024 A=5, mappo MLP h64, ppo_epoch=10"),
+    # BASELINE.json configs[3] shapes (SMAC MMM2), recurrent policy, chunk 10
+    "smac": dict(T=400, N=512, A=10, Do=370, Ds=435, na=18, cpu_sample_N=8,
+                 flags=["--algorithm_name", "rmappo", "--hidden_size", "64", "--layer_N", "1",
+                        "--ppo_epoch", "5", "--num_mini_batch", "2", "--data_chunk_length", "10",
+                        "--gain", "1"],
+                 recurrent=True,
+                 label="synthetic SMAC MMM2 shapes T=400 N=512 A=10, rmappo GRU h64 chunk 10, ppo_epoch=5, 2 minibatches"),
+}
+
+
+class Box(object):
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+
+class Discrete(object):
+    def __init__(self, n):
+        self.n = n
+
+
+def make_args(wl, n_threads, extra=()):
+    from onpolicy.config import get_config
+    argv = ["--episode_length", str(wl["T"]), "--n_rollout_threads", str(n_threads)] + wl["flags"] + list(extra)
+    args = get_config().parse_known_args(argv)[0]
+    # scripts/train/train_mpe.py:68-80 of the reference: algorithm name decides the recurrent flags
+    args.use_recurrent_policy = bool(wl["recurrent"])
+    args.use_naive_recurrent_policy = False
+    return args
+
+
+def fill_synthetic(buf, wl, seed):
+    """Random-obs / random-reward trajectory with the distributions of SURVEY.md section 8d, generated
+    on the device (data: synthetic)."""
+    g = torch.Generator(device=buf.device)
+    g.manual_seed(seed)
+    for name in ("share_obs", "obs", "rewards"):
+        getattr(buf, name).normal_(generator=g)
+    buf.value_preds[:-1].normal_(generator=g)
+    na = wl["na"]
+    buf.actions.copy_(torch.randint(0, na, buf.actions.shape, generator=g, device=buf.device).float())
+    buf.action_log_probs.fill_(-float(np.log(na)))
+    buf.masks.copy_((torch.rand(buf.masks.shape, generator=g, device=buf.device) >= 1.0 / 25).float())
+    if wl["recurrent"]:
+        buf.rnn_states.normal_(generator=g)
+        buf.rnn_states_critic.normal_(generator=g)
+        buf.active_masks.copy_((torch.rand(buf.masks.shape, generator=g, device=buf.device) < 0.9).float())
+        av = (torch.rand(buf.available_actions.shape, generator=g, device=buf.device) < 0.7).float()
+        av[..., 0] = 1.0
+        buf.available_actions.copy_(av)
+    nv = torch.empty(buf.value_preds.shape[1:], device=buf.device).normal_(generator=g)
+    return nv
+
+
+def cpu_baseline(wl, budget_note):
+    """The same path on host cores: oracle buffer (C restatement of the reference's compute_returns
+    and numpy gathers) + the same PyTorch trainer on CPU tensors, on a bounded sample (fewer rollout
+    threads, identical T / A / dims / hyper-parameters)."""
+    from oracle import oracle
+    from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO
+    from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n = wl["cpu_sample_N"]
+    args = make_args(wl, n)
+    spaces = Box((wl["Do"],)), Box((wl["Ds"],)), Discrete(wl["na"])
+    torch.manual_seed(1)
+    policy = R_MAPPOPolicy(args, *spaces)
+    trainer = R_MAPPO(args, policy)
+    buf = oracle.OracleBuffer(args, wl["A"], *spaces)
+    rng = np.random.default_rng(0)
+    f32 = np.float32
+    for name in ("share_obs", "obs", "rewards", "rnn_states", "rnn_states_critic"):
+        getattr(buf, name)[...] = rng.standard_normal(getattr(buf, name).shape, dtype=f32)
+    buf.value_preds[:-1] = rng.standard_normal(buf.value_preds[:-1].shape, dtype=f32)
+    buf.actions[...] = rng.integers(0, wl["na"], buf.actions.shape).astype(f32)
+    buf.action_log_probs[...] = -np.log(wl["na"])
+    buf.masks[...] = (rng.random(buf.masks.shape) >= 1.0 / 25).astype(f32)
+    nv = rng.standard_normal(buf.value_preds.shape[1:], dtype=f32)
+    trainer.prep_training()
+    t0 = time.perf_counter()
+    buf.compute_returns(nv, trainer.value_normalizer)
+    t1 = time.perf_counter()
+    trainer.train(buf)
+    buf.after_update()
+    t2 = time.perf_counter()
+    total = t2 - t0
+    return {"value": wl["T"] * n / total, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "1 iteration at n_rollout_threads=%d (same T=%d, A=%d, dims, ppo_epoch, minibatches): "
+                      "%.3f s compute_returns + %.2f s train; %s" % (n, wl["T"], wl["A"], t1 - t0, t2 - t1, budget_note)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="ns", choices=sorted(WORKLOADS))
+    ap.add_argument("--threads", type=int, default=None, help="override the global n_rollout_threads")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sampler-rng", default="device", choices=["device", "host"])
+    opt = ap.parse_args()
+
+    wl = dict(WORKLOADS[opt.workload])
+    if opt.threads:
+        wl["N"] = opt.threads
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py measures the HIP path and needs an MI355X"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from onpolicy.utils import dist as mdist
+    if world > 1:
+        mdist.init_from_env(dev)
+    lo, hi = mdist.shard_threads(wl["N"], rank, world)
+    n_local = hi - lo
+
+    from onpolicy.utils.shared_buffer import SharedReplayBuffer
+    from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO
+    from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy
+
+    args = make_args(wl, n_local, ["--sampler_rng", opt.sampler_rng])
+    spaces = Box((wl["Do"],)), Box((wl["Ds"],)), Discrete(wl["na"])
+    torch.manual_seed(1)          # identical replicas on every rank (init draws come from the CPU stream)
+    np.random.seed(1)
+    policy = R_MAPPOPolicy(args, *spaces, device=dev)
+    trainer = R_MAPPO(args, policy, device=dev)
+    buf = SharedReplayBuffer(args, wl["A"], *spaces, device=dev)
+    next_value = fill_synthetic(buf, wl, seed=1234 + rank)
+    trainer.prep_training()
+
+    def step():
+        buf.compute_returns(next_value, trainer.value_normalizer)
+        info = trainer.train(buf)
+        buf.after_update()
+        return info
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(opt.warmup):
+        step()
+    buf.profile_kernels(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(opt.steps):
+        info = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kt = buf.kernel_times()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / opt.steps
+        value = wl["T"] * wl["N"] * opt.steps / elapsed
+
+        def roof(name):
+            if name not in kt:
+                return None
+            launches, ms, nbytes = kt[name]
+            achieved = nbytes / (ms * 1e-3) / 1e9
+            return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launch_ms": round(ms, 5), "launches": launches, "algorithmic_bytes": int(nbytes)}
+
+        out = {
+            "metric": "env-steps/sec through GAE+ppo_update, 4096 threads×8 agents×400 steps",
+            "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": opt.steps,
+            "warmup": opt.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["label"], "T": wl["T"], "n_rollout_threads": wl["N"],
+                       "threads_per_gpu": n_local, "agents": wl["A"], "obs_dim": wl["Do"],
+                       "share_obs_dim": wl["Ds"], "actions": wl["na"], "ppo_epoch": args.ppo_epoch,
+                       "num_mini_batch": args.num_mini_batch, "sampler_rng": opt.sampler_rng,
+                       "parallelism": "dp%d over rollout threads" % world},
+            "roofline": roof("mappo_gae_f32"),
+            "roofline_gather": roof("mappo_gather_chunks" if wl["recurrent"] else "mappo_gather_rows"),
+            "train_info": {k: round(float(v), 6) for k, v in info.items()},
+        }
+        if world == 1 and not opt.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, "GPU/CPU ratio = %.0fx on env-steps/s" % 0.0)
+            ratio = value / out["cpu_baseline"]["value"]
+            out["cpu_baseline"]["sample"] = out["cpu_baseline"]["sample"].replace(
+                "GPU/CPU ratio = 0x", "GPU/CPU ratio = %.0fx" % ratio)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -40,6 +40,7 @@ struct GaeArgs {
     float* adv;
     const float* active;
     double* partials;
+    long long partial_rows;  // rows of `partials`; rows >= gridDim.x are zero-filled by block 0
     int T;
     long long C;
     float gamma;
@@ -81,6 +82,19 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
+}
+
+
+// Rows of the partials array that no workgroup owns are zeroed by workgroup 0, so that the
+// fixed-size reduction needs no separate memset launch.
+__device__ __forceinline__ void zero_unowned_partials(double* partials, long long rows) {
+    if (partials != nullptr && blockIdx.x == 0) {
+        for (long long r = (long long)gridDim.x + threadIdx.x; r < rows; r += blockDim.x) {
+            partials[r * 3 + 0] = 0.0;
+            partials[r * 3 + 1] = 0.0;
+            partials[r * 3 + 2] = 0.0;
+        }
+    }
 }
 
 // ------------------------------------------------------------------ strip kernel ----
@@ -209,6 +223,7 @@ __global__ void __launch_bounds__(NWAVES * 64) gae_strip_kernel(GaeArgs a) {
         __syncthreads();
     }
 
+    zero_unowned_partials(a.partials, a.partial_rows);
     if (walker && a.partials != nullptr) {
         s1 = wave_sum(s1);
         s2 = wave_sum(s2);
@@ -310,6 +325,7 @@ __global__ void __launch_bounds__(64) gae_column_kernel(GaeArgs a) {
             }
         }
     }
+    zero_unowned_partials(a.partials, a.partial_rows);
     if (a.partials != nullptr) {
         s1 = wave_sum(s1);
         s2 = wave_sum(s2);
@@ -368,7 +384,9 @@ constexpr int kAdvBlocks = 1024;
 // r_mappo.py:179-186 as one grid-stride pass: advantages + per-block partial moments.
 __global__ void __launch_bounds__(256) advantages_kernel(const float* ret, const float* vp,
                                                           const float* denorm, const float* active,
-                                                          float* adv, double* partials, long long n) {
+                                                          float* adv, double* partials, long long n,
+                                                          long long partial_rows) {
+    zero_unowned_partials(partials, partial_rows);
     float sigma = 1.f, mu = 0.f;
     const bool dn = denorm != nullptr;
     if (dn) {
@@ -467,15 +485,11 @@ extern "C" int mappo_advantages_f32(const float* returns, const float* value_pre
     if (!returns || !value_preds || !advantages) return MAPPO_E_NULL;
     if (T <= 0 || C <= 0) return MAPPO_E_SHAPE;
     const long long n = (long long)T * C;
-    if (adv_partials) {
-        hipError_t e = hipMemsetAsync(adv_partials, 0,
-                                      (size_t)mappo_gae_partial_rows(C) * 3 * sizeof(double), stream);
-        if (e != hipSuccess) return (int)e;
-    }
     long long blocks = (n + 256 * 8 - 1) / (256 * 8);
     if (blocks > kAdvBlocks) blocks = kAdvBlocks;
     hipLaunchKernelGGL(advantages_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, returns,
-                       value_preds, denorm, active_masks, advantages, adv_partials, n);
+                       value_preds, denorm, active_masks, advantages, adv_partials, n,
+                       (long long)mappo_gae_partial_rows(C));
     return (int)hipGetLastError();
 }
 
@@ -514,16 +528,11 @@ extern "C" int mappo_gae_f32(const float* rewards, float* value_preds, const flo
     a.adv = advantages;
     a.active = active_masks;
     a.partials = adv_partials;
+    a.partial_rows = mappo_gae_partial_rows(C);
     a.T = T;
     a.C = C;
     a.gamma = (float)gamma;
     a.gl = (float)(gamma * gae_lambda);
-
-    if (adv_partials) {
-        hipError_t e = hipMemsetAsync(adv_partials, 0,
-                                      (size_t)mappo_gae_partial_rows(C) * 3 * sizeof(double), stream);
-        if (e != hipSuccess) return (int)e;
-    }
 
     const bool strip_ok = (flags & MAPPO_GAE_USE_GAE) && (C % 4 == 0) && aligned16(rewards) &&
                           aligned16(value_preds) && aligned16(masks) &&

@@ -132,6 +132,7 @@ class SharedReplayBuffer(object):
         self._adv_stats = torch.zeros(2, **f32)
         self._adv_fresh = False   # advantages/moments match the current returns & value_preds
         self._stats_fresh = False
+        self._events = None       # kernel name -> [(start, end, algorithmic bytes)], see profile_kernels
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
@@ -153,6 +154,34 @@ class SharedReplayBuffer(object):
 
     def _stream(self):
         return _native.stream_of(self.device)
+
+    # -- optional per-launch timing of the HIP kernels with events on the launch stream
+    def profile_kernels(self, enabled=True):
+        self._events = {} if enabled else None
+
+    def _timed(self, name, nbytes):
+        if self._events is None:
+            return None
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), nbytes)
+        self._events.setdefault(name, []).append(ev)
+        ev[0].record(torch.cuda.current_stream(self.device))
+        return ev
+
+    def _timed_end(self, ev):
+        if ev is not None:
+            ev[1].record(torch.cuda.current_stream(self.device))
+
+    def kernel_times(self, reset=True):
+        """{kernel: (launches, mean ms, mean algorithmic bytes)} since profiling was enabled."""
+        torch.cuda.synchronize(self.device)
+        out = {}
+        for name, evs in (self._events or {}).items():
+            if evs:
+                ms = [a.elapsed_time(b) for a, b, _ in evs]
+                out[name] = (len(evs), sum(ms) / len(ms), sum(n for _, _, n in evs) / len(evs))
+        if reset and self._events is not None:
+            self._events = {}
+        return out
 
     def _dev(self, x):
         """Anything array-like -> contiguous float32 tensor on the buffer's device."""
@@ -282,11 +311,15 @@ class SharedReplayBuffer(object):
             raise ValueError("next_value has %d elements, expected %d" % (nv.numel(), N * A))
         denorm = self._denorm_scalars(value_normalizer)
         p = _native.ptr
+        # algorithmic bytes: r, v, m reads + returns write (16 B) + advantages write + active read
+        # (+8 B) [+ bad_masks read 4 B] per (t, n, a) element  
+        ev = self._timed("mappo_gae_f32", (24 + (4 if self._use_proper_time_limits else 0)) * T * N * A)
         code = self._lib.mappo_gae_f32(
             p(self.rewards), p(self.value_preds), p(nv), p(self.masks),
             p(self.bad_masks) if self._use_proper_time_limits else None, p(self.returns), p(denorm),
             p(self.advantages), p(self.active_masks), p(self._adv_partials),
             T, N * A, float(self.gamma), float(self.gae_lambda), self._gae_flags(denorm), self._stream())
+        self._timed_end(ev)
         _native.check(code, "mappo_gae_f32")
         self._adv_fresh = True
         self._stats_fresh = False
@@ -375,6 +408,10 @@ class SharedReplayBuffer(object):
             outs.append(dst)
         arr = (_native.Field * len(fields))(*fields)
         sp = None if stats is None else stats.data_ptr()
+        # algorithmic bytes: every gathered row is read once and written once, + the int64 indices
+        nbytes = sum(2 * 4 * f.width * (mb if (f.first_only or chunk_len is None) else rows_out)
+                     for f in fields) + 8 * mb
+        ev = self._timed("mappo_gather_rows" if chunk_len is None else "mappo_gather_chunks", nbytes)
         if chunk_len is None:
             code = self._lib.mappo_gather_rows(arr, len(fields), idx.data_ptr(), mb, sp, self._stream())
             _native.check(code, "mappo_gather_rows")
@@ -382,6 +419,7 @@ class SharedReplayBuffer(object):
             code = self._lib.mappo_gather_chunks(arr, len(fields), idx.data_ptr(), mb, chunk_len, T, N, A,
                                                  sp, self._stream())
             _native.check(code, "mappo_gather_chunks")
+        self._timed_end(ev)
         return tuple(outs)
 
     def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None):

@@ -1,0 +1,70 @@
+"""CPU-side checks of the C ABI: the shared library loads and exports every symbol that
+include/mappo_hip.h declares, the ctypes table covers the header, and argument validation rejects
+bad calls before anything is enqueued (no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from onpolicy import _native
+
+HEADER = os.path.join(ROOT, "include", "mappo_hip.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mappo_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported_and_bound():
+    names = _declared()
+    assert len(names) >= 13
+    lib = _native.lib()
+    for n in names:
+        assert hasattr(lib, n), "libmappo_hip.so does not export %s" % n
+        assert n in _native.SIGNATURES, "ctypes table misses %s" % n
+    assert sorted(_native.SIGNATURES) == names
+    assert lib.mappo_abi_version() == 1
+    assert b"gfx950" in lib.mappo_build_info()
+
+
+def test_struct_layouts_match_header():
+    # struct mappo_field: 2 pointers + 4 int32 = 32 bytes; struct mappo_slab: 2 pointers + int64 = 24
+    assert ctypes.sizeof(_native.Field) == 32
+    assert ctypes.sizeof(_native.Slab) == 24
+
+
+def test_argument_validation_without_device():
+    lib = _native.lib()
+    assert lib.mappo_gae_f32(None, None, None, None, None, None, None, None, None, None, 4, 4,
+                             0.99, 0.95, 1, None) == -1
+    assert lib.mappo_adv_reduce(None, 1, None, None) == -1
+    assert lib.mappo_gather_rows(None, 1, None, 1, None, None) == -1
+    assert lib.mappo_slab_copy(None, 1, None) == -1
+    assert lib.mappo_gae_partial_rows(0) == 0
+    assert lib.mappo_gae_partial_rows(32768) == 2048
+    assert lib.mappo_error_string(-2).decode().startswith("a size")
+    assert lib.mappo_error_string(0) == b"ok"
+
+
+def test_buffer_refuses_cpu():
+    """The product path has no CPU fallback: it must fail loudly."""
+    import torch
+    from helpers import Box, Discrete, make_args
+    from onpolicy.utils.shared_buffer import SharedReplayBuffer
+    args = make_args(episode_length=4, n_rollout_threads=2)
+    with pytest.raises(RuntimeError, match="HIP"):
+        SharedReplayBuffer(args, 2, Box((3,)), Box((6,)), Discrete(5), device=torch.device("cpu"))
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="HIP"):
+            SharedReplayBuffer(args, 2, Box((3,)), Box((6,)), Discrete(5))
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_native.NativeError, match="no CPU fallback"):
+        _native.lib()

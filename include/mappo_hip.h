@@ -160,6 +160,11 @@ int mappo_gather_chunks(const mappo_field_t* fields, int n_fields, const int64_t
                         int64_t mb, int L, int T, int64_t N, int A, const float* stats,
                         mappo_stream_t stream);
 
+/* Tuning hook for benchmarks (results do not depend on it): bits 0-1 log2 of the loads in
+ * flight per lane, bit 2 non-temporal accesses, bits 4.. workgroups per CU (0 = occupancy).
+ * Returns the previous value. */
+int mappo_gather_set_variant(int variant);
+
 /* ------------------------------------------------------------ K2: slab writes ----
  * Replaces the per-field `buf[step] = x.copy()` statements of insert / chooseinsert /
  * after_update / chooseafter_update (shared_buffer.py:107-121,142-156,162-170,

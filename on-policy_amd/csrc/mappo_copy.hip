@@ -21,8 +21,8 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kUnroll = 8;                       // independent loads per lane per pass
-constexpr unsigned kTileUnits = kThreads * kUnroll;
+constexpr int kMaxUnroll = 8;                    // independent loads per lane per pass (slab copy)
+constexpr unsigned kTileUnits = kThreads * kMaxUnroll;
 
 struct GField {
     const float* src;
@@ -31,6 +31,7 @@ struct GField {
     unsigned vec;            // floats per unit (1, 2, 4)
     unsigned upr;            // units per row
     unsigned rows_per_tile;
+    unsigned inv_upr;        // ceil(2^32 / upr): i / upr == mulhi(i, inv_upr) for i * upr < 2^32
     unsigned rows_out;       // output rows of this field
     unsigned tile_begin;     // first global tile id of this field
     unsigned first_only;
@@ -48,18 +49,21 @@ struct GatherArgs {
     const float* stats;
 };
 
+// native clang vectors (the non-temporal builtins do not take HIP's float4 struct)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int VEC> struct VecT;
-template <> struct VecT<4> { using type = float4; };
-template <> struct VecT<2> { using type = float2; };
+template <> struct VecT<4> { using type = f32x4; };
+template <> struct VecT<2> { using type = f32x2; };
 template <> struct VecT<1> { using type = float; };
 
 __device__ __forceinline__ float norm1(float x, float mean, float den) { return (x - mean) / den; }
 __device__ __forceinline__ void normv(float& v, float m, float d) { v = norm1(v, m, d); }
-__device__ __forceinline__ void normv(float2& v, float m, float d) {
+__device__ __forceinline__ void normv(f32x2& v, float m, float d) {
     v.x = norm1(v.x, m, d);
     v.y = norm1(v.y, m, d);
 }
-__device__ __forceinline__ void normv(float4& v, float m, float d) {
+__device__ __forceinline__ void normv(f32x4& v, float m, float d) {
     v.x = norm1(v.x, m, d);
     v.y = norm1(v.y, m, d);
     v.z = norm1(v.z, m, d);
@@ -84,9 +88,20 @@ __device__ __forceinline__ unsigned source_row(const GatherArgs& a, const GField
     return (t * a.N + n) * a.A + ag;
 }
 
-template <int VEC>
+template <bool NT, typename V>
+__device__ __forceinline__ V ld(const V* p) {
+    return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool NT, typename V>
+__device__ __forceinline__ void st(V* p, V v) {
+    if (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+template <int VEC, int UNROLL, bool NT>
 __device__ __forceinline__ void copy_tile(const GatherArgs& a, const GField& fd, unsigned tile_local) {
     using V = typename VecT<VEC>::type;
+    constexpr unsigned kPass = kThreads * UNROLL;
     const unsigned row0 = tile_local * fd.rows_per_tile;
     unsigned nrows = fd.rows_out - row0;
     if (nrows > fd.rows_per_tile) nrows = fd.rows_per_tile;
@@ -96,33 +111,35 @@ __device__ __forceinline__ void copy_tile(const GatherArgs& a, const GField& fd,
         mean = a.stats[0];
         den = a.stats[1] + 1e-5f;  // r_mappo.py:187
     }
-    for (unsigned i0 = 0; i0 < nunits; i0 += kTileUnits) {
-        V val[kUnroll];
-        long long doff[kUnroll];
+    for (unsigned i0 = 0; i0 < nunits; i0 += kPass) {
+        V val[UNROLL];
+        long long doff[UNROLL];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
+        for (int u = 0; u < UNROLL; ++u) {
             unsigned i = i0 + u * kThreads + threadIdx.x;
             doff[u] = -1;
+            val[u] = V(0.f);
             if (i < nunits) {
-                unsigned r = (fd.upr == 1) ? i : i / fd.upr;
+                unsigned r = (fd.upr == 1) ? i : __umulhi(i, fd.inv_upr);
                 unsigned w = i - r * fd.upr;
                 unsigned orow = row0 + r;
                 unsigned srow = source_row(a, fd, orow);
-                val[u] = *reinterpret_cast<const V*>(fd.src + (long long)srow * fd.width + w * VEC);
+                val[u] = ld<NT>(reinterpret_cast<const V*>(fd.src + (long long)srow * fd.width + w * VEC));
                 doff[u] = (long long)orow * fd.width + w * VEC;
             }
         }
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
+        for (int u = 0; u < UNROLL; ++u) {
             if (doff[u] >= 0) {
                 V v = val[u];
                 if (fd.normalize) normv(v, mean, den);
-                *reinterpret_cast<V*>(fd.dst + doff[u]) = v;
+                st<NT>(reinterpret_cast<V*>(fd.dst + doff[u]), v);
             }
         }
     }
 }
 
+template <int UNROLL, bool NT>
 __global__ void __launch_bounds__(kThreads) gather_kernel(GatherArgs a) {
     for (unsigned tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
         int f = 0;
@@ -131,10 +148,30 @@ __global__ void __launch_bounds__(kThreads) gather_kernel(GatherArgs a) {
             if (tile >= a.f[k].tile_begin) f = k;
         const GField& fd = a.f[f];
         const unsigned tl = tile - fd.tile_begin;
-        if (fd.vec == 4) copy_tile<4>(a, fd, tl);
-        else if (fd.vec == 2) copy_tile<2>(a, fd, tl);
-        else copy_tile<1>(a, fd, tl);
+        if (fd.vec == 4) copy_tile<4, UNROLL, NT>(a, fd, tl);
+        else if (fd.vec == 2) copy_tile<2, UNROLL, NT>(a, fd, tl);
+        else copy_tile<1, UNROLL, NT>(a, fd, tl);
     }
+}
+
+int g_gather_variant = 0;  // bits 0-1: log2(unroll), bit 2: nontemporal, bits 4+: blocks per CU (0 = occupancy)
+
+template <int UNROLL, bool NT>
+hipError_t launch_gather(const GatherArgs& a, unsigned tile_units, int blocks_per_cu, hipStream_t stream) {
+    static int occ = 0;  // resident workgroups per CU for this instantiation
+    if (occ == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gather_kernel<UNROLL, NT>, kThreads, 0) != hipSuccess || n <= 0)
+            n = 4;
+        occ = n;
+    }
+    // a persistent grid: exactly the resident workgroups (a second, partial wave of workgroups
+    // would run at reduced occupancy), each walking the tile list with stride gridDim.x
+    int per_cu = blocks_per_cu > 0 ? blocks_per_cu : occ;
+    unsigned grid = (unsigned)(mappo::kCUs * per_cu);
+    if (a.total_tiles < grid) grid = a.total_tiles;
+    hipLaunchKernelGGL((gather_kernel<UNROLL, NT>), dim3(grid), dim3(kThreads), 0, stream, a);
+    return hipGetLastError();
 }
 
 int build_and_launch(const mappo_field_t* fields, int n_fields, const int64_t* idx, int64_t mb,
@@ -148,6 +185,11 @@ int build_and_launch(const mappo_field_t* fields, int n_fields, const int64_t* i
         if (L <= 0 || T <= 0 || N <= 0 || A <= 0) return MAPPO_E_SHAPE;
         if ((long long)T * N * A >= (1ll << 31) || mb * (long long)L >= (1ll << 31)) return MAPPO_E_SHAPE;
     }
+    const int variant = g_gather_variant;
+    const int unroll = 1 << (variant & 3);
+    const bool nt = (variant & 4) != 0;
+    const int blocks_per_cu = variant >> 4;
+    const unsigned tile_units = (unsigned)(kThreads * unroll);
     GatherArgs a;
     a.nf = n_fields;
     a.idx = reinterpret_cast<const long long*>(idx);
@@ -171,7 +213,8 @@ int build_and_launch(const mappo_field_t* fields, int n_fields, const int64_t* i
         g.width = (unsigned)s.width;
         g.vec = (unsigned)mappo::row_vec(s.src, s.dst, s.width);
         g.upr = g.width / g.vec;
-        g.rows_per_tile = g.upr >= kTileUnits ? 1u : kTileUnits / g.upr;
+        g.rows_per_tile = g.upr >= tile_units ? 1u : tile_units / g.upr;
+        g.inv_upr = (unsigned)(((1ull << 32) + g.upr - 1) / g.upr);
         g.first_only = (chunked && s.first_only) ? 1u : 0u;
         g.normalize = s.normalize ? 1u : 0u;
         long long rows_out = (chunked && !g.first_only) ? mb * (long long)L : mb;
@@ -181,10 +224,18 @@ int build_and_launch(const mappo_field_t* fields, int n_fields, const int64_t* i
         if (tiles >= (1ull << 32)) return MAPPO_E_SHAPE;
     }
     a.total_tiles = (unsigned)tiles;
-    unsigned grid = a.total_tiles < (unsigned)(mappo::kCUs * 8) ? a.total_tiles
-                                                                  : (unsigned)(mappo::kCUs * 8);
-    hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(kThreads), 0, stream, a);
-    return (int)hipGetLastError();
+    hipError_t e;
+    switch ((variant & 3) | (nt ? 4 : 0)) {
+        case 0: e = launch_gather<1, false>(a, tile_units, blocks_per_cu, stream); break;
+        case 1: e = launch_gather<2, false>(a, tile_units, blocks_per_cu, stream); break;
+        case 2: e = launch_gather<4, false>(a, tile_units, blocks_per_cu, stream); break;
+        case 3: e = launch_gather<8, false>(a, tile_units, blocks_per_cu, stream); break;
+        case 4: e = launch_gather<1, true>(a, tile_units, blocks_per_cu, stream); break;
+        case 5: e = launch_gather<2, true>(a, tile_units, blocks_per_cu, stream); break;
+        case 6: e = launch_gather<4, true>(a, tile_units, blocks_per_cu, stream); break;
+        default: e = launch_gather<8, true>(a, tile_units, blocks_per_cu, stream); break;
+    }
+    return (int)e;
 }
 
 // ------------------------------------------------------------------ K2: slabs ----
@@ -207,33 +258,42 @@ __global__ void __launch_bounds__(kThreads) slab_kernel(SlabArgs a) {
 #pragma unroll 1
         for (int q = 1; q < a.n; ++q)
             if (tile >= a.s[q].tile_begin) k = q;
-        const Slab& s = a.s[k];
-        unsigned long long base = (unsigned long long)(tile - s.tile_begin) * kTileUnits;
-        if (s.vec == 4) {
-            const float4* src = reinterpret_cast<const float4*>(s.src);
-            float4* dst = reinterpret_cast<float4*>(s.dst);
-            float4 v[kUnroll];
+        // copy the descriptor into registers (indexing the by-value argument with a runtime k
+        // otherwise sends it through scratch memory)
+        const float* s_src = a.s[k].src;
+        float* s_dst = a.s[k].dst;
+        const unsigned long long units = a.s[k].units;
+        const unsigned vec = a.s[k].vec;
+        unsigned long long base = (unsigned long long)(tile - a.s[k].tile_begin) * kTileUnits;
+        if (vec == 4) {
+            const float4* src = reinterpret_cast<const float4*>(s_src);
+            float4* dst = reinterpret_cast<float4*>(s_dst);
+            float4 v[kMaxUnroll];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
+            for (int u = 0; u < kMaxUnroll; ++u) {
                 unsigned long long i = base + u * kThreads + threadIdx.x;
-                if (i < s.units) v[u] = src[i];
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < units) v[u] = src[i];
             }
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
+            for (int u = 0; u < kMaxUnroll; ++u) {
                 unsigned long long i = base + u * kThreads + threadIdx.x;
-                if (i < s.units) dst[i] = v[u];
+                if (i < units) dst[i] = v[u];
             }
         } else {
-            float v[kUnroll];
+            const float* src = s_src;
+            float* dst = s_dst;
+            float v[kMaxUnroll];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
+            for (int u = 0; u < kMaxUnroll; ++u) {
                 unsigned long long i = base + u * kThreads + threadIdx.x;
-                if (i < s.units) v[u] = s.src[i];
+                v[u] = 0.f;
+                if (i < units) v[u] = src[i];
             }
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
+            for (int u = 0; u < kMaxUnroll; ++u) {
                 unsigned long long i = base + u * kThreads + threadIdx.x;
-                if (i < s.units) s.dst[i] = v[u];
+                if (i < units) dst[i] = v[u];
             }
         }
     }
@@ -281,6 +341,12 @@ extern "C" int mappo_slab_copy(const mappo_slab_t* slabs, int n_slabs, mappo_str
     hipLaunchKernelGGL(slab_kernel, dim3(grid), dim3(kThreads), 0,
                        static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
+}
+
+extern "C" int mappo_gather_set_variant(int variant) {
+    int old = g_gather_variant;
+    g_gather_variant = variant;
+    return old;
 }
 
 extern "C" int mappo_abi_version(void) { return MAPPO_ABI_VERSION; }

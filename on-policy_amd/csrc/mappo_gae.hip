@@ -99,18 +99,24 @@ __device__ __forceinline__ void zero_unowned_partials(double* partials, long lon
 
 // ------------------------------------------------------------------ strip kernel ----
 // W      columns per strip (multiple of 4, <= 64)
-// NWAVES waves per workgroup (all load; wave 0 walks the recurrence)
+// NWAVES waves per workgroup (wave 0 walks the recurrence; LOADERS selects who streams)
 // TC     time steps per tile
-template <int W, int NWAVES, int TC, bool PTL, bool DENORM>
+// NBUF   register prefetch depth in tiles (1 or 2): tiles k+1 .. k+NBUF are in flight while
+//        tile k is walked
+// WLOAD  whether the walker wave also issues loads (false: waves 1.. are pure producers)
+template <int W, int NWAVES, int TC, int NBUF, bool WLOAD, bool PTL, bool DENORM>
 __global__ void __launch_bounds__(NWAVES * 64) gae_strip_kernel(GaeArgs a) {
     constexpr int NT = NWAVES * 64;
+    constexpr int NL = WLOAD ? NT : NT - 64;    // loader threads
     constexpr int V = W / 4;                    // float4 per tile row
     constexpr int NVEC = TC * V;                // float4 per field per tile
-    constexpr int PER = (NVEC + NT - 1) / NT;   // float4 per thread per field
+    constexpr int PER = (NVEC + NL - 1) / NL;   // float4 per loader thread per field
     constexpr int NFMAX = 5;                    // r, v, m, bad, active
     static_assert(W % 4 == 0 && W <= 64, "strip width");
+    static_assert(WLOAD || NWAVES > 1, "pure-walker needs producer waves");
+    static_assert(NBUF == 1 || NBUF == 2, "prefetch depth");
 
-    extern __shared__ float4 lds4[];            // [NF][TC][V]
+    extern __shared__ float4 lds4[];            // [slots][TC][V], slots = fields in use
     float* ldsf = reinterpret_cast<float*>(lds4);
 
     const int tid = threadIdx.x;
@@ -119,46 +125,48 @@ __global__ void __launch_bounds__(NWAVES * 64) gae_strip_kernel(GaeArgs a) {
     const int T = a.T;
     const bool has_act = a.active != nullptr;
     const bool has_adv = a.adv != nullptr;
+    const bool loader = WLOAD || tid >= 64;
+    const int ltid = WLOAD ? tid : tid - 64;    // index among loader threads
 
-    // field f: base pointer and row offset (masks / bad_masks are read at t+1)
+    // field f: base pointer (masks / bad_masks are read at row t+1) and LDS slot
     const float* fbase[NFMAX] = {a.rewards, a.value_preds, a.masks + C, PTL ? a.bad + C : nullptr,
                                  a.active};
+    const int act_slot = PTL ? 4 : 3;
 
-    float4 pre[NFMAX][PER];
+    float4 pre[NBUF][NFMAX][PER];
 
-    auto load_tile = [&](int tbase) {
-#pragma unroll
-        for (int f = 0; f < NFMAX; ++f) {
-            if (f == 3 && !PTL) continue;
-            if (f == 4 && !has_act) continue;
-#pragma unroll
-            for (int p = 0; p < PER; ++p) {
-                int i = tid + p * NT;
-                int row = i / V;
-                int c4 = i - row * V;
-                int t = tbase + row;
-                long long col = col0 + c4 * 4;
-                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i < NVEC && t >= 0 && col < C)
-                    val = *reinterpret_cast<const float4*>(fbase[f] + (long long)t * C + col);
-                pre[f][p] = val;
-            }
-        }
-    };
-    auto stash_tile = [&]() {
-#pragma unroll
-        for (int f = 0; f < NFMAX; ++f) {
-            if (f == 3 && !PTL) continue;
-            if (f == 4 && !has_act) continue;
-#pragma unroll
-            for (int p = 0; p < PER; ++p) {
-                int i = tid + p * NT;
-                if (i < NVEC) lds4[f * NVEC + i] = pre[f][p];
-            }
-        }
-    };
+#define MAPPO_LOAD_TILE(B, TBASE)                                                               \
+    if (loader) {                                                                               \
+        _Pragma("unroll") for (int f = 0; f < NFMAX; ++f) {                                     \
+            if (f == 3 && !PTL) continue;                                                       \
+            if (f == 4 && !has_act) continue;                                                   \
+            _Pragma("unroll") for (int p = 0; p < PER; ++p) {                                   \
+                int i = ltid + p * NL;                                                          \
+                int row = i / V;                                                                \
+                int c4 = i - row * V;                                                           \
+                int t = (TBASE) + row;                                                          \
+                long long lc = col0 + c4 * 4;                                                   \
+                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);                                   \
+                if (i < NVEC && t >= 0 && lc < C)                                               \
+                    val = *reinterpret_cast<const float4*>(fbase[f] + (long long)t * C + lc);   \
+                pre[B][f][p] = val;                                                             \
+            }                                                                                   \
+        }                                                                                       \
+    }
+#define MAPPO_STASH_TILE(B)                                                                     \
+    if (loader) {                                                                               \
+        _Pragma("unroll") for (int f = 0; f < NFMAX; ++f) {                                     \
+            if (f == 3 && !PTL) continue;                                                       \
+            if (f == 4 && !has_act) continue;                                                   \
+            const int slot = f == 4 ? act_slot : f;                                             \
+            _Pragma("unroll") for (int p = 0; p < PER; ++p) {                                   \
+                int i = ltid + p * NL;                                                          \
+                if (i < NVEC) lds4[slot * NVEC + i] = pre[B][f][p];                             \
+            }                                                                                   \
+        }                                                                                       \
+    }
 
-    const int lane = tid;  // only wave 0 computes: lane == tid there
+    const int lane = tid;  // only wave 0 walks: lane == tid there
     const long long col = col0 + lane;
     const bool walker = (tid < 64);
     const bool live = walker && lane < W && col < C;
@@ -183,45 +191,55 @@ __global__ void __launch_bounds__(NWAVES * 64) gae_strip_kernel(GaeArgs a) {
     }
 
     const int nch = (T + TC - 1) / TC;
-    load_tile(T - TC);
-    for (int k = 0; k < nch; ++k) {
-        const int tbase = T - (k + 1) * TC;
-        stash_tile();
-        __syncthreads();
-        if (k + 1 < nch) load_tile(tbase - TC);  // in flight while wave 0 walks this tile
-        if (walker) {
-            const int lc = lane < W ? lane : 0;  // lanes beyond the strip stay in bounds
-            const float* lr = ldsf + 0 * NVEC * 4 + lc;
-            const float* lv = ldsf + 1 * NVEC * 4 + lc;
-            const float* lm = ldsf + 2 * NVEC * 4 + lc;
-            const float* lb = ldsf + 3 * NVEC * 4 + lc;
-            const float* la = ldsf + 4 * NVEC * 4 + lc;
-            const int slo = tbase < 0 ? -tbase : 0;
+    MAPPO_LOAD_TILE(0, T - TC)
+    if (NBUF == 2) {
+        if (nch > 1) MAPPO_LOAD_TILE(NBUF - 1, T - 2 * TC)
+    }
+    for (int k0 = 0; k0 < nch; k0 += NBUF) {
+#pragma unroll
+        for (int b = 0; b < NBUF; ++b) {
+            const int k = k0 + b;
+            if (k >= nch) break;
+            const int tbase = T - (k + 1) * TC;
+            MAPPO_STASH_TILE(b)
+            __syncthreads();
+            if (k + NBUF < nch) MAPPO_LOAD_TILE(b, tbase - NBUF * TC)  // in flight during the walk(s)
+            if (walker) {
+                const int lc = lane < W ? lane : 0;  // lanes beyond the strip stay in bounds
+                const float* lr = ldsf + 0 * NVEC * 4 + lc;
+                const float* lv = ldsf + 1 * NVEC * 4 + lc;
+                const float* lm = ldsf + 2 * NVEC * 4 + lc;
+                const float* lb = ldsf + 3 * NVEC * 4 + lc;
+                const float* la = ldsf + act_slot * NVEC * 4 + lc;
+                const int slo = tbase < 0 ? -tbase : 0;
 #pragma unroll 8
-            for (int s = TC - 1; s >= slo; --s) {
-                float r = lr[s * W], v0 = lv[s * W], m1 = lm[s * W];
-                float bad1 = PTL ? lb[s * W] : 1.f;
-                float dv0;
-                float ret = gae_step<PTL, DENORM>(r, v0, m1, bad1, sigma, mu, gamma, gl, dv1, g, dv0);
-                if (live) {
-                    long long o = (long long)(tbase + s) * C + col;
-                    a.returns[o] = ret;
-                    if (has_adv) {
-                        float adv = ret - dv0;  // r_mappo.py:180 (from the rounded return)
-                        a.adv[o] = adv;
-                        float am = has_act ? la[s * W] : 1.f;
-                        if (am != 0.f) {
-                            double d = (double)adv;
-                            s1 += d;
-                            s2 += d * d;
-                            cnt += 1.0;
+                for (int s = TC - 1; s >= slo; --s) {
+                    float r = lr[s * W], v0 = lv[s * W], m1 = lm[s * W];
+                    float bad1 = PTL ? lb[s * W] : 1.f;
+                    float dv0;
+                    float ret = gae_step<PTL, DENORM>(r, v0, m1, bad1, sigma, mu, gamma, gl, dv1, g, dv0);
+                    if (live) {
+                        long long o = (long long)(tbase + s) * C + col;
+                        a.returns[o] = ret;
+                        if (has_adv) {
+                            float adv = ret - dv0;  // r_mappo.py:180 (from the rounded return)
+                            a.adv[o] = adv;
+                            float am = has_act ? la[s * W] : 1.f;
+                            if (am != 0.f) {
+                                double d = (double)adv;
+                                s1 += d;
+                                s2 += d * d;
+                                cnt += 1.0;
+                            }
                         }
                     }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
+#undef MAPPO_LOAD_TILE
+#undef MAPPO_STASH_TILE
 
     zero_unowned_partials(a.partials, a.partial_rows);
     if (walker && a.partials != nullptr) {
@@ -429,20 +447,21 @@ __global__ void __launch_bounds__(256) advantages_kernel(const float* ret, const
 
 int g_variant = 0;
 
-template <int W, int NWAVES, int TC>
+template <int W, int NWAVES, int TC, int NBUF = 1, bool WLOAD = true>
 hipError_t launch_strip(const GaeArgs& a, unsigned flags, hipStream_t stream) {
     const bool ptl = flags & MAPPO_GAE_PROPER_TIME_LIMITS;
     const bool den = flags & MAPPO_GAE_DENORM;
-    const size_t lds = (size_t)5 * TC * W * sizeof(float);  // r, v, m, bad, active slots
+    const int slots = 3 + (ptl ? 1 : 0) + (a.active ? 1 : 0);
+    const size_t lds = (size_t)slots * TC * W * sizeof(float);
     dim3 grid((unsigned)((a.C + W - 1) / W)), block(NWAVES * 64);
     if (ptl && den)
-        hipLaunchKernelGGL((gae_strip_kernel<W, NWAVES, TC, true, true>), grid, block, lds, stream, a);
+        hipLaunchKernelGGL((gae_strip_kernel<W, NWAVES, TC, NBUF, WLOAD, true, true>), grid, block, lds, stream, a);
     else if (ptl)
-        hipLaunchKernelGGL((gae_strip_kernel<W, NWAVES, TC, true, false>), grid, block, lds, stream, a);
+        hipLaunchKernelGGL((gae_strip_kernel<W, NWAVES, TC, NBUF, WLOAD, true, false>), grid, block, lds, stream, a);
     else if (den)
-        hipLaunchKernelGGL((gae_strip_kernel<W, NWAVES, TC, false, true>), grid, block, lds, stream, a);
+        hipLaunchKernelGGL((gae_strip_kernel<W, NWAVES, TC, NBUF, WLOAD, false, true>), grid, block, lds, stream, a);
     else
-        hipLaunchKernelGGL((gae_strip_kernel<W, NWAVES, TC, false, false>), grid, block, lds, stream, a);
+        hipLaunchKernelGGL((gae_strip_kernel<W, NWAVES, TC, NBUF, WLOAD, false, false>), grid, block, lds, stream, a);
     return hipGetLastError();
 }
 
@@ -461,7 +480,8 @@ hipError_t launch_column(const GaeArgs& a, unsigned flags, hipStream_t stream) {
     } else {
         if (ptl && den) MAPPO_COL(false, true, true);
         else if (ptl) MAPPO_COL(false, true, false);
-        else MAPPO_COL(false, false, false);  // DENORM is irrelevant without PTL
+        else if (den) MAPPO_COL(false, false, true);  // D() only enters the fused advantages here
+        else MAPPO_COL(false, false, false);
     }
 #undef MAPPO_COL
     return hipGetLastError();
@@ -539,18 +559,25 @@ extern "C" int mappo_gae_f32(const float* rewards, float* value_preds, const flo
                           (!a.bad || aligned16(bad_masks)) && (!a.active || aligned16(active_masks));
     int variant = g_variant;
     if (!strip_ok) variant = 99;
-    if (variant == 0) variant = (C >= 64 * 256) ? 1 : (C >= 32 * 256 ? 3 : 6);
+    if (variant == 0) variant = (C >= 64 * 256) ? 2 : (C >= 32 * 256 ? 3 : 6);
 
     hipError_t e;
     switch (variant) {
         case 1: e = launch_strip<64, 1, 32>(a, flags, stream); break;
         case 2: e = launch_strip<64, 4, 32>(a, flags, stream); break;
         case 3: e = launch_strip<32, 1, 32>(a, flags, stream); break;
-        case 4: e = launch_strip<32, 1, 64>(a, flags, stream); break;
         case 5: e = launch_strip<64, 2, 32>(a, flags, stream); break;
         case 6: e = launch_strip<16, 1, 64>(a, flags, stream); break;
-        case 7: e = launch_strip<64, 1, 16>(a, flags, stream); break;
-        case 8: e = launch_strip<32, 2, 64>(a, flags, stream); break;
+        case 10: e = launch_strip<64, 4, 32, 2>(a, flags, stream); break;
+        case 11: e = launch_strip<64, 4, 64, 1>(a, flags, stream); break;
+        case 12: e = launch_strip<64, 8, 64, 1>(a, flags, stream); break;
+        case 13: e = launch_strip<64, 8, 32, 2>(a, flags, stream); break;
+        case 14: e = launch_strip<64, 4, 16, 2>(a, flags, stream); break;
+        case 15: e = launch_strip<64, 4, 32, 1, false>(a, flags, stream); break;
+        case 16: e = launch_strip<64, 4, 32, 2, false>(a, flags, stream); break;
+        case 17: e = launch_strip<64, 8, 64, 2, false>(a, flags, stream); break;
+        case 18: e = launch_strip<32, 4, 64, 2>(a, flags, stream); break;
+        case 19: e = launch_strip<64, 8, 64, 2>(a, flags, stream); break;
         default: e = launch_column(a, flags, stream); break;
     }
     return (int)e;

@@ -43,6 +43,7 @@ SIGNATURES = {
     "mappo_adv_normalize": (_int, [_vp, _vp, _vp, _i64, _vp]),
     "mappo_gather_rows": (_int, [ctypes.POINTER(Field), _int, _vp, _i64, _vp, _vp]),
     "mappo_gather_chunks": (_int, [ctypes.POINTER(Field), _int, _vp, _i64, _int, _int, _i64, _int, _vp, _vp]),
+    "mappo_gather_set_variant": (_int, [_int]),
     "mappo_slab_copy": (_int, [ctypes.POINTER(Slab), _int, _vp]),
     "mappo_abi_version": (_int, []),
     "mappo_build_info": (ctypes.c_char_p, []),

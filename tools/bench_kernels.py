@@ -47,7 +47,8 @@ def main():
     ap.add_argument("--T", type=int, default=400)
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--A", type=int, default=8)
-    ap.add_argument("--variants", default="1,2,3,4,5,6,7,8,99")
+    ap.add_argument("--variants", default="1,2,3,5,10,11,12,13,14,15,16,17,18,19,99")
+    ap.add_argument("--gather-variants", default="0,1,2,3,4,5,6,7,18,19,34,35")
     ap.add_argument("--sets", type=int, default=6)
     ap.add_argument("--iters", type=int, default=24)
     ap.add_argument("--gather-N", type=int, default=1024)
@@ -77,6 +78,33 @@ def main():
                  ret=torch.zeros(T + 1, C, device=dev), adv=torch.zeros(T, C, device=dev),
                  nv=torch.randn(C, device=dev, generator=g))
         sets.append(d)
+    # ceilings for the scan's traffic mix (3 reads + 1 write), flat and in the strip pattern
+    import ctypes
+    probe_path = os.path.join(ROOT, "tools", "libprobe.so")
+    if os.path.exists(probe_path):
+        P = ctypes.CDLL(probe_path)
+        vp = ctypes.c_void_p
+        P.probe_flat.argtypes = [vp, vp, vp, vp, ctypes.c_longlong, ctypes.c_int, vp]
+        P.probe_strip.argtypes = [vp, vp, vp, vp, ctypes.c_int, ctypes.c_longlong, ctypes.c_int, vp]
+        pr = {}
+        n = T * C
+        for blocks in (2048, 4096, 8192):
+            def fn(i):
+                d = sets[i]
+                assert P.probe_flat(d["r"].data_ptr(), d["v"].data_ptr(), d["m"].data_ptr(), d["ret"].data_ptr(),
+                                    n, blocks, stream) == 0
+            t = time_launches(fn, opt.sets, opt.iters)
+            t["GBps_b2b"] = 16 * n / (t["b2b_us"] * 1e-6) / 1e9
+            pr["flat_%d" % blocks] = t
+        for v in (0, 1, 2, 3):
+            def fn(i):
+                d = sets[i]
+                assert P.probe_strip(d["r"].data_ptr(), d["v"].data_ptr(), d["m"].data_ptr(), d["ret"].data_ptr(),
+                                     T, C, v, stream) == 0
+            t = time_launches(fn, opt.sets, opt.iters)
+            t["GBps_b2b"] = 16 * n / (t["b2b_us"] * 1e-6) / 1e9
+            pr["strip_v%d" % v] = t
+        out["probe_3r1w"] = pr
     den = torch.tensor([0.1, 0.0], device=dev)
     rows = lib.mappo_gae_partial_rows(C)
     partials = torch.zeros(rows, 3, dtype=torch.float64, device=dev)
@@ -110,12 +138,28 @@ def main():
         dst = {k: torch.empty(B, w, device=dev) for k, w in widths.items()}
         stats = torch.tensor([0.0, 1.0], device=dev)
         gres = {}
-        for label, names in (("all_fields", list(widths)), ("share_obs_only", ["share_obs"]),
-                             ("scalars_only", ["actions", "value_preds", "returns", "masks", "active_masks", "logp", "adv"])):
+        perms = [torch.randperm(B, device=dev) for _ in range(2)]
+        combos = [("all_fields", list(widths)), ("share_obs_only", ["share_obs"]),
+                  ("scalars_only", ["actions", "value_preds", "returns", "masks", "active_masks", "logp", "adv"])]
+        for gv in [int(v) for v in opt.gather_variants.split(",")]:
+            lib.mappo_gather_set_variant(gv)
+            for label, names in combos[:2]:
+                fields = (_native.Field * len(names))(*[
+                    _native.Field(src[k].data_ptr(), dst[k].data_ptr(), widths[k], 0, 1 if k == "adv" else 0, 0)
+                    for k in names])
+
+                def fn(i):
+                    code = lib.mappo_gather_rows(fields, len(names), perms[i].data_ptr(), B, p(stats), stream)
+                    assert code == 0, code
+                t = time_launches(fn, 2, 4, warm=1)
+                nbytes = sum(2 * 4 * widths[k] for k in names) * B + 8 * B
+                gres["gv%d_%s" % (gv, label)] = {"ms": t["median_us"] / 1e3,
+                                                 "GBps": nbytes / (t["median_us"] * 1e-6) / 1e9}
+        lib.mappo_gather_set_variant(0)
+        for label, names in combos:
             fields = (_native.Field * len(names))(*[
                 _native.Field(src[k].data_ptr(), dst[k].data_ptr(), widths[k], 0, 1 if k == "adv" else 0, 0)
                 for k in names])
-            perms = [torch.randperm(B, device=dev) for _ in range(2)]
 
             def fn(i):
                 code = lib.mappo_gather_rows(fields, len(names), perms[i].data_ptr(), B, p(stats), stream)

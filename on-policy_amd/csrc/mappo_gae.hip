@@ -26,6 +26,7 @@
 #include "mappo_internal.h"
 
 #pragma clang fp contract(off)
+typedef float vf4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -97,152 +98,115 @@ __device__ __forceinline__ void zero_unowned_partials(double* partials, long lon
     }
 }
 
-// ------------------------------------------------------------------ strip kernel ----
-// W      columns per strip (multiple of 4, <= 64)
-// NWAVES waves per workgroup (wave 0 walks the recurrence; LOADERS selects who streams)
-// TC     time steps per tile
-// NBUF   register prefetch depth in tiles (1 or 2): tiles k+1 .. k+NBUF are in flight while
-//        tile k is walked
-// WLOAD  whether the walker wave also issues loads (false: waves 1.. are pure producers)
-template <int W, int NWAVES, int TC, int NBUF, bool WLOAD, bool PTL, bool DENORM>
-__global__ void __launch_bounds__(NWAVES * 64) gae_strip_kernel(GaeArgs a) {
-    constexpr int NT = NWAVES * 64;
-    constexpr int NL = WLOAD ? NT : NT - 64;    // loader threads
-    constexpr int V = W / 4;                    // float4 per tile row
-    constexpr int NVEC = TC * V;                // float4 per field per tile
-    constexpr int PER = (NVEC + NL - 1) / NL;   // float4 per loader thread per field
-    constexpr int NFMAX = 5;                    // r, v, m, bad, active
-    static_assert(W % 4 == 0 && W <= 64, "strip width");
-    static_assert(WLOAD || NWAVES > 1, "pure-walker needs producer waves");
-    static_assert(NBUF == 1 || NBUF == 2, "prefetch depth");
+// ------------------------------------------------------------------ strip kernels ----
+// Shared pieces of the two strip kernels.  A tile is TC consecutive time steps of one strip
+// of W columns; in LDS it is [slot][TC][W] floats with slots r, v, m, [bad], [active].
+//
+// Loads are branch-free: out-of-range rows / columns / surplus lanes are CLAMPED to a valid
+// address instead of predicated, so that every tile issues the same straight-line sequence of
+// global_load_dwordx4 and the compiler can wait for the oldest tile with a counted
+// s_waitcnt vmcnt(N) while younger tiles stay in flight (a predicated load makes it fall back
+// to vmcnt(0), which drains the whole prefetch queue).
+// Implemented as macros over local arrays with literal indices: anything the compiler cannot
+// fully scalarise (arrays passed by reference, runtime buffer indices) lands in scratch memory.
+#define MAPPO_TILE_CONSTS(W_, TC_, NL_, PTL_, ACT_)                                              \
+    constexpr int V = (W_) / 4;                    /* float4 per tile row */                     \
+    constexpr int NVEC = (TC_) * V;                /* float4 per field per tile */               \
+    constexpr int PER = (NVEC + (NL_) - 1) / (NL_);/* float4 per loader thread per field */      \
+    constexpr int NF = 3 + ((PTL_) ? 1 : 0) + ((ACT_) ? 1 : 0);                                  \
+    constexpr int NLOAD = (NL_);
 
-    extern __shared__ float4 lds4[];            // [slots][TC][V], slots = fields in use
-    float* ldsf = reinterpret_cast<float*>(lds4);
+// slot s -> field base pointer (masks / bad_masks are read at row t+1)
+#define MAPPO_SLOT_BASE(s)                                                                       \
+    ((s) == 0 ? a.rewards : (s) == 1 ? (const float*)a.value_preds : (s) == 2 ? a.masks + a.C    \
+     : ((s) == 3 && PTL) ? a.bad + a.C : a.active)
 
-    const int tid = threadIdx.x;
-    const long long col0 = (long long)blockIdx.x * W;
-    const long long C = a.C;
-    const int T = a.T;
-    const bool has_act = a.active != nullptr;
+#define MAPPO_LOAD_TILE(PRE, LTID, TBASE)                                                        \
+    _Pragma("unroll") for (int s_ = 0; s_ < NF; ++s_) {                                          \
+        const float* fb_ = MAPPO_SLOT_BASE(s_);                                                  \
+        _Pragma("unroll") for (int p_ = 0; p_ < PER; ++p_) {                                     \
+            int i_ = (LTID) + p_ * NLOAD;                                                        \
+            if (i_ > NVEC - 1) i_ = NVEC - 1;                                                    \
+            int row_ = i_ / V;                                                                   \
+            int c4_ = i_ - row_ * V;                                                             \
+            int t_ = (TBASE) + row_;                                                             \
+            if (t_ < 0) t_ = 0;                                                                  \
+            long long lc_ = col0 + c4_ * 4;                                                      \
+            if (lc_ > a.C - 4) lc_ = a.C - 4;                                                    \
+            PRE[s_][p_] = *reinterpret_cast<const vf4*>(fb_ + (long long)t_ * a.C + lc_);     \
+        }                                                                                        \
+    }
+
+#define MAPPO_STASH_TILE(PRE, LTID, LDS4)                                                        \
+    _Pragma("unroll") for (int s_ = 0; s_ < NF; ++s_) {                                          \
+        _Pragma("unroll") for (int p_ = 0; p_ < PER; ++p_) {                                     \
+            int i_ = (LTID) + p_ * NLOAD;                                                        \
+            if ((NVEC % NLOAD == 0) || i_ < NVEC) (LDS4)[s_ * NVEC + i_] = PRE[s_][p_];          \
+        }                                                                                        \
+    }
+
+// Walk one tile backwards in time out of LDS (one lane per column).
+template <int W, int TC, bool PTL, bool DENORM, bool ACT>
+__device__ __forceinline__ void walk_tile(const GaeArgs& a, const float* ldsf, int lane, long long col,
+                                          bool live, int tbase, float sigma, float mu, float& g,
+                                          float& dv1, double& s1, double& s2, double& cnt) {
+    constexpr int TILE = TC * W;
     const bool has_adv = a.adv != nullptr;
-    const bool loader = WLOAD || tid >= 64;
-    const int ltid = WLOAD ? tid : tid - 64;    // index among loader threads
-
-    // field f: base pointer (masks / bad_masks are read at row t+1) and LDS slot
-    const float* fbase[NFMAX] = {a.rewards, a.value_preds, a.masks + C, PTL ? a.bad + C : nullptr,
-                                 a.active};
-    const int act_slot = PTL ? 4 : 3;
-
-    float4 pre[NBUF][NFMAX][PER];
-
-#define MAPPO_LOAD_TILE(B, TBASE)                                                               \
-    if (loader) {                                                                               \
-        _Pragma("unroll") for (int f = 0; f < NFMAX; ++f) {                                     \
-            if (f == 3 && !PTL) continue;                                                       \
-            if (f == 4 && !has_act) continue;                                                   \
-            _Pragma("unroll") for (int p = 0; p < PER; ++p) {                                   \
-                int i = ltid + p * NL;                                                          \
-                int row = i / V;                                                                \
-                int c4 = i - row * V;                                                           \
-                int t = (TBASE) + row;                                                          \
-                long long lc = col0 + c4 * 4;                                                   \
-                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);                                   \
-                if (i < NVEC && t >= 0 && lc < C)                                               \
-                    val = *reinterpret_cast<const float4*>(fbase[f] + (long long)t * C + lc);   \
-                pre[B][f][p] = val;                                                             \
-            }                                                                                   \
-        }                                                                                       \
+    const int lc = lane < W ? lane : 0;  // lanes beyond the strip stay in bounds
+    const float* lr = ldsf + 0 * TILE + lc;
+    const float* lv = ldsf + 1 * TILE + lc;
+    const float* lm = ldsf + 2 * TILE + lc;
+    const float* lb = ldsf + 3 * TILE + lc;
+    const float* la = ldsf + (PTL ? 4 : 3) * TILE + lc;
+    const int slo = tbase < 0 ? -tbase : 0;
+    const float gamma = a.gamma, gl = a.gl;
+    const long long C = a.C;
+#pragma unroll 8
+    for (int s = TC - 1; s >= slo; --s) {
+        float r = lr[s * W], v0 = lv[s * W], m1 = lm[s * W];
+        float bad1 = PTL ? lb[s * W] : 1.f;
+        float dv0;
+        float ret = gae_step<PTL, DENORM>(r, v0, m1, bad1, sigma, mu, gamma, gl, dv1, g, dv0);
+        if (live) {
+            long long o = (long long)(tbase + s) * C + col;
+            a.returns[o] = ret;
+            if (has_adv) {
+                float adv = ret - dv0;  // r_mappo.py:180 (from the rounded return)
+                a.adv[o] = adv;
+                float am = ACT ? la[s * W] : 1.f;
+                if (am != 0.f) {
+                    double d = (double)adv;
+                    s1 += d;
+                    s2 += d * d;
+                    cnt += 1.0;
+                }
+            }
+        }
     }
-#define MAPPO_STASH_TILE(B)                                                                     \
-    if (loader) {                                                                               \
-        _Pragma("unroll") for (int f = 0; f < NFMAX; ++f) {                                     \
-            if (f == 3 && !PTL) continue;                                                       \
-            if (f == 4 && !has_act) continue;                                                   \
-            const int slot = f == 4 ? act_slot : f;                                             \
-            _Pragma("unroll") for (int p = 0; p < PER; ++p) {                                   \
-                int i = ltid + p * NL;                                                          \
-                if (i < NVEC) lds4[slot * NVEC + i] = pre[B][f][p];                             \
-            }                                                                                   \
-        }                                                                                       \
-    }
+}
 
-    const int lane = tid;  // only wave 0 walks: lane == tid there
-    const long long col = col0 + lane;
-    const bool walker = (tid < 64);
-    const bool live = walker && lane < W && col < C;
-
-    float sigma = 1.f, mu = 0.f;
-    if (DENORM) {
+__device__ __forceinline__ void walker_prologue(const GaeArgs& a, bool live, long long col, bool denorm,
+                                                float& sigma, float& mu, float& dv1) {
+    sigma = 1.f;
+    mu = 0.f;
+    if (denorm) {
         sigma = a.denorm[0];
         mu = a.denorm[1];
     }
-    const float gamma = a.gamma, gl = a.gl;
-
-    float g = 0.f, dv1 = 0.f;
-    double s1 = 0.0, s2 = 0.0, cnt = 0.0;
+    dv1 = 0.f;
     if (live) {
         float nv = a.next_value[col];
-        a.value_preds[(long long)T * C + col] = nv;  // shared_buffer.py:187,218
+        a.value_preds[(long long)a.T * a.C + col] = nv;  // shared_buffer.py:187,218
         dv1 = nv;
-        if (DENORM) {
+        if (denorm) {
             float s = nv * sigma;
             dv1 = s + mu;
         }
     }
+}
 
-    const int nch = (T + TC - 1) / TC;
-    MAPPO_LOAD_TILE(0, T - TC)
-    if (NBUF == 2) {
-        if (nch > 1) MAPPO_LOAD_TILE(NBUF - 1, T - 2 * TC)
-    }
-    for (int k0 = 0; k0 < nch; k0 += NBUF) {
-#pragma unroll
-        for (int b = 0; b < NBUF; ++b) {
-            const int k = k0 + b;
-            if (k >= nch) break;
-            const int tbase = T - (k + 1) * TC;
-            MAPPO_STASH_TILE(b)
-            __syncthreads();
-            if (k + NBUF < nch) MAPPO_LOAD_TILE(b, tbase - NBUF * TC)  // in flight during the walk(s)
-            if (walker) {
-                const int lc = lane < W ? lane : 0;  // lanes beyond the strip stay in bounds
-                const float* lr = ldsf + 0 * NVEC * 4 + lc;
-                const float* lv = ldsf + 1 * NVEC * 4 + lc;
-                const float* lm = ldsf + 2 * NVEC * 4 + lc;
-                const float* lb = ldsf + 3 * NVEC * 4 + lc;
-                const float* la = ldsf + act_slot * NVEC * 4 + lc;
-                const int slo = tbase < 0 ? -tbase : 0;
-#pragma unroll 8
-                for (int s = TC - 1; s >= slo; --s) {
-                    float r = lr[s * W], v0 = lv[s * W], m1 = lm[s * W];
-                    float bad1 = PTL ? lb[s * W] : 1.f;
-                    float dv0;
-                    float ret = gae_step<PTL, DENORM>(r, v0, m1, bad1, sigma, mu, gamma, gl, dv1, g, dv0);
-                    if (live) {
-                        long long o = (long long)(tbase + s) * C + col;
-                        a.returns[o] = ret;
-                        if (has_adv) {
-                            float adv = ret - dv0;  // r_mappo.py:180 (from the rounded return)
-                            a.adv[o] = adv;
-                            float am = has_act ? la[s * W] : 1.f;
-                            if (am != 0.f) {
-                                double d = (double)adv;
-                                s1 += d;
-                                s2 += d * d;
-                                cnt += 1.0;
-                            }
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
-#undef MAPPO_LOAD_TILE
-#undef MAPPO_STASH_TILE
-
-    zero_unowned_partials(a.partials, a.partial_rows);
-    if (walker && a.partials != nullptr) {
+__device__ __forceinline__ void walker_epilogue(const GaeArgs& a, int lane, double s1, double s2, double cnt) {
+    if (a.partials != nullptr) {
         s1 = wave_sum(s1);
         s2 = wave_sum(s2);
         cnt = wave_sum(cnt);
@@ -254,6 +218,222 @@ __global__ void __launch_bounds__(NWAVES * 64) gae_strip_kernel(GaeArgs a) {
         }
     }
 }
+
+// ---- "pipe" kernel: one walker wave + NPROD producer waves per strip ---------------------
+// Producers keep NBUF tiles in flight in registers (global -> VGPR), drop the oldest into
+// one half of a double-buffered LDS tile while the walker consumes the other half, and meet
+// the walker at ONE barrier per tile.  The walker does nothing but the recurrence.
+template <int W, int NPROD, int TC, int NBUF, bool PTL, bool DENORM, bool ACT>
+__global__ void __launch_bounds__((NPROD + 1) * 64) gae_pipe_kernel(GaeArgs a) {
+    MAPPO_TILE_CONSTS(W, TC, NPROD * 64, PTL, ACT)
+    static_assert(NBUF >= 1 && NBUF <= 4, "prefetch depth");
+    constexpr int TILE4 = NF * NVEC;             // float4 per LDS tile buffer
+    extern __shared__ vf4 lds4[];             // [2][NF][TC][V]
+    const int T = a.T;
+    const int nch = (T + TC - 1) / TC;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const long long col0 = (long long)blockIdx.x * W;
+    zero_unowned_partials(a.partials, a.partial_rows);
+
+    if (wave == 0) {
+        const int lane = threadIdx.x;
+        const long long col = col0 + lane;
+        const bool live = lane < W && col < a.C;
+        float sigma, mu, dv1, g = 0.f;
+        double s1 = 0.0, s2 = 0.0, cnt = 0.0;
+        walker_prologue(a, live, col, DENORM, sigma, mu, dv1);
+        __syncthreads();                                        // tile 0 is in LDS half 0
+        for (int k = 0; k < nch; ++k) {
+            const float* tile = reinterpret_cast<const float*>(lds4 + (k & 1) * TILE4);
+            walk_tile<W, TC, PTL, DENORM, ACT>(a, tile, lane, col, live, T - (k + 1) * TC, sigma, mu, g,
+                                               dv1, s1, s2, cnt);
+            __syncthreads();                                    // tile k+1 stashed, tile k released
+        }
+        walker_epilogue(a, lane, s1, s2, cnt);
+    } else {
+        const int ltid = threadIdx.x - 64;
+        // tile m lives in register buffer m % NBUF
+        vf4 pre0[NF][PER], pre1[NF][PER], pre2[NF][PER], pre3[NF][PER];
+        MAPPO_LOAD_TILE(pre0, ltid, T - 1 * TC)
+        if (NBUF > 1) { MAPPO_LOAD_TILE(pre1, ltid, T - 2 * TC) }
+        if (NBUF > 2) { MAPPO_LOAD_TILE(pre2, ltid, T - 3 * TC) }
+        if (NBUF > 3) { MAPPO_LOAD_TILE(pre3, ltid, T - 4 * TC) }
+        MAPPO_STASH_TILE(pre0, ltid, lds4)
+        MAPPO_LOAD_TILE(pre0, ltid, T - (NBUF + 1) * TC)
+        __syncthreads();
+        // step k: the walker walks tile k; producers stash tile k+1 into LDS half (k+1)&1 and
+        // refill its register buffer with tile k+1+NBUF
+#define MAPPO_PIPE_STEP(PRE)                                                                     \
+        if (k < nch) {                                                                           \
+            MAPPO_STASH_TILE(PRE, ltid, lds4 + ((k + 1) & 1) * TILE4)                            \
+            MAPPO_LOAD_TILE(PRE, ltid, T - (k + 2 + NBUF) * TC)                                  \
+            __syncthreads();                                                                     \
+        }                                                                                        \
+        ++k;
+        for (int k = 0; k < nch;) {
+            if (NBUF == 1) { MAPPO_PIPE_STEP(pre0) }
+            if (NBUF == 2) { MAPPO_PIPE_STEP(pre1) MAPPO_PIPE_STEP(pre0) }
+            if (NBUF == 3) { MAPPO_PIPE_STEP(pre1) MAPPO_PIPE_STEP(pre2) MAPPO_PIPE_STEP(pre0) }
+            if (NBUF == 4) { MAPPO_PIPE_STEP(pre1) MAPPO_PIPE_STEP(pre2) MAPPO_PIPE_STEP(pre3) MAPPO_PIPE_STEP(pre0) }
+        }
+#undef MAPPO_PIPE_STEP
+        (void)pre1; (void)pre2; (void)pre3;
+    }
+}
+
+// ---- "dma" kernel: producers stream tiles straight into an LDS ring with LDS-DMA ---------
+// (global_load_lds_dwordx4: global -> LDS without passing through VGPRs, gfx950).  One walker
+// wave + NPROD producer waves per strip of W columns; the ring holds R tiles of TC steps.
+// While the walker consumes tile k, tiles k+1 .. k+R-1 are in flight or landed.  The DMA
+// loads are issued from inline asm, so the compiler neither counts nor drains them: the
+// producers wait for exactly the oldest tile with a counted s_waitcnt vmcnt(N) and then meet
+// the walker at one s_barrier per tile (DMA data is visible to other waves after the issuing
+// wave's vmcnt wait + a barrier).
+//
+// One wave instruction moves 64 lanes x 16 B = 1 KiB: RPI = 256 / W consecutive tile rows of
+// one field; LDS destination = wave-uniform base + lane * 16 (so a tile slot is [TC][W] floats,
+// rows contiguous), global source address is per lane.
+__device__ __forceinline__ void lds_dma_16B(const float* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int W, int NPROD, int TC, int R, bool PTL, bool DENORM, bool ACT>
+__global__ void __launch_bounds__((NPROD + 1) * 64) gae_dma_kernel(GaeArgs a) {
+    constexpr int NF = 3 + (PTL ? 1 : 0) + (ACT ? 1 : 0);
+    constexpr int RPI = 256 / W;                   // tile rows per wave instruction
+    constexpr int IPS = TC / RPI;                  // instructions per slot (field) per tile
+    constexpr int IPT = NF * IPS;                  // instructions per tile
+    constexpr int LPT = IPT / NPROD;               // instructions per producer wave per tile
+    constexpr int TILE_FLOATS = NF * TC * W;
+    static_assert(TC % RPI == 0 && IPS % NPROD == 0, "row groups must split evenly over the producers");
+    static_assert(R >= 2 && (R - 2) * LPT < 64, "ring depth vs the 6-bit vmcnt");
+    static_assert(R * TILE_FLOATS * 4 <= 65536, "LDS-DMA destinations are kept inside the first 64 KiB");
+
+    extern __shared__ vf4 lds4[];                  // [R][NF][TC][W / 4]
+    float* ldsf = reinterpret_cast<float*>(lds4);
+    const int T = a.T;
+    const int nch = (T + TC - 1) / TC;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const long long col0 = (long long)blockIdx.x * W;
+    zero_unowned_partials(a.partials, a.partial_rows);
+
+    if (wave == 0) {
+        const int lane = threadIdx.x;
+        const long long col = col0 + lane;
+        const bool live = lane < W && col < a.C;
+        float sigma, mu, dv1, g = 0.f;
+        double s1 = 0.0, s2 = 0.0, cnt = 0.0;
+        walker_prologue(a, live, col, DENORM, sigma, mu, dv1);
+        __syncthreads();                                        // tile 0 landed
+        int slot = 0;
+        for (int k = 0; k < nch; ++k) {
+            walk_tile<W, TC, PTL, DENORM, ACT>(a, ldsf + slot * TILE_FLOATS, lane, col, live,
+                                               T - (k + 1) * TC, sigma, mu, g, dv1, s1, s2, cnt);
+            slot = slot + 1 == R ? 0 : slot + 1;
+            __syncthreads();                                    // tile k+1 landed, tile k released
+        }
+        walker_epilogue(a, lane, s1, s2, cnt);
+    } else {
+        const int lane = threadIdx.x & 63;
+        const int pw = wave - 1;                                // producer index
+        const unsigned lds_base = (unsigned)(uintptr_t)ldsf;    // LDS byte address of the ring
+        // this lane's place inside one instruction: row r0 (of RPI), 4-column group c4
+        const int r0 = lane / (W / 4);
+        const int c4 = lane - r0 * (W / 4);
+        long long lc = col0 + c4 * 4;
+        if (lc > a.C - 4) lc = a.C - 4;                         // clamp instead of predicating
+        const float* fb0 = a.rewards + lc;
+        const float* fb1 = a.value_preds + lc;
+        const float* fb2 = a.masks + a.C + lc;
+        const float* fb3 = (PTL ? a.bad + a.C : a.active) + lc;
+        const float* fb4 = a.active + lc;
+
+        // tile with time base `tbase` -> ring slot `slot`; field index is compile-time, this
+        // wave takes row groups pw, pw + NPROD, ... of every field
+        auto issue_tile = [&](int tbase, int slot) {
+            const unsigned slot_addr = lds_base + (unsigned)slot * (TILE_FLOATS * 4);
+#pragma unroll
+            for (int s = 0; s < NF; ++s) {
+                const float* fbs = s == 0 ? fb0 : s == 1 ? fb1 : s == 2 ? fb2 : (s == 3 && PTL) ? fb3 : fb4;
+#pragma unroll
+                for (int q = 0; q < IPS / NPROD; ++q) {
+                    const int rg = pw + q * NPROD;              // row group inside the tile
+                    int t = tbase + rg * RPI + r0;
+                    if (t < 0) t = 0;
+                    lds_dma_16B(fbs + (long long)t * a.C, slot_addr + (unsigned)((s * TC + rg * RPI) * W * 4));
+                }
+            }
+        };
+
+        // prologue: tiles 0 .. R-2 in flight, wait for tile 0
+#pragma unroll
+        for (int m = 0; m < R - 1; ++m) issue_tile(T - (m + 1) * TC, m);
+        wait_vmcnt<(R - 2) * LPT>();
+        __syncthreads();
+        int slot = R - 1;                     // ring slot of tile k + R - 1
+        for (int k = 0; k < nch; ++k) {
+            issue_tile(T - (k + R) * TC, slot);   // the slot the walker released at the last barrier
+            slot = slot + 1 == R ? 0 : slot + 1;
+            wait_vmcnt<(R - 2) * LPT>();      // tile k+1 has landed; k+2 .. k+R-1 stay in flight
+            __syncthreads();
+        }
+        wait_vmcnt<0>();
+    }
+}
+
+// ---- "coop" kernel: every wave loads, wave 0 walks, single LDS tile (small strips) ---------
+template <int W, int NWAVES, int TC, bool PTL, bool DENORM, bool ACT>
+__global__ void __launch_bounds__(NWAVES * 64) gae_strip_kernel(GaeArgs a) {
+    MAPPO_TILE_CONSTS(W, TC, NWAVES * 64, PTL, ACT)
+    extern __shared__ vf4 lds4[];            // [NF][TC][V]
+    const int tid = threadIdx.x;
+    const long long col0 = (long long)blockIdx.x * W;
+    const int T = a.T;
+    const int lane = tid;
+    const long long col = col0 + lane;
+    const bool walker = tid < 64;
+    const bool live = walker && lane < W && col < a.C;
+
+    vf4 pre[NF][PER];
+    float sigma, mu, dv1, g = 0.f;
+    double s1 = 0.0, s2 = 0.0, cnt = 0.0;
+    walker_prologue(a, live, col, DENORM, sigma, mu, dv1);
+
+    const int nch = (T + TC - 1) / TC;
+    MAPPO_LOAD_TILE(pre, tid, T - TC)
+    for (int k = 0; k < nch; ++k) {
+        const int tbase = T - (k + 1) * TC;
+        MAPPO_STASH_TILE(pre, tid, lds4)
+        __syncthreads();
+        MAPPO_LOAD_TILE(pre, tid, tbase - TC)    // in flight while wave 0 walks this tile
+        if (walker)
+            walk_tile<W, TC, PTL, DENORM, ACT>(a, reinterpret_cast<const float*>(lds4), lane, col, live,
+                                               tbase, sigma, mu, g, dv1, s1, s2, cnt);
+        __syncthreads();
+    }
+    zero_unowned_partials(a.partials, a.partial_rows);
+    if (walker) walker_epilogue(a, lane, s1, s2, cnt);
+}
+
+#undef MAPPO_LOAD_TILE
+#undef MAPPO_STASH_TILE
+#undef MAPPO_SLOT_BASE
+#undef MAPPO_TILE_CONSTS
 
 // ----------------------------------------------------------------- column kernel ----
 // One lane per column, any C, all seven reference branches.
@@ -447,21 +627,49 @@ __global__ void __launch_bounds__(256) advantages_kernel(const float* ret, const
 
 int g_variant = 0;
 
-template <int W, int NWAVES, int TC, int NBUF = 1, bool WLOAD = true>
+#define MAPPO_DISPATCH_FLAGS(KERNEL, ...)                                                        \
+    do {                                                                                         \
+        const bool ptl = flags & MAPPO_GAE_PROPER_TIME_LIMITS;                                   \
+        const bool den = flags & MAPPO_GAE_DENORM;                                               \
+        const bool act = a.active != nullptr;                                                    \
+        const int sel = (ptl ? 4 : 0) | (den ? 2 : 0) | (act ? 1 : 0);                           \
+        switch (sel) {                                                                           \
+            case 0: hipLaunchKernelGGL((KERNEL<__VA_ARGS__, false, false, false>), grid, block, lds, stream, a); break; \
+            case 1: hipLaunchKernelGGL((KERNEL<__VA_ARGS__, false, false, true>), grid, block, lds, stream, a); break;  \
+            case 2: hipLaunchKernelGGL((KERNEL<__VA_ARGS__, false, true, false>), grid, block, lds, stream, a); break;  \
+            case 3: hipLaunchKernelGGL((KERNEL<__VA_ARGS__, false, true, true>), grid, block, lds, stream, a); break;   \
+            case 4: hipLaunchKernelGGL((KERNEL<__VA_ARGS__, true, false, false>), grid, block, lds, stream, a); break;  \
+            case 5: hipLaunchKernelGGL((KERNEL<__VA_ARGS__, true, false, true>), grid, block, lds, stream, a); break;   \
+            case 6: hipLaunchKernelGGL((KERNEL<__VA_ARGS__, true, true, false>), grid, block, lds, stream, a); break;   \
+            default: hipLaunchKernelGGL((KERNEL<__VA_ARGS__, true, true, true>), grid, block, lds, stream, a); break;   \
+        }                                                                                        \
+    } while (0)
+
+inline int gae_slots(const GaeArgs& a, unsigned flags) {
+    return 3 + ((flags & MAPPO_GAE_PROPER_TIME_LIMITS) ? 1 : 0) + (a.active ? 1 : 0);
+}
+
+template <int W, int NWAVES, int TC>
 hipError_t launch_strip(const GaeArgs& a, unsigned flags, hipStream_t stream) {
-    const bool ptl = flags & MAPPO_GAE_PROPER_TIME_LIMITS;
-    const bool den = flags & MAPPO_GAE_DENORM;
-    const int slots = 3 + (ptl ? 1 : 0) + (a.active ? 1 : 0);
-    const size_t lds = (size_t)slots * TC * W * sizeof(float);
+    const size_t lds = (size_t)gae_slots(a, flags) * TC * W * sizeof(float);
     dim3 grid((unsigned)((a.C + W - 1) / W)), block(NWAVES * 64);
-    if (ptl && den)
-        hipLaunchKernelGGL((gae_strip_kernel<W, NWAVES, TC, NBUF, WLOAD, true, true>), grid, block, lds, stream, a);
-    else if (ptl)
-        hipLaunchKernelGGL((gae_strip_kernel<W, NWAVES, TC, NBUF, WLOAD, true, false>), grid, block, lds, stream, a);
-    else if (den)
-        hipLaunchKernelGGL((gae_strip_kernel<W, NWAVES, TC, NBUF, WLOAD, false, true>), grid, block, lds, stream, a);
-    else
-        hipLaunchKernelGGL((gae_strip_kernel<W, NWAVES, TC, NBUF, WLOAD, false, false>), grid, block, lds, stream, a);
+    MAPPO_DISPATCH_FLAGS(gae_strip_kernel, W, NWAVES, TC);
+    return hipGetLastError();
+}
+
+template <int W, int NPROD, int TC, int R>
+hipError_t launch_dma(const GaeArgs& a, unsigned flags, hipStream_t stream) {
+    const size_t lds = (size_t)R * gae_slots(a, flags) * TC * W * sizeof(float);
+    dim3 grid((unsigned)((a.C + W - 1) / W)), block((NPROD + 1) * 64);
+    MAPPO_DISPATCH_FLAGS(gae_dma_kernel, W, NPROD, TC, R);
+    return hipGetLastError();
+}
+
+template <int W, int NPROD, int TC, int NBUF>
+hipError_t launch_pipe(const GaeArgs& a, unsigned flags, hipStream_t stream) {
+    const size_t lds = (size_t)2 * gae_slots(a, flags) * TC * W * sizeof(float);
+    dim3 grid((unsigned)((a.C + W - 1) / W)), block((NPROD + 1) * 64);
+    MAPPO_DISPATCH_FLAGS(gae_pipe_kernel, W, NPROD, TC, NBUF);
     return hipGetLastError();
 }
 
@@ -554,30 +762,31 @@ extern "C" int mappo_gae_f32(const float* rewards, float* value_preds, const flo
     a.gamma = (float)gamma;
     a.gl = (float)(gamma * gae_lambda);
 
-    const bool strip_ok = (flags & MAPPO_GAE_USE_GAE) && (C % 4 == 0) && aligned16(rewards) &&
+    const bool strip_ok = (flags & MAPPO_GAE_USE_GAE) && (C % 4 == 0) && C >= 4 && aligned16(rewards) &&
                           aligned16(value_preds) && aligned16(masks) &&
                           (!a.bad || aligned16(bad_masks)) && (!a.active || aligned16(active_masks));
     int variant = g_variant;
     if (!strip_ok) variant = 99;
-    if (variant == 0) variant = (C >= 64 * 256) ? 2 : (C >= 32 * 256 ? 3 : 6);
+    if (variant == 0) variant = (C >= 64 * 256) ? 20 : (C >= 32 * 256 ? 3 : 6);
 
     hipError_t e;
     switch (variant) {
-        case 1: e = launch_strip<64, 1, 32>(a, flags, stream); break;
         case 2: e = launch_strip<64, 4, 32>(a, flags, stream); break;
         case 3: e = launch_strip<32, 1, 32>(a, flags, stream); break;
-        case 5: e = launch_strip<64, 2, 32>(a, flags, stream); break;
         case 6: e = launch_strip<16, 1, 64>(a, flags, stream); break;
-        case 10: e = launch_strip<64, 4, 32, 2>(a, flags, stream); break;
-        case 11: e = launch_strip<64, 4, 64, 1>(a, flags, stream); break;
-        case 12: e = launch_strip<64, 8, 64, 1>(a, flags, stream); break;
-        case 13: e = launch_strip<64, 8, 32, 2>(a, flags, stream); break;
-        case 14: e = launch_strip<64, 4, 16, 2>(a, flags, stream); break;
-        case 15: e = launch_strip<64, 4, 32, 1, false>(a, flags, stream); break;
-        case 16: e = launch_strip<64, 4, 32, 2, false>(a, flags, stream); break;
-        case 17: e = launch_strip<64, 8, 64, 2, false>(a, flags, stream); break;
-        case 18: e = launch_strip<32, 4, 64, 2>(a, flags, stream); break;
-        case 19: e = launch_strip<64, 8, 64, 2>(a, flags, stream); break;
+        case 20: e = launch_pipe<64, 4, 32, 2>(a, flags, stream); break;
+        case 21: e = launch_pipe<64, 4, 32, 3>(a, flags, stream); break;
+        case 22: e = launch_pipe<64, 4, 16, 3>(a, flags, stream); break;
+        case 23: e = launch_pipe<64, 2, 16, 2>(a, flags, stream); break;
+        case 24: e = launch_pipe<32, 2, 32, 2>(a, flags, stream); break;
+        case 25: e = launch_pipe<64, 4, 16, 4>(a, flags, stream); break;
+        case 26: e = launch_pipe<64, 8, 32, 2>(a, flags, stream); break;
+        case 30: e = launch_dma<64, 1, 16, 3>(a, flags, stream); break;
+        case 31: e = launch_dma<64, 2, 8, 4>(a, flags, stream); break;
+        case 32: e = launch_dma<64, 1, 8, 6>(a, flags, stream); break;
+        case 33: e = launch_dma<64, 2, 16, 3>(a, flags, stream); break;
+        case 34: e = launch_dma<32, 1, 16, 4>(a, flags, stream); break;
+        case 35: e = launch_dma<64, 1, 4, 12>(a, flags, stream); break;
         default: e = launch_column(a, flags, stream); break;
     }
     return (int)e;

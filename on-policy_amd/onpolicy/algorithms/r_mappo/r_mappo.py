@@ -91,10 +91,14 @@ class R_MAPPO():
     def cal_value_loss(self, values, value_preds_batch, return_batch, active_masks_batch):
         """Clipped (huber | mse) value loss against normalised returns
         (reference r_mappo.py:52-89); updates the value normaliser as a side effect."""
+        return self._value_loss(values, value_preds_batch, return_batch, active_masks_batch, True)
+
+    def _value_loss(self, values, value_preds_batch, return_batch, active_masks_batch, update_normalizer):
         value_pred_clipped = value_preds_batch + (values - value_preds_batch).clamp(-self.clip_param,
                                                                                     self.clip_param)
         if self._use_popart or self._use_valuenorm:
-            self._normalizer_update(return_batch)
+            if update_normalizer:
+                self._normalizer_update(return_batch)
             target = self.value_normalizer.normalize(return_batch)
         else:
             target = return_batch
@@ -120,6 +124,25 @@ class R_MAPPO():
         return value_loss
 
     # ------------------------------------------------------------------ one minibatch
+    # PyTorch-ROCm's LayerNorm (and other row-wise kernels) index with 32 bits: at the north-star
+    # size one minibatch is 13.1 M rows x 384 features = 5.0e9 elements and the kernels silently
+    # wrap / fault.  Minibatches above this many elements per tensor are therefore evaluated in
+    # row spans; gradients accumulate, so the update is the same full-minibatch update.
+    MAX_TENSOR_ELEMENTS = 1 << 30
+
+    def _row_spans(self, sample):
+        rows = sample[10].shape[0] if sample[10] is not None else sample[5].shape[0]
+        widest = max(int(np.prod(t.shape[1:])) for t in (sample[0], sample[1]) if t is not None)
+        cap = max(1, self.MAX_TENSOR_ELEMENTS // max(1, widest))
+        if rows <= cap:
+            return [(0, rows)]
+        if sample[2] is not None and sample[2].shape[0] != rows:
+            raise RuntimeError("a recurrent minibatch of %d rows x %d features exceeds what PyTorch-ROCm can "
+                               "index; raise --num_mini_batch" % (rows, widest))
+        n = -(-rows // cap)
+        step = -(-rows // n)
+        return [(lo, min(rows, lo + step)) for lo in range(0, rows, step)]
+
     def ppo_update(self, sample, update_actor=True):
         """One actor step and one critic step on a minibatch (reference r_mappo.py:91-169).
         -> (value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights)."""
@@ -133,20 +156,8 @@ class R_MAPPO():
         return_batch = check(return_batch).to(**self.tpdv)
         active_masks_batch = check(active_masks_batch).to(**self.tpdv)
 
-        values, action_log_probs, dist_entropy = self.policy.evaluate_actions(
-            share_obs_batch, obs_batch, rnn_states_batch, rnn_states_critic_batch, actions_batch,
-            masks_batch, available_actions_batch, active_masks_batch)
-
-        # clipped surrogate
-        imp_weights = torch.exp(action_log_probs - old_action_log_probs_batch)
-        surr1 = imp_weights * adv_targ
-        surr2 = torch.clamp(imp_weights, 1.0 - self.clip_param, 1.0 + self.clip_param) * adv_targ
-        per_sample = -torch.sum(torch.min(surr1, surr2), dim=-1, keepdim=True)
-        if self._use_policy_active_masks:
-            policy_loss = (per_sample * active_masks_batch).sum() / active_masks_batch.sum()
-        else:
-            policy_loss = per_sample.mean()
-
+        spans = self._row_spans(sample)
+        rows = adv_targ.shape[0]
         # In a data-parallel job each rank's loss is a mean over ITS minibatch; weighting it by
         # (local denominator / global denominator) makes the all-reduced gradient the gradient of
         # the global-batch mean.  Weights are exactly 1 for world size 1.
@@ -154,11 +165,59 @@ class R_MAPPO():
             active_masks_batch, self._use_policy_active_masks, self._use_value_active_masks)
 
         self.dp.zero_grad(self.policy.actor_optimizer, self.policy.critic_optimizer)
-        if update_actor:
-            ((policy_loss - dist_entropy * self.entropy_coef) * w_actor).backward()
+        if (self._use_popart or self._use_valuenorm) and len(spans) > 1:
+            self._normalizer_update(return_batch)   # once per minibatch, before it is used (r_mappo.py:65-66)
 
-        value_loss = self.cal_value_loss(values, value_preds_batch, return_batch, active_masks_batch)
-        (value_loss * self.value_loss_coef * w_critic).backward()
+        single = len(spans) == 1
+
+        def cut(x, lo, hi):
+            return x if (x is None or single) else x[lo:hi]
+
+        value_loss = policy_loss = dist_entropy = None
+        ratios = []
+        for lo, hi in spans:
+            am = active_masks_batch[lo:hi]
+            values, action_log_probs, entropy = self.policy.evaluate_actions(
+                cut(share_obs_batch, lo, hi), cut(obs_batch, lo, hi), cut(rnn_states_batch, lo, hi),
+                cut(rnn_states_critic_batch, lo, hi), cut(actions_batch, lo, hi), cut(masks_batch, lo, hi),
+                cut(available_actions_batch, lo, hi), am)
+
+            # clipped surrogate (r_mappo.py:129-139)
+            imp_weights = torch.exp(action_log_probs - old_action_log_probs_batch[lo:hi])
+            surr1 = imp_weights * adv_targ[lo:hi]
+            surr2 = torch.clamp(imp_weights, 1.0 - self.clip_param, 1.0 + self.clip_param) * adv_targ[lo:hi]
+            per_sample = -torch.sum(torch.min(surr1, surr2), dim=-1, keepdim=True)
+            if self._use_policy_active_masks:
+                p_loss = (per_sample * am).sum() / am.sum()
+            else:
+                p_loss = per_sample.mean()
+            v_loss = self._value_loss(values, value_preds_batch[lo:hi], return_batch[lo:hi], am,
+                                      update_normalizer=len(spans) == 1)
+
+            # span weights: this span's share of the minibatch denominators (exactly 1 for one span)
+            if len(spans) == 1:
+                sw_actor = sw_critic = 1.0
+            else:
+                frac_rows = float(hi - lo) / rows
+                frac_active = am.sum() / active_masks_batch.sum()
+                sw_actor = frac_active if self._use_policy_active_masks else frac_rows
+                sw_critic = frac_active if self._use_value_active_masks else frac_rows
+
+            if update_actor:
+                ((p_loss - entropy * self.entropy_coef) * (sw_actor * w_actor)).backward()
+            (v_loss * self.value_loss_coef * (sw_critic * w_critic)).backward()
+
+            if len(spans) == 1:
+                value_loss, policy_loss, dist_entropy = v_loss, p_loss, entropy
+            else:
+                acc = lambda tot, x, w: x.detach() * w if tot is None else tot + x.detach() * w
+                value_loss = acc(value_loss, v_loss, sw_critic)
+                policy_loss = acc(policy_loss, p_loss, sw_actor)
+                dist_entropy = acc(dist_entropy, entropy, sw_actor)
+            ratios.append(imp_weights.detach() if len(spans) > 1 else imp_weights)
+            del values, action_log_probs, entropy, surr1, surr2, per_sample, p_loss, v_loss
+
+        imp_weights = ratios[0] if len(ratios) == 1 else torch.cat(ratios, 0)
 
         self.dp.all_reduce_grads()  # no-op for world size 1
 

@@ -103,7 +103,7 @@ def _random_case(T, N, A, seed, device):
     return arrays
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 5, 6, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 99])
+@pytest.mark.parametrize("variant", [2, 3, 6, 20, 21, 22, 23, 24, 25, 26, 30, 31, 32, 33, 34, 35, 99])
 @pytest.mark.parametrize("ptl,norm", [(False, True), (True, True), (False, False), (True, False)])
 def test_gae_variants_vs_oracle(variant, ptl, norm):
     """Every kernel variant is bit-identical to the oracle, including ragged strips (C % W != 0),
@@ -168,7 +168,7 @@ def test_gae_north_star_size_vs_oracle():
     nvd = torch.from_numpy(nv).to(dev)
     exp_ret, exp_v = oracle.compute_returns(arrays["rewards"], arrays["value_preds"], nv, arrays["masks"],
                                             sigma=sigma, mu=mu, denorm=True)
-    for variant in (0, 1, 3, 99):
+    for variant in (0, 2, 20, 31, 99):
         lib.mappo_gae_set_variant(variant)
         ret.zero_()
         code = lib.mappo_gae_f32(t["rewards"].data_ptr(), t["value_preds"].data_ptr(), nvd.data_ptr(),
@@ -204,7 +204,9 @@ def _gen_buffer(z, recurrent=True):
     buf = _buffer(args, A, Do=z["gen_buf_obs"].shape[-1], Ds=sh[-1], na=z["gen_buf_available_actions"].shape[-1])
     for name in ("share_obs", "obs", "rnn_states", "rnn_states_critic", "actions", "value_preds", "returns",
                  "masks", "active_masks", "action_log_probs", "available_actions", "rewards"):
-        getattr(buf, name).copy_(torch.from_numpy(z["gen_buf_" + name]))
+        dst = getattr(buf, name)
+        if dst.stride()[0] != 0:      # a feed-forward buffer keeps no RNN-state storage
+            dst.copy_(torch.from_numpy(z["gen_buf_" + name]))
     return buf
 
 
@@ -372,8 +374,10 @@ def test_train_on_device_vs_reference(gold, cname):
     np.random.seed(1)
     policy = R_MAPPOPolicy(args, *spaces, device=dev)
     trainer = R_MAPPO(args, policy, device=dev)
-    for k, v in policy.actor.state_dict().items():      # CPU-side init => identical start weights
-        np.testing.assert_array_equal(v.cpu().numpy(), z[key + "init_actor." + k])
+    # init draws come from the CPU generator on every device; orthogonal_ runs a host LAPACK QR whose
+    # rounding depends on the host CPU / BLAS build, hence 1e-6 instead of bit equality across boxes
+    for k, v in policy.actor.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), z[key + "init_actor." + k], rtol=1e-5, atol=1e-6)
     buf = SharedReplayBuffer(args, spec["A"], *spaces, device=dev)
     for name in ("share_obs", "obs", "rnn_states", "rnn_states_critic", "actions", "value_preds", "masks",
                  "bad_masks", "active_masks", "action_log_probs", "available_actions", "rewards"):

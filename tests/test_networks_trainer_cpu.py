@@ -101,3 +101,32 @@ def test_train_matches_reference(gold, cname):
         vn = trainer.value_normalizer
         got = np.array([float(vn.running_mean), float(vn.running_mean_sq), float(vn.debiasing_term)])
         np.testing.assert_allclose(got, z[key + "final_norm"], rtol=1e-5, atol=1e-9)
+
+
+def test_row_span_microbatching_is_equivalent(gold):
+    """Minibatches too large for PyTorch-ROCm's 32-bit row kernels are evaluated in row spans with
+    gradient accumulation; that must give the same update as one pass (float32 summation order
+    aside)."""
+    z = gold.npz("trainer_cases")
+    key = "trn_mlp_"
+    results = []
+    for cap in (1 << 30, 200):     # 200 elements / 11 features -> spans of 18 rows
+        meta, spec, args, spaces, policy, trainer = _build(gold, "mlp")
+        trainer.MAX_TENSOR_ELEMENTS = cap
+        buf = oracle.OracleBuffer(args, spec["A"], *spaces)
+        for name in ("share_obs", "obs", "rnn_states", "rnn_states_critic", "actions", "value_preds", "masks",
+                     "bad_masks", "active_masks", "action_log_probs", "available_actions", "rewards"):
+            getattr(buf, name)[...] = z[key + "buf_" + name]
+        buf.compute_returns(z[key + "next_value"], trainer.value_normalizer)
+        trainer.prep_training()
+        torch.manual_seed(21)
+        info = trainer.train(buf)
+        results.append((info, {k: v.clone() for k, v in policy.actor.state_dict().items()},
+                        {k: v.clone() for k, v in policy.critic.state_dict().items()}))
+    (i0, a0, c0), (i1, a1, c1) = results
+    for k in i0:
+        assert i1[k] == pytest.approx(i0[k], rel=1e-4, abs=1e-6), k
+    for k in a0:
+        np.testing.assert_allclose(a1[k].numpy(), a0[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+    for k in c0:
+        np.testing.assert_allclose(c1[k].numpy(), c0[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)

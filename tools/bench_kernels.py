@@ -47,8 +47,8 @@ def main():
     ap.add_argument("--T", type=int, default=400)
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--A", type=int, default=8)
-    ap.add_argument("--variants", default="1,2,3,5,10,11,12,13,14,15,16,17,18,19,99")
-    ap.add_argument("--gather-variants", default="0,1,2,3,4,5,6,7,18,19,34,35")
+    ap.add_argument("--variants", default="2,3,20,21,22,23,24,25,26,30,31,32,33,34,35,99")
+    ap.add_argument("--gather-variants", default="1,5,2,3,113,133,69,101")
     ap.add_argument("--sets", type=int, default=6)
     ap.add_argument("--iters", type=int, default=24)
     ap.add_argument("--gather-N", type=int, default=1024)

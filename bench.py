@@ -108,7 +108,9 @@ def cpu_baseline(wl, budget_note):
     from oracle import oracle
     from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO
     from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy
-    cores = os.cpu_count() or 1
+    # PyTorch's CPU ops stop scaling (and then slow down) beyond a few dozen threads at these
+    # batch sizes; 32 is the best case measured on the 256-core host of the MI355X box
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     n = wl["cpu_sample_N"]
     args = make_args(wl, n)

@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(kThreads) gather_kernel(GatherArgs a) {
     }
 }
 
-int g_gather_variant = 0;  // bits 0-1: log2(unroll), bit 2: nontemporal, bits 4+: blocks per CU (0 = occupancy)
+int g_gather_variant = 5;  // default: 2 loads in flight per lane, non-temporal.  bits 0-1: log2(unroll), bit 2: nontemporal, bits 4+: blocks per CU (0 = occupancy)
 
 template <int UNROLL, bool NT>
 hipError_t launch_gather(const GatherArgs& a, unsigned tile_units, int blocks_per_cu, hipStream_t stream) {

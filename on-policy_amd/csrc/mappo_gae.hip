@@ -767,7 +767,7 @@ extern "C" int mappo_gae_f32(const float* rewards, float* value_preds, const flo
                           (!a.bad || aligned16(bad_masks)) && (!a.active || aligned16(active_masks));
     int variant = g_variant;
     if (!strip_ok) variant = 99;
-    if (variant == 0) variant = (C >= 64 * 256) ? 20 : (C >= 32 * 256 ? 3 : 6);
+    if (variant == 0) variant = (C >= 64 * 256) ? 31 : (C >= 32 * 256 ? 34 : 6);
 
     hipError_t e;
     switch (variant) {

@@ -164,6 +164,11 @@ class SharedReplayBuffer(object):
             return None
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), nbytes)
         self._events.setdefault(name, []).append(ev)
+        # Keep the stream busy for ~0.1 ms first: on an idle stream the start event would fire at
+        # once and the interval would include the host's launch latency (tens of microseconds of
+        # Python / ctypes), not just the kernel.  Behind the spin, start event, kernel and end event
+        # are all queued before the GPU reaches them, so the interval is the kernel's duration.
+        torch.cuda._sleep(250000)
         ev[0].record(torch.cuda.current_stream(self.device))
         return ev
 

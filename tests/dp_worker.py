@@ -1,0 +1,74 @@
+"""Worker for the world_size-2 gloo tests: one rank of a data-parallel MAPPO update on a shard of the
+rollout threads (host OracleBuffer as the minibatch source, product trainer + DataParallel)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (os.path.join(ROOT, "on-policy_amd"), ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def build_case(n_threads, args_over):
+    from helpers import Box, Discrete, make_args, fill_buffer_arrays, buffer_shapes
+    T, A, Do, Ds, na, H = 6, 3, 5, 9, 4, 16
+    args = make_args(episode_length=T, n_rollout_threads=n_threads, hidden_size=H, ppo_epoch=2,
+                     num_mini_batch=1, **args_over)
+    spaces = Box((Do,)), Box((Ds,)), Discrete(na)
+    return args, spaces, (T, A, Do, Ds, na, H)
+
+
+def full_arrays(N, dims):
+    from helpers import fill_buffer_arrays, buffer_shapes
+    T, A, Do, Ds, na, H = dims
+    arrays = fill_buffer_arrays(buffer_shapes(T, N, A, Do, Ds, na, H), np.random.default_rng(5), na=na)
+    av = arrays["available_actions"][:-1]
+    pick = np.random.default_rng(6).random(av.shape) * av
+    arrays["actions"] = pick.argmax(-1)[..., None].astype(np.float32)
+    return arrays
+
+
+def run_update(N_global, lo, hi, args_over):
+    """compute_returns + train on rollout threads [lo, hi) of the global case."""
+    from oracle import oracle
+    from helpers import load_into
+    from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy
+    from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO
+    args, spaces, dims = build_case(hi - lo, args_over)
+    arrays = full_arrays(N_global, dims)
+    shard = {k: (v[:, lo:hi] if k != "next_value" else v[lo:hi]) for k, v in arrays.items()}
+    torch.manual_seed(1)
+    np.random.seed(1)
+    policy = R_MAPPOPolicy(args, *spaces)
+    trainer = R_MAPPO(args, policy)
+    buf = oracle.OracleBuffer(args, dims[1], *spaces)
+    load_into(buf, shard)
+    buf.compute_returns(shard["next_value"], trainer.value_normalizer)
+    trainer.prep_training()
+    torch.manual_seed(100)
+    info = trainer.train(buf)
+    sd = {"actor." + k: v.clone() for k, v in policy.actor.state_dict().items()}
+    sd.update({"critic." + k: v.clone() for k, v in policy.critic.state_dict().items()})
+    if trainer.value_normalizer is not None and hasattr(trainer.value_normalizer, "running_mean"):
+        sd["vn.mean"] = trainer.value_normalizer.running_mean.clone()
+        sd["vn.sq"] = trainer.value_normalizer.running_mean_sq.clone()
+    return info, sd, trainer.dp.world_size
+
+
+def worker(rank, world, port, N_global, args_over, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from onpolicy.utils import dist as mdist
+    mdist.init_from_env(torch.device("cpu"))
+    assert dist.get_backend() == "gloo"
+    lo, hi = mdist.shard_threads(N_global, rank, world)
+    info, sd, ws = run_update(N_global, lo, hi, args_over)
+    assert ws == world
+    torch.save({"info": info, "sd": sd, "span": (lo, hi)}, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()

@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--iters", type=int, default=24)
     ap.add_argument("--gather-N", type=int, default=1024)
     ap.add_argument("--skip-gather", action="store_true")
+    ap.add_argument("--cold", action="store_true", help="also time single launches after flushing caches/TLBs with an 8 GB copy")
     opt = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -124,6 +125,26 @@ def main():
             t["GBps_median"] = nbytes / (t["median_us"] * 1e-6) / 1e9
             t["GBps_b2b"] = nbytes / (t["b2b_us"] * 1e-6) / 1e9
             res["v%d_%s" % (variant, mode)] = t
+    if opt.cold:
+        big_a = torch.empty(2 * 1024 ** 3, dtype=torch.float32, device=dev)
+        big_b = torch.empty_like(big_a)
+        cold = {}
+        for variant in [int(v) for v in opt.variants.split(",")]:
+            lib.mappo_gae_set_variant(variant)
+            ms = []
+            for i in range(6):
+                big_b.copy_(big_a)            # 16 GB of traffic: evicts L2 / MALL / TLBs
+                d = sets[i % opt.sets]
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                code = lib.mappo_gae_f32(p(d["r"]), p(d["v"]), p(d["nv"]), p(d["m"]), None, p(d["ret"]), p(den),
+                                         p(d["adv"]), p(d["am"]), p(partials), T, C, 0.99, 0.95, 1 | 4, stream)
+                b.record()
+                torch.cuda.synchronize()
+                ms.append(a.elapsed_time(b))
+            cold["v%d_fused24_cold_us" % variant] = [round(1e3 * x, 1) for x in ms]
+        out["gae_cold"] = cold
+        del big_a, big_b
     lib.mappo_gae_set_variant(0)
     out["gae"] = res
     del sets

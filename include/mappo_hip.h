@@ -179,6 +179,27 @@ typedef struct mappo_slab {
 
 int mappo_slab_copy(const mappo_slab_t* slabs, int n_slabs, mappo_stream_t stream);
 
+/* ------------------------------------------------------------ K6: row LayerNorm ----
+ * The LayerNorm the reference applies to the observations and after every Linear / GRU of the
+ * actor and critic trunks (onpolicy/algorithms/utils/mlp.py:17-22,47-53, rnn.py:22,79:
+ * nn.LayerNorm over the last dimension, eps = 1e-5, biased variance), as one streaming kernel per
+ * direction for [M, D] float32 rows with D up to 2048 (multiple of 4) / 1536 (any).
+ *
+ * mappo_layernorm_fwd: y = (x - mean) * rstd * weight + bias; also writes mean[M], rstd[M]
+ *                      (saved for the backward).
+ * mappo_layernorm_bwd: dx (NULL to skip: input does not require grad), dweight[D], dbias[D] from
+ *                      dy, x and the saved statistics.  `partials` is a device workspace of
+ *                      2 * mappo_layernorm_max_blocks() * D floats (per-workgroup column sums,
+ *                      reduced in a fixed order: deterministic).
+ * Returns MAPPO_E_SHAPE for an unsupported D (callers then use the framework's own LayerNorm).
+ */
+int mappo_layernorm_max_blocks(void);
+int mappo_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y, float* mean,
+                        float* rstd, int64_t M, int D, float eps, mappo_stream_t stream);
+int mappo_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                        const float* weight, float* dx, float* dweight, float* dbias, float* partials,
+                        int64_t M, int D, mappo_stream_t stream);
+
 /* --------------------------------------------------------------------- misc ---- */
 int         mappo_abi_version(void);
 const char* mappo_build_info(void);        /* "gfx950 ..." static string */

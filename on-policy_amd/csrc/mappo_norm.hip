@@ -1,0 +1,326 @@
+// K6 -- row LayerNorm (forward / backward) for the narrow feature widths of the MAPPO networks.
+//
+// The actor / critic trunks apply nn.LayerNorm after every Linear and to the raw observation
+// (reference onpolicy/algorithms/utils/mlp.py:17-22,47-53, rnn.py:22,79).  With hidden sizes of 64
+// and minibatches of 10^6..10^7 rows this is pure HBM streaming ([rows, D] in, [rows, D] out), but
+// PyTorch-ROCm's generic kernels assign one workgroup per row and reach ~0.5 TB/s on D = 64: at the
+// north-star size they are 54 % of the whole update (profiles/r01_bench_ns_kernel_stats.csv).
+//
+// Here a row is owned by LPR lanes (LPR = power of two <= 64 covering D / VEC units), so a wave
+// handles 64 / LPR rows at once with 16-byte accesses; statistics are two-pass in registers (mean,
+// then centred sum of squares) and reduced with lane shuffles inside the LPR-lane group.  The
+// backward keeps the weight / bias gradient partials of the lanes' columns in registers across the
+// grid-stride row loop and writes one [D] partial per workgroup (deterministic, no atomics).
+//
+//   y      = (x - mean) * rstd * w + b,  mean / rstd over the last dimension, biased variance
+//   dx     = rstd * (g - mean_D(g) - xhat * mean_D(g * xhat)),  g = dy * w, xhat = (x - mean) * rstd
+//   dw     = sum_rows dy * xhat,  db = sum_rows dy
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mappo_hip.h"
+#include "mappo_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int VEC> struct Unit;
+template <> struct Unit<4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct Unit<1> { typedef float type; };
+
+template <int VEC>
+__device__ __forceinline__ float elem(const typename Unit<VEC>::type& u, int k) {
+    if constexpr (VEC == 1) return u;
+    else return u[k];
+}
+template <int VEC>
+__device__ __forceinline__ void set_elem(typename Unit<VEC>::type& u, int k, float v) {
+    if constexpr (VEC == 1) u = v;
+    else u[k] = v;
+}
+
+// ------------------------------------------------------------------------ forward ----
+template <int VEC, int LPR, int EPL>
+__global__ void __launch_bounds__(kThreads) ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float* __restrict__ y,
+                                                          float* __restrict__ mean, float* __restrict__ rstd,
+                                                          long long M, int D, float eps) {
+    using U = typename Unit<VEC>::type;
+    constexpr int RPB = kThreads / LPR;            // rows per workgroup pass
+    const int lane = threadIdx.x % LPR;
+    const int rib = threadIdx.x / LPR;
+    const int units = D / VEC;
+    const float invD = 1.0f / (float)D;
+
+    U wv[EPL], bv[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        int u = lane + e * LPR;
+        wv[e] = U(0.f);
+        bv[e] = U(0.f);
+        if (u < units) {
+            wv[e] = reinterpret_cast<const U*>(w)[u];
+            bv[e] = reinterpret_cast<const U*>(b)[u];
+        }
+    }
+    for (long long row = (long long)blockIdx.x * RPB + rib; row < M; row += (long long)gridDim.x * RPB) {
+        const U* xr = reinterpret_cast<const U*>(x + row * D);
+        U xv[EPL];
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            int u = lane + e * LPR;
+            xv[e] = U(0.f);
+            if (u < units) xv[e] = xr[u];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) s += elem<VEC>(xv[e], k);
+        }
+        const float mu = group_sum<LPR>(s) * invD;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            int u = lane + e * LPR;
+            if (u < units) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    float d = elem<VEC>(xv[e], k) - mu;
+                    q += d * d;
+                }
+            }
+        }
+        const float var = group_sum<LPR>(q) * invD;
+        const float r = 1.0f / sqrtf(var + eps);
+        U* yr = reinterpret_cast<U*>(y + row * D);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            int u = lane + e * LPR;
+            if (u < units) {
+                U o;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k)
+                    set_elem<VEC>(o, k, (elem<VEC>(xv[e], k) - mu) * r * elem<VEC>(wv[e], k) + elem<VEC>(bv[e], k));
+                yr[u] = o;
+            }
+        }
+        if (lane == 0) {
+            mean[row] = mu;
+            rstd[row] = r;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------- backward ----
+template <int VEC, int LPR, int EPL, bool NEED_DX>
+__global__ void __launch_bounds__(kThreads) ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ w, float* __restrict__ dx,
+                                                          float* __restrict__ pw, float* __restrict__ pb,
+                                                          long long M, int D) {
+    using U = typename Unit<VEC>::type;
+    constexpr int RPB = kThreads / LPR;
+    extern __shared__ float red[];                 // [2][RPB][D]
+    const int lane = threadIdx.x % LPR;
+    const int rib = threadIdx.x / LPR;
+    const int units = D / VEC;
+    const float invD = 1.0f / (float)D;
+
+    U wv[EPL], aw[EPL], ab[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        int u = lane + e * LPR;
+        wv[e] = U(0.f);
+        aw[e] = U(0.f);
+        ab[e] = U(0.f);
+        if (u < units) wv[e] = reinterpret_cast<const U*>(w)[u];
+    }
+    for (long long row = (long long)blockIdx.x * RPB + rib; row < M; row += (long long)gridDim.x * RPB) {
+        const U* xr = reinterpret_cast<const U*>(x + row * D);
+        const U* gr = reinterpret_cast<const U*>(dy + row * D);
+        const float mu = mean[row], r = rstd[row];
+        U xh[EPL], gv[EPL];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            int u = lane + e * LPR;
+            xh[e] = U(0.f);
+            gv[e] = U(0.f);
+            if (u < units) {
+                U xv = xr[u];
+                U dv = gr[u];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    float h = (elem<VEC>(xv, k) - mu) * r;
+                    float d = elem<VEC>(dv, k);
+                    float g = d * elem<VEC>(wv[e], k);
+                    set_elem<VEC>(xh[e], k, h);
+                    set_elem<VEC>(gv[e], k, g);
+                    s1 += g;
+                    s2 += g * h;
+                    set_elem<VEC>(aw[e], k, elem<VEC>(aw[e], k) + d * h);
+                    set_elem<VEC>(ab[e], k, elem<VEC>(ab[e], k) + d);
+                }
+            }
+        }
+        if (NEED_DX) {
+            const float m1 = group_sum<LPR>(s1) * invD;
+            const float m2 = group_sum<LPR>(s2) * invD;
+            U* dr = reinterpret_cast<U*>(dx + row * D);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                int u = lane + e * LPR;
+                if (u < units) {
+                    U o;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k)
+                        set_elem<VEC>(o, k, r * (elem<VEC>(gv[e], k) - m1 - elem<VEC>(xh[e], k) * m2));
+                    dr[u] = o;
+                }
+            }
+        }
+    }
+    // workgroup partials of dw / db: rows-in-block -> LDS -> column sums
+    float* rw = red;
+    float* rb = red + (size_t)RPB * D;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        int u = lane + e * LPR;
+        if (u < units) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                rw[(size_t)rib * D + u * VEC + k] = elem<VEC>(aw[e], k);
+                rb[(size_t)rib * D + u * VEC + k] = elem<VEC>(ab[e], k);
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += kThreads) {
+        float sw = 0.f, sb = 0.f;
+#pragma unroll 4
+        for (int q = 0; q < RPB; ++q) {
+            sw += rw[(size_t)q * D + c];
+            sb += rb[(size_t)q * D + c];
+        }
+        pw[(size_t)blockIdx.x * D + c] = sw;
+        pb[(size_t)blockIdx.x * D + c] = sb;
+    }
+}
+
+__global__ void __launch_bounds__(kThreads) ln_reduce_kernel(const float* __restrict__ pw, const float* __restrict__ pb,
+                                                             float* __restrict__ dw, float* __restrict__ db,
+                                                             int nblk, int D) {
+    int c = blockIdx.x * kThreads + threadIdx.x;
+    if (c >= D) return;
+    float sw = 0.f, sb = 0.f;
+    for (int q = 0; q < nblk; ++q) {
+        sw += pw[(size_t)q * D + c];
+        sb += pb[(size_t)q * D + c];
+    }
+    dw[c] = sw;
+    db[c] = sb;
+}
+
+struct Shape {
+    int vec, lpr, epl;
+};
+
+// VEC = 4 when rows are 16-byte aligned, LPR = power of two covering the units (<= 64),
+// EPL = units per lane rounded up to an instantiated size; epl == 0 -> unsupported width.
+Shape pick_shape(const void* a, const void* b, int D) {
+    Shape s;
+    s.vec = (D % 4 == 0 && mappo::aligned_to(a, 16) && mappo::aligned_to(b, 16)) ? 4 : 1;
+    int units = D / s.vec;
+    int lpr = 4;
+    while (lpr < units && lpr < 64) lpr <<= 1;
+    s.lpr = lpr;
+    int epl = (units + lpr - 1) / lpr;
+    const int sizes[] = {1, 2, 4, 8, 16, 24};
+    s.epl = 0;
+    for (int z : sizes)
+        if (epl <= z) {
+            s.epl = z;
+            break;
+        }
+    if (s.vec == 4 && s.epl > 8) s.epl = 0;
+    return s;
+}
+
+int ln_grid(long long M, int lpr) {
+    long long rpb = kThreads / lpr;
+    long long blocks = (M + rpb - 1) / rpb;
+    long long cap = (long long)mappo::kCUs * 8;
+    return (int)(blocks < cap ? blocks : cap);
+}
+
+#define LN_FOR_SHAPES(X)                                                                         \
+    X(4, 4, 1) X(4, 8, 1) X(4, 16, 1) X(4, 32, 1) X(4, 64, 1) X(4, 64, 2) X(4, 64, 4) X(4, 64, 8) \
+    X(1, 4, 1) X(1, 8, 1) X(1, 16, 1) X(1, 32, 1) X(1, 64, 1) X(1, 64, 2) X(1, 64, 4) X(1, 64, 8) \
+    X(1, 64, 16) X(1, 64, 24)
+
+}  // namespace
+
+extern "C" int mappo_layernorm_max_blocks(void) { return mappo::kCUs * 8; }
+
+extern "C" int mappo_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y,
+                                   float* mean, float* rstd, int64_t M, int D, float eps,
+                                   mappo_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !weight || !bias || !y || !mean || !rstd) return MAPPO_E_NULL;
+    if (M <= 0 || D <= 0) return MAPPO_E_SHAPE;
+    Shape s = pick_shape(x, y, D);
+    if (s.vec == 4 && !(mappo::aligned_to(weight, 16) && mappo::aligned_to(bias, 16))) s = pick_shape((void*)1, (void*)1, D);
+    if (s.epl == 0) return MAPPO_E_SHAPE;
+    dim3 grid(ln_grid(M, s.lpr)), block(kThreads);
+#define LN_LAUNCH_FWD(V, L, E)                                                                   \
+    if (s.vec == V && s.lpr == L && s.epl == E) {                                                \
+        hipLaunchKernelGGL((ln_fwd_kernel<V, L, E>), grid, block, 0, stream, x, weight, bias, y, mean, rstd, \
+                           (long long)M, D, eps);                                                \
+        return (int)hipGetLastError();                                                           \
+    }
+    LN_FOR_SHAPES(LN_LAUNCH_FWD)
+#undef LN_LAUNCH_FWD
+    return MAPPO_E_SHAPE;
+}
+
+extern "C" int mappo_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                                   const float* weight, float* dx, float* dweight, float* dbias,
+                                   float* partials, int64_t M, int D, mappo_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!dy || !x || !mean || !rstd || !weight || !dweight || !dbias || !partials) return MAPPO_E_NULL;
+    if (M <= 0 || D <= 0) return MAPPO_E_SHAPE;
+    Shape s = pick_shape(x, dy, D);
+    if (s.vec == 4 && !(mappo::aligned_to(weight, 16) && (!dx || mappo::aligned_to(dx, 16))))
+        s = pick_shape((void*)1, (void*)1, D);
+    if (s.epl == 0) return MAPPO_E_SHAPE;
+    const int nblk = ln_grid(M, s.lpr);
+    float* pw = partials;
+    float* pb = partials + (size_t)mappo::kCUs * 8 * D;
+    const size_t lds = (size_t)2 * (kThreads / s.lpr) * D * sizeof(float);
+    dim3 grid(nblk), block(kThreads);
+    bool launched = false;
+#define LN_LAUNCH_BWD(V, L, E)                                                                   \
+    if (!launched && s.vec == V && s.lpr == L && s.epl == E) {                                   \
+        if (dx)                                                                                  \
+            hipLaunchKernelGGL((ln_bwd_kernel<V, L, E, true>), grid, block, lds, stream, dy, x, mean, rstd, \
+                               weight, dx, pw, pb, (long long)M, D);                             \
+        else                                                                                     \
+            hipLaunchKernelGGL((ln_bwd_kernel<V, L, E, false>), grid, block, lds, stream, dy, x, mean, rstd, \
+                               weight, dx, pw, pb, (long long)M, D);                             \
+        launched = true;                                                                         \
+    }
+    LN_FOR_SHAPES(LN_LAUNCH_BWD)
+#undef LN_LAUNCH_BWD
+    if (!launched) return MAPPO_E_SHAPE;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(ln_reduce_kernel, dim3((D + kThreads - 1) / kThreads), block, 0, stream, pw, pb, dweight,
+                       dbias, nblk, D);
+    return (int)hipGetLastError();
+}

@@ -45,6 +45,9 @@ SIGNATURES = {
     "mappo_gather_chunks": (_int, [ctypes.POINTER(Field), _int, _vp, _i64, _int, _int, _i64, _int, _vp, _vp]),
     "mappo_gather_set_variant": (_int, [_int]),
     "mappo_slab_copy": (_int, [ctypes.POINTER(Slab), _int, _vp]),
+    "mappo_layernorm_max_blocks": (_int, []),
+    "mappo_layernorm_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, ctypes.c_float, _vp]),
+    "mappo_layernorm_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]),
     "mappo_abi_version": (_int, []),
     "mappo_build_info": (ctypes.c_char_p, []),
     "mappo_error_string": (ctypes.c_char_p, [_int]),

@@ -6,6 +6,7 @@ MLPBase :33), so reference checkpoints load and a given seed yields the same wei
 """
 import torch.nn as nn
 
+from .fused_norm import FusedLayerNorm
 from .util import init
 
 
@@ -20,7 +21,7 @@ def _zero_bias(b):
 def _block(in_dim, out_dim, use_orthogonal, use_ReLU, act):
     gain = nn.init.calculate_gain('relu' if use_ReLU else 'tanh')
     linear = init(nn.Linear(in_dim, out_dim), _weight_init(use_orthogonal), _zero_bias, gain=gain)
-    return nn.Sequential(linear, act, nn.LayerNorm(out_dim))
+    return nn.Sequential(linear, act, FusedLayerNorm(out_dim))
 
 
 class MLPLayer(nn.Module):
@@ -50,7 +51,7 @@ class MLPBase(nn.Module):
         self.hidden_size = args.hidden_size
         obs_dim = obs_shape[0]
         if self._use_feature_normalization:
-            self.feature_norm = nn.LayerNorm(obs_dim)
+            self.feature_norm = FusedLayerNorm(obs_dim)
         self.mlp = MLPLayer(obs_dim, self.hidden_size, self._layer_N, self._use_orthogonal, self._use_ReLU)
 
     def forward(self, x):

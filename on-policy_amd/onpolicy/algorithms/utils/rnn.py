@@ -19,6 +19,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .fused_norm import FusedLayerNorm
+
 
 class RNNLayer(nn.Module):
     def __init__(self, inputs_dim, outputs_dim, recurrent_N, use_orthogonal):
@@ -34,7 +36,7 @@ class RNNLayer(nn.Module):
                     nn.init.orthogonal_(param)
                 else:
                     nn.init.xavier_uniform_(param)
-        self.norm = nn.LayerNorm(outputs_dim)
+        self.norm = FusedLayerNorm(outputs_dim)
 
     def _layer_weights(self, k):
         g = self.rnn

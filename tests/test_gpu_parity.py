@@ -405,36 +405,48 @@ def test_train_on_device_vs_reference(gold, cname):
 @pytest.mark.parametrize("D", [48, 64, 384, 18, 54, 370, 435, 512, 1285, 30, 150, 4, 3, 2048, 1536])
 def test_fused_layernorm_vs_torch(D):
     """Forward and backward of the HIP LayerNorm against torch's float32 LayerNorm on the same
-    device: 1e-5 relative on outputs / input grads; weight / bias grads are sums over all rows in a
-    different order, 2e-4 relative to their scale."""
+    device, both judged against a float64 evaluation: the HIP kernel's error must be within
+    4x torch's own float32 error + 1e-5 relative to the tensor's scale (rows with a tiny variance
+    amplify rounding in ANY float32 implementation, so a fixed tolerance between the two float32
+    results would be meaningless for small D)."""
     from onpolicy.algorithms.utils.fused_norm import FusedLayerNorm
     dev = _dev()
     g = torch.Generator(device=dev)
     g.manual_seed(D)
+
+    def close(mine, theirs, exact, what):
+        scale = float(exact.abs().max()) + 1e-30
+        e_mine = float((mine.double() - exact).abs().max()) / scale
+        e_torch = float((theirs.double() - exact).abs().max()) / scale
+        assert e_mine <= 4 * e_torch + 1e-5, (what, D, e_mine, e_torch)
+
     for M in (1, 7, 1000, 70001):
         ln = FusedLayerNorm(D).to(dev)
         ref = torch.nn.LayerNorm(D).to(dev)
+        ref64 = torch.nn.LayerNorm(D).to(dev).double()
         with torch.no_grad():
             ln.weight.copy_(torch.randn(D, device=dev, generator=g))
             ln.bias.copy_(torch.randn(D, device=dev, generator=g))
             ref.weight.copy_(ln.weight)
             ref.bias.copy_(ln.bias)
+            ref64.weight.copy_(ln.weight.double())
+            ref64.bias.copy_(ln.bias.double())
         for need_dx in (True, False):
             x = (torch.randn(M, D, device=dev, generator=g) * 3 + 1).requires_grad_(need_dx)
             xr = x.detach().clone().requires_grad_(need_dx)
+            x64 = x.detach().double().requires_grad_(need_dx)
             dy = torch.randn(M, D, device=dev, generator=g)
-            y = ln(x)
-            yr = ref(xr)
-            torch.testing.assert_close(y, yr, rtol=1e-5, atol=2e-5)
+            y, yr, y64 = ln(x), ref(xr), ref64(x64)
+            close(y, yr, y64.detach(), "y")
             y.backward(dy)
             yr.backward(dy)
+            y64.backward(dy.double())
             if need_dx:
-                torch.testing.assert_close(x.grad, xr.grad, rtol=1e-4, atol=5e-5)
-            scale = max(1.0, float(M) ** 0.5)
-            torch.testing.assert_close(ln.weight.grad, ref.weight.grad, rtol=2e-4, atol=2e-4 * scale)
-            torch.testing.assert_close(ln.bias.grad, ref.bias.grad, rtol=2e-4, atol=2e-4 * scale)
-            ln.zero_grad()
-            ref.zero_grad()
+                close(x.grad, xr.grad, x64.grad, "dx")
+            close(ln.weight.grad, ref.weight.grad, ref64.weight.grad, "dw")
+            close(ln.bias.grad, ref.bias.grad, ref64.bias.grad, "db")
+            for m in (ln, ref, ref64):
+                m.zero_grad()
     # 3-d input (the GRU path normalises [L*B, H] but keep the general case right)
     x = torch.randn(5, 9, D, device=dev, generator=g)
-    torch.testing.assert_close(ln(x), ref(x), rtol=1e-5, atol=2e-5)
+    close(ln(x), ref(x), ref64(x.double()).detach(), "y3d")

@@ -213,18 +213,36 @@ __global__ void __launch_bounds__(kThreads) ln_bwd_kernel(const float* __restric
     }
 }
 
-__global__ void __launch_bounds__(kThreads) ln_reduce_kernel(const float* __restrict__ pw, const float* __restrict__ pb,
-                                                             float* __restrict__ dw, float* __restrict__ db,
-                                                             int nblk, int D) {
-    int c = blockIdx.x * kThreads + threadIdx.x;
-    if (c >= D) return;
-    float sw = 0.f, sb = 0.f;
-    for (int q = 0; q < nblk; ++q) {
-        sw += pw[(size_t)q * D + c];
-        sb += pb[(size_t)q * D + c];
+// Column sums of the per-workgroup partials: 64 columns x 16 row groups per workgroup, fixed order.
+constexpr int kReduceThreads = 1024;
+__global__ void __launch_bounds__(kReduceThreads) ln_reduce_kernel(const float* __restrict__ pw,
+                                                                    const float* __restrict__ pb,
+                                                                    float* __restrict__ dw, float* __restrict__ db,
+                                                                    int nblk, int D) {
+    __shared__ float sw[16][64], sb[16][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float aw = 0.f, ab = 0.f;
+    if (c < D) {
+#pragma unroll 8
+        for (int q = g; q < nblk; q += 16) {
+            aw += pw[(size_t)q * D + c];
+            ab += pb[(size_t)q * D + c];
+        }
     }
-    dw[c] = sw;
-    db[c] = sb;
+    sw[g][cl] = aw;
+    sb[g][cl] = ab;
+    __syncthreads();
+    if (g == 0 && c < D) {
+        float tw = 0.f, tb = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            tw += sw[q][cl];
+            tb += sb[q][cl];
+        }
+        dw[c] = tw;
+        db[c] = tb;
+    }
 }
 
 struct Shape {
@@ -320,7 +338,7 @@ extern "C" int mappo_layernorm_bwd(const float* dy, const float* x, const float*
     if (!launched) return MAPPO_E_SHAPE;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(ln_reduce_kernel, dim3((D + kThreads - 1) / kThreads), block, 0, stream, pw, pb, dweight,
+    hipLaunchKernelGGL(ln_reduce_kernel, dim3((D + 63) / 64), dim3(kReduceThreads), 0, stream, pw, pb, dweight,
                        dbias, nblk, D);
     return (int)hipGetLastError();
 }

@@ -16,6 +16,7 @@ from onpolicy.algorithms.utils.mlp import MLPBase
 from onpolicy.algorithms.utils.rnn import RNNLayer
 from onpolicy.algorithms.utils.act import ACTLayer
 from onpolicy.algorithms.utils.popart import PopArt
+from onpolicy.algorithms.utils.tall_linear import TallLinear
 from onpolicy.utils.util import get_shape_from_obs_space
 
 
@@ -91,7 +92,7 @@ class R_Critic(nn.Module, _DeviceMixin):
         self.base = _trunk(args, get_shape_from_obs_space(cent_obs_space))
         if self._recurrent:
             self.rnn = RNNLayer(self.hidden_size, self.hidden_size, self._recurrent_N, self._use_orthogonal)
-        head = PopArt(self.hidden_size, 1, device=device) if self._use_popart else nn.Linear(self.hidden_size, 1)
+        head = PopArt(self.hidden_size, 1, device=device) if self._use_popart else TallLinear(self.hidden_size, 1)
         self.v_out = init(head, w_init, lambda b: nn.init.constant_(b, 0))
         self.to(device)
 

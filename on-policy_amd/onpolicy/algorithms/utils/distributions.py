@@ -14,6 +14,7 @@ assignment (distributions.py:67), which on a GPU costs a device->host sync per c
 import torch
 import torch.nn as nn
 
+from .tall_linear import TallLinear
 from .util import init
 
 
@@ -79,7 +80,7 @@ class FixedBernoulli(torch.distributions.Bernoulli):
 
 def _head(num_inputs, num_outputs, use_orthogonal, gain):
     w_init = nn.init.orthogonal_ if use_orthogonal else nn.init.xavier_uniform_
-    return init(nn.Linear(num_inputs, num_outputs), w_init, lambda b: nn.init.constant_(b, 0), gain)
+    return init(TallLinear(num_inputs, num_outputs), w_init, lambda b: nn.init.constant_(b, 0), gain)
 
 
 class Categorical(nn.Module):

@@ -1,0 +1,56 @@
+"""``nn.Linear`` whose weight / bias gradients are computed with a split-K batched GEMM when the
+input is a tall matrix (10^5 .. 10^7 rows by a few dozen features -- every Linear of the MAPPO
+networks during the update, reference onpolicy/algorithms/utils/mlp.py:17-22, act.py / distributions.py
+heads, r_actor_critic.py v_out).
+
+Why: ``dW = dY^T @ X`` reduces over the row dimension.  For [2.6 M, 64]^T x [2.6 M, 64] the BLAS
+library launches a handful of workgroups that each walk millions of rows (3.3 ms, 0.4 TB/s on an
+MI355X; profiles/r01_bench_ns_kernel_stats.csv), and ``dY.sum(0)`` for the bias is as slow.  Cutting
+the rows into S slabs turns it into a batched GEMM [S, N, R] x [S, R, K] with thousands of
+independent tiles followed by a small sum over S -- same maths, float32 summation order aside.
+Everything is ordinary PyTorch (bmm / sum); parameters, init and state_dict are those of nn.Linear.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+_MIN_ROWS = 1 << 16      # below this the library GEMM is fine
+_SLAB_ROWS = 4096        # rows per slab (R)
+
+
+class _TallLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, N = dy.shape
+        K = x.shape[1]
+        dx = dy @ weight if ctx.needs_input_grad[0] else None
+        S = M // _SLAB_ROWS
+        main = S * _SLAB_ROWS
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            # [S, N, R] x [S, R, K] -> [S, N, K] -> sum over slabs
+            dw = torch.bmm(dy[:main].view(S, _SLAB_ROWS, N).transpose(1, 2),
+                           x[:main].view(S, _SLAB_ROWS, K)).sum(0)
+            if main < M:
+                dw = dw + dy[main:].t() @ x[main:]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy[:main].view(S, _SLAB_ROWS, N).sum(1).sum(0)
+            if main < M:
+                db = db + dy[main:].sum(0)
+        return dx, dw, db
+
+
+class TallLinear(nn.Linear):
+    def forward(self, x):
+        if x.dim() == 2 and x.is_cuda and x.shape[0] >= _MIN_ROWS and torch.is_grad_enabled() \
+                and x.is_contiguous():
+            return _TallLinearFn.apply(x, self.weight, self.bias)
+        return F.linear(x, self.weight, self.bias)

@@ -450,3 +450,35 @@ def test_fused_layernorm_vs_torch(D):
     # 3-d input (the GRU path normalises [L*B, H] but keep the general case right)
     x = torch.randn(5, 9, D, device=dev, generator=g)
     close(ln(x), ref(x), ref64(x.double()).detach(), "y3d")
+
+
+def test_tall_linear_backward_vs_torch():
+    """Split-K weight / bias gradients against torch's own Linear backward (float64 as judge)."""
+    from onpolicy.algorithms.utils.tall_linear import TallLinear
+    dev = _dev()
+    torch.manual_seed(3)
+    for M, K, N in [(70001, 48, 64), (262144, 64, 5), (100000, 384, 64), (65536, 64, 1)]:
+        lin = TallLinear(K, N).to(dev)
+        ref = torch.nn.Linear(K, N).to(dev)
+        ref64 = torch.nn.Linear(K, N).to(dev).double()
+        with torch.no_grad():
+            ref.weight.copy_(lin.weight)
+            ref.bias.copy_(lin.bias)
+            ref64.weight.copy_(lin.weight.double())
+            ref64.bias.copy_(lin.bias.double())
+        x = torch.randn(M, K, device=dev, requires_grad=True)
+        xr = x.detach().clone().requires_grad_(True)
+        x64 = x.detach().double().requires_grad_(True)
+        dy = torch.randn(M, N, device=dev)
+        y, yr, y64 = lin(x), ref(xr), ref64(x64)
+        assert torch.equal(y, yr)
+        y.backward(dy)
+        yr.backward(dy)
+        y64.backward(dy.double())
+        for mine, theirs, exact, what in ((x.grad, xr.grad, x64.grad, "dx"),
+                                          (lin.weight.grad, ref.weight.grad, ref64.weight.grad, "dw"),
+                                          (lin.bias.grad, ref.bias.grad, ref64.bias.grad, "db")):
+            scale = float(exact.abs().max())
+            e_mine = float((mine.double() - exact).abs().max()) / scale
+            e_torch = float((theirs.double() - exact).abs().max()) / scale
+            assert e_mine <= 4 * e_torch + 1e-5, (what, M, K, N, e_mine, e_torch)

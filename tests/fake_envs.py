@@ -1,0 +1,96 @@
+"""Deterministic stand-ins for the vectorised envs the runners talk to (same reset / step
+protocol and space lists as onpolicy/envs/env_wrappers.py of the reference, class-name-typed
+spaces).  They record what they emitted so that tests can compare it with the buffer."""
+import numpy as np
+
+from helpers import Box, Discrete
+
+
+class FakeMPEVecEnv(object):
+    """SubprocVecEnv protocol of the MPE wrappers: reset() -> obs [N, A, Do];
+    step(one_hot_actions [N, A, na]) -> obs, rewards [N, A, 1], dones [N, A], infos."""
+
+    def __init__(self, n_threads, n_agents, obs_dim, n_actions, done_every=5, seed=0):
+        self.n, self.a, self.do, self.na = n_threads, n_agents, obs_dim, n_actions
+        self.observation_space = [Box((obs_dim,)) for _ in range(n_agents)]
+        self.share_observation_space = [Box((obs_dim * n_agents,)) for _ in range(n_agents)]
+        self.action_space = [Discrete(n_actions) for _ in range(n_agents)]
+        self.done_every = done_every
+        self.rng = np.random.default_rng(seed)
+        self.t = 0
+        self.log = []
+
+    def _obs(self):
+        return self.rng.standard_normal((self.n, self.a, self.do)).astype(np.float32)
+
+    def reset(self):
+        self.t = 0
+        obs = self._obs()
+        self.log.append(dict(kind="reset", obs=obs))
+        return obs
+
+    def step(self, actions):
+        assert actions.shape == (self.n, self.a, self.na) and np.all(actions.sum(-1) == 1)
+        self.t += 1
+        obs = self._obs()
+        act_id = actions.argmax(-1)
+        rewards = (act_id[..., None] * 0.1 + obs[..., :1]).astype(np.float32)
+        dones = np.zeros((self.n, self.a), dtype=bool)
+        if self.t % self.done_every == 0:
+            dones[self.t % self.n] = True
+        infos = [[{"individual_reward": float(rewards[i, j, 0])} for j in range(self.a)] for i in range(self.n)]
+        self.log.append(dict(kind="step", obs=obs, rewards=rewards, dones=dones, actions=act_id))
+        return obs, rewards, dones, infos
+
+    def close(self):
+        pass
+
+
+class FakeSMACVecEnv(object):
+    """ShareSubprocVecEnv protocol of the SMAC wrappers: reset() -> obs, share_obs, available_actions;
+    step(actions [N, A, 1]) -> obs, share_obs, rewards, dones, infos, available_actions."""
+
+    def __init__(self, n_threads, n_agents, obs_dim, state_dim, n_actions, seed=0):
+        self.n, self.a, self.do, self.ds, self.na = n_threads, n_agents, obs_dim, state_dim, n_actions
+        self.observation_space = [Box((obs_dim,)) for _ in range(n_agents)]
+        self.share_observation_space = [Box((state_dim,)) for _ in range(n_agents)]
+        self.action_space = [Discrete(n_actions) for _ in range(n_agents)]
+        self.rng = np.random.default_rng(seed)
+        self.t = 0
+        self.avail = None
+        self.log = []
+
+    def _emit(self):
+        obs = self.rng.standard_normal((self.n, self.a, self.do)).astype(np.float32)
+        share = self.rng.standard_normal((self.n, self.a, self.ds)).astype(np.float32)
+        avail = (self.rng.random((self.n, self.a, self.na)) < 0.6).astype(np.float32)
+        avail[..., 0] = 1.0
+        self.avail = avail
+        return obs, share, avail
+
+    def reset(self):
+        self.t = 0
+        obs, share, avail = self._emit()
+        self.log.append(dict(kind="reset", obs=obs, share_obs=share, available_actions=avail))
+        return obs, share, avail
+
+    def step(self, actions):
+        actions = np.asarray(actions)
+        assert actions.shape == (self.n, self.a, 1)
+        act = actions[..., 0].astype(np.int64)
+        # the policy must respect the availability mask it was given
+        assert np.all(np.take_along_axis(self.avail, act[..., None], -1) == 1.0)
+        self.t += 1
+        obs, share, avail = self._emit()
+        rewards = self.rng.standard_normal((self.n, self.a, 1)).astype(np.float32)
+        dones = self.rng.random((self.n, self.a)) < 0.15            # individual deaths
+        if self.t % 4 == 0:
+            dones[self.t % self.n] = True                            # a whole team finishes
+        infos = [[{"bad_transition": bool((self.t + i + j) % 7 == 0), "battles_won": self.t // 4,
+                   "battles_game": self.t // 2, "won": True} for j in range(self.a)] for i in range(self.n)]
+        self.log.append(dict(kind="step", obs=obs, share_obs=share, rewards=rewards, dones=dones,
+                             available_actions=avail, actions=act, infos=infos))
+        return obs, share, rewards, dones, infos, avail
+
+    def close(self):
+        pass

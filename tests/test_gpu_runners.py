@@ -1,0 +1,99 @@
+"""-m gpu: the runner classes (the callers on either side of the hot path) driving the device
+buffer with deterministic fake envs: what the envs emitted must be what the buffer holds, in the
+reference's row conventions (observation-like fields at step+1, action-like at step), and
+training must run through compute / train / after_update / save."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_args
+from fake_envs import FakeMPEVecEnv, FakeSMACVecEnv
+
+pytestmark = pytest.mark.gpu
+
+
+def _config(args, envs, A, tmp_path):
+    return {"all_args": args, "envs": envs, "eval_envs": None, "num_agents": A,
+            "device": torch.device("cuda", 0), "run_dir": tmp_path}
+
+
+@pytest.mark.parametrize("recurrent", [False, True])
+def test_mpe_runner_rollout_and_update(tmp_path, recurrent):
+    from onpolicy.runner.shared.mpe_runner import MPERunner
+    T, N, A, Do, na = 8, 4, 3, 6, 5
+    args = make_args(env_name="MPE", episode_length=T, n_rollout_threads=N, num_env_steps=2 * T * N,
+                     hidden_size=16, ppo_epoch=2, num_mini_batch=2, use_recurrent_policy=recurrent,
+                     algorithm_name="rmappo" if recurrent else "mappo", data_chunk_length=4, log_interval=1,
+                     use_wandb=False)
+    args.scenario_name = "fake_spread"
+    envs = FakeMPEVecEnv(N, A, Do, na)
+    torch.manual_seed(1)
+    runner = MPERunner(_config(args, envs, A, tmp_path))
+    runner.warmup()
+    b = runner.buffer
+    np.testing.assert_array_equal(b.obs[0].cpu().numpy(), envs.log[0]["obs"])
+    np.testing.assert_array_equal(b.share_obs[0, :, 1].cpu().numpy(), envs.log[0]["obs"].reshape(N, -1))
+    for step in range(T):
+        out = runner.collect(step)
+        values, actions = out[0], out[1]
+        assert values.is_cuda and actions.is_cuda
+        obs, rewards, dones, infos = envs.step(out[5])
+        runner.insert((obs, rewards, dones, infos) + tuple(out[:5]))
+        rec = envs.log[-1]
+        np.testing.assert_array_equal(b.obs[step + 1].cpu().numpy(), rec["obs"])
+        np.testing.assert_array_equal(b.rewards[step].cpu().numpy(), rec["rewards"])
+        np.testing.assert_array_equal(b.actions[step, :, :, 0].cpu().numpy(), rec["actions"])
+        np.testing.assert_array_equal(b.masks[step + 1, :, :, 0].cpu().numpy(), 1.0 - rec["dones"])
+        np.testing.assert_array_equal(b.value_preds[step].cpu().numpy(), values.cpu().numpy())
+        if recurrent:   # finished agents restart from a zero state
+            assert float(b.rnn_states[step + 1][torch.as_tensor(rec["dones"])].abs().sum()) == 0.0
+    assert b.step == 0
+    runner.compute()
+    assert float(b.returns[:-1].abs().sum()) > 0
+    info = runner.train()
+    assert all(np.isfinite(v) for v in info.values())
+    np.testing.assert_array_equal(b.obs[0].cpu().numpy(), envs.log[-1]["obs"])     # after_update
+    runner.save()
+    assert os.path.exists(os.path.join(runner.save_dir, "actor.pt"))
+    # the whole loop, as the train script drives it
+    runner.run()
+    lines = open(os.path.join(runner.log_dir, "scalars.jsonl")).read().strip().splitlines()
+    assert any(json.loads(l)["tag"] == "value_loss" for l in lines)
+    runner.writter.export_scalars_to_json(os.path.join(runner.log_dir, "summary.json"))
+
+
+def test_smac_runner_masks(tmp_path):
+    from onpolicy.runner.shared.smac_runner import SMACRunner
+    T, N, A, Do, Ds, na = 8, 3, 4, 7, 9, 6
+    args = make_args(env_name="StarCraft2", episode_length=T, n_rollout_threads=N, num_env_steps=2 * T * N,
+                     hidden_size=16, ppo_epoch=1, num_mini_batch=1, use_recurrent_policy=True,
+                     algorithm_name="rmappo", data_chunk_length=4, log_interval=1, use_wandb=False,
+                     use_proper_time_limits=True)
+    args.map_name = "fake"
+    envs = FakeSMACVecEnv(N, A, Do, Ds, na)
+    torch.manual_seed(1)
+    runner = SMACRunner(_config(args, envs, A, tmp_path))
+    runner.warmup()
+    b = runner.buffer
+    np.testing.assert_array_equal(b.available_actions[0].cpu().numpy(), envs.log[0]["available_actions"])
+    for step in range(T):
+        out = runner.collect(step)
+        obs, share_obs, rewards, dones, infos, avail = envs.step(out[1].cpu().numpy())
+        runner.insert((obs, share_obs, rewards, dones, infos, avail) + tuple(out))
+        rec = envs.log[-1]
+        dones_env = rec["dones"].all(1)
+        exp_masks = np.ones((N, A)); exp_masks[dones_env] = 0
+        exp_active = np.ones((N, A)); exp_active[rec["dones"]] = 0; exp_active[dones_env] = 1
+        exp_bad = np.array([[0.0 if i[a]["bad_transition"] else 1.0 for a in range(A)] for i in rec["infos"]])
+        np.testing.assert_array_equal(b.masks[step + 1, :, :, 0].cpu().numpy(), exp_masks)
+        np.testing.assert_array_equal(b.active_masks[step + 1, :, :, 0].cpu().numpy(), exp_active)
+        np.testing.assert_array_equal(b.bad_masks[step + 1, :, :, 0].cpu().numpy(), exp_bad)
+        np.testing.assert_array_equal(b.share_obs[step + 1].cpu().numpy(), rec["share_obs"])
+        np.testing.assert_array_equal(b.available_actions[step + 1].cpu().numpy(), rec["available_actions"])
+    runner.compute()
+    info = runner.train()
+    assert all(np.isfinite(v) for v in info.values())
+    runner.run()

@@ -163,7 +163,7 @@ def main():
     torch.cuda.set_device(dev)
 
     from onpolicy.utils import dist as mdist
-    if world > 1:
+    if world > 1 or os.environ.get("MAPPO_FORCE_DIST", "0") == "1":
         mdist.init_from_env(dev)
     lo, hi = mdist.shard_threads(wl["N"], rank, world)
     n_local = hi - lo
@@ -242,7 +242,7 @@ def main():
             out["cpu_baseline"]["sample"] = out["cpu_baseline"]["sample"].replace(
                 "GPU/CPU ratio = 0x", "GPU/CPU ratio = %.0fx" % ratio)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -77,7 +77,7 @@ class R_MAPPO():
     # ------------------------------------------------------------------ losses
     def _normalizer_update(self, return_batch):
         """ValueNorm / PopArt EMA update (reference r_mappo.py:65) from GLOBAL batch moments."""
-        if self.dp.world_size == 1:
+        if not self.dp.active:
             self.value_normalizer.update(return_batch)
             return
         x = return_batch.detach()
@@ -228,7 +228,7 @@ class R_MAPPO():
             actor_grad_norm = get_gard_norm(self.policy.actor.parameters())
             critic_grad_norm = get_gard_norm(self.policy.critic.parameters())
 
-        if update_actor or self.dp.world_size == 1:
+        if update_actor or not self.dp.active:
             self.policy.actor_optimizer.step()
         self.policy.critic_optimizer.step()
 
@@ -238,7 +238,7 @@ class R_MAPPO():
     def _advantages(self, buffer):
         """Normalised advantages for the samplers (reference r_mappo.py:179-187)."""
         if hasattr(buffer, "normalized_advantages"):
-            reduce_fn = self.dp.all_reduce if self.dp.world_size > 1 else None
+            reduce_fn = self.dp.all_reduce if self.dp.active else None
             return buffer.normalized_advantages(self.value_normalizer, all_reduce=reduce_fn)
         # Foreign buffers that hold host arrays in the reference's format (e.g. the reference's own
         # SharedReplayBuffer): same arithmetic in torch on this trainer's device.
@@ -251,7 +251,7 @@ class R_MAPPO():
         on = active != 0.0
         sums = torch.stack([adv[on].double().sum(), (adv[on].double() ** 2).sum(),
                             on.sum().double()]).to(self.device)
-        if self.dp.world_size > 1:
+        if self.dp.active:
             self.dp.all_reduce(sums)
         sums = sums.cpu()
         mean = sums[0] / sums[2]

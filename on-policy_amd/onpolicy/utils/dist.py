@@ -23,15 +23,23 @@ import torch.distributed as dist
 
 
 def is_distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """True when a process group is up and there is more than one rank -- or MAPPO_FORCE_DIST=1, which
+    sends a single rank through the same bucket / collective code path (used to smoke-test RCCL on a
+    one-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("MAPPO_FORCE_DIST", "0") == "1"
 
 
 def init_from_env(device=None):
     """Initialise the default process group from torchrun-style environment variables
     (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).  No-op for a single process."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1 or (dist.is_available() and dist.is_initialized()):
+    forced = os.environ.get("MAPPO_FORCE_DIST", "0") == "1"
+    if (world <= 1 and not forced) or (dist.is_available() and dist.is_initialized()):
         return world
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("MASTER_PORT", "29533")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     backend = "nccl" if (device is not None and torch.device(device).type == "cuda") else "gloo"
     kwargs = {}
@@ -57,11 +65,12 @@ class DataParallel(object):
 
     def __init__(self, actor, critic, device, group=None):
         self.group = group
-        self.world_size = dist.get_world_size(group) if is_distributed() else 1
-        self.rank = dist.get_rank(group) if is_distributed() else 0
+        self.active = is_distributed()       # collectives are issued (world size may still be 1 when forced)
+        self.world_size = dist.get_world_size(group) if self.active else 1
+        self.rank = dist.get_rank(group) if self.active else 0
         self.device = device
         self._flat = None
-        if self.world_size > 1:
+        if self.active:
             params = [p for net in (actor, critic) for p in net.parameters() if p.requires_grad]
             total = sum(p.numel() for p in params)
             self._flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
@@ -86,25 +95,25 @@ class DataParallel(object):
 
     def all_reduce(self, tensor):
         """In-place sum over ranks (no-op for one process)."""
-        if self.world_size > 1:
+        if self.active:
             dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
         return tensor
 
     def zero_grad(self, *optimizers):
-        if self.world_size == 1:
+        if not self.active:
             for opt in optimizers:
                 opt.zero_grad()
         else:
             self._flat.zero_()  # grads are views of the bucket: one memset, nothing set to None
 
     def all_reduce_grads(self):
-        if self.world_size > 1:
+        if self.active:
             dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
 
     def loss_weights(self, active_masks, policy_masked, value_masked):
         """(w_actor, w_critic): local / global denominators of the masked means
         (reference r_mappo.py:135-139, 84-87)."""
-        if self.world_size == 1:
+        if not self.active:
             return 1.0, 1.0
         local = torch.stack([active_masks.detach().sum().double(),
                              torch.tensor(float(active_masks.shape[0]), dtype=torch.float64,
@@ -116,7 +125,7 @@ class DataParallel(object):
 
     def average_info(self, totals):
         """Logged scalars: mean over ranks of the per-rank means."""
-        if self.world_size > 1:
+        if self.active:
             self.all_reduce(totals)
             totals = totals / self.world_size
         return totals

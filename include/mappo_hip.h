@@ -193,7 +193,17 @@ int mappo_slab_copy(const mappo_slab_t* slabs, int n_slabs, mappo_stream_t strea
  *                      reduced in a fixed order: deterministic).
  * Returns MAPPO_E_SHAPE for an unsupported D (callers then use the framework's own LayerNorm).
  */
+/* mappo_act_layernorm_fwd/_bwd: the same with an elementwise activation fused in front,
+ * y = LayerNorm(act(x)), act: 0 = identity, 1 = tanh, 2 = relu -- one pass over the rows instead of
+ * two for the `Linear -> act -> LayerNorm` blocks of mlp.py:17-22.  `x` is the PRE-activation in
+ * both directions (the backward recomputes act(x)); dx is the gradient w.r.t. the pre-activation.
+ */
 int mappo_layernorm_max_blocks(void);
+int mappo_act_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y, float* mean,
+                            float* rstd, int64_t M, int D, float eps, int act, mappo_stream_t stream);
+int mappo_act_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                            const float* weight, float* dx, float* dweight, float* dbias, float* partials,
+                            int64_t M, int D, int act, mappo_stream_t stream);
 int mappo_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y, float* mean,
                         float* rstd, int64_t M, int D, float eps, mappo_stream_t stream);
 int mappo_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,

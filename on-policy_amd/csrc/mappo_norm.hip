@@ -47,8 +47,24 @@ __device__ __forceinline__ void set_elem(typename Unit<VEC>::type& u, int k, flo
     else u[k] = v;
 }
 
+// Optional activation fused in front of the normalisation (the trunks are Linear -> act ->
+// LayerNorm, ref mlp.py:17-22): ACT 0 = none, 1 = tanh, 2 = relu.
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float z) {
+    if constexpr (ACT == 1) return tanhf(z);
+    else if constexpr (ACT == 2) return z > 0.f ? z : 0.f;
+    else return z;
+}
+// derivative given the pre-activation z and the activation value a
+template <int ACT>
+__device__ __forceinline__ float act_grad(float z, float a) {
+    if constexpr (ACT == 1) return 1.f - a * a;
+    else if constexpr (ACT == 2) return z > 0.f ? 1.f : 0.f;
+    else return 1.f;
+}
+
 // ------------------------------------------------------------------------ forward ----
-template <int VEC, int LPR, int EPL>
+template <int VEC, int LPR, int EPL, int ACT>
 __global__ void __launch_bounds__(kThreads) ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ b, float* __restrict__ y,
                                                           float* __restrict__ mean, float* __restrict__ rstd,
@@ -79,7 +95,13 @@ __global__ void __launch_bounds__(kThreads) ln_fwd_kernel(const float* __restric
         for (int e = 0; e < EPL; ++e) {
             int u = lane + e * LPR;
             xv[e] = U(0.f);
-            if (u < units) xv[e] = xr[u];
+            if (u < units) {
+                xv[e] = xr[u];
+                if (ACT != 0) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) set_elem<VEC>(xv[e], k, act_fwd<ACT>(elem<VEC>(xv[e], k)));
+                }
+            }
 #pragma unroll
             for (int k = 0; k < VEC; ++k) s += elem<VEC>(xv[e], k);
         }
@@ -118,7 +140,7 @@ __global__ void __launch_bounds__(kThreads) ln_fwd_kernel(const float* __restric
 }
 
 // ----------------------------------------------------------------------- backward ----
-template <int VEC, int LPR, int EPL, bool NEED_DX>
+template <int VEC, int LPR, int EPL, bool NEED_DX, int ACT>
 __global__ void __launch_bounds__(kThreads) ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ w, float* __restrict__ dx,
@@ -145,19 +167,23 @@ __global__ void __launch_bounds__(kThreads) ln_bwd_kernel(const float* __restric
         const U* xr = reinterpret_cast<const U*>(x + row * D);
         const U* gr = reinterpret_cast<const U*>(dy + row * D);
         const float mu = mean[row], r = rstd[row];
-        U xh[EPL], gv[EPL];
+        U xh[EPL], gv[EPL], ag[EPL];   // xhat, dy*w, activation derivative
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             int u = lane + e * LPR;
             xh[e] = U(0.f);
             gv[e] = U(0.f);
+            ag[e] = U(1.f);
             if (u < units) {
                 U xv = xr[u];
                 U dv = gr[u];
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
-                    float h = (elem<VEC>(xv, k) - mu) * r;
+                    float zin = elem<VEC>(xv, k);
+                    float av = act_fwd<ACT>(zin);
+                    if (ACT != 0) set_elem<VEC>(ag[e], k, act_grad<ACT>(zin, av));
+                    float h = (av - mu) * r;
                     float d = elem<VEC>(dv, k);
                     float g = d * elem<VEC>(wv[e], k);
                     set_elem<VEC>(xh[e], k, h);
@@ -180,7 +206,8 @@ __global__ void __launch_bounds__(kThreads) ln_bwd_kernel(const float* __restric
                     U o;
 #pragma unroll
                     for (int k = 0; k < VEC; ++k)
-                        set_elem<VEC>(o, k, r * (elem<VEC>(gv[e], k) - m1 - elem<VEC>(xh[e], k) * m2));
+                        set_elem<VEC>(o, k, r * (elem<VEC>(gv[e], k) - m1 - elem<VEC>(xh[e], k) * m2) *
+                                               elem<VEC>(ag[e], k));
                     dr[u] = o;
                 }
             }
@@ -286,9 +313,9 @@ int ln_grid(long long M, int lpr) {
 
 extern "C" int mappo_layernorm_max_blocks(void) { return mappo::kCUs * 8; }
 
-extern "C" int mappo_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y,
-                                   float* mean, float* rstd, int64_t M, int D, float eps,
-                                   mappo_stream_t stream_) {
+extern "C" int mappo_act_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y,
+                                       float* mean, float* rstd, int64_t M, int D, float eps, int act,
+                                       mappo_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!x || !weight || !bias || !y || !mean || !rstd) return MAPPO_E_NULL;
     if (M <= 0 || D <= 0) return MAPPO_E_SHAPE;
@@ -296,10 +323,18 @@ extern "C" int mappo_layernorm_fwd(const float* x, const float* weight, const fl
     if (s.vec == 4 && !(mappo::aligned_to(weight, 16) && mappo::aligned_to(bias, 16))) s = pick_shape((void*)1, (void*)1, D);
     if (s.epl == 0) return MAPPO_E_SHAPE;
     dim3 grid(ln_grid(M, s.lpr)), block(kThreads);
+    if (act < 0 || act > 2) return MAPPO_E_FLAGS;
 #define LN_LAUNCH_FWD(V, L, E)                                                                   \
     if (s.vec == V && s.lpr == L && s.epl == E) {                                                \
-        hipLaunchKernelGGL((ln_fwd_kernel<V, L, E>), grid, block, 0, stream, x, weight, bias, y, mean, rstd, \
-                           (long long)M, D, eps);                                                \
+        if (act == 0)                                                                            \
+            hipLaunchKernelGGL((ln_fwd_kernel<V, L, E, 0>), grid, block, 0, stream, x, weight, bias, y, mean, \
+                               rstd, (long long)M, D, eps);                                      \
+        else if (act == 1)                                                                       \
+            hipLaunchKernelGGL((ln_fwd_kernel<V, L, E, 1>), grid, block, 0, stream, x, weight, bias, y, mean, \
+                               rstd, (long long)M, D, eps);                                      \
+        else                                                                                     \
+            hipLaunchKernelGGL((ln_fwd_kernel<V, L, E, 2>), grid, block, 0, stream, x, weight, bias, y, mean, \
+                               rstd, (long long)M, D, eps);                                      \
         return (int)hipGetLastError();                                                           \
     }
     LN_FOR_SHAPES(LN_LAUNCH_FWD)
@@ -307,9 +342,15 @@ extern "C" int mappo_layernorm_fwd(const float* x, const float* weight, const fl
     return MAPPO_E_SHAPE;
 }
 
-extern "C" int mappo_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
-                                   const float* weight, float* dx, float* dweight, float* dbias,
-                                   float* partials, int64_t M, int D, mappo_stream_t stream_) {
+extern "C" int mappo_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y,
+                                   float* mean, float* rstd, int64_t M, int D, float eps,
+                                   mappo_stream_t stream) {
+    return mappo_act_layernorm_fwd(x, weight, bias, y, mean, rstd, M, D, eps, 0, stream);
+}
+
+extern "C" int mappo_act_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                                       const float* weight, float* dx, float* dweight, float* dbias,
+                                       float* partials, int64_t M, int D, int act, mappo_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!dy || !x || !mean || !rstd || !weight || !dweight || !dbias || !partials) return MAPPO_E_NULL;
     if (M <= 0 || D <= 0) return MAPPO_E_SHAPE;
@@ -323,14 +364,21 @@ extern "C" int mappo_layernorm_bwd(const float* dy, const float* x, const float*
     const size_t lds = (size_t)2 * (kThreads / s.lpr) * D * sizeof(float);
     dim3 grid(nblk), block(kThreads);
     bool launched = false;
+    if (act < 0 || act > 2) return MAPPO_E_FLAGS;
+#define LN_BWD_ONE(V, L, E, DX, A)                                                               \
+    hipLaunchKernelGGL((ln_bwd_kernel<V, L, E, DX, A>), grid, block, lds, stream, dy, x, mean, rstd, weight, \
+                       dx, pw, pb, (long long)M, D)
 #define LN_LAUNCH_BWD(V, L, E)                                                                   \
     if (!launched && s.vec == V && s.lpr == L && s.epl == E) {                                   \
-        if (dx)                                                                                  \
-            hipLaunchKernelGGL((ln_bwd_kernel<V, L, E, true>), grid, block, lds, stream, dy, x, mean, rstd, \
-                               weight, dx, pw, pb, (long long)M, D);                             \
-        else                                                                                     \
-            hipLaunchKernelGGL((ln_bwd_kernel<V, L, E, false>), grid, block, lds, stream, dy, x, mean, rstd, \
-                               weight, dx, pw, pb, (long long)M, D);                             \
+        if (dx) {                                                                                \
+            if (act == 0) LN_BWD_ONE(V, L, E, true, 0);                                          \
+            else if (act == 1) LN_BWD_ONE(V, L, E, true, 1);                                     \
+            else LN_BWD_ONE(V, L, E, true, 2);                                                   \
+        } else {                                                                                 \
+            if (act == 0) LN_BWD_ONE(V, L, E, false, 0);                                         \
+            else if (act == 1) LN_BWD_ONE(V, L, E, false, 1);                                    \
+            else LN_BWD_ONE(V, L, E, false, 2);                                                  \
+        }                                                                                        \
         launched = true;                                                                         \
     }
     LN_FOR_SHAPES(LN_LAUNCH_BWD)
@@ -341,4 +389,10 @@ extern "C" int mappo_layernorm_bwd(const float* dy, const float* x, const float*
     hipLaunchKernelGGL(ln_reduce_kernel, dim3((D + 63) / 64), dim3(kReduceThreads), 0, stream, pw, pb, dweight,
                        dbias, nblk, D);
     return (int)hipGetLastError();
+}
+
+extern "C" int mappo_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                                   const float* weight, float* dx, float* dweight, float* dbias,
+                                   float* partials, int64_t M, int D, mappo_stream_t stream) {
+    return mappo_act_layernorm_bwd(dy, x, mean, rstd, weight, dx, dweight, dbias, partials, M, D, 0, stream);
 }

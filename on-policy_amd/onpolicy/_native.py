@@ -46,6 +46,8 @@ SIGNATURES = {
     "mappo_gather_set_variant": (_int, [_int]),
     "mappo_slab_copy": (_int, [ctypes.POINTER(Slab), _int, _vp]),
     "mappo_layernorm_max_blocks": (_int, []),
+    "mappo_act_layernorm_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, ctypes.c_float, _int, _vp]),
+    "mappo_act_layernorm_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),
     "mappo_layernorm_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, ctypes.c_float, _vp]),
     "mappo_layernorm_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]),
     "mappo_abi_version": (_int, []),

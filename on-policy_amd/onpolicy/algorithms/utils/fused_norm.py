@@ -23,9 +23,15 @@ def supported(x, D):
     return (D % 4 == 0 and D <= 2048) or D <= 1536
 
 
+ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
+
+
 class _LayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(act(x)) over the last dimension; ``x`` is saved as the pre-activation and the
+    backward recomputes act(x), so the activation output is never materialised."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
+    def forward(ctx, x, weight, bias, eps, act=ACT_NONE):
         from onpolicy import _native
         lib = _native.lib()
         D = x.shape[-1]
@@ -37,11 +43,13 @@ class _LayerNormFn(torch.autograd.Function):
         w = weight.contiguous()
         b = bias.contiguous()
         if M > 0:
-            _native.check(lib.mappo_layernorm_fwd(x2.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(),
-                                                  mean.data_ptr(), rstd.data_ptr(), M, D, float(eps),
-                                                  _native.stream_of(x.device)), "mappo_layernorm_fwd")
+            _native.check(lib.mappo_act_layernorm_fwd(x2.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(),
+                                                      mean.data_ptr(), rstd.data_ptr(), M, D, float(eps),
+                                                      int(act), _native.stream_of(x.device)),
+                          "mappo_act_layernorm_fwd")
         ctx.save_for_backward(x2, w, mean, rstd)
         ctx.x_shape = x.shape
+        ctx.act = int(act)
         return y.view(x.shape)
 
     @staticmethod
@@ -55,19 +63,40 @@ class _LayerNormFn(torch.autograd.Function):
         dw = torch.empty(D, dtype=torch.float32, device=x2.device)
         db = torch.empty(D, dtype=torch.float32, device=x2.device)
         partials = torch.empty(2 * lib.mappo_layernorm_max_blocks() * D, dtype=torch.float32, device=x2.device)
-        _native.check(lib.mappo_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                              w.data_ptr(), None if dx is None else dx.data_ptr(),
-                                              dw.data_ptr(), db.data_ptr(), partials.data_ptr(), M, D,
-                                              _native.stream_of(x2.device)), "mappo_layernorm_bwd")
-        return (None if dx is None else dx.view(ctx.x_shape)), dw, db, None
+        _native.check(lib.mappo_act_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                  w.data_ptr(), None if dx is None else dx.data_ptr(),
+                                                  dw.data_ptr(), db.data_ptr(), partials.data_ptr(), M, D,
+                                                  ctx.act, _native.stream_of(x2.device)),
+                      "mappo_act_layernorm_bwd")
+        return (None if dx is None else dx.view(ctx.x_shape)), dw, db, None, None
 
 
 class FusedLayerNorm(nn.LayerNorm):
     """nn.LayerNorm(D) whose forward / backward run the HIP streaming kernels on the GPU."""
 
+    def _fusable(self, x):
+        return len(self.normalized_shape) == 1 and self.elementwise_affine and self.bias is not None \
+            and x.numel() > 0 and supported(x, self.normalized_shape[-1])
+
     def forward(self, x):
-        D = self.normalized_shape[-1]
-        if len(self.normalized_shape) == 1 and self.elementwise_affine and self.bias is not None \
-                and x.numel() > 0 and supported(x, D):
-            return _LayerNormFn.apply(x, self.weight, self.bias, self.eps)
+        if self._fusable(x):
+            return _LayerNormFn.apply(x, self.weight, self.bias, self.eps, ACT_NONE)
         return F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
+
+    def forward_act(self, z, act_module):
+        """LayerNorm(act(z)) with the activation fused into the kernels when possible."""
+        kind = ACT_TANH if isinstance(act_module, nn.Tanh) else ACT_RELU if isinstance(act_module, nn.ReLU) else None
+        if kind is not None and self._fusable(z):
+            return _LayerNormFn.apply(z, self.weight, self.bias, self.eps, kind)
+        return self.forward(act_module(z))
+
+
+class DenseBlock(nn.Sequential):
+    """``Sequential(Linear, act, LayerNorm)`` -- same children indices / state_dict keys as the
+    reference's blocks (mlp.py:17-22) -- evaluated as Linear followed by ONE fused act+LayerNorm pass."""
+
+    def forward(self, x):
+        linear, act, norm = self[0], self[1], self[2]
+        if isinstance(norm, FusedLayerNorm):
+            return norm.forward_act(linear(x), act)
+        return norm(act(linear(x)))

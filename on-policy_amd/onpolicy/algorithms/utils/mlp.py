@@ -6,7 +6,7 @@ MLPBase :33), so reference checkpoints load and a given seed yields the same wei
 """
 import torch.nn as nn
 
-from .fused_norm import FusedLayerNorm
+from .fused_norm import FusedLayerNorm, DenseBlock
 from .tall_linear import TallLinear
 from .util import init
 
@@ -22,7 +22,7 @@ def _zero_bias(b):
 def _block(in_dim, out_dim, use_orthogonal, use_ReLU, act):
     gain = nn.init.calculate_gain('relu' if use_ReLU else 'tanh')
     linear = init(TallLinear(in_dim, out_dim), _weight_init(use_orthogonal), _zero_bias, gain=gain)
-    return nn.Sequential(linear, act, FusedLayerNorm(out_dim))
+    return DenseBlock(linear, act, FusedLayerNorm(out_dim))
 
 
 class MLPLayer(nn.Module):

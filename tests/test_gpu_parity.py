@@ -482,3 +482,35 @@ def test_tall_linear_backward_vs_torch():
             e_mine = float((mine.double() - exact).abs().max()) / scale
             e_torch = float((theirs.double() - exact).abs().max()) / scale
             assert e_mine <= 4 * e_torch + 1e-5, (what, M, K, N, e_mine, e_torch)
+
+
+@pytest.mark.parametrize("act", ["tanh", "relu"])
+def test_fused_act_layernorm_block_vs_torch(act):
+    """DenseBlock (Linear -> act -> LayerNorm with the activation fused into the LayerNorm kernels)
+    against the plain torch modules, float64 as judge."""
+    from onpolicy.algorithms.utils.fused_norm import FusedLayerNorm, DenseBlock
+    dev = _dev()
+    torch.manual_seed(5)
+    A = torch.nn.Tanh if act == "tanh" else torch.nn.ReLU
+    for M, K, N in [(1000, 48, 64), (70001, 64, 64), (4097, 30, 512)]:
+        blk = DenseBlock(torch.nn.Linear(K, N), A(), FusedLayerNorm(N)).to(dev)
+        ref = torch.nn.Sequential(torch.nn.Linear(K, N), A(), torch.nn.LayerNorm(N)).to(dev)
+        ref.load_state_dict(blk.state_dict())
+        ref64 = torch.nn.Sequential(torch.nn.Linear(K, N), A(), torch.nn.LayerNorm(N)).to(dev).double()
+        ref64.load_state_dict({k: v.double() for k, v in blk.state_dict().items()})
+        x = torch.randn(M, K, device=dev, requires_grad=True)
+        xr = x.detach().clone().requires_grad_(True)
+        x64 = x.detach().double().requires_grad_(True)
+        dy = torch.randn(M, N, device=dev)
+        y, yr, y64 = blk(x), ref(xr), ref64(x64)
+        y.backward(dy)
+        yr.backward(dy)
+        y64.backward(dy.double())
+        pairs = [(y, yr, y64.detach(), "y"), (x.grad, xr.grad, x64.grad, "dx")]
+        for (n1, p1), (_, p2), (_, p3) in zip(blk.named_parameters(), ref.named_parameters(), ref64.named_parameters()):
+            pairs.append((p1.grad, p2.grad, p3.grad, n1))
+        for mine, theirs, exact, what in pairs:
+            scale = float(exact.abs().max())
+            e_mine = float((mine.detach().double() - exact).abs().max()) / scale
+            e_torch = float((theirs.detach().double() - exact).abs().max()) / scale
+            assert e_mine <= 4 * e_torch + 2e-5, (what, act, M, e_mine, e_torch)

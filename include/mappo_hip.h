@@ -150,7 +150,9 @@ typedef struct mappo_field {
     int32_t      width; /* floats per row (> 0)                                */
     int32_t      first_only; /* chunk gather only: copy the l = 0 row per chunk */
     int32_t      normalize;  /* dst = (src - stats[0]) / (stats[1] + 1e-5f)     */
-    int32_t      reserved;
+    int32_t      standardize; /* dst row = (row - mean(row)) / sqrt(var(row) + 1e-5): the parameter-free
+                                 part of the input nn.LayerNorm (ref algorithms/utils/mlp.py:47-53),
+                                 applied while the row is copied; widths as for mappo_layernorm_fwd */
 } mappo_field_t;
 
 int mappo_gather_rows(const mappo_field_t* fields, int n_fields, const int64_t* idx,

@@ -42,10 +42,7 @@ struct GatherArgs {
     GField f[MAPPO_MAX_FIELDS];
     int nf;
     unsigned total_tiles;
-    const long long* idx;
-    unsigned mb;
-    int chunked;             // 0: rows mode, 1: chunk mode
-    unsigned L, T, N, A;
+    mappo::RowMap map;
     const float* stats;
 };
 
@@ -70,22 +67,8 @@ __device__ __forceinline__ void normv(f32x4& v, float m, float d) {
     v.w = norm1(v.w, m, d);
 }
 
-// Source row (in the time-major [T, N, A] row space) of output row `r` of a field.
 __device__ __forceinline__ unsigned source_row(const GatherArgs& a, const GField& fd, unsigned r) {
-    if (!a.chunked) return (unsigned)a.idx[r];  // shared_buffer.py:379-396
-    // shared_buffer.py:554-569 on the (n, a, t)-ordered view, 574-604 for the output order
-    unsigned l = 0, j = r;
-    if (!fd.first_only) {
-        l = r / a.mb;
-        j = r - l * a.mb;
-    }
-    unsigned f = (unsigned)a.idx[j] * a.L + l;
-    unsigned at = a.A * a.T;
-    unsigned n = f / at;
-    unsigned rem = f - n * at;
-    unsigned ag = rem / a.T;
-    unsigned t = rem - ag * a.T;
-    return (t * a.N + n) * a.A + ag;
+    return mappo::source_row(a.map, fd.first_only, r);
 }
 
 template <bool NT, typename V>
@@ -191,23 +174,31 @@ int build_and_launch(const mappo_field_t* fields, int n_fields, const int64_t* i
     const int blocks_per_cu = variant >> 4;
     const unsigned tile_units = (unsigned)(kThreads * unroll);
     GatherArgs a;
-    a.nf = n_fields;
-    a.idx = reinterpret_cast<const long long*>(idx);
-    a.mb = (unsigned)mb;
-    a.chunked = chunked;
-    a.L = (unsigned)L;
-    a.T = (unsigned)T;
-    a.N = (unsigned)N;
-    a.A = (unsigned)A;
+    a.map.idx = reinterpret_cast<const long long*>(idx);
+    a.map.mb = (unsigned)mb;
+    a.map.chunked = chunked;
+    a.map.L = (unsigned)L;
+    a.map.T = (unsigned)T;
+    a.map.N = (unsigned)N;
+    a.map.A = (unsigned)A;
     a.stats = stats;
     unsigned long long tiles = 0;
+    int nf = 0;
     for (int k = 0; k < n_fields; ++k) {
         const mappo_field_t& s = fields[k];
         if (!s.src || !s.dst) return MAPPO_E_NULL;
         if (s.width <= 0) return MAPPO_E_SHAPE;
         if (!mappo::aligned_to(s.src, 4) || !mappo::aligned_to(s.dst, 4)) return MAPPO_E_ALIGN;
         if (s.normalize && !stats) return MAPPO_E_NULL;
-        GField& g = a.f[k];
+        if (s.standardize) {
+            // row-standardised fields go through the row-owning kernel (it needs whole-row statistics)
+            const unsigned fo = (chunked && s.first_only) ? 1u : 0u;
+            const long long rows = (chunked && !fo) ? mb * (long long)L : mb;
+            int rc = mappo::gather_standardize(s.src, s.dst, s.width, rows, a.map, fo, 1e-5f, stream);
+            if (rc != 0) return rc;
+            continue;
+        }
+        GField& g = a.f[nf++];
         g.src = s.src;
         g.dst = s.dst;
         g.width = (unsigned)s.width;
@@ -223,7 +214,9 @@ int build_and_launch(const mappo_field_t* fields, int n_fields, const int64_t* i
         tiles += (unsigned long long)((rows_out + g.rows_per_tile - 1) / g.rows_per_tile);
         if (tiles >= (1ull << 32)) return MAPPO_E_SHAPE;
     }
+    a.nf = nf;
     a.total_tiles = (unsigned)tiles;
+    if (nf == 0) return 0;
     hipError_t e;
     switch ((variant & 3) | (nt ? 4 : 0)) {
         case 0: e = launch_gather<1, false>(a, tile_units, blocks_per_cu, stream); break;

@@ -21,5 +21,35 @@ inline int row_vec(const void* src, const void* dst, long long width) {
     return 1;
 }
 
+// Source-row mapping of the samplers (shared by the tile gather and the standardising gather).
+struct RowMap {
+    const long long* idx;
+    unsigned mb;
+    int chunked;      // 0: rows mode (shared_buffer.py:379-396), 1: chunk mode (:554-604)
+    unsigned L, T, N, A;
+};
+
+// Source row (in the time-major [T, N, A] row space) of output row `r`.
+__device__ __forceinline__ unsigned source_row(const RowMap& m, unsigned first_only, unsigned r) {
+    if (!m.chunked) return (unsigned)m.idx[r];
+    unsigned l = 0, j = r;
+    if (!first_only) {
+        l = r / m.mb;
+        j = r - l * m.mb;
+    }
+    unsigned f = (unsigned)m.idx[j] * m.L + l;
+    unsigned at = m.A * m.T;
+    unsigned n = f / at;
+    unsigned rem = f - n * at;
+    unsigned ag = rem / m.T;
+    unsigned t = rem - ag * m.T;
+    return (t * m.N + n) * m.A + ag;
+}
+
+// dst[r, :] = standardise(src[source_row(r), :]) = (x - mean) / sqrt(var + eps), row statistics over
+// `width` elements (mappo_norm.hip).  Returns a MAPPO_E_* / hipError_t code.
+int gather_standardize(const float* src, float* dst, int width, long long rows_out, const RowMap& map,
+                       unsigned first_only, float eps, hipStream_t stream);
+
 }  // namespace mappo
 #endif

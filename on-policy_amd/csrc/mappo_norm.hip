@@ -139,6 +139,60 @@ __global__ void __launch_bounds__(kThreads) ln_fwd_kernel(const float* __restric
     }
 }
 
+// ------------------------------------------------ gather + standardise (K3/K4 + K6) ----
+// dst[r, :] = (x - mean(x)) * rsqrt(var(x) + eps) with x = src[source_row(r), :]: the parameter-free
+// half of the input LayerNorm, done while the sampler copies the row anyway.
+template <int VEC, int LPR, int EPL>
+__global__ void __launch_bounds__(kThreads) gather_std_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                              long long M, int D, mappo::RowMap map,
+                                                              unsigned first_only, float eps) {
+    using U = typename Unit<VEC>::type;
+    constexpr int RPB = kThreads / LPR;
+    const int lane = threadIdx.x % LPR;
+    const int rib = threadIdx.x / LPR;
+    const int units = D / VEC;
+    const float invD = 1.0f / (float)D;
+    for (long long row = (long long)blockIdx.x * RPB + rib; row < M; row += (long long)gridDim.x * RPB) {
+        const unsigned srow = mappo::source_row(map, first_only, (unsigned)row);
+        const U* xr = reinterpret_cast<const U*>(x + (long long)srow * D);
+        U xv[EPL];
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            int u = lane + e * LPR;
+            xv[e] = U(0.f);
+            if (u < units) xv[e] = __builtin_nontemporal_load(xr + u);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) s += elem<VEC>(xv[e], k);
+        }
+        const float mu = group_sum<LPR>(s) * invD;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            int u = lane + e * LPR;
+            if (u < units) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    float d = elem<VEC>(xv[e], k) - mu;
+                    q += d * d;
+                }
+            }
+        }
+        const float r = 1.0f / sqrtf(group_sum<LPR>(q) * invD + eps);
+        U* yr = reinterpret_cast<U*>(y + row * D);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            int u = lane + e * LPR;
+            if (u < units) {
+                U o;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) set_elem<VEC>(o, k, (elem<VEC>(xv[e], k) - mu) * r);
+                __builtin_nontemporal_store(o, yr + u);
+            }
+        }
+    }
+}
+
 // ----------------------------------------------------------------------- backward ----
 template <int VEC, int LPR, int EPL, bool NEED_DX, int ACT>
 __global__ void __launch_bounds__(kThreads) ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -310,6 +364,23 @@ int ln_grid(long long M, int lpr) {
     X(1, 64, 16) X(1, 64, 24)
 
 }  // namespace
+
+int mappo::gather_standardize(const float* src, float* dst, int width, long long rows_out,
+                              const mappo::RowMap& map, unsigned first_only, float eps, hipStream_t stream) {
+    if (rows_out <= 0 || width <= 0) return MAPPO_E_SHAPE;
+    Shape s = pick_shape(src, dst, width);
+    if (s.epl == 0) return MAPPO_E_SHAPE;
+    dim3 grid(ln_grid(rows_out, s.lpr)), block(kThreads);
+#define LN_LAUNCH_GS(V, L, E)                                                                    \
+    if (s.vec == V && s.lpr == L && s.epl == E) {                                                \
+        hipLaunchKernelGGL((gather_std_kernel<V, L, E>), grid, block, 0, stream, src, dst, rows_out, width, \
+                           map, first_only, eps);                                                \
+        return (int)hipGetLastError();                                                           \
+    }
+    LN_FOR_SHAPES(LN_LAUNCH_GS)
+#undef LN_LAUNCH_GS
+    return MAPPO_E_SHAPE;
+}
 
 extern "C" int mappo_layernorm_max_blocks(void) { return mappo::kCUs * 8; }
 

@@ -23,7 +23,7 @@ _int = ctypes.c_int
 class Field(ctypes.Structure):
     """struct mappo_field (include/mappo_hip.h)."""
     _fields_ = [("src", _vp), ("dst", _vp), ("width", ctypes.c_int32), ("first_only", ctypes.c_int32),
-                ("normalize", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("normalize", ctypes.c_int32), ("standardize", ctypes.c_int32)]
 
 
 class Slab(ctypes.Structure):

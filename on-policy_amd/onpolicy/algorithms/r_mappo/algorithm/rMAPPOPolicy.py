@@ -43,12 +43,19 @@ class R_MAPPOPolicy:
     def get_values(self, cent_obs, rnn_states_critic, masks):
         return self.critic(cent_obs, rnn_states_critic, masks)[0]
 
+    def can_fold_input_norm(self):
+        """Both trunks can take row-standardised observations (see MLPBase.forward)."""
+        bases = (self.actor.base, self.critic.base)
+        return all(hasattr(b, "can_fold_input_norm") and b.can_fold_input_norm() for b in bases)
+
     def evaluate_actions(self, cent_obs, obs, rnn_states_actor, rnn_states_critic, action, masks,
-                         available_actions=None, active_masks=None):
-        """-> (values, action_log_probs, dist_entropy)."""
+                         available_actions=None, active_masks=None, obs_standardized=False):
+        """-> (values, action_log_probs, dist_entropy).  ``obs_standardized``: cent_obs / obs rows were
+        standardised by the sampler (SharedReplayBuffer generators, standardize_obs=True)."""
         action_log_probs, dist_entropy = self.actor.evaluate_actions(obs, rnn_states_actor, action, masks,
-                                                                     available_actions, active_masks)
-        values = self.critic(cent_obs, rnn_states_critic, masks)[0]
+                                                                     available_actions, active_masks,
+                                                                     obs_standardized=obs_standardized)
+        values = self.critic(cent_obs, rnn_states_critic, masks, obs_standardized=obs_standardized)[0]
         return values, action_log_probs, dist_entropy
 
     def act(self, obs, rnn_states_actor, masks, available_actions=None, deterministic=False):

@@ -56,8 +56,8 @@ class R_Actor(nn.Module, _DeviceMixin):
     def _recurrent(self):
         return self._use_naive_recurrent_policy or self._use_recurrent_policy
 
-    def _features(self, obs, rnn_states, masks):
-        feats = self.base(obs)
+    def _features(self, obs, rnn_states, masks, obs_standardized=False):
+        feats = self.base(obs, standardized=True) if obs_standardized else self.base(obs)
         if self._recurrent:
             feats, rnn_states = self.rnn(feats, rnn_states, masks)
         return feats, rnn_states
@@ -68,10 +68,11 @@ class R_Actor(nn.Module, _DeviceMixin):
         actions, action_log_probs = self.act(feats, available_actions, deterministic)
         return actions, action_log_probs, rnn_states
 
-    def evaluate_actions(self, obs, rnn_states, action, masks, available_actions=None, active_masks=None):
+    def evaluate_actions(self, obs, rnn_states, action, masks, available_actions=None, active_masks=None,
+                         obs_standardized=False):
         obs, rnn_states, action, masks, available_actions, active_masks = self._to_device(
             obs, rnn_states, action, masks, available_actions, active_masks)
-        feats, _ = self._features(obs, rnn_states, masks)
+        feats, _ = self._features(obs, rnn_states, masks, obs_standardized)
         return self.act.evaluate_actions(
             feats, action, available_actions,
             active_masks=active_masks if self._use_policy_active_masks else None)
@@ -100,9 +101,9 @@ class R_Critic(nn.Module, _DeviceMixin):
     def _recurrent(self):
         return self._use_naive_recurrent_policy or self._use_recurrent_policy
 
-    def forward(self, cent_obs, rnn_states, masks):
+    def forward(self, cent_obs, rnn_states, masks, obs_standardized=False):
         cent_obs, rnn_states, masks = self._to_device(cent_obs, rnn_states, masks)
-        feats = self.base(cent_obs)
+        feats = self.base(cent_obs, standardized=True) if obs_standardized else self.base(cent_obs)
         if self._recurrent:
             feats, rnn_states = self.rnn(feats, rnn_states, masks)
         return self.v_out(feats), rnn_states

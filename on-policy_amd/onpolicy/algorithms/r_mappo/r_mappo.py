@@ -73,6 +73,8 @@ class R_MAPPO():
 
         # data parallelism over rollout threads; world size 1 unless torch.distributed is up
         self.dp = mdist.DataParallel(self.policy.actor, self.policy.critic, device)
+        # set by train() while it feeds ppo_update with row-standardised observations
+        self._obs_standardized = False
 
     # ------------------------------------------------------------------ losses
     def _normalizer_update(self, return_batch):
@@ -180,7 +182,7 @@ class R_MAPPO():
             values, action_log_probs, entropy = self.policy.evaluate_actions(
                 cut(share_obs_batch, lo, hi), cut(obs_batch, lo, hi), cut(rnn_states_batch, lo, hi),
                 cut(rnn_states_critic_batch, lo, hi), cut(actions_batch, lo, hi), cut(masks_batch, lo, hi),
-                cut(available_actions_batch, lo, hi), am)
+                cut(available_actions_batch, lo, hi), am, **self._eval_kwargs())
 
             # clipped surrogate (r_mappo.py:129-139)
             imp_weights = torch.exp(action_log_probs - old_action_log_probs_batch[lo:hi])
@@ -234,6 +236,9 @@ class R_MAPPO():
 
         return value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights
 
+    def _eval_kwargs(self):
+        return {"obs_standardized": True} if self._obs_standardized else {}
+
     # ------------------------------------------------------------------ one update phase
     def _advantages(self, buffer):
         """Normalised advantages for the samplers (reference r_mappo.py:179-187)."""
@@ -263,6 +268,10 @@ class R_MAPPO():
         -> dict with value_loss, policy_loss, dist_entropy, actor_grad_norm, critic_grad_norm, ratio
         (means over the updates; global-batch values in a data-parallel job)."""
         advantages = self._advantages(buffer)
+        # let the sampler do the parameter-free half of the input LayerNorm while it copies the rows
+        fold = bool(getattr(buffer, "supports_standardized_obs", False)) and \
+            hasattr(self.policy, "can_fold_input_norm") and self.policy.can_fold_input_norm()
+        gen_kwargs = {"standardize_obs": True} if fold else {}
 
         keys = ('value_loss', 'policy_loss', 'dist_entropy', 'actor_grad_norm', 'critic_grad_norm', 'ratio')
         totals = torch.zeros(len(keys), dtype=torch.float32, device=self.device)
@@ -270,15 +279,19 @@ class R_MAPPO():
         for _ in range(self.ppo_epoch):
             if self._use_recurrent_policy:
                 data_generator = buffer.recurrent_generator(advantages, self.num_mini_batch,
-                                                            self.data_chunk_length)
+                                                            self.data_chunk_length, **gen_kwargs)
             elif self._use_naive_recurrent:
-                data_generator = buffer.naive_recurrent_generator(advantages, self.num_mini_batch)
+                data_generator = buffer.naive_recurrent_generator(advantages, self.num_mini_batch, **gen_kwargs)
             else:
-                data_generator = buffer.feed_forward_generator(advantages, self.num_mini_batch)
+                data_generator = buffer.feed_forward_generator(advantages, self.num_mini_batch, **gen_kwargs)
 
             for sample in data_generator:
-                value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights \
-                    = self.ppo_update(sample, update_actor)
+                self._obs_standardized = fold
+                try:
+                    value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights \
+                        = self.ppo_update(sample, update_actor)
+                finally:
+                    self._obs_standardized = False
                 with torch.no_grad():
                     totals += torch.stack([
                         value_loss.detach().reshape(()), policy_loss.detach().reshape(()),

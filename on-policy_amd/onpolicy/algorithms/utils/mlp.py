@@ -7,7 +7,7 @@ MLPBase :33), so reference checkpoints load and a given seed yields the same wei
 import torch.nn as nn
 
 from .fused_norm import FusedLayerNorm, DenseBlock
-from .tall_linear import TallLinear
+from .tall_linear import TallLinear, tall_linear
 from .util import init
 
 
@@ -55,7 +55,26 @@ class MLPBase(nn.Module):
             self.feature_norm = FusedLayerNorm(obs_dim)
         self.mlp = MLPLayer(obs_dim, self.hidden_size, self._layer_N, self._use_orthogonal, self._use_ReLU)
 
-    def forward(self, x):
-        if self._use_feature_normalization:
-            x = self.feature_norm(x)
-        return self.mlp(x)
+    def can_fold_input_norm(self):
+        """True if ``forward(x, standardized=True)`` is available: the input LayerNorm exists and its
+        eps is the one the standardising gather uses."""
+        return bool(self._use_feature_normalization) and abs(self.feature_norm.eps - 1e-5) < 1e-12
+
+    def forward(self, x, standardized=False):
+        """``standardized=True``: ``x`` already holds (x - mean) / sqrt(var + eps) per row (the sampler
+        computed it while gathering).  The LayerNorm's affine half is then folded into the first
+        Linear, LN(x) W^T + b = xhat (W * gamma)^T + (b + W beta): the same function of the same
+        parameters (autograd reaches gamma / beta through the two tiny products), without ever
+        materialising the normalised [rows, D] input or its gradient."""
+        if not self._use_feature_normalization:
+            return self.mlp(x)
+        if not standardized:
+            return self.mlp(self.feature_norm(x))
+        first = self.mlp.fc1
+        linear, act, norm = first[0], first[1], first[2]
+        w_eff = linear.weight * self.feature_norm.weight
+        b_eff = linear.bias + linear.weight @ self.feature_norm.bias
+        h = norm.forward_act(tall_linear(x, w_eff, b_eff), act)
+        for layer in self.mlp.fc2:
+            h = layer(h)
+        return h

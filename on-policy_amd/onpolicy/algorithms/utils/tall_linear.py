@@ -48,9 +48,14 @@ class _TallLinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
+def tall_linear(x, weight, bias):
+    """F.linear with the split-K backward when ``x`` is a tall HIP matrix."""
+    if x.dim() == 2 and x.is_cuda and x.shape[0] >= _MIN_ROWS and torch.is_grad_enabled() \
+            and x.is_contiguous():
+        return _TallLinearFn.apply(x, weight, bias)
+    return F.linear(x, weight, bias)
+
+
 class TallLinear(nn.Linear):
     def forward(self, x):
-        if x.dim() == 2 and x.is_cuda and x.shape[0] >= _MIN_ROWS and torch.is_grad_enabled() \
-                and x.is_contiguous():
-            return _TallLinearFn.apply(x, self.weight, self.bias)
-        return F.linear(x, self.weight, self.bias)
+        return tall_linear(x, self.weight, self.bias)

@@ -391,7 +391,9 @@ class SharedReplayBuffer(object):
         table.append(("available_actions", self.available_actions, False))
         return table, stats
 
-    def _gather(self, table, stats, idx, mb, chunk_len=None):
+    supports_standardized_obs = True   # generators take standardize_obs=True (see feed_forward_generator)
+
+    def _gather(self, table, stats, idx, mb, chunk_len=None, standardize_obs=False):
         """One fused gather launch (K3 / K4) -> the 12-tuple of fresh device tensors."""
         T, N, A = self.episode_length, self.n_rollout_threads, self.num_agents
         rows_out = mb if chunk_len is None else mb * chunk_len
@@ -409,7 +411,8 @@ class SharedReplayBuffer(object):
             n_rows = mb if (first_only or chunk_len is None) else rows_out
             dst = torch.empty((n_rows,) + tail, dtype=torch.float32, device=self.device)
             normalize = 1 if (name == "advantages" and stats is not None) else 0
-            fields.append(_native.Field(src.data_ptr(), dst.data_ptr(), width, first_only, normalize, 0))
+            standardize = 1 if (standardize_obs and name in ("share_obs", "obs") and len(tail) == 1) else 0
+            fields.append(_native.Field(src.data_ptr(), dst.data_ptr(), width, first_only, normalize, standardize))
             outs.append(dst)
         arr = (_native.Field * len(fields))(*fields)
         sp = None if stats is None else stats.data_ptr()
@@ -427,11 +430,17 @@ class SharedReplayBuffer(object):
         self._timed_end(ev)
         return tuple(outs)
 
-    def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None):
+    def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None,
+                               standardize_obs=False):
         """Minibatches of independent (t, n, a) samples for MLP policies
         (reference shared_buffer.py:340-400).  Yields
         (share_obs, obs, rnn_states, rnn_states_critic, actions, value_preds, returns, masks,
-        active_masks, old_action_log_probs, adv_targ, available_actions) as device tensors."""
+        active_masks, old_action_log_probs, adv_targ, available_actions) as device tensors.
+
+        ``standardize_obs=True`` (all three generators): share_obs / obs rows come out standardised,
+        ``(x - mean(x)) / sqrt(var(x) + 1e-5)`` per row -- the parameter-free half of the networks'
+        input LayerNorm, computed while the row is being copied.  The trainer asks for it when the
+        policy can fold the LayerNorm's affine half into its first Linear (MLPBase)."""
         T, N, A = self.episode_length, self.n_rollout_threads, self.num_agents
         batch_size = N * T * A
         if mini_batch_size is None:
@@ -445,9 +454,9 @@ class SharedReplayBuffer(object):
         table, stats = self._field_table(advantages)
         for i in range(num_mini_batch):
             idx = rand[i * mini_batch_size:(i + 1) * mini_batch_size]
-            yield self._gather(table, stats, idx, mini_batch_size)
+            yield self._gather(table, stats, idx, mini_batch_size, standardize_obs=standardize_obs)
 
-    def recurrent_generator(self, advantages, num_mini_batch, data_chunk_length):
+    def recurrent_generator(self, advantages, num_mini_batch, data_chunk_length, standardize_obs=False):
         """Minibatches of length-L chunks for truncated BPTT (reference shared_buffer.py:499-608):
         sequence fields come out as [L*mb, dim] (row l*mb + j), RNN states as [mb, R, H] (chunk
         start only)."""
@@ -459,9 +468,10 @@ class SharedReplayBuffer(object):
         table, stats = self._field_table(advantages)
         for i in range(num_mini_batch):
             idx = rand[i * mini_batch_size:(i + 1) * mini_batch_size]
-            yield self._gather(table, stats, idx, mini_batch_size, chunk_len=data_chunk_length)
+            yield self._gather(table, stats, idx, mini_batch_size, chunk_len=data_chunk_length,
+                               standardize_obs=standardize_obs)
 
-    def naive_recurrent_generator(self, advantages, num_mini_batch):
+    def naive_recurrent_generator(self, advantages, num_mini_batch, standardize_obs=False):
         """Whole-trajectory minibatches (reference shared_buffer.py:402-497): a chunk gather with
         L = T over a permutation of the N*A trajectories."""
         T, N, A = self.episode_length, self.n_rollout_threads, self.num_agents
@@ -475,7 +485,7 @@ class SharedReplayBuffer(object):
         table, stats = self._field_table(advantages)
         for start in range(0, batch_size, num_envs_per_batch):
             idx = perm[start:start + num_envs_per_batch]
-            yield self._gather(table, stats, idx, idx.numel(), chunk_len=T)
+            yield self._gather(table, stats, idx, idx.numel(), chunk_len=T, standardize_obs=standardize_obs)
 
     def feed_forward_generator_transformer(self, advantages, num_mini_batch=None, mini_batch_size=None):
         raise NotImplementedError("the MAT sampler is outside the MAPPO hot path (SURVEY.md section 8f)")

@@ -514,3 +514,31 @@ def test_fused_act_layernorm_block_vs_torch(act):
             e_mine = float((mine.detach().double() - exact).abs().max()) / scale
             e_torch = float((theirs.detach().double() - exact).abs().max()) / scale
             assert e_mine <= 4 * e_torch + 2e-5, (what, act, M, e_mine, e_torch)
+
+
+def test_gather_standardize_vs_torch():
+    """standardize_obs=True: rows of share_obs / obs come out as (x - mean) / sqrt(var + 1e-5),
+    for the vectorised and the odd-width paths, feed-forward and chunked."""
+    T, N, A, L = 12, 6, 5, 4
+    rng = np.random.default_rng(3)
+    for Do, Ds in [(48, 384), (18, 54), (370, 435)]:
+        args = make_args(episode_length=T, n_rollout_threads=N, hidden_size=8, use_recurrent_policy=True,
+                         sampler_rng="host")
+        buf = _buffer(args, A, Do=Do, Ds=Ds, na=7)
+        arrays = fill_buffer_arrays(buffer_shapes(T, N, A, Do, Ds, 7, 8), rng, na=7)
+        load_into(buf, arrays)
+        adv = rng.standard_normal((T, N, A, 1)).astype(np.float32)
+        for gen in ("ff", "rec"):
+            torch.manual_seed(9)
+            plain = list(buf.feed_forward_generator(adv, 3) if gen == "ff" else buf.recurrent_generator(adv, 2, L))
+            torch.manual_seed(9)
+            std = list(buf.feed_forward_generator(adv, 3, standardize_obs=True) if gen == "ff"
+                       else buf.recurrent_generator(adv, 2, L, standardize_obs=True))
+            for p, s in zip(plain, std):
+                for f in (0, 1):
+                    x = p[f].double()
+                    exp = (x - x.mean(-1, keepdim=True)) / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-5)
+                    torch.testing.assert_close(s[f].double(), exp, rtol=1e-5, atol=2e-5)
+                for f in range(2, 12):      # every other field is untouched
+                    if p[f] is not None:
+                        assert torch.equal(p[f], s[f])

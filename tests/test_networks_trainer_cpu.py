@@ -130,3 +130,56 @@ def test_row_span_microbatching_is_equivalent(gold):
         np.testing.assert_allclose(a1[k].numpy(), a0[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
     for k in c0:
         np.testing.assert_allclose(c1[k].numpy(), c0[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+class _StandardizingOracleBuffer(oracle.OracleBuffer):
+    """Host buffer whose samplers hand out row-standardised observations, like the device buffer's
+    standardize_obs=True mode (test infrastructure)."""
+    supports_standardized_obs = True
+
+    @staticmethod
+    def _std(x):
+        x64 = x.astype(np.float64)
+        mu = x64.mean(-1, keepdims=True)
+        var = x64.var(-1, keepdims=True)
+        return ((x64 - mu) / np.sqrt(var + 1e-5)).astype(np.float32)
+
+    def _wrap(self, gen, standardize_obs):
+        for sample in gen:
+            if standardize_obs:
+                sample = (self._std(sample[0]), self._std(sample[1])) + tuple(sample[2:])
+            yield sample
+
+    def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None, standardize_obs=False):
+        return self._wrap(super().feed_forward_generator(advantages, num_mini_batch, mini_batch_size), standardize_obs)
+
+    def recurrent_generator(self, advantages, num_mini_batch, data_chunk_length, standardize_obs=False):
+        return self._wrap(super().recurrent_generator(advantages, num_mini_batch, data_chunk_length), standardize_obs)
+
+
+@pytest.mark.parametrize("cname", ["mlp", "gru"])
+def test_folded_input_layernorm_is_equivalent(gold, cname):
+    """Sampler-side row standardisation + the LayerNorm affine folded into the first Linear gives the
+    same update as LayerNorm inside the network (float32 rounding aside)."""
+    z = gold.npz("trainer_cases")
+    key = "trn_%s_" % cname
+    results = []
+    for cls in (oracle.OracleBuffer, _StandardizingOracleBuffer):
+        meta, spec, args, spaces, policy, trainer = _build(gold, cname)
+        buf = cls(args, spec["A"], *spaces)
+        for name in ("share_obs", "obs", "rnn_states", "rnn_states_critic", "actions", "value_preds", "masks",
+                     "bad_masks", "active_masks", "action_log_probs", "available_actions", "rewards"):
+            getattr(buf, name)[...] = z[key + "buf_" + name]
+        buf.compute_returns(z[key + "next_value"], trainer.value_normalizer)
+        assert policy.can_fold_input_norm()
+        trainer.prep_training()
+        torch.manual_seed(21)
+        info = trainer.train(buf)
+        results.append((info, {k: v.clone() for k, v in policy.actor.state_dict().items()},
+                        {k: v.clone() for k, v in policy.critic.state_dict().items()}))
+    (i0, a0, c0), (i1, a1, c1) = results
+    for k in i0:
+        assert i1[k] == pytest.approx(i0[k], rel=2e-4, abs=2e-6), k
+    for sd0, sd1 in ((a0, a1), (c0, c1)):
+        for k in sd0:
+            np.testing.assert_allclose(sd1[k].numpy(), sd0[k].numpy(), rtol=2e-4, atol=2e-5, err_msg=k)

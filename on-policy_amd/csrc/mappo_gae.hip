@@ -42,6 +42,7 @@ struct GaeArgs {
     const float* active;
     double* partials;
     long long partial_rows;  // rows of `partials`; rows >= gridDim.x are zero-filled by block 0
+    int opts;                // tuning bits: 1 = XCD-contiguous strip order, 2 = non-temporal DMA loads
     int T;
     long long C;
     float gamma;
@@ -293,17 +294,38 @@ __global__ void __launch_bounds__((NPROD + 1) * 64) gae_pipe_kernel(GaeArgs a) {
 // One wave instruction moves 64 lanes x 16 B = 1 KiB: RPI = 256 / W consecutive tile rows of
 // one field; LDS destination = wave-uniform base + lane * 16 (so a tile slot is [TC][W] floats,
 // rows contiguous), global source address is per lane.
+template <bool NT>
 __device__ __forceinline__ void lds_dma_16B(const float* gsrc, unsigned lds_dst) {
     unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst)
-        : "memory");
+    if (NT)
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off nt\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gsrc), "s"(lds_dst)
+            : "memory");
+    else
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gsrc), "s"(lds_dst)
+            : "memory");
+}
+
+// Workgroup -> strip.  Workgroup b runs on XCD b % 8 (observed placement, used for speed only):
+// with opts bit 0 the strips of one XCD are consecutive, so each XCD's L2 / fabric port streams
+// contiguous 64 * W * 4-byte row segments instead of every 8th 256-byte piece.
+__device__ __forceinline__ unsigned strip_of_block(const GaeArgs& a) {
+    const unsigned b = blockIdx.x, nb = gridDim.x;
+    if ((a.opts & 1) && (nb % 8u) == 0u) return (b % 8u) * (nb / 8u) + b / 8u;
+    return b;
 }
 
 template <int N>
@@ -329,7 +351,8 @@ __global__ void __launch_bounds__((NPROD + 1) * 64) gae_dma_kernel(GaeArgs a) {
     const int T = a.T;
     const int nch = (T + TC - 1) / TC;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const long long col0 = (long long)blockIdx.x * W;
+    const long long col0 = (long long)strip_of_block(a) * W;
+    const bool nt = (a.opts & 2) != 0;
     zero_unowned_partials(a.partials, a.partial_rows);
 
     if (wave == 0) {
@@ -375,7 +398,10 @@ __global__ void __launch_bounds__((NPROD + 1) * 64) gae_dma_kernel(GaeArgs a) {
                     const int rg = pw + q * NPROD;              // row group inside the tile
                     int t = tbase + rg * RPI + r0;
                     if (t < 0) t = 0;
-                    lds_dma_16B(fbs + (long long)t * a.C, slot_addr + (unsigned)((s * TC + rg * RPI) * W * 4));
+                    const float* src = fbs + (long long)t * a.C;
+                    const unsigned dst = slot_addr + (unsigned)((s * TC + rg * RPI) * W * 4);
+                    if (nt) lds_dma_16B<true>(src, dst);
+                    else lds_dma_16B<false>(src, dst);
                 }
             }
         };
@@ -765,9 +791,10 @@ extern "C" int mappo_gae_f32(const float* rewards, float* value_preds, const flo
     const bool strip_ok = (flags & MAPPO_GAE_USE_GAE) && (C % 4 == 0) && C >= 4 && aligned16(rewards) &&
                           aligned16(value_preds) && aligned16(masks) &&
                           (!a.bad || aligned16(bad_masks)) && (!a.active || aligned16(active_masks));
-    int variant = g_variant;
+    int variant = g_variant % 1000;
+    a.opts = g_variant / 1000;
     if (!strip_ok) variant = 99;
-    if (variant == 0) variant = (C >= 64 * 256) ? 31 : (C >= 32 * 256 ? 34 : 6);
+    if (variant == 0) variant = (C >= 64 * 256) ? 31 : (C >= 32 * 256 ? 34 : 36);
 
     hipError_t e;
     switch (variant) {
@@ -787,6 +814,11 @@ extern "C" int mappo_gae_f32(const float* rewards, float* value_preds, const flo
         case 33: e = launch_dma<64, 2, 16, 3>(a, flags, stream); break;
         case 34: e = launch_dma<32, 1, 16, 4>(a, flags, stream); break;
         case 35: e = launch_dma<64, 1, 4, 12>(a, flags, stream); break;
+        case 36: e = launch_dma<16, 1, 16, 4>(a, flags, stream); break;
+        case 37: e = launch_dma<16, 1, 32, 3>(a, flags, stream); break;
+        case 38: e = launch_dma<64, 2, 8, 6>(a, flags, stream); break;
+        case 39: e = launch_dma<64, 4, 16, 3>(a, flags, stream); break;
+        case 40: e = launch_dma<32, 2, 16, 4>(a, flags, stream); break;
         default: e = launch_column(a, flags, stream); break;
     }
     return (int)e;

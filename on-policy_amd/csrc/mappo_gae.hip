@@ -794,7 +794,12 @@ extern "C" int mappo_gae_f32(const float* rewards, float* value_preds, const flo
     int variant = g_variant % 1000;
     a.opts = g_variant / 1000;
     if (!strip_ok) variant = 99;
-    if (variant == 0) variant = (C >= 64 * 256) ? 31 : (C >= 32 * 256 ? 34 : 36);
+    if (variant == 0) {
+        // LDS-DMA ring kernel; strip width by column count so that >= 256 workgroups exist;
+        // XCD-contiguous strip order + non-temporal DMA (measured best on cold data)
+        variant = (C >= 64 * 256) ? 33 : (C >= 32 * 256 ? 34 : 36);
+        a.opts = 3;
+    }
 
     hipError_t e;
     switch (variant) {

@@ -162,6 +162,32 @@ int mappo_gather_chunks(const mappo_field_t* fields, int n_fields, const int64_t
                         int64_t mb, int L, int T, int64_t N, int A, const float* stats,
                         mappo_stream_t stream);
 
+/* Packed records of the NARROW fields.  A 4-byte gather costs a whole HBM sector, so the per-sample
+ * scalars of feed_forward_generator / recurrent_generator (actions, value_preds, returns, masks,
+ * active_masks, action_log_probs, advantages, and small rows such as available_actions;
+ * shared_buffer.py:383-396, 558-566) are first packed into one record per (t, n, a) row:
+ *   mappo_pack_records:   records[row, offset_k .. offset_k + width_k) = src_k[row, :], rows in
+ *                         (t, n, a) order; record_width a multiple of 4, <= 32; padding zeroed.
+ *   mappo_gather_records: dst_k[j, :] = records[source_row(j), offset_k ..] (normalised like
+ *                         mappo_field.normalize if asked) -- one record read per sample.
+ *                         L = 0: rows mode (source_row(j) = idx[j]); L > 0: chunk mode with the row
+ *                         mapping of mappo_gather_chunks (no first_only fields here).
+ * Bit-identical to gathering the fields one by one.  `fields` is a HOST array. */
+typedef struct mappo_record_field {
+    const float* src;    /* pack: field base (rows of `width` floats); unused by gather          */
+    float*       dst;    /* gather: output base (rows of `width` floats); unused by pack         */
+    int32_t      width;
+    int32_t      offset; /* first component of this field inside a record                        */
+    int32_t      normalize;
+    int32_t      reserved;
+} mappo_record_field_t;
+
+int mappo_pack_records(const mappo_record_field_t* fields, int n_fields, float* records,
+                       int record_width, int64_t rows, mappo_stream_t stream);
+int mappo_gather_records(const float* records, int record_width, const mappo_record_field_t* fields,
+                         int n_fields, const int64_t* idx, int64_t mb, int L, int T, int64_t N, int A,
+                         const float* stats, mappo_stream_t stream);
+
 /* Tuning hook for benchmarks (results do not depend on it): bits 0-1 log2 of the loads in
  * flight per lane, bit 2 non-temporal accesses, bits 4.. workgroups per CU (0 = occupancy).
  * Returns the previous value. */

@@ -231,6 +231,113 @@ int build_and_launch(const mappo_field_t* fields, int n_fields, const int64_t* i
     return (int)e;
 }
 
+// ------------------------------------------------ packed records of the narrow fields ----
+// A 4-byte gather costs a whole 64-byte HBM sector, so the seven per-sample scalars (action,
+// value_pred, return, mask, active_mask, log-prob, advantage) and the small available-actions
+// row would cost 8 sectors per sample when gathered field by field.  Once per epoch they are
+// packed into one record per (t, n, a) row ([rows, RW] floats, RW a multiple of 4); the sampler
+// then reads ONE record per sample and scatters its components to the per-field outputs.
+struct RecField {
+    const float* src;   // pack: field base, rows of `width` floats
+    float* dst;         // unpack: output base, rows of `width` floats
+    unsigned width;
+    unsigned offset;    // first component inside the record
+    unsigned normalize;
+};
+struct RecArgs {
+    RecField f[MAPPO_MAX_FIELDS];
+    int nf;
+    unsigned rw;        // record width in floats
+    float* records;
+    unsigned long long rows;
+    mappo::RowMap map;
+    const float* stats;
+};
+
+constexpr int kRecMaxWidth = 32;
+
+__global__ void __launch_bounds__(kThreads) pack_records_kernel(RecArgs a) {
+    __shared__ float tile[kThreads * kRecMaxWidth];
+    const unsigned rw = a.rw;
+    for (unsigned long long row0 = (unsigned long long)blockIdx.x * kThreads; row0 < a.rows;
+         row0 += (unsigned long long)gridDim.x * kThreads) {
+        const unsigned long long row = row0 + threadIdx.x;
+        const bool ok = row < a.rows;
+        for (unsigned c = threadIdx.x; c < kThreads * rw; c += kThreads) tile[c] = 0.f;
+        __syncthreads();
+        for (int k = 0; k < a.nf; ++k) {
+            const float* src = a.f[k].src;
+            const unsigned w = a.f[k].width, off = a.f[k].offset;
+            // coalesced read of the [256, w] block of this field, scattered into the LDS records
+            for (unsigned e = threadIdx.x; e < kThreads * w; e += kThreads) {
+                unsigned r = e / w, c = e - r * w;
+                if (row0 + r < a.rows) tile[r * rw + off + c] = src[(row0 + r) * w + c];
+            }
+        }
+        __syncthreads();
+        const unsigned long long base = row0 * rw;
+        const unsigned long long limit = a.rows * rw;
+        for (unsigned e = threadIdx.x; e < kThreads * rw; e += kThreads)
+            if (base + e < limit) a.records[base + e] = tile[e];
+        __syncthreads();
+        (void)ok;
+    }
+}
+
+__global__ void __launch_bounds__(kThreads) gather_records_kernel(RecArgs a, unsigned long long rows_out) {
+    __shared__ float tile[kThreads * kRecMaxWidth];
+    const unsigned rw = a.rw, q4 = rw / 4;
+    float mean = 0.f, den = 1.f;
+    if (a.stats) {
+        mean = a.stats[0];
+        den = a.stats[1] + 1e-5f;
+    }
+    for (unsigned long long row0 = (unsigned long long)blockIdx.x * kThreads; row0 < rows_out;
+         row0 += (unsigned long long)gridDim.x * kThreads) {
+        const unsigned long long j = row0 + threadIdx.x;
+        if (j < rows_out) {
+            const unsigned srow = mappo::source_row(a.map, 0u, (unsigned)j);
+            const f32x4* rec = reinterpret_cast<const f32x4*>(a.records + (unsigned long long)srow * rw);
+            f32x4* mine = reinterpret_cast<f32x4*>(tile + threadIdx.x * rw);
+            for (unsigned q = 0; q < q4; ++q) mine[q] = __builtin_nontemporal_load(rec + q);
+        }
+        __syncthreads();
+        const unsigned nrows = rows_out - row0 < (unsigned long long)kThreads ? (unsigned)(rows_out - row0) : kThreads;
+        for (int k = 0; k < a.nf; ++k) {
+            float* dst = a.f[k].dst;
+            const unsigned w = a.f[k].width, off = a.f[k].offset;
+            const bool norm = a.f[k].normalize != 0;
+            // coalesced write of the [nrows, w] output block
+            for (unsigned e = threadIdx.x; e < nrows * w; e += kThreads) {
+                unsigned r = e / w, c = e - r * w;
+                float v = tile[r * rw + off + c];
+                if (norm) v = (v - mean) / den;
+                dst[row0 * w + e] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int fill_rec_args(RecArgs& a, const mappo_record_field_t* fields, int n_fields, int record_width, bool packing) {
+    if (!fields) return MAPPO_E_NULL;
+    if (n_fields <= 0 || record_width <= 0 || record_width % 4 != 0 || record_width > kRecMaxWidth) return MAPPO_E_SHAPE;
+    if (n_fields > MAPPO_MAX_FIELDS) return MAPPO_E_TOO_MANY;
+    a.nf = n_fields;
+    a.rw = (unsigned)record_width;
+    for (int k = 0; k < n_fields; ++k) {
+        const mappo_record_field_t& s = fields[k];
+        if (packing ? !s.src : !s.dst) return MAPPO_E_NULL;
+        if (s.width <= 0 || s.offset < 0 || s.offset + s.width > record_width) return MAPPO_E_SHAPE;
+        a.f[k].src = s.src;
+        a.f[k].dst = s.dst;
+        a.f[k].width = (unsigned)s.width;
+        a.f[k].offset = (unsigned)s.offset;
+        a.f[k].normalize = s.normalize ? 1u : 0u;
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------ K2: slabs ----
 struct Slab {
     const float* src;
@@ -333,6 +440,58 @@ extern "C" int mappo_slab_copy(const mappo_slab_t* slabs, int n_slabs, mappo_str
                                                                   : (unsigned)(mappo::kCUs * 8);
     hipLaunchKernelGGL(slab_kernel, dim3(grid), dim3(kThreads), 0,
                        static_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mappo_pack_records(const mappo_record_field_t* fields, int n_fields, float* records,
+                                  int record_width, int64_t rows, mappo_stream_t stream) {
+    if (!records) return MAPPO_E_NULL;
+    if (rows <= 0) return MAPPO_E_SHAPE;
+    if (!mappo::aligned_to(records, 16)) return MAPPO_E_ALIGN;
+    RecArgs a;
+    int rc = fill_rec_args(a, fields, n_fields, record_width, true);
+    if (rc != 0) return rc;
+    a.records = records;
+    a.rows = (unsigned long long)rows;
+    a.stats = nullptr;
+    long long blocks = (rows + kThreads - 1) / kThreads;
+    if (blocks > mappo::kCUs * 8) blocks = mappo::kCUs * 8;
+    hipLaunchKernelGGL(pack_records_kernel, dim3((unsigned)blocks), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mappo_gather_records(const float* records, int record_width, const mappo_record_field_t* fields,
+                                    int n_fields, const int64_t* idx, int64_t mb, int L, int T, int64_t N,
+                                    int A, const float* stats, mappo_stream_t stream) {
+    if (!records || !idx) return MAPPO_E_NULL;
+    if (mb <= 0 || mb >= (1ll << 31)) return MAPPO_E_SHAPE;
+    if (!mappo::aligned_to(records, 16)) return MAPPO_E_ALIGN;
+    const int chunked = L > 0 ? 1 : 0;
+    if (chunked && (T <= 0 || N <= 0 || A <= 0 || (long long)T * N * A >= (1ll << 31) ||
+                    mb * (long long)L >= (1ll << 31)))
+        return MAPPO_E_SHAPE;
+    RecArgs a;
+    int rc = fill_rec_args(a, fields, n_fields, record_width, false);
+    if (rc != 0) return rc;
+    bool any_norm = false;
+    for (int k = 0; k < n_fields; ++k) any_norm = any_norm || fields[k].normalize;
+    if (any_norm && !stats) return MAPPO_E_NULL;
+    a.records = const_cast<float*>(records);
+    a.rows = 0;
+    a.stats = any_norm ? stats : nullptr;
+    a.map.idx = reinterpret_cast<const long long*>(idx);
+    a.map.mb = (unsigned)mb;
+    a.map.chunked = chunked;
+    a.map.L = (unsigned)(chunked ? L : 1);
+    a.map.T = (unsigned)T;
+    a.map.N = (unsigned)N;
+    a.map.A = (unsigned)A;
+    const unsigned long long rows_out = chunked ? (unsigned long long)mb * L : (unsigned long long)mb;
+    long long blocks = (long long)((rows_out + kThreads - 1) / kThreads);
+    if (blocks > mappo::kCUs * 8) blocks = mappo::kCUs * 8;
+    hipLaunchKernelGGL(gather_records_kernel, dim3((unsigned)blocks), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream), a, rows_out);
     return (int)hipGetLastError();
 }
 

@@ -26,6 +26,12 @@ class Field(ctypes.Structure):
                 ("normalize", ctypes.c_int32), ("standardize", ctypes.c_int32)]
 
 
+class RecordField(ctypes.Structure):
+    """struct mappo_record_field (include/mappo_hip.h)."""
+    _fields_ = [("src", _vp), ("dst", _vp), ("width", ctypes.c_int32), ("offset", ctypes.c_int32),
+                ("normalize", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 class Slab(ctypes.Structure):
     """struct mappo_slab (include/mappo_hip.h)."""
     _fields_ = [("src", _vp), ("dst", _vp), ("count", _i64)]
@@ -43,6 +49,9 @@ SIGNATURES = {
     "mappo_adv_normalize": (_int, [_vp, _vp, _vp, _i64, _vp]),
     "mappo_gather_rows": (_int, [ctypes.POINTER(Field), _int, _vp, _i64, _vp, _vp]),
     "mappo_gather_chunks": (_int, [ctypes.POINTER(Field), _int, _vp, _i64, _int, _int, _i64, _int, _vp, _vp]),
+    "mappo_pack_records": (_int, [ctypes.POINTER(RecordField), _int, _vp, _int, _i64, _vp]),
+    "mappo_gather_records": (_int, [_vp, _int, ctypes.POINTER(RecordField), _int, _vp, _i64, _int, _int, _i64,
+                                    _int, _vp, _vp]),
     "mappo_gather_set_variant": (_int, [_int]),
     "mappo_slab_copy": (_int, [ctypes.POINTER(Slab), _int, _vp]),
     "mappo_layernorm_max_blocks": (_int, []),

@@ -393,11 +393,44 @@ class SharedReplayBuffer(object):
 
     supports_standardized_obs = True   # generators take standardize_obs=True (see feed_forward_generator)
 
-    def _gather(self, table, stats, idx, mb, chunk_len=None, standardize_obs=False):
-        """One fused gather launch (K3 / K4) -> the 12-tuple of fresh device tensors."""
+    # fields at most this wide are packed into one record per sample before sampling
+    _NARROW = 8
+    _MAX_RECORD = 32
+
+    def _pack_records(self, table):
+        """Pack the narrow fields (per-sample scalars, available_actions, ...) into one
+        [T*N*A, RW] record array (mappo_pack_records) -> (records, RW, {name: (offset, width)}).
+        Done once per generator call, i.e. per epoch: ~1 GB of traffic against ~47 GB per gather."""
+        T, N, A = self.episode_length, self.n_rollout_threads, self.num_agents
+        layout, fields, off = {}, [], 0
+        for name, src, is_state in table:
+            if src is None or is_state:
+                continue
+            tail = tuple(src.shape[3:])
+            width = int(np.prod(tail)) if tail else 1
+            if width > self._NARROW or off + width > self._MAX_RECORD:
+                continue
+            layout[name] = (off, width)
+            fields.append(_native.RecordField(src.data_ptr(), None, width, off, 0, 0))
+            off += width
+        if not fields:
+            return None, 0, {}
+        rw = (off + 3) // 4 * 4
+        rows = T * N * A
+        if getattr(self, "_records", None) is None or self._records.numel() < rows * rw:
+            self._records = torch.empty(rows * rw, dtype=torch.float32, device=self.device)
+        arr = (_native.RecordField * len(fields))(*fields)
+        _native.check(self._lib.mappo_pack_records(arr, len(fields), self._records.data_ptr(), rw, rows,
+                                                   self._stream()), "mappo_pack_records")
+        return self._records, rw, layout
+
+    def _gather(self, table, stats, idx, mb, chunk_len=None, standardize_obs=False, packed=None):
+        """One minibatch -> the 12-tuple of fresh device tensors: wide fields through the fused tile
+        gather / standardising gather (K3 / K4), narrow fields through one record gather."""
         T, N, A = self.episode_length, self.n_rollout_threads, self.num_agents
         rows_out = mb if chunk_len is None else mb * chunk_len
-        outs, fields = [], []
+        records, rw, layout = packed if packed is not None else (None, 0, {})
+        outs, fields, rec_fields = [], [], []
         for name, src, is_state in table:
             if src is None:
                 outs.append(None)
@@ -411,22 +444,34 @@ class SharedReplayBuffer(object):
             n_rows = mb if (first_only or chunk_len is None) else rows_out
             dst = torch.empty((n_rows,) + tail, dtype=torch.float32, device=self.device)
             normalize = 1 if (name == "advantages" and stats is not None) else 0
-            standardize = 1 if (standardize_obs and name in ("share_obs", "obs") and len(tail) == 1) else 0
-            fields.append(_native.Field(src.data_ptr(), dst.data_ptr(), width, first_only, normalize, standardize))
+            if name in layout:
+                off, w = layout[name]
+                rec_fields.append(_native.RecordField(None, dst.data_ptr(), w, off, normalize, 0))
+            else:
+                standardize = 1 if (standardize_obs and name in ("share_obs", "obs") and len(tail) == 1) else 0
+                fields.append(_native.Field(src.data_ptr(), dst.data_ptr(), width, first_only, normalize,
+                                            standardize))
             outs.append(dst)
-        arr = (_native.Field * len(fields))(*fields)
         sp = None if stats is None else stats.data_ptr()
         # algorithmic bytes: every gathered row is read once and written once, + the int64 indices
         nbytes = sum(2 * 4 * f.width * (mb if (f.first_only or chunk_len is None) else rows_out)
-                     for f in fields) + 8 * mb
+                     for f in fields) + sum(2 * 4 * f.width * rows_out for f in rec_fields) + 8 * mb
         ev = self._timed("mappo_gather_rows" if chunk_len is None else "mappo_gather_chunks", nbytes)
-        if chunk_len is None:
-            code = self._lib.mappo_gather_rows(arr, len(fields), idx.data_ptr(), mb, sp, self._stream())
-            _native.check(code, "mappo_gather_rows")
-        else:
-            code = self._lib.mappo_gather_chunks(arr, len(fields), idx.data_ptr(), mb, chunk_len, T, N, A,
-                                                 sp, self._stream())
-            _native.check(code, "mappo_gather_chunks")
+        if fields:
+            arr = (_native.Field * len(fields))(*fields)
+            if chunk_len is None:
+                code = self._lib.mappo_gather_rows(arr, len(fields), idx.data_ptr(), mb, sp, self._stream())
+                _native.check(code, "mappo_gather_rows")
+            else:
+                code = self._lib.mappo_gather_chunks(arr, len(fields), idx.data_ptr(), mb, chunk_len, T, N, A,
+                                                     sp, self._stream())
+                _native.check(code, "mappo_gather_chunks")
+        if rec_fields:
+            arr = (_native.RecordField * len(rec_fields))(*rec_fields)
+            code = self._lib.mappo_gather_records(records.data_ptr(), rw, arr, len(rec_fields), idx.data_ptr(), mb,
+                                                  0 if chunk_len is None else chunk_len, T, N, A, sp,
+                                                  self._stream())
+            _native.check(code, "mappo_gather_records")
         self._timed_end(ev)
         return tuple(outs)
 
@@ -452,9 +497,10 @@ class SharedReplayBuffer(object):
             mini_batch_size = batch_size // num_mini_batch
         rand = self._randperm(batch_size)
         table, stats = self._field_table(advantages)
+        packed = self._pack_records(table)
         for i in range(num_mini_batch):
             idx = rand[i * mini_batch_size:(i + 1) * mini_batch_size]
-            yield self._gather(table, stats, idx, mini_batch_size, standardize_obs=standardize_obs)
+            yield self._gather(table, stats, idx, mini_batch_size, standardize_obs=standardize_obs, packed=packed)
 
     def recurrent_generator(self, advantages, num_mini_batch, data_chunk_length, standardize_obs=False):
         """Minibatches of length-L chunks for truncated BPTT (reference shared_buffer.py:499-608):
@@ -466,10 +512,11 @@ class SharedReplayBuffer(object):
         mini_batch_size = data_chunks // num_mini_batch
         rand = self._randperm(data_chunks)
         table, stats = self._field_table(advantages)
+        packed = self._pack_records(table)
         for i in range(num_mini_batch):
             idx = rand[i * mini_batch_size:(i + 1) * mini_batch_size]
             yield self._gather(table, stats, idx, mini_batch_size, chunk_len=data_chunk_length,
-                               standardize_obs=standardize_obs)
+                               standardize_obs=standardize_obs, packed=packed)
 
     def naive_recurrent_generator(self, advantages, num_mini_batch, standardize_obs=False):
         """Whole-trajectory minibatches (reference shared_buffer.py:402-497): a chunk gather with
@@ -483,9 +530,11 @@ class SharedReplayBuffer(object):
         num_envs_per_batch = batch_size // num_mini_batch
         perm = self._randperm(batch_size)
         table, stats = self._field_table(advantages)
+        packed = self._pack_records(table)
         for start in range(0, batch_size, num_envs_per_batch):
             idx = perm[start:start + num_envs_per_batch]
-            yield self._gather(table, stats, idx, idx.numel(), chunk_len=T, standardize_obs=standardize_obs)
+            yield self._gather(table, stats, idx, idx.numel(), chunk_len=T, standardize_obs=standardize_obs,
+                               packed=packed)
 
     def feed_forward_generator_transformer(self, advantages, num_mini_batch=None, mini_batch_size=None):
         raise NotImplementedError("the MAT sampler is outside the MAPPO hot path (SURVEY.md section 8f)")

@@ -20,6 +20,7 @@ There is no CPU implementation here: the constructor raises unless it gets a HIP
 ``libmappo_hip.so`` (see onpolicy/_native.py).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -403,9 +404,11 @@ class SharedReplayBuffer(object):
         Done once per generator call, i.e. per epoch: ~1 GB of traffic against ~47 GB per gather."""
         T, N, A = self.episode_length, self.n_rollout_threads, self.num_agents
         layout, fields, off = {}, [], 0
+        if os.environ.get("MAPPO_PACK_RECORDS", "1") == "0":
+            return None, 0, {}
         for name, src, is_state in table:
-            if src is None or is_state:
-                continue
+            if src is None or is_state or name in ("share_obs", "obs"):
+                continue   # observations / RNN states keep their own (wide or standardising) path
             tail = tuple(src.shape[3:])
             width = int(np.prod(tail)) if tail else 1
             if width > self._NARROW or off + width > self._MAX_RECORD:

@@ -49,6 +49,13 @@ WORKLOADS = {
                  recurrent=False,
                  label="synthetic T=200 N=1024 A=5, mappo MLP h64, ppo_epoch=10"),
     # BASELINE.json configs[3] shapes (SMAC MMM2), recurrent policy, chunk 10
+    # BASELINE.json configs[4] shapes (Hanabi-Full, 5 players), feed-forward, hidden 512 x 2 layers
+    "hanabi": dict(T=100, N=8192, A=5, Do=1285, Ds=1385, na=48, cpu_sample_N=16,
+                   flags=["--algorithm_name", "mappo", "--hidden_size", "512", "--layer_N", "2",
+                          "--ppo_epoch", "15", "--num_mini_batch", "1", "--lr", "7e-4", "--critic_lr", "1e-3",
+                          "--gain", "0.01", "--use_ReLU"],
+                   recurrent=False,
+                   label="synthetic Hanabi-Full 5p shapes T=100 N=8192 A=5, mappo MLP h512 x2, ppo_epoch=15"),
     "smac": dict(T=400, N=512, A=10, Do=370, Ds=435, na=18, cpu_sample_N=8,
                  flags=["--algorithm_name", "rmappo", "--hidden_size", "64", "--layer_N", "1",
                         "--ppo_epoch", "5", "--num_mini_batch", "2", "--data_chunk_length", "10",
@@ -213,13 +220,26 @@ def main():
         ms_per_step = 1e3 * elapsed / opt.steps
         value = wl["T"] * wl["N"] * opt.steps / elapsed
 
+        def pmc_traffic(name, nbytes):
+            """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_summary.json:
+            2 x FETCH_SIZE + WRITE_SIZE, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950) --
+            only quoted when the profiled launch had the same algorithmic byte count."""
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+                    rec = json.load(f).get(name)
+                if rec and abs(rec["algorithmic_bytes"] - nbytes) <= 0.01 * nbytes:
+                    return rec["hbm_bytes"]
+            except Exception:
+                pass
+            return None
+
         def roof(name):
             if name not in kt:
                 return None
             launches, ms, nbytes = kt[name]
             achieved = nbytes / (ms * 1e-3) / 1e9
             return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(name, nbytes),
                     "launch_ms": round(ms, 5), "launches": launches, "algorithmic_bytes": int(nbytes)}
 
         out = {

@@ -18,6 +18,19 @@ from .tall_linear import TallLinear
 from .util import init
 
 
+# 'device': torch.multinomial on the tensor's own device (fast path).  'host': draw the noise on
+# the CPU generator exactly as torch.multinomial does there (one Exponential(1) per probability,
+# argmax of p / q) and upload it, so that a GPU run reproduces the reference's CPU action stream
+# for identical probabilities (integer-sampling parity mode).
+SAMPLING_RNG = "device"
+
+
+def set_sampling_rng(mode):
+    global SAMPLING_RNG
+    assert mode in ("device", "host")
+    SAMPLING_RNG = mode
+
+
 class FixedCategorical(object):
     def __init__(self, logits):
         self.logits = logits - logits.logsumexp(dim=-1, keepdim=True)
@@ -32,6 +45,9 @@ class FixedCategorical(object):
     def sample(self):
         p = self.probs
         flat = p.reshape(-1, p.size(-1))
+        if SAMPLING_RNG == "host" and flat.is_cuda:
+            q = torch.empty(flat.shape, dtype=flat.dtype).exponential_(1)      # CPU generator
+            return (flat / q.to(flat.device)).argmax(-1, keepdim=True).reshape(p.shape[:-1] + (1,))
         return torch.multinomial(flat, 1, True).reshape(p.shape[:-1] + (1,))
 
     def log_prob(self, value):

@@ -543,3 +543,51 @@ def test_gather_standardize_vs_torch():
                 for f in range(2, 12):      # every other field is untouched
                     if p[f] is not None:
                         assert torch.equal(p[f], s[f])
+
+
+def test_chooseinsert_and_chooseafter_update_vs_oracle():
+    """Turn-based (Hanabi) storage semantics: observations / active masks / available actions at row
+    ``step`` (reference shared_buffer.py:125-158), chooseafter_update copies only states and masks."""
+    T, N, A, H = 5, 4, 3, 8
+    args = make_args(episode_length=T, n_rollout_threads=N, hidden_size=H, use_recurrent_policy=True)
+    buf = _buffer(args, A, Do=6, Ds=18, na=5)
+    ob = oracle.OracleBuffer(args, A, Box((6,)), Box((18,)), Discrete(5))
+    rng = np.random.default_rng(8)
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)
+    for step in range(2 * T):
+        data = dict(share_obs=f(N, A, 18), obs=f(N, A, 6), rnn_states=f(N, A, 1, H), rnn_states_critic=f(N, A, 1, H),
+                    actions=f(N, A, 1), action_log_probs=f(N, A, 1), value_preds=f(N, A, 1), rewards=f(N, A, 1),
+                    masks=f(N, A, 1), bad_masks=f(N, A, 1), active_masks=f(N, A, 1), available_actions=f(N, A, 5))
+        buf.chooseinsert(**data)
+        ob.chooseinsert(**data)
+        if buf.step == 0:
+            buf.chooseafter_update()
+            ob.chooseafter_update()
+    for name in ("share_obs", "obs", "rnn_states", "rnn_states_critic", "actions", "action_log_probs",
+                 "value_preds", "rewards", "masks", "bad_masks", "active_masks", "available_actions"):
+        np.testing.assert_array_equal(getattr(buf, name).cpu().numpy(), getattr(ob, name), err_msg=name)
+
+
+def test_host_parity_action_sampling():
+    """Integer-sampling parity mode: with the noise drawn on the CPU generator, device sampling gives
+    exactly the actions torch.multinomial gives on the CPU for the same probabilities and seed."""
+    from onpolicy.algorithms.utils import distributions as D
+    dev = _dev()
+    torch.manual_seed(3)
+    logits = torch.randn(4096, 18)
+    avail = (torch.rand(4096, 18) < 0.6).float()
+    avail[:, 0] = 1
+    logits = torch.where(avail == 0, torch.full_like(logits, -1e10), logits)
+    cpu = D.FixedCategorical(logits)
+    gpu = D.FixedCategorical(logits.to(dev))
+    gpu._probs = cpu.probs.to(dev)          # identical probabilities on both sides
+    D.set_sampling_rng("host")
+    try:
+        torch.manual_seed(77)
+        a_cpu = cpu.sample()
+        torch.manual_seed(77)
+        a_gpu = gpu.sample()
+    finally:
+        D.set_sampling_rng("device")
+    assert a_gpu.is_cuda and torch.equal(a_cpu, a_gpu.cpu())
+    assert bool((torch.gather(avail, 1, a_cpu) == 1).all())

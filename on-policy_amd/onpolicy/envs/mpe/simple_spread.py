@@ -1,0 +1,103 @@
+"""Cooperative navigation ("simple_spread") of the multi-agent particle environment, vectorised over
+rollout threads in numpy.
+
+Scope note: environments are outside the hot path of this repository ("next"
+row f2).  This module exists so that BASELINE.json's configs[0] (MPE simple_spread, 3 agents,
+8 rollout threads, episode length 25) runs end to end without gym / seaborn / subprocess workers.
+It follows the published MPE dynamics (Lowe et al. 2017; the reference vendors them under
+onpolicy/envs/mpe/{core,environment}.py and scenarios/simple_spread.py): point-mass agents with
+damping 0.25, dt 0.1, action sensitivity 5, soft contact forces, shared reward
+-sum_landmarks min_agents dist - collisions.  All ``n_threads`` worlds advance in one set of array
+operations, so a rollout step costs one numpy pass instead of ``n_threads`` pipe round trips.
+
+VecEnv protocol (reference onpolicy/envs/env_wrappers.py:235-298): ``reset() -> obs [N, A, Do]``,
+``step(one_hot_actions [N, A, 5]) -> obs, rewards [N, A, 1], dones [N, A], infos``.
+"""
+import numpy as np
+
+from onpolicy.envs.spaces import Box, Discrete
+
+_DT = 0.1
+_DAMPING = 0.25
+_SENSITIVITY = 5.0
+_CONTACT_FORCE = 1e2
+_CONTACT_MARGIN = 1e-3
+_AGENT_SIZE = 0.15
+
+
+class VecSimpleSpread(object):
+    def __init__(self, n_threads, num_agents=3, num_landmarks=None, episode_length=25, seed=1):
+        self.n, self.a = int(n_threads), int(num_agents)
+        self.l = int(num_landmarks) if num_landmarks is not None else self.a
+        self.world_length = int(episode_length)
+        self.rng = np.random.default_rng(seed)
+        obs_dim = 4 + 2 * self.l + 4 * (self.a - 1)
+        self.observation_space = [Box(shape=(obs_dim,)) for _ in range(self.a)]
+        self.share_observation_space = [Box(shape=(obs_dim * self.a,)) for _ in range(self.a)]
+        self.action_space = [Discrete(5) for _ in range(self.a)]
+        self.pos = np.zeros((self.n, self.a, 2))
+        self.vel = np.zeros((self.n, self.a, 2))
+        self.landmarks = np.zeros((self.n, self.l, 2))
+        self.t = np.zeros(self.n, dtype=np.int64)
+
+    # -- helpers
+    def _reset_worlds(self, which):
+        k = int(which.sum())
+        if k:
+            self.pos[which] = self.rng.uniform(-1, 1, (k, self.a, 2))
+            self.vel[which] = 0.0
+            self.landmarks[which] = self.rng.uniform(-1, 1, (k, self.l, 2))
+            self.t[which] = 0
+
+    def _obs(self):
+        n, a = self.n, self.a
+        rel_land = (self.landmarks[:, None, :, :] - self.pos[:, :, None, :]).reshape(n, a, -1)
+        rel_other = self.pos[:, None, :, :] - self.pos[:, :, None, :]          # [n, i, j, 2] = pos_j - pos_i
+        keep = ~np.eye(a, dtype=bool)
+        rel_other = rel_other[:, keep].reshape(n, a, (a - 1) * 2)
+        comm = np.zeros((n, a, (a - 1) * 2))                                   # agents are silent
+        return np.concatenate([self.vel, self.pos, rel_land, rel_other, comm], -1).astype(np.float32)
+
+    def _collision_forces(self):
+        delta = self.pos[:, :, None, :] - self.pos[:, None, :, :]              # [n, i, j, 2]
+        dist = np.sqrt((delta ** 2).sum(-1))
+        dist_min = 2 * _AGENT_SIZE
+        k = _CONTACT_MARGIN
+        pen = np.logaddexp(0.0, -(dist - dist_min) / k) * k
+        with np.errstate(divide="ignore", invalid="ignore"):
+            f = _CONTACT_FORCE * delta / dist[..., None] * pen[..., None]
+        f[:, np.arange(self.a), np.arange(self.a)] = 0.0                        # no self force
+        return np.nan_to_num(f).sum(2)                                          # force on i
+
+    def _reward(self):
+        d = np.sqrt(((self.pos[:, :, None, :] - self.landmarks[:, None, :, :]) ** 2).sum(-1))  # [n, a, l]
+        cover = -d.min(1).sum(-1)                                                               # [n]
+        dd = np.sqrt(((self.pos[:, :, None, :] - self.pos[:, None, :, :]) ** 2).sum(-1))
+        hits = (dd < 2 * _AGENT_SIZE) & ~np.eye(self.a, dtype=bool)
+        per_agent = cover[:, None] - hits.sum(-1)                                               # [n, a]
+        return per_agent
+
+    # -- VecEnv protocol
+    def reset(self):
+        self._reset_worlds(np.ones(self.n, dtype=bool))
+        return self._obs()
+
+    def step(self, actions):
+        actions = np.asarray(actions, dtype=np.float64)
+        assert actions.shape == (self.n, self.a, 5), actions.shape
+        u = np.stack([actions[..., 1] - actions[..., 2], actions[..., 3] - actions[..., 4]], -1) * _SENSITIVITY
+        force = u + self._collision_forces()
+        self.vel = self.vel * (1 - _DAMPING) + force * _DT
+        self.pos = self.pos + self.vel * _DT
+        self.t += 1
+        per_agent = self._reward()
+        shared = per_agent.sum(-1, keepdims=True)                              # shared reward: sum over agents
+        rewards = np.repeat(shared, self.a, 1)[..., None].astype(np.float32)
+        done_env = self.t >= self.world_length
+        dones = np.repeat(done_env[:, None], self.a, 1)
+        infos = [[{"individual_reward": float(per_agent[i, j])} for j in range(self.a)] for i in range(self.n)]
+        self._reset_worlds(done_env)                                           # auto-reset like the vec-env workers
+        return self._obs(), rewards, dones, infos
+
+    def close(self):
+        pass

@@ -68,8 +68,11 @@ class PopArt(nn.Module):
         self.stddev.copy_((self.mean_sq - self.mean ** 2).sqrt().clamp(min=1e-4))
         new_mean, new_var = self.debiased_mean_var()
         new_stddev = torch.sqrt(new_var)
-        self.weight.mul_((old_stddev / new_stddev).unsqueeze(-1))
-        self.bias.copy_((old_stddev * self.bias + old_mean - new_mean) / new_stddev)
+        # Rebind .data instead of writing in place: the forward pass of the current minibatch has
+        # already saved the old weights for its backward (update() runs between forward and
+        # backward, r_mappo.py:65), and those saved tensors must stay untouched.
+        self.weight.data = self.weight.data * (old_stddev / new_stddev).unsqueeze(-1)
+        self.bias.data = (old_stddev * self.bias.data + old_mean - new_mean) / new_stddev
 
     def debiased_mean_var(self):
         debias = self.debiasing_term.clamp(min=self.epsilon)

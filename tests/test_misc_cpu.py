@@ -1,0 +1,100 @@
+"""CPU checks of the pieces that are not on the benchmarked configuration but belong to the same
+API surface: PopArt, the non-Discrete action heads, ValueNorm numpy/tensor round trips."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import Box, Discrete, make_args
+
+from onpolicy.algorithms.utils.popart import PopArt
+from onpolicy.algorithms.utils.act import ACTLayer
+from onpolicy.utils.valuenorm import ValueNorm
+
+
+def test_popart_update_preserves_unnormalised_output():
+    """PopArt's defining property: after a statistics update the de-normalised output of the layer is
+    unchanged (the reference's update raises TypeError on CPU, popart.py:64,69-70; this one works)."""
+    torch.manual_seed(0)
+    layer = PopArt(16, 1)
+    x = torch.randn(32, 16)
+    layer.update(torch.randn(64, 1) * 3 + 2)          # warm statistics
+    before = layer.denormalize(layer(x)).detach().clone()
+    layer.update(torch.randn(64, 1) * 5 - 1)
+    after = layer.denormalize(layer(x)).detach()
+    torch.testing.assert_close(after, before, rtol=1e-4, atol=1e-4)
+    s = layer.denorm_scalars()
+    mean, var = layer.debiased_mean_var()
+    assert float(s[0]) == pytest.approx(float(var.sqrt())) and float(s[1]) == pytest.approx(float(mean))
+    # numpy in -> numpy out, tensor in -> tensor out
+    assert isinstance(layer.denormalize(np.zeros((3, 1), np.float32)), np.ndarray)
+    assert torch.is_tensor(layer.denormalize(torch.zeros(3, 1)))
+
+
+def test_popart_trainer_runs():
+    from oracle import oracle
+    from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy
+    from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO
+    from helpers import fill_buffer_arrays, buffer_shapes, load_into
+    T, N, A, Do, Ds, na = 6, 3, 2, 5, 9, 4
+    args = make_args(episode_length=T, n_rollout_threads=N, hidden_size=16, ppo_epoch=2, num_mini_batch=2,
+                     use_popart=True, use_valuenorm=False)
+    spaces = Box((Do,)), Box((Ds,)), Discrete(na)
+    torch.manual_seed(1)
+    policy = R_MAPPOPolicy(args, *spaces)
+    trainer = R_MAPPO(args, policy)
+    assert trainer.value_normalizer is policy.critic.v_out
+    buf = oracle.OracleBuffer(args, A, *spaces)
+    arrays = fill_buffer_arrays(buffer_shapes(T, N, A, Do, Ds, na, 16), np.random.default_rng(0), na=na)
+    load_into(buf, arrays)
+    buf.compute_returns(arrays["next_value"], trainer.value_normalizer)
+    info = trainer.train(buf)
+    assert all(np.isfinite(v) for v in info.values())
+    assert float(policy.critic.v_out.debiasing_term) > 0
+
+
+def test_valuenorm_roundtrip_and_types():
+    vn = ValueNorm(1)
+    x = torch.randn(100, 1) * 4 + 3
+    vn.update(x)
+    torch.testing.assert_close(vn.denormalize(vn.normalize(x)), x, rtol=1e-5, atol=1e-5)
+    out = vn.denormalize(x.numpy())
+    assert isinstance(out, np.ndarray)
+    np.testing.assert_allclose(out, vn.denormalize(x).numpy(), rtol=1e-6)
+    assert set(vn.state_dict()) == {"running_mean", "running_mean_sq", "debiasing_term"}
+
+
+class _MultiDiscrete(object):
+    def __init__(self, nvec):
+        self.high = np.array(nvec) - 1
+        self.low = np.zeros(len(nvec), dtype=np.int64)
+        self.shape = len(nvec)
+
+
+_MultiDiscrete.__name__ = "MultiDiscrete"
+
+
+class _MultiBinary(object):
+    def __init__(self, n):
+        self.shape = (n,)
+
+
+_MultiBinary.__name__ = "MultiBinary"
+
+
+@pytest.mark.parametrize("space,act_dim", [(Discrete(5), 1), (Box((3,)), 3), (_MultiDiscrete([3, 4]), 2),
+                                           (_MultiBinary(4), 4)])
+def test_action_heads_shapes_and_consistency(space, act_dim):
+    torch.manual_seed(0)
+    layer = ACTLayer(space, 16, True, 0.01)
+    x = torch.randn(10, 16)
+    actions, logp = layer(x)
+    assert actions.shape == (10, act_dim)
+    det, _ = layer(x, deterministic=True)
+    assert det.shape == actions.shape
+    ev_logp, ent = layer.evaluate_actions(x, actions.float(), active_masks=torch.ones(10, 1))
+    assert torch.isfinite(ent)
+    if space.__class__.__name__ in ("Discrete", "Box", "MultiBinary"):
+        torch.testing.assert_close(ev_logp, logp, rtol=1e-5, atol=1e-6)      # log-prob of the drawn action
+    probs = layer.get_probs(x) if space.__class__.__name__ != "Box" else None
+    if space.__class__.__name__ == "Discrete":
+        torch.testing.assert_close(probs.sum(-1), torch.ones(10), rtol=1e-5, atol=1e-6)

@@ -94,3 +94,59 @@ class FakeSMACVecEnv(object):
 
     def close(self):
         pass
+
+
+class FakeChooseVecEnv(object):
+    """ChooseSubprocVecEnv protocol of the Hanabi wrappers: one acting player per env and step.
+    reset(choose [N] bool) -> obs [N, Do], share_obs [N, Ds], available_actions [N, na] (zeros for
+    envs that are not reset); step(actions [N, 1], -1 = idle) -> obs, share_obs, rewards [N, A, 1]...
+    here rewards are [N, 1] broadcast to all players like the Hanabi env, dones (True / False / None
+    for idle envs), infos, available_actions."""
+
+    def __init__(self, n_threads, n_agents, obs_dim, state_dim, n_actions, seed=0):
+        self.n, self.a, self.do, self.ds, self.na = n_threads, n_agents, obs_dim, state_dim, n_actions
+        self.observation_space = [Box((obs_dim,)) for _ in range(n_agents)]
+        self.share_observation_space = [Box((state_dim,)) for _ in range(n_agents)]
+        self.action_space = [Discrete(n_actions) for _ in range(n_agents)]
+        self.rng = np.random.default_rng(seed)
+        self.left = np.zeros(n_threads, dtype=np.int64)       # moves left in the current game
+        self.steps = 0
+        self.games = 0
+
+    def _emit(self, which):
+        obs = np.zeros((self.n, self.do), np.float32)
+        share = np.zeros((self.n, self.ds), np.float32)
+        avail = np.zeros((self.n, self.na), np.float32)
+        k = int(which.sum())
+        if k:
+            obs[which] = self.rng.standard_normal((k, self.do))
+            share[which] = self.rng.standard_normal((k, self.ds))
+            av = (self.rng.random((k, self.na)) < 0.5).astype(np.float32)
+            av[:, 0] = 1.0
+            avail[which] = av
+        return obs, share, avail
+
+    def reset(self, choose):
+        choose = np.asarray(choose, dtype=bool)
+        self.left[choose] = self.rng.integers(5, 14, int(choose.sum()))
+        return self._emit(choose)
+
+    def step(self, actions):
+        actions = np.asarray(actions)
+        assert actions.shape == (self.n, 1)
+        acting = actions[:, 0] >= 0
+        assert np.all(self.left[acting] > 0), "an env without a running game was asked to act"
+        self.steps += int(acting.sum())
+        self.left[acting] -= 1
+        finished = acting & (self.left == 0)
+        running = acting & ~finished
+        obs, share, avail = self._emit(running)
+        rewards = np.zeros((self.n, self.a, 1), np.float32)
+        rewards[acting] = self.rng.random((int(acting.sum()), 1, 1)).astype(np.float32)
+        dones = np.array([True if f else (False if r else None) for f, r in zip(finished, running)], dtype=object)
+        infos = [{"score": float(self.rng.integers(0, 25))} if f else {} for f in finished]
+        self.games += int(finished.sum())
+        return obs, share, rewards, dones, infos, avail
+
+    def close(self):
+        pass

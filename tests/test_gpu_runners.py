@@ -97,3 +97,30 @@ def test_smac_runner_masks(tmp_path):
     info = runner.train()
     assert all(np.isfinite(v) for v in info.values())
     runner.run()
+
+
+def test_hanabi_runner_turn_based(tmp_path):
+    """Turn-based runner on a fake choose-env: the loop (collect per player, chooseinsert, reward
+    shift, compute, train, chooseafter_update, selective resets) runs, respects availability and
+    counts only real moves."""
+    from onpolicy.runner.shared.hanabi_runner_forward import HanabiRunner
+    from fake_envs import FakeChooseVecEnv
+    T, N, A, Do, Ds, na = 6, 5, 3, 9, 12, 7
+    args = make_args(env_name="Hanabi", episode_length=T, n_rollout_threads=N, num_env_steps=4 * T * N,
+                     hidden_size=16, ppo_epoch=2, num_mini_batch=1, algorithm_name="mappo", log_interval=1,
+                     use_wandb=False)
+    args.hanabi_name = "fake"
+    envs = FakeChooseVecEnv(N, A, Do, Ds, na)
+    torch.manual_seed(1)
+    runner = HanabiRunner(_config(args, envs, A, tmp_path))
+    runner.run()
+    assert runner.true_total_num_steps == envs.steps > 0
+    assert envs.games > 0 and len(runner.scores) >= 0
+    b = runner.buffer
+    assert torch.isfinite(b.returns).all() and torch.isfinite(b.rewards).all()
+    # masks / active masks only ever hold 0 or 1
+    for name in ("masks", "active_masks"):
+        v = getattr(b, name)
+        assert bool(((v == 0) | (v == 1)).all())
+    lines = [json.loads(l) for l in open(os.path.join(runner.log_dir, "scalars.jsonl"))]
+    assert any(r["tag"] == "value_loss" for r in lines) and any(r["tag"] == "average_score" for r in lines)

@@ -165,6 +165,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MAPPO_SINGLE_DEVICE", "0") == "1":
+        local_rank = 0          # all ranks on one GPU (test mode, with MAPPO_DIST_BACKEND=gloo)
     assert torch.cuda.is_available(), "bench.py measures the HIP path and needs an MI355X"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)

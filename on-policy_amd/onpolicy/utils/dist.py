@@ -42,6 +42,9 @@ def init_from_env(device=None):
     os.environ.setdefault("MASTER_PORT", "29533")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     backend = "nccl" if (device is not None and torch.device(device).type == "cuda") else "gloo"
+    # MAPPO_DIST_BACKEND=gloo lets several ranks share ONE GPU (RCCL refuses duplicate devices); used
+    # to exercise the multi-rank device path on a single-GPU box
+    backend = os.environ.get("MAPPO_DIST_BACKEND", backend)
     kwargs = {}
     if backend == "nccl":
         kwargs["device_id"] = torch.device(device)

@@ -39,3 +39,24 @@ def test_bench_contract_and_rccl_single_rank():
     # same seeds, same host permutations: the RCCL path must reproduce the plain update
     for k, v in plain["train_info"].items():
         assert forced["train_info"][k] == pytest.approx(v, rel=2e-3, abs=1e-5), k
+
+
+def test_two_ranks_on_one_gpu_strong_scaling_path():
+    """The driver's multi-GPU launch line with 2 ranks, both mapped onto the one GPU of this box (gloo
+    carries the collectives because RCCL refuses duplicate devices): sharding of the rollout threads,
+    per-rank buffers, flat-bucket gradient all-reduce on device tensors, max-over-ranks timing and the
+    single JSON line from rank 0."""
+    env = dict(os.environ)
+    env.update(MAPPO_DIST_BACKEND="gloo", MAPPO_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29611", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "1", "--warmup", "1", "--threads", "64", "--sampler-rng", "host"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines          # exactly one JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["threads_per_gpu"] == 32 and d["config"]["n_rollout_threads"] == 64
+    assert "cpu_baseline" not in d
+    assert all(abs(v) < 1e6 for v in d["train_info"].values())

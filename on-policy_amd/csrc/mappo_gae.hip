@@ -89,9 +89,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // Rows of the partials array that no workgroup owns are zeroed by workgroup 0, so that the
 // fixed-size reduction needs no separate memset launch.
-__device__ __forceinline__ void zero_unowned_partials(double* partials, long long rows) {
+__device__ __forceinline__ void zero_unowned_partials(double* partials, long long rows, int per_block = 1) {
     if (partials != nullptr && blockIdx.x == 0) {
-        for (long long r = (long long)gridDim.x + threadIdx.x; r < rows; r += blockDim.x) {
+        for (long long r = (long long)gridDim.x * per_block + threadIdx.x; r < rows; r += blockDim.x) {
             partials[r * 3 + 0] = 0.0;
             partials[r * 3 + 1] = 0.0;
             partials[r * 3 + 2] = 0.0;
@@ -150,10 +150,12 @@ __device__ __forceinline__ void zero_unowned_partials(double* partials, long lon
 template <int W, int TC, bool PTL, bool DENORM, bool ACT>
 __device__ __forceinline__ void walk_tile(const GaeArgs& a, const float* ldsf, int lane, long long col,
                                           bool live, int tbase, float sigma, float mu, float& g,
-                                          float& dv1, double& s1, double& s2, double& cnt) {
+                                          float& dv1, double& s1, double& s2, double& cnt, int lds_col = -1) {
     constexpr int TILE = TC * W;
     const bool has_adv = a.adv != nullptr;
-    const int lc = lane < W ? lane : 0;  // lanes beyond the strip stay in bounds
+    // LDS column of this lane: its lane for strips up to one wave wide (lanes beyond the strip stay in
+    // bounds), or the caller's column for strips shared by several walker waves
+    const int lc = lds_col >= 0 ? lds_col : (lane < W ? lane : 0);
     const float* lr = ldsf + 0 * TILE + lc;
     const float* lv = ldsf + 1 * TILE + lc;
     const float* lm = ldsf + 2 * TILE + lc;
@@ -335,16 +337,18 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <int W, int NPROD, int TC, int R, bool PTL, bool DENORM, bool ACT>
-__global__ void __launch_bounds__((NPROD + 1) * 64) gae_dma_kernel(GaeArgs a) {
+__global__ void __launch_bounds__((NPROD + (W + 63) / 64) * 64) gae_dma_kernel(GaeArgs a) {
+    constexpr int NWALK = (W + 63) / 64;           // walker waves (64 columns each)
     constexpr int NF = 3 + (PTL ? 1 : 0) + (ACT ? 1 : 0);
     constexpr int RPI = 256 / W;                   // tile rows per wave instruction
     constexpr int IPS = TC / RPI;                  // instructions per slot (field) per tile
     constexpr int IPT = NF * IPS;                  // instructions per tile
     constexpr int LPT = IPT / NPROD;               // instructions per producer wave per tile
     constexpr int TILE_FLOATS = NF * TC * W;
+    static_assert(W <= 256 && (W <= 64 || W % 64 == 0), "strip width");
     static_assert(TC % RPI == 0 && IPS % NPROD == 0, "row groups must split evenly over the producers");
     static_assert(R >= 2 && (R - 2) * LPT < 64, "ring depth vs the 6-bit vmcnt");
-    static_assert(R * TILE_FLOATS * 4 <= 65536, "LDS-DMA destinations are kept inside the first 64 KiB");
+    static_assert(R * TILE_FLOATS * 4 <= 160 * 1024, "LDS ring");
 
     extern __shared__ vf4 lds4[];                  // [R][NF][TC][W / 4]
     float* ldsf = reinterpret_cast<float*>(lds4);
@@ -353,12 +357,13 @@ __global__ void __launch_bounds__((NPROD + 1) * 64) gae_dma_kernel(GaeArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const long long col0 = (long long)strip_of_block(a) * W;
     const bool nt = (a.opts & 2) != 0;
-    zero_unowned_partials(a.partials, a.partial_rows);
+    zero_unowned_partials(a.partials, a.partial_rows, NWALK);
 
-    if (wave == 0) {
-        const int lane = threadIdx.x;
-        const long long col = col0 + lane;
-        const bool live = lane < W && col < a.C;
+    if (wave < NWALK) {
+        const int lane = threadIdx.x & 63;
+        const int lds_col = NWALK > 1 ? wave * 64 + lane : -1;
+        const long long col = col0 + (NWALK > 1 ? wave * 64 : 0) + lane;
+        const bool live = (NWALK > 1 || lane < W) && col < a.C;
         float sigma, mu, dv1, g = 0.f;
         double s1 = 0.0, s2 = 0.0, cnt = 0.0;
         walker_prologue(a, live, col, DENORM, sigma, mu, dv1);
@@ -366,14 +371,24 @@ __global__ void __launch_bounds__((NPROD + 1) * 64) gae_dma_kernel(GaeArgs a) {
         int slot = 0;
         for (int k = 0; k < nch; ++k) {
             walk_tile<W, TC, PTL, DENORM, ACT>(a, ldsf + slot * TILE_FLOATS, lane, col, live,
-                                               T - (k + 1) * TC, sigma, mu, g, dv1, s1, s2, cnt);
+                                               T - (k + 1) * TC, sigma, mu, g, dv1, s1, s2, cnt, lds_col);
             slot = slot + 1 == R ? 0 : slot + 1;
             __syncthreads();                                    // tile k+1 landed, tile k released
         }
-        walker_epilogue(a, lane, s1, s2, cnt);
+        if (a.partials != nullptr) {
+            s1 = wave_sum(s1);
+            s2 = wave_sum(s2);
+            cnt = wave_sum(cnt);
+            if (lane == 0) {
+                double* p = a.partials + ((long long)blockIdx.x * NWALK + wave) * 3;
+                p[0] = s1;
+                p[1] = s2;
+                p[2] = cnt;
+            }
+        }
     } else {
         const int lane = threadIdx.x & 63;
-        const int pw = wave - 1;                                // producer index
+        const int pw = wave - NWALK;                            // producer index
         const unsigned lds_base = (unsigned)(uintptr_t)ldsf;    // LDS byte address of the ring
         // this lane's place inside one instruction: row r0 (of RPI), 4-column group c4
         const int r0 = lane / (W / 4);
@@ -686,7 +701,20 @@ hipError_t launch_strip(const GaeArgs& a, unsigned flags, hipStream_t stream) {
 template <int W, int NPROD, int TC, int R>
 hipError_t launch_dma(const GaeArgs& a, unsigned flags, hipStream_t stream) {
     const size_t lds = (size_t)R * gae_slots(a, flags) * TC * W * sizeof(float);
-    dim3 grid((unsigned)((a.C + W - 1) / W)), block((NPROD + 1) * 64);
+    dim3 grid((unsigned)((a.C + W - 1) / W)), block((NPROD + (W + 63) / 64) * 64);
+    if (lds > 64 * 1024) {   // opt in to more than 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
+        const bool ptl = flags & MAPPO_GAE_PROPER_TIME_LIMITS;
+        const bool den = flags & MAPPO_GAE_DENORM;
+        const bool act = a.active != nullptr;
+#define MAPPO_SET_LDS(P, D, A_)                                                                   \
+        if (ptl == P && den == D && act == A_)                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gae_dma_kernel<W, NPROD, TC, R, P, D, A_>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        MAPPO_SET_LDS(false, false, false) MAPPO_SET_LDS(false, false, true) MAPPO_SET_LDS(false, true, false)
+        MAPPO_SET_LDS(false, true, true) MAPPO_SET_LDS(true, false, false) MAPPO_SET_LDS(true, false, true)
+        MAPPO_SET_LDS(true, true, false) MAPPO_SET_LDS(true, true, true)
+#undef MAPPO_SET_LDS
+    }
     MAPPO_DISPATCH_FLAGS(gae_dma_kernel, W, NPROD, TC, R);
     return hipGetLastError();
 }
@@ -824,6 +852,13 @@ extern "C" int mappo_gae_f32(const float* rewards, float* value_preds, const flo
         case 38: e = launch_dma<64, 2, 8, 6>(a, flags, stream); break;
         case 39: e = launch_dma<64, 4, 16, 3>(a, flags, stream); break;
         case 40: e = launch_dma<32, 2, 16, 4>(a, flags, stream); break;
+        case 41: e = launch_dma<64, 2, 16, 6>(a, flags, stream); break;    // 120 KB ring: M0 > 64 KiB probe
+        case 42: e = launch_dma<128, 2, 8, 3>(a, flags, stream); break;    // 2 walkers, ring 60 KB
+        case 43: e = launch_dma<128, 4, 8, 3>(a, flags, stream); break;
+        case 44: e = launch_dma<128, 6, 12, 3>(a, flags, stream); break;   // 8 waves, ring 90 KB
+        case 45: e = launch_dma<128, 2, 8, 6>(a, flags, stream); break;    // ring 120 KB
+        case 46: e = launch_dma<128, 4, 16, 3>(a, flags, stream); break;   // ring 120 KB
+        case 47: e = launch_dma<128, 2, 4, 6>(a, flags, stream); break;    // ring 60 KB, 5 tiles ahead
         default: e = launch_column(a, flags, stream); break;
     }
     return (int)e;

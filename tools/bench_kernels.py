@@ -97,7 +97,7 @@ def main():
             t = time_launches(fn, opt.sets, opt.iters)
             t["GBps_b2b"] = 16 * n / (t["b2b_us"] * 1e-6) / 1e9
             pr["flat_%d" % blocks] = t
-        for v in (0, 1, 2, 3):
+        for v in (0, 1, 2, 3, 4, 5, 6, 7, 8):
             def fn(i):
                 d = sets[i]
                 assert P.probe_strip(d["r"].data_ptr(), d["v"].data_ptr(), d["m"].data_ptr(), d["ret"].data_ptr(),

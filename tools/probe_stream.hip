@@ -16,11 +16,11 @@ __global__ void __launch_bounds__(256) flat_kernel(const float4* a, const float4
     }
 }
 
-template <int NWAVES, int TC>
+template <int NWAVES, int TC, int W = 64>
 __global__ void __launch_bounds__(NWAVES * 64) strip_kernel(const float* a, const float* b, const float* c,
                                                              float* out, int T, long long C) {
-    constexpr int NT = NWAVES * 64, V = 16, NVEC = TC * V, PER = NVEC / NT;
-    const long long col0 = (long long)blockIdx.x * 64;
+    constexpr int NT = NWAVES * 64, V = W / 4, NVEC = TC * V, PER = NVEC / NT;
+    const long long col0 = (long long)blockIdx.x * W;
     for (int tb = T - TC; tb > -TC; tb -= TC) {
         float4 x[PER], y[PER], z[PER];
 #pragma unroll
@@ -57,6 +57,11 @@ extern "C" int probe_strip(const float* a, const float* b, const float* c, float
     if (variant == 0) hipLaunchKernelGGL((strip_kernel<4, 32>), grid, dim3(256), 0, (hipStream_t)stream, a, b, c, out, T, C);
     else if (variant == 1) hipLaunchKernelGGL((strip_kernel<4, 64>), grid, dim3(256), 0, (hipStream_t)stream, a, b, c, out, T, C);
     else if (variant == 2) hipLaunchKernelGGL((strip_kernel<8, 64>), grid, dim3(512), 0, (hipStream_t)stream, a, b, c, out, T, C);
-    else hipLaunchKernelGGL((strip_kernel<1, 32>), grid, dim3(64), 0, (hipStream_t)stream, a, b, c, out, T, C);
+    else if (variant == 3) hipLaunchKernelGGL((strip_kernel<1, 32>), grid, dim3(64), 0, (hipStream_t)stream, a, b, c, out, T, C);
+    else if (variant == 4) hipLaunchKernelGGL((strip_kernel<4, 32, 128>), dim3((unsigned)(C / 128)), dim3(256), 0, (hipStream_t)stream, a, b, c, out, T, C);
+    else if (variant == 5) hipLaunchKernelGGL((strip_kernel<8, 16, 256>), dim3((unsigned)(C / 256)), dim3(512), 0, (hipStream_t)stream, a, b, c, out, T, C);
+    else if (variant == 6) hipLaunchKernelGGL((strip_kernel<4, 16, 256>), dim3((unsigned)(C / 256)), dim3(256), 0, (hipStream_t)stream, a, b, c, out, T, C);
+    else if (variant == 7) hipLaunchKernelGGL((strip_kernel<8, 16, 128>), dim3((unsigned)(C / 128)), dim3(512), 0, (hipStream_t)stream, a, b, c, out, T, C);
+    else hipLaunchKernelGGL((strip_kernel<4, 16>), grid, dim3(256), 0, (hipStream_t)stream, a, b, c, out, T, C);
     return (int)hipGetLastError();
 }

@@ -146,46 +146,93 @@ __device__ __forceinline__ void zero_unowned_partials(double* partials, long lon
         }                                                                                        \
     }
 
-// Walk one tile backwards in time out of LDS (one lane per column).
-template <int W, int TC, bool PTL, bool DENORM, bool ACT>
-__device__ __forceinline__ void walk_tile(const GaeArgs& a, const float* ldsf, int lane, long long col,
-                                          bool live, int tbase, float sigma, float mu, float& g,
-                                          float& dv1, double& s1, double& s2, double& cnt, int lds_col = -1) {
+// Walk one tile backwards in time out of LDS (one lane per column).  The walker wave is the serial
+// part of the kernel (400 dependent steps), so its instruction stream is kept lean:
+//   * the LDS operands of U consecutive steps are fetched in one batch before they are needed (they
+//     do not depend on the recurrence), so one LDS round trip is exposed per U steps, not per step;
+//   * no per-step branches: dead lanes leave before the loop (there is no barrier inside), the
+//     moment accumulation uses selects, output pointers are decremented instead of recomputed.
+template <int W, int TC, bool PTL, bool DENORM, bool ACT, bool ADV>
+__device__ __forceinline__ void walk_tile_impl(const GaeArgs& a, const float* ldsf, int lane, long long col,
+                                               bool live, int tbase, float sigma, float mu, float& g,
+                                               float& dv1, double& s1, double& s2, double& cnt, int lds_col) {
     constexpr int TILE = TC * W;
-    const bool has_adv = a.adv != nullptr;
-    // LDS column of this lane: its lane for strips up to one wave wide (lanes beyond the strip stay in
-    // bounds), or the caller's column for strips shared by several walker waves
-    const int lc = lds_col >= 0 ? lds_col : (lane < W ? lane : 0);
+    constexpr int U = TC % 8 == 0 ? 8 : (TC % 4 == 0 ? 4 : (TC % 2 == 0 ? 2 : 1));
+    static_assert(TC % U == 0, "tile length vs walker batch");
+    if (!live) return;
+    constexpr bool has_adv = ADV;
+    // LDS column of this lane: its lane for strips up to one wave wide, or the caller's column for
+    // strips shared by several walker waves
+    const int lc = lds_col >= 0 ? lds_col : lane;
     const float* lr = ldsf + 0 * TILE + lc;
     const float* lv = ldsf + 1 * TILE + lc;
     const float* lm = ldsf + 2 * TILE + lc;
     const float* lb = ldsf + 3 * TILE + lc;
     const float* la = ldsf + (PTL ? 4 : 3) * TILE + lc;
-    const int slo = tbase < 0 ? -tbase : 0;
+    const int slo = tbase < 0 ? -tbase : 0;            // rows below t = 0 do not exist (last tile only)
     const float gamma = a.gamma, gl = a.gl;
     const long long C = a.C;
-#pragma unroll 8
-    for (int s = TC - 1; s >= slo; --s) {
-        float r = lr[s * W], v0 = lv[s * W], m1 = lm[s * W];
-        float bad1 = PTL ? lb[s * W] : 1.f;
-        float dv0;
-        float ret = gae_step<PTL, DENORM>(r, v0, m1, bad1, sigma, mu, gamma, gl, dv1, g, dv0);
-        if (live) {
-            long long o = (long long)(tbase + s) * C + col;
-            a.returns[o] = ret;
-            if (has_adv) {
-                float adv = ret - dv0;  // r_mappo.py:180 (from the rounded return)
-                a.adv[o] = adv;
-                float am = ACT ? la[s * W] : 1.f;
-                if (am != 0.f) {
-                    double d = (double)adv;
+    float* pret = a.returns + (long long)(tbase + TC - 1) * C + col;
+    float* padv = has_adv ? a.adv + (long long)(tbase + TC - 1) * C + col : nullptr;
+    for (int s0 = TC - 1; s0 >= slo; s0 -= U) {
+        float r[U], v0[U], m1[U], b1[U], am[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int s = s0 - u;                      // always inside the tile (TC % U == 0)
+            r[u] = lr[s * W];
+            v0[u] = lv[s * W];
+            m1[u] = lm[s * W];
+            b1[u] = PTL ? lb[s * W] : 1.f;
+            am[u] = ACT ? la[s * W] : 1.f;
+        }
+        const int nvalid = s0 - slo + 1 < U ? s0 - slo + 1 : U;
+        if (nvalid == U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float dv0;
+                float ret = gae_step<PTL, DENORM>(r[u], v0[u], m1[u], b1[u], sigma, mu, gamma, gl, dv1, g, dv0);
+                *pret = ret;
+                pret -= C;
+                if (has_adv) {
+                    float adv = ret - dv0;             // r_mappo.py:180 (from the rounded return)
+                    *padv = adv;
+                    padv -= C;
+                    double d = (am[u] != 0.f) ? (double)adv : 0.0;
                     s1 += d;
                     s2 += d * d;
-                    cnt += 1.0;
+                    cnt += (am[u] != 0.f) ? 1.0 : 0.0;
+                }
+            }
+        } else {
+            for (int u = 0; u < nvalid; ++u) {
+                float dv0;
+                float ret = gae_step<PTL, DENORM>(r[u], v0[u], m1[u], b1[u], sigma, mu, gamma, gl, dv1, g, dv0);
+                *pret = ret;
+                pret -= C;
+                if (has_adv) {
+                    float adv = ret - dv0;
+                    *padv = adv;
+                    padv -= C;
+                    double d = (am[u] != 0.f) ? (double)adv : 0.0;
+                    s1 += d;
+                    s2 += d * d;
+                    cnt += (am[u] != 0.f) ? 1.0 : 0.0;
                 }
             }
         }
     }
+}
+
+template <int W, int TC, bool PTL, bool DENORM, bool ACT>
+__device__ __forceinline__ void walk_tile(const GaeArgs& a, const float* ldsf, int lane, long long col,
+                                          bool live, int tbase, float sigma, float mu, float& g,
+                                          float& dv1, double& s1, double& s2, double& cnt, int lds_col = -1) {
+    if (a.adv != nullptr)   // wave-uniform: the fused-epilogue and the plain loop are separate code
+        walk_tile_impl<W, TC, PTL, DENORM, ACT, true>(a, ldsf, lane, col, live, tbase, sigma, mu, g, dv1, s1, s2,
+                                                      cnt, lds_col);
+    else
+        walk_tile_impl<W, TC, PTL, DENORM, ACT, false>(a, ldsf, lane, col, live, tbase, sigma, mu, g, dv1, s1,
+                                                       s2, cnt, lds_col);
 }
 
 __device__ __forceinline__ void walker_prologue(const GaeArgs& a, bool live, long long col, bool denorm,

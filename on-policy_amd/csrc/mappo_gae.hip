@@ -484,6 +484,199 @@ __global__ void __launch_bounds__((NPROD + (W + 63) / 64) * 64) gae_dma_kernel(G
     }
 }
 
+// ---- "dma-epi" kernel: the DMA ring kernel with the epilogue moved off the walker ---------
+// The walker wave is the serial critical path, so here it does nothing but the recurrence: it reads
+// r, v, m[, bad] from the LDS tile and writes the return of every step into a small LDS output
+// tile.  The producer waves -- idle between DMA issues -- run the whole epilogue one tile behind:
+// they re-derive D(v) (same two roundings as the walker), form the advantage from the rounded
+// return, store returns / advantages with 16-byte row-contiguous stores and accumulate the float64
+// moments across all their lanes.  Timeline of barrier interval k (tile k is being walked):
+//   producers: issue DMA of tile k+R-2 (into the slot of tile k-2) -> epilogue of tile k-1 ->
+//              counted wait until tile k+1 has landed -> barrier.
+// The ring therefore holds tiles k-1 .. k+R-2; the output tile is double buffered.
+template <int W, int NPROD, int TC, int R, bool PTL, bool DENORM, bool ACT>
+__global__ void __launch_bounds__((NPROD + (W + 63) / 64) * 64) gae_dma_epi_kernel(GaeArgs a) {
+    constexpr int NWALK = (W + 63) / 64;
+    constexpr int NF = 3 + (PTL ? 1 : 0) + (ACT ? 1 : 0);
+    constexpr int RPI = 256 / W;
+    constexpr int IPS = TC / RPI;
+    constexpr int LPT = NF * IPS / NPROD;          // DMA instructions per producer wave per tile
+    constexpr int TILE = TC * W;                   // floats per field per tile
+    constexpr int TILE_FLOATS = NF * TILE;
+    constexpr int V = W / 4;
+    constexpr int GROUPS = TC * V;                 // float4 groups per tile
+    constexpr int GPL = (GROUPS + NPROD * 64 - 1) / (NPROD * 64);   // groups per producer lane
+    static_assert(W <= 256 && (W <= 64 || W % 64 == 0), "strip width");
+    static_assert(TC % RPI == 0 && IPS % NPROD == 0, "row groups must split evenly over the producers");
+    static_assert(R >= 3 && (R - 3) * LPT < 64, "ring depth vs the 6-bit vmcnt");
+    static_assert((R * TILE_FLOATS + 2 * TILE) * 4 <= 160 * 1024, "LDS ring + output tiles");
+
+    extern __shared__ vf4 lds4[];                  // [R][NF][TC][V] ring, then [2][TC][V] output tiles
+    float* ldsf = reinterpret_cast<float*>(lds4);
+    float* outf = ldsf + R * TILE_FLOATS;
+    const int T = a.T;
+    const int nch = (T + TC - 1) / TC;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const long long col0 = (long long)strip_of_block(a) * W;
+    const long long C = a.C;
+    zero_unowned_partials(a.partials, a.partial_rows, NPROD);
+
+    float sigma = 1.f, mu = 0.f;
+    if (DENORM) {
+        sigma = a.denorm[0];
+        mu = a.denorm[1];
+    }
+
+    if (wave < NWALK) {
+        // ---------------------------------------------------------------- walker
+        const int lane = threadIdx.x & 63;
+        const int lc = NWALK > 1 ? wave * 64 + lane : lane;
+        const long long col = col0 + lc;
+        const bool live = lc < W && col < C;
+        float dv1 = 0.f, g = 0.f;
+        if (live) {
+            float nv = a.next_value[col];
+            a.value_preds[(long long)T * C + col] = nv;  // shared_buffer.py:187,218
+            dv1 = nv;
+            if (DENORM) {
+                float s = nv * sigma;
+                dv1 = s + mu;
+            }
+        }
+        const float gamma = a.gamma, gl = a.gl;
+        constexpr int U = TC % 8 == 0 ? 8 : (TC % 4 == 0 ? 4 : (TC % 2 == 0 ? 2 : 1));
+        __syncthreads();                                        // tile 0 landed
+        int slot = 0;
+        for (int k = 0; k < nch; ++k) {
+            if (live) {
+                const float* base = ldsf + slot * TILE_FLOATS + lc;
+                float* po = outf + (k & 1) * TILE + lc;
+                for (int s0 = TC - 1; s0 >= 0; s0 -= U) {       // rows below t = 0 are computed but never stored
+                    float r[U], v0[U], m1[U], b1[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int sidx = (s0 - u) * W;
+                        r[u] = base[0 * TILE + sidx];
+                        v0[u] = base[1 * TILE + sidx];
+                        m1[u] = base[2 * TILE + sidx];
+                        b1[u] = PTL ? base[3 * TILE + sidx] : 1.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        float dv0;
+                        po[(s0 - u) * W] = gae_step<PTL, DENORM>(r[u], v0[u], m1[u], b1[u], sigma, mu, gamma, gl,
+                                                                 dv1, g, dv0);
+                    }
+                }
+            }
+            slot = slot + 1 == R ? 0 : slot + 1;
+            __syncthreads();                                    // tile k+1 landed; output tile k published
+        }
+    } else {
+        // -------------------------------------------------------------- producers
+        const int lane = threadIdx.x & 63;
+        const int pw = wave - NWALK;
+        const int ptid = pw * 64 + lane;                        // index among the producer lanes
+        const unsigned lds_base = (unsigned)(uintptr_t)ldsf;
+        const bool nt = (a.opts & 2) != 0;
+        const bool has_adv = a.adv != nullptr;
+        const int r0 = lane / V;
+        const int c4 = lane - r0 * V;
+        long long lcol = col0 + c4 * 4;
+        if (lcol > C - 4) lcol = C - 4;
+        const float* fb0 = a.rewards + lcol;
+        const float* fb1 = a.value_preds + lcol;
+        const float* fb2 = a.masks + C + lcol;
+        const float* fb3 = (PTL ? a.bad + C : a.active) + lcol;
+        const float* fb4 = a.active + lcol;
+        double s1 = 0.0, s2 = 0.0, cnt = 0.0;
+
+        auto issue_tile = [&](int tbase, int slot) {
+            const unsigned slot_addr = lds_base + (unsigned)slot * (TILE_FLOATS * 4);
+#pragma unroll
+            for (int s = 0; s < NF; ++s) {
+                const float* fbs = s == 0 ? fb0 : s == 1 ? fb1 : s == 2 ? fb2 : (s == 3 && PTL) ? fb3 : fb4;
+#pragma unroll
+                for (int q = 0; q < IPS / NPROD; ++q) {
+                    const int rg = pw + q * NPROD;
+                    int t = tbase + rg * RPI + r0;
+                    if (t < 0) t = 0;
+                    const float* src = fbs + (long long)t * C;
+                    const unsigned dst = slot_addr + (unsigned)((s * TC + rg * RPI) * W * 4);
+                    if (nt) lds_dma_16B<true>(src, dst);
+                    else lds_dma_16B<false>(src, dst);
+                }
+            }
+        };
+        // epilogue of tile m (walked during the previous interval): returns / advantages / moments
+        auto epilogue = [&](int m) {
+            const int tbase = T - (m + 1) * TC;
+            const float* in = ldsf + (m % R) * TILE_FLOATS;
+            const float* out = outf + (m & 1) * TILE;
+#pragma unroll
+            for (int q = 0; q < GPL; ++q) {
+                const int i = ptid + q * NPROD * 64;
+                const int row = i / V;
+                const int cg = i - row * V;
+                const int t = tbase + row;
+                const long long col = col0 + cg * 4;
+                if (i < GROUPS && t >= 0 && col < C) {
+                    const vf4 ret = *reinterpret_cast<const vf4*>(out + row * W + cg * 4);
+                    const long long o = (long long)t * C + col;
+                    __builtin_nontemporal_store(ret, reinterpret_cast<vf4*>(a.returns + o));
+                    if (has_adv) {
+                        const vf4 v = *reinterpret_cast<const vf4*>(in + 1 * TILE + row * W + cg * 4);
+                        vf4 am = vf4(1.f);
+                        if (ACT) am = *reinterpret_cast<const vf4*>(in + (PTL ? 4 : 3) * TILE + row * W + cg * 4);
+                        vf4 adv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float dv0 = v[e];
+                            if (DENORM) {
+                                float sc = v[e] * sigma;   // valuenorm.py:75, same two roundings as the walker
+                                dv0 = sc + mu;
+                            }
+                            adv[e] = ret[e] - dv0;          // r_mappo.py:180 (from the rounded return)
+                            double d = (am[e] != 0.f) ? (double)adv[e] : 0.0;
+                            s1 += d;
+                            s2 += d * d;
+                            cnt += (am[e] != 0.f) ? 1.0 : 0.0;
+                        }
+                        __builtin_nontemporal_store(adv, reinterpret_cast<vf4*>(a.adv + o));
+                    }
+                }
+            }
+        };
+
+        // prologue: tiles 0 .. R-3 in flight, wait for tile 0
+#pragma unroll
+        for (int m = 0; m < R - 2; ++m) issue_tile(T - (m + 1) * TC, m);
+        wait_vmcnt<(R - 3) * LPT>();
+        __syncthreads();
+        int slot = R - 2;                     // ring slot of tile k + R - 2
+        for (int k = 0; k < nch; ++k) {
+            issue_tile(T - (k + R - 1) * TC, slot);             // tile k+R-2 -> the slot tile k-2 has left
+            slot = slot + 1 == R ? 0 : slot + 1;
+            if (k >= 1) epilogue(k - 1);
+            wait_vmcnt<(R - 3) * LPT>();                        // tile k+1 has landed
+            __syncthreads();
+        }
+        epilogue(nch - 1);
+        if (a.partials != nullptr) {
+            s1 = wave_sum(s1);
+            s2 = wave_sum(s2);
+            cnt = wave_sum(cnt);
+            if (lane == 0) {
+                double* p = a.partials + ((long long)blockIdx.x * NPROD + pw) * 3;
+                p[0] = s1;
+                p[1] = s2;
+                p[2] = cnt;
+            }
+        }
+        wait_vmcnt<0>();
+    }
+}
+
 // ---- "coop" kernel: every wave loads, wave 0 walks, single LDS tile (small strips) ---------
 template <int W, int NWAVES, int TC, bool PTL, bool DENORM, bool ACT>
 __global__ void __launch_bounds__(NWAVES * 64) gae_strip_kernel(GaeArgs a) {
@@ -766,6 +959,27 @@ hipError_t launch_dma(const GaeArgs& a, unsigned flags, hipStream_t stream) {
     return hipGetLastError();
 }
 
+template <int W, int NPROD, int TC, int R>
+hipError_t launch_dma_epi(const GaeArgs& a, unsigned flags, hipStream_t stream) {
+    const size_t lds = ((size_t)R * gae_slots(a, flags) + 2) * TC * W * sizeof(float);
+    dim3 grid((unsigned)((a.C + W - 1) / W)), block((NPROD + (W + 63) / 64) * 64);
+    if (lds > 64 * 1024) {
+        const bool ptl = flags & MAPPO_GAE_PROPER_TIME_LIMITS;
+        const bool den = flags & MAPPO_GAE_DENORM;
+        const bool act = a.active != nullptr;
+#define MAPPO_SET_LDS(P, D, A_)                                                                   \
+        if (ptl == P && den == D && act == A_)                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gae_dma_epi_kernel<W, NPROD, TC, R, P, D, A_>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        MAPPO_SET_LDS(false, false, false) MAPPO_SET_LDS(false, false, true) MAPPO_SET_LDS(false, true, false)
+        MAPPO_SET_LDS(false, true, true) MAPPO_SET_LDS(true, false, false) MAPPO_SET_LDS(true, false, true)
+        MAPPO_SET_LDS(true, true, false) MAPPO_SET_LDS(true, true, true)
+#undef MAPPO_SET_LDS
+    }
+    MAPPO_DISPATCH_FLAGS(gae_dma_epi_kernel, W, NPROD, TC, R);
+    return hipGetLastError();
+}
+
 template <int W, int NPROD, int TC, int NBUF>
 hipError_t launch_pipe(const GaeArgs& a, unsigned flags, hipStream_t stream) {
     const size_t lds = (size_t)2 * gae_slots(a, flags) * TC * W * sizeof(float);
@@ -906,6 +1120,14 @@ extern "C" int mappo_gae_f32(const float* rewards, float* value_preds, const flo
         case 45: e = launch_dma<128, 2, 8, 6>(a, flags, stream); break;    // ring 120 KB
         case 46: e = launch_dma<128, 4, 16, 3>(a, flags, stream); break;   // ring 120 KB
         case 47: e = launch_dma<128, 2, 4, 6>(a, flags, stream); break;    // ring 60 KB, 5 tiles ahead
+        case 50: e = launch_dma_epi<128, 2, 8, 4>(a, flags, stream); break;
+        case 51: e = launch_dma_epi<128, 4, 8, 4>(a, flags, stream); break;
+        case 52: e = launch_dma_epi<128, 2, 8, 5>(a, flags, stream); break;
+        case 53: e = launch_dma_epi<128, 4, 8, 6>(a, flags, stream); break;
+        case 54: e = launch_dma_epi<64, 2, 16, 4>(a, flags, stream); break;
+        case 55: e = launch_dma_epi<64, 2, 8, 5>(a, flags, stream); break;
+        case 56: e = launch_dma_epi<32, 2, 16, 4>(a, flags, stream); break;
+        case 57: e = launch_dma_epi<128, 6, 12, 4>(a, flags, stream); break;
         default: e = launch_column(a, flags, stream); break;
     }
     return (int)e;

@@ -104,7 +104,7 @@ def _random_case(T, N, A, seed, device):
 
 
 @pytest.mark.parametrize("variant", [2, 3, 6, 20, 21, 22, 23, 24, 25, 26, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40,
-                                     41, 42, 43, 44, 45, 46, 47, 3043, 1031, 2031, 3031, 3034, 99])
+                                     41, 42, 43, 44, 45, 46, 47, 50, 51, 52, 53, 54, 55, 56, 57, 3050, 3043, 1031, 2031, 3031, 3034, 99])
 @pytest.mark.parametrize("ptl,norm", [(False, True), (True, True), (False, False), (True, False)])
 def test_gae_variants_vs_oracle(variant, ptl, norm):
     """Every kernel variant is bit-identical to the oracle, including ragged strips (C % W != 0),

@@ -1086,7 +1086,7 @@ extern "C" int mappo_gae_f32(const float* rewards, float* value_preds, const flo
     if (variant == 0) {
         // LDS-DMA ring kernel; strip width by column count so that >= 256 workgroups exist;
         // XCD-contiguous strip order + non-temporal DMA (measured best on cold data)
-        variant = (C >= 128 * 256) ? 42 : (C >= 64 * 256) ? 33 : (C >= 32 * 256 ? 34 : 36);
+        variant = (C >= 128 * 256) ? 57 : (C >= 64 * 256) ? 54 : (C >= 32 * 256 ? 56 : 36);
         a.opts = 3;
     }
 

@@ -591,3 +591,46 @@ def test_host_parity_action_sampling():
         D.set_sampling_rng("device")
     assert a_gpu.is_cuda and torch.equal(a_cpu, a_gpu.cpu())
     assert bool((torch.gather(avail, 1, a_cpu) == 1).all())
+
+
+def test_gae_properties_at_scale():
+    """Size-independent properties of the scan on a large buffer:
+    (1) with all masks 1 and lambda = 1, returns are the discounted reward-to-go plus the discounted
+        bootstrap value, whatever the value predictions are (float64 closed form, 1e-4 relative);
+    (2) permuting the rollout threads permutes the outputs bit for bit (columns are independent)."""
+    T, N, A = 200, 1024, 8
+    dev = _dev()
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    args = make_args(episode_length=T, n_rollout_threads=N, gae_lambda=1.0, use_valuenorm=False)
+    buf = _buffer(args, A)
+    buf.rewards.normal_(generator=g)
+    buf.value_preds.normal_(generator=g)
+    nv = torch.randn(N, A, 1, device=dev, generator=g)
+    buf.compute_returns(nv, None)
+    gamma = args.gamma
+    ret64 = torch.zeros(T + 1, N, A, 1, dtype=torch.float64, device=dev)
+    ret64[T] = nv.double()
+    for t in range(T - 1, -1, -1):
+        ret64[t] = buf.rewards[t].double() + gamma * ret64[t + 1]
+    torch.testing.assert_close(buf.returns[:T].double(), ret64[:T], rtol=1e-4, atol=1e-4)
+
+    # (2) thread permutation equivariance, default flags (valuenorm on), random masks
+    args = make_args(episode_length=T, n_rollout_threads=N)
+    a, b = _buffer(args, A), _buffer(args, A)
+    perm = torch.randperm(N, device=dev, generator=g)
+    for name in ("rewards", "value_preds", "masks", "active_masks"):
+        src = getattr(a, name)
+        if name in ("masks", "active_masks"):
+            src.copy_((torch.rand(src.shape, device=dev, generator=g) > 0.05).float())
+        else:
+            src.normal_(generator=g)
+        getattr(b, name).copy_(src[:, perm])
+    vn = _vn([0.7e-4, 3.1e-4, 2.5e-5])
+    a.compute_returns(nv, vn)
+    b.compute_returns(nv[perm], vn)
+    assert torch.equal(a.returns[:, perm], b.returns)
+    assert torch.equal(a.advantages[:, perm], b.advantages)
+    sa = a.normalized_advantages(vn).stats.clone()
+    sb = b.normalized_advantages(vn).stats.clone()
+    torch.testing.assert_close(sa, sb, rtol=1e-6, atol=1e-7)

@@ -19,7 +19,6 @@ constructor, attributes, methods and 12-tuple minibatch protocol, but
 There is no CPU implementation here: the constructor raises unless it gets a HIP device and
 ``libmappo_hip.so`` (see onpolicy/_native.py).
 """
-import ctypes
 import os
 
 import numpy as np
@@ -27,10 +26,6 @@ import torch
 
 from onpolicy import _native
 from onpolicy.utils.util import get_shape_from_obs_space, get_shape_from_act_space
-
-
-def _flatten(T, N, x):
-    return x.reshape(T * N, *x.shape[2:])
 
 
 class AdvantageHandle(object):

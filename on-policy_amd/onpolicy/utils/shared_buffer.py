@@ -126,6 +126,7 @@ class SharedReplayBuffer(object):
         self._adv_partials = torch.zeros((rows, 3), dtype=torch.float64, device=dev)
         self._adv_sums = torch.zeros(3, dtype=torch.float64, device=dev)
         self._adv_stats = torch.zeros(2, **f32)
+        self._content_version = 0  # bumped by every method that writes buffer fields
         self._adv_fresh = False   # advantages/moments match the current returns & value_preds
         self._stats_fresh = False
         self._events = None       # kernel name -> [(start, end, algorithmic bytes)], see profile_kernels
@@ -208,6 +209,7 @@ class SharedReplayBuffer(object):
             slabs.append((src.data_ptr(), dst.data_ptr(), dst.numel()))
         arr = (_native.Slab * len(slabs))(*[_native.Slab(s, d, n) for s, d, n in slabs])
         _native.check(self._lib.mappo_slab_copy(arr, len(slabs), self._stream()), "mappo_slab_copy")
+        self._content_version += 1
 
     # ------------------------------------------------------------------ storage
     def insert(self, share_obs, obs, rnn_states_actor, rnn_states_critic, actions, action_log_probs,
@@ -322,6 +324,7 @@ class SharedReplayBuffer(object):
             T, N * A, float(self.gamma), float(self.gae_lambda), self._gae_flags(denorm), self._stream())
         self._timed_end(ev)
         _native.check(code, "mappo_gae_f32")
+        self._content_version += 1
         self._adv_fresh = True
         self._stats_fresh = False
 
@@ -340,6 +343,7 @@ class SharedReplayBuffer(object):
                                                   p(self.active_masks), p(self.advantages),
                                                   p(self._adv_partials), T, N * A, self._stream())
             _native.check(code, "mappo_advantages_f32")
+            self._content_version += 1
             self._adv_fresh = True
             self._stats_fresh = False
         if not self._stats_fresh or all_reduce is not None:
@@ -398,7 +402,7 @@ class SharedReplayBuffer(object):
         [T*N*A, RW] record array (mappo_pack_records) -> (records, RW, {name: (offset, width)}).
         Done once per generator call, i.e. per epoch: ~1 GB of traffic against ~47 GB per gather."""
         T, N, A = self.episode_length, self.n_rollout_threads, self.num_agents
-        layout, fields, off = {}, [], 0
+        layout, fields, off, versions = {}, [], 0, []
         if os.environ.get("MAPPO_PACK_RECORDS", "1") == "0":
             return None, 0, {}
         for name, src, is_state in table:
@@ -410,16 +414,24 @@ class SharedReplayBuffer(object):
                 continue
             layout[name] = (off, width)
             fields.append(_native.RecordField(src.data_ptr(), None, width, off, 0, 0))
+            versions.append(src._version)      # in-place torch writes to the field (setitem, copy_, ...)
             off += width
         if not fields:
             return None, 0, {}
         rw = (off + 3) // 4 * 4
         rows = T * N * A
+        # the packed fields only change when the buffer is written -- by this class's kernels
+        # (_content_version) or by in-place torch ops on the field tensors (tensor._version): within
+        # one train() every epoch reuses the records of the first
+        key = (self._content_version, tuple(versions), tuple((f.src, f.width, f.offset) for f in fields))
+        if getattr(self, "_records_key", None) == key:
+            return self._records, rw, layout
         if getattr(self, "_records", None) is None or self._records.numel() < rows * rw:
             self._records = torch.empty(rows * rw, dtype=torch.float32, device=self.device)
         arr = (_native.RecordField * len(fields))(*fields)
         _native.check(self._lib.mappo_pack_records(arr, len(fields), self._records.data_ptr(), rw, rows,
                                                    self._stream()), "mappo_pack_records")
+        self._records_key = key
         return self._records, rw, layout
 
     def _gather(self, table, stats, idx, mb, chunk_len=None, standardize_obs=False, packed=None):

@@ -634,3 +634,37 @@ def test_gae_properties_at_scale():
     sa = a.normalized_advantages(vn).stats.clone()
     sb = b.normalized_advantages(vn).stats.clone()
     torch.testing.assert_close(sa, sb, rtol=1e-6, atol=1e-7)
+
+
+def test_packed_record_cache_invalidation():
+    """The per-epoch record pack is cached; any write to a packed field -- through the buffer's
+    kernels or through plain torch in-place ops -- must invalidate it."""
+    T, N, A = 6, 4, 2
+    args = make_args(episode_length=T, n_rollout_threads=N, hidden_size=8, sampler_rng="host")
+    buf = _buffer(args, A, Do=5, Ds=9, na=4)
+    arrays = fill_buffer_arrays(buffer_shapes(T, N, A, 5, 9, 4, 8), np.random.default_rng(1), na=4)
+    load_into(buf, arrays)
+    adv = torch.zeros(T, N, A, 1, device=buf.device)
+    B = T * N * A
+
+    def first_sample():
+        torch.manual_seed(3)
+        return next(iter(buf.feed_forward_generator(adv, 1)))
+    s0 = first_sample()
+    idx = torch.randperm(B, generator=torch.Generator().manual_seed(3))
+    torch.manual_seed(3)
+    idx = torch.randperm(B).to(buf.device)
+    assert torch.equal(s0[6], buf.returns[:-1].reshape(B, 1)[idx])
+    buf.returns[2] = 7.0                                     # torch in-place write
+    s1 = first_sample()
+    assert torch.equal(s1[6], buf.returns[:-1].reshape(B, 1)[idx]) and float(s1[6].max()) == 7.0
+    buf.compute_returns(arrays["next_value"], _vn())         # kernel write
+    s2 = first_sample()
+    assert torch.equal(s2[6], buf.returns[:-1].reshape(B, 1)[idx])
+    buf.insert(**{k: np.zeros_like(v) for k, v in dict(
+        share_obs=arrays["share_obs"][0], obs=arrays["obs"][0], rnn_states_actor=arrays["rnn_states"][0],
+        rnn_states_critic=arrays["rnn_states_critic"][0], actions=arrays["actions"][0],
+        action_log_probs=arrays["action_log_probs"][0], value_preds=arrays["value_preds"][0] + 5,
+        rewards=arrays["rewards"][0], masks=arrays["masks"][0]).items()})
+    s3 = first_sample()
+    assert torch.equal(s3[5], buf.value_preds[:-1].reshape(B, 1)[idx])

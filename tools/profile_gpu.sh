@@ -15,7 +15,7 @@ tail -2 $OUT/prof_bench.log
 
 # 2. counters of the GAE scan (separate passes: FETCH_SIZE and WRITE_SIZE do not fit together)
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C -f csv -d $OUT/prof_gae_$C -o gae -- python $REPO/tools/bench_kernels.py --variants 31 --skip-gather --iters 6 --sets 6 > $OUT/prof_gae_$C.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C -f csv -d $OUT/prof_gae_$C -o gae -- python $REPO/tools/bench_kernels.py --variants 0 --skip-gather --iters 6 --sets 6 > $OUT/prof_gae_$C.log 2>&1
 done
 # 3. counters of the gather
 for C in FETCH_SIZE WRITE_SIZE; do

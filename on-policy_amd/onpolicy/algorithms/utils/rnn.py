@@ -20,6 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .fused_norm import FusedLayerNorm
+from .tall_linear import tall_linear
 
 
 class RNNLayer(nn.Module):
@@ -54,19 +55,36 @@ class RNNLayer(nn.Module):
         return (1.0 - z) * n + z * h
 
     def _run(self, x, h0, masks):
-        """x [L, B, in], h0 [B, R, H], masks [L, B, 1] -> (y [L, B, H], h_last [B, R, H])."""
-        L = x.size(0)
+        """x [L, B, in], h0 [B, R, H], masks [L, B, 1] -> (y [L, B, H], h_last [B, R, H]).
+
+        On HIP tensors the gate arithmetic of a step is ONE fused kernel (aten::_thnn_fused_gru_cell,
+        forward and backward) fed by two GEMMs whose weight gradients use the split-K form of
+        ``tall_linear`` (they reduce over the 10^5-row batch); time steps are taken apart with
+        ``unbind`` / ``stack`` so that autograd does one scatter per tensor instead of one per step.
+        CPU tensors use the explicit cell below (same formulas)."""
+        L, B = x.size(0), x.size(1)
+        fused = x.is_cuda
+        mask_steps = masks.unbind(0)
         layer_in = x
         finals = []
         for k in range(self._recurrent_N):
             w_ih, w_hh, b_ih, b_hh = self._layer_weights(k)
-            gi_all = F.linear(layer_in, w_ih, b_ih)          # one GEMM for all L steps
+            if fused:       # biases are added inside the fused cell
+                gi_all = tall_linear(layer_in.reshape(L * B, -1), w_ih, None).view(L, B, -1)
+            else:
+                gi_all = F.linear(layer_in, w_ih, b_ih)          # one GEMM for all L steps
+            gi_steps = gi_all.unbind(0)
             h = h0[:, k]
             outs = []
             for t in range(L):
-                h = self._cell(gi_all[t], h * masks[t], w_hh, b_hh)
+                hm = h * mask_steps[t]
+                if fused:
+                    gh = tall_linear(hm, w_hh, None)
+                    h = torch.ops.aten._thnn_fused_gru_cell(gi_steps[t], gh, hm, b_ih, b_hh)[0]
+                else:
+                    h = self._cell(gi_steps[t], hm, w_hh, b_hh)
                 outs.append(h)
-            layer_in = outs[0].unsqueeze(0) if L == 1 else torch.stack(outs, 0)
+            layer_in = torch.stack(outs, 0)
             finals.append(h)
         return layer_in, torch.stack(finals, 1)
 

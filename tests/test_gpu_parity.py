@@ -668,3 +668,41 @@ def test_packed_record_cache_invalidation():
         rewards=arrays["rewards"][0], masks=arrays["masks"][0]).items()})
     s3 = first_sample()
     assert torch.equal(s3[5], buf.value_preds[:-1].reshape(B, 1)[idx])
+
+
+def test_gru_layer_device_vs_cpu():
+    """RNNLayer on the GPU (fused gate kernel + split-K weight gradients) against the explicit CPU
+    cell with the same weights: outputs, final state and every gradient within float32 tolerance,
+    for the rollout (one step) and the update (L-step chunks with mask resets) call shapes."""
+    from onpolicy.algorithms.utils.rnn import RNNLayer
+    torch.manual_seed(2)
+    H, R, L, B = 64, 1, 10, 70000
+    cpu = RNNLayer(H, H, R, True)
+    gpu = RNNLayer(H, H, R, True).to(_dev())
+    gpu.load_state_dict(cpu.state_dict())
+    x = torch.randn(L * B, H)
+    h0 = torch.randn(B, R, H)
+    masks = (torch.rand(L * B, 1) > 0.1).float()
+    outs = []
+    for layer, dev in ((cpu, "cpu"), (gpu, _dev())):
+        xi = x.to(dev).requires_grad_(True)
+        hi = h0.to(dev).requires_grad_(True)
+        y, hT = layer(xi, hi, masks.to(dev))
+        (y.sum() + (hT ** 2).sum()).backward()
+        outs.append((y.detach().cpu(), hT.detach().cpu(), xi.grad.cpu(), hi.grad.cpu(),
+                     {k: p.grad.detach().cpu() for k, p in layer.named_parameters()}))
+    (y0, h0_, gx0, gh0, gp0), (y1, h1_, gx1, gh1, gp1) = outs
+    torch.testing.assert_close(y1, y0, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(h1_, h0_, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(gx1, gx0, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(gh1, gh0, rtol=1e-3, atol=1e-4)
+    for k in gp0:
+        scale = float(gp0[k].abs().max())
+        assert float((gp1[k] - gp0[k]).abs().max()) <= 2e-4 * scale + 1e-5, k
+    # rollout shape: one step, x rows == state rows
+    xr, hr, mr = torch.randn(4096, H), torch.randn(4096, R, H), (torch.rand(4096, 1) > 0.2).float()
+    with torch.no_grad():
+        a = cpu(xr, hr, mr)
+        b = gpu(xr.to(_dev()), hr.to(_dev()), mr.to(_dev()))
+    torch.testing.assert_close(b[0].cpu(), a[0], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(b[1].cpu(), a[1], rtol=1e-4, atol=2e-5)

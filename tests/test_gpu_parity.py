@@ -685,8 +685,8 @@ def test_gru_layer_device_vs_cpu():
     masks = (torch.rand(L * B, 1) > 0.1).float()
     outs = []
     for layer, dev in ((cpu, "cpu"), (gpu, _dev())):
-        xi = x.to(dev).requires_grad_(True)
-        hi = h0.to(dev).requires_grad_(True)
+        xi = x.detach().clone().to(dev).requires_grad_(True)
+        hi = h0.detach().clone().to(dev).requires_grad_(True)
         y, hT = layer(xi, hi, masks.to(dev))
         (y.sum() + (hT ** 2).sum()).backward()
         outs.append((y.detach().cpu(), hT.detach().cpu(), xi.grad.cpu(), hi.grad.cpu(),

@@ -1092,40 +1092,19 @@ extern "C" int mappo_gae_f32(const float* rewards, float* value_preds, const flo
 
     hipError_t e;
     switch (variant) {
+        // cooperative strip (all waves load, wave 0 walks): the simplest LDS-staged form
         case 2: e = launch_strip<64, 4, 32>(a, flags, stream); break;
-        case 3: e = launch_strip<32, 1, 32>(a, flags, stream); break;
         case 6: e = launch_strip<16, 1, 64>(a, flags, stream); break;
+        // register-prefetch pipe (1 walker + 4 producers, 2 tiles in flight in VGPRs)
         case 20: e = launch_pipe<64, 4, 32, 2>(a, flags, stream); break;
-        case 21: e = launch_pipe<64, 4, 32, 3>(a, flags, stream); break;
-        case 22: e = launch_pipe<64, 4, 16, 3>(a, flags, stream); break;
-        case 23: e = launch_pipe<64, 2, 16, 2>(a, flags, stream); break;
-        case 24: e = launch_pipe<32, 2, 32, 2>(a, flags, stream); break;
-        case 25: e = launch_pipe<64, 4, 16, 4>(a, flags, stream); break;
-        case 26: e = launch_pipe<64, 8, 32, 2>(a, flags, stream); break;
-        case 30: e = launch_dma<64, 1, 16, 3>(a, flags, stream); break;
-        case 31: e = launch_dma<64, 2, 8, 4>(a, flags, stream); break;
-        case 32: e = launch_dma<64, 1, 8, 6>(a, flags, stream); break;
+        // LDS-DMA ring, walker does the epilogue
         case 33: e = launch_dma<64, 2, 16, 3>(a, flags, stream); break;
         case 34: e = launch_dma<32, 1, 16, 4>(a, flags, stream); break;
-        case 35: e = launch_dma<64, 1, 4, 12>(a, flags, stream); break;
         case 36: e = launch_dma<16, 1, 16, 4>(a, flags, stream); break;
-        case 37: e = launch_dma<16, 1, 32, 3>(a, flags, stream); break;
-        case 38: e = launch_dma<64, 2, 8, 6>(a, flags, stream); break;
-        case 39: e = launch_dma<64, 4, 16, 3>(a, flags, stream); break;
-        case 40: e = launch_dma<32, 2, 16, 4>(a, flags, stream); break;
-        case 41: e = launch_dma<64, 2, 16, 6>(a, flags, stream); break;    // 120 KB ring: M0 > 64 KiB probe
-        case 42: e = launch_dma<128, 2, 8, 3>(a, flags, stream); break;    // 2 walkers, ring 60 KB
-        case 43: e = launch_dma<128, 4, 8, 3>(a, flags, stream); break;
-        case 44: e = launch_dma<128, 6, 12, 3>(a, flags, stream); break;   // 8 waves, ring 90 KB
-        case 45: e = launch_dma<128, 2, 8, 6>(a, flags, stream); break;    // ring 120 KB
-        case 46: e = launch_dma<128, 4, 16, 3>(a, flags, stream); break;   // ring 120 KB
-        case 47: e = launch_dma<128, 2, 4, 6>(a, flags, stream); break;    // ring 60 KB, 5 tiles ahead
-        case 50: e = launch_dma_epi<128, 2, 8, 4>(a, flags, stream); break;
+        case 42: e = launch_dma<128, 2, 8, 3>(a, flags, stream); break;
+        // LDS-DMA ring, epilogue on the producer waves (defaults)
         case 51: e = launch_dma_epi<128, 4, 8, 4>(a, flags, stream); break;
-        case 52: e = launch_dma_epi<128, 2, 8, 5>(a, flags, stream); break;
-        case 53: e = launch_dma_epi<128, 4, 8, 6>(a, flags, stream); break;
         case 54: e = launch_dma_epi<64, 2, 16, 4>(a, flags, stream); break;
-        case 55: e = launch_dma_epi<64, 2, 8, 5>(a, flags, stream); break;
         case 56: e = launch_dma_epi<32, 2, 16, 4>(a, flags, stream); break;
         case 57: e = launch_dma_epi<128, 6, 12, 4>(a, flags, stream); break;
         default: e = launch_column(a, flags, stream); break;

@@ -103,8 +103,7 @@ def _random_case(T, N, A, seed, device):
     return arrays
 
 
-@pytest.mark.parametrize("variant", [2, 3, 6, 20, 21, 22, 23, 24, 25, 26, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40,
-                                     41, 42, 43, 44, 45, 46, 47, 50, 51, 52, 53, 54, 55, 56, 57, 3050, 3043, 1031, 2031, 3031, 3034, 99])
+@pytest.mark.parametrize("variant", [2, 6, 20, 33, 34, 36, 42, 51, 54, 56, 57, 3033, 3042, 3057, 2057, 1054, 99])
 @pytest.mark.parametrize("ptl,norm", [(False, True), (True, True), (False, False), (True, False)])
 def test_gae_variants_vs_oracle(variant, ptl, norm):
     """Every kernel variant is bit-identical to the oracle, including ragged strips (C % W != 0),
@@ -169,7 +168,7 @@ def test_gae_north_star_size_vs_oracle():
     nvd = torch.from_numpy(nv).to(dev)
     exp_ret, exp_v = oracle.compute_returns(arrays["rewards"], arrays["value_preds"], nv, arrays["masks"],
                                             sigma=sigma, mu=mu, denorm=True)
-    for variant in (0, 2, 20, 31, 99):
+    for variant in (0, 2, 20, 33, 57, 99):
         lib.mappo_gae_set_variant(variant)
         ret.zero_()
         code = lib.mappo_gae_f32(t["rewards"].data_ptr(), t["value_preds"].data_ptr(), nvd.data_ptr(),

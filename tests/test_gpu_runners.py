@@ -124,3 +124,30 @@ def test_hanabi_runner_turn_based(tmp_path):
         assert bool(((v == 0) | (v == 1)).all())
     lines = [json.loads(l) for l in open(os.path.join(runner.log_dir, "scalars.jsonl"))]
     assert any(r["tag"] == "value_loss" for r in lines) and any(r["tag"] == "average_score" for r in lines)
+
+
+def test_naive_recurrent_trainer_on_device():
+    """--use_naive_recurrent_policy: whole-trajectory minibatches (chunk gather with L = T) through
+    the trainer on the device buffer."""
+    from helpers import Box, Discrete, fill_buffer_arrays, buffer_shapes, load_into
+    from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy
+    from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO
+    from onpolicy.utils.shared_buffer import SharedReplayBuffer
+    T, N, A, Do, Ds, na = 8, 6, 2, 5, 9, 4
+    args = make_args(episode_length=T, n_rollout_threads=N, hidden_size=16, ppo_epoch=2, num_mini_batch=3,
+                     use_naive_recurrent_policy=True, use_recurrent_policy=False, algorithm_name="rmappo")
+    dev = torch.device("cuda", 0)
+    spaces = Box((Do,)), Box((Ds,)), Discrete(na)
+    torch.manual_seed(1)
+    policy = R_MAPPOPolicy(args, *spaces, device=dev)
+    trainer = R_MAPPO(args, policy, device=dev)
+    buf = SharedReplayBuffer(args, A, *spaces, device=dev)
+    assert buf.rnn_states.stride()[0] != 0          # recurrent => real state storage
+    arrays = fill_buffer_arrays(buffer_shapes(T, N, A, Do, Ds, na, 16), np.random.default_rng(0), na=na)
+    av = arrays["available_actions"][:-1]
+    arrays["actions"] = (np.random.default_rng(1).random(av.shape) * av).argmax(-1)[..., None].astype(np.float32)
+    load_into(buf, arrays)
+    buf.compute_returns(arrays["next_value"], trainer.value_normalizer)
+    trainer.prep_training()
+    info = trainer.train(buf)
+    assert all(np.isfinite(v) for v in info.values()), info

@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--T", type=int, default=400)
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--A", type=int, default=8)
-    ap.add_argument("--variants", default="2,3,20,21,22,23,24,25,26,30,31,32,33,34,35,99")
+    ap.add_argument("--variants", default="0,2,20,33,42,3042,51,3051,54,3054,57,3057,99")
     ap.add_argument("--gather-variants", default="1,5,2,3,113,133,69,101")
     ap.add_argument("--sets", type=int, default=6)
     ap.add_argument("--iters", type=int, default=24)

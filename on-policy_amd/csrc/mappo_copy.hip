@@ -284,25 +284,33 @@ __global__ void __launch_bounds__(kThreads) pack_records_kernel(RecArgs a) {
     }
 }
 
+constexpr int kRecPerThread = 2;    // records per thread per pass (independent loads in flight)
+
 __global__ void __launch_bounds__(kThreads) gather_records_kernel(RecArgs a, unsigned long long rows_out) {
     __shared__ float tile[kThreads * kRecMaxWidth];
     const unsigned rw = a.rw, q4 = rw / 4;
+    // rows per pass: limited by the LDS tile (kThreads * kRecMaxWidth floats)
+    const unsigned per_thread = (kRecPerThread * rw <= (unsigned)kRecMaxWidth) ? kRecPerThread : 1;
+    const unsigned pass_rows = kThreads * per_thread;
     float mean = 0.f, den = 1.f;
     if (a.stats) {
         mean = a.stats[0];
         den = a.stats[1] + 1e-5f;
     }
-    for (unsigned long long row0 = (unsigned long long)blockIdx.x * kThreads; row0 < rows_out;
-         row0 += (unsigned long long)gridDim.x * kThreads) {
-        const unsigned long long j = row0 + threadIdx.x;
-        if (j < rows_out) {
-            const unsigned srow = mappo::source_row(a.map, 0u, (unsigned)j);
-            const f32x4* rec = reinterpret_cast<const f32x4*>(a.records + (unsigned long long)srow * rw);
-            f32x4* mine = reinterpret_cast<f32x4*>(tile + threadIdx.x * rw);
-            for (unsigned q = 0; q < q4; ++q) mine[q] = __builtin_nontemporal_load(rec + q);
+    for (unsigned long long row0 = (unsigned long long)blockIdx.x * pass_rows; row0 < rows_out;
+         row0 += (unsigned long long)gridDim.x * pass_rows) {
+        for (unsigned p = 0; p < per_thread; ++p) {
+            const unsigned lr = threadIdx.x + p * kThreads;         // local row inside the pass
+            const unsigned long long j = row0 + lr;
+            if (j < rows_out) {
+                const unsigned srow = mappo::source_row(a.map, 0u, (unsigned)j);
+                const f32x4* rec = reinterpret_cast<const f32x4*>(a.records + (unsigned long long)srow * rw);
+                f32x4* mine = reinterpret_cast<f32x4*>(tile + lr * rw);
+                for (unsigned q = 0; q < q4; ++q) mine[q] = __builtin_nontemporal_load(rec + q);
+            }
         }
         __syncthreads();
-        const unsigned nrows = rows_out - row0 < (unsigned long long)kThreads ? (unsigned)(rows_out - row0) : kThreads;
+        const unsigned nrows = rows_out - row0 < (unsigned long long)pass_rows ? (unsigned)(rows_out - row0) : pass_rows;
         for (int k = 0; k < a.nf; ++k) {
             float* dst = a.f[k].dst;
             const unsigned w = a.f[k].width, off = a.f[k].offset;
@@ -489,7 +497,7 @@ extern "C" int mappo_gather_records(const float* records, int record_width, cons
     a.map.A = (unsigned)A;
     const unsigned long long rows_out = chunked ? (unsigned long long)mb * L : (unsigned long long)mb;
     long long blocks = (long long)((rows_out + kThreads - 1) / kThreads);
-    if (blocks > mappo::kCUs * 8) blocks = mappo::kCUs * 8;
+    if (blocks > mappo::kCUs * 5) blocks = mappo::kCUs * 5;     // 32 KB of LDS per workgroup: 5 per CU
     hipLaunchKernelGGL(gather_records_kernel, dim3((unsigned)blocks), dim3(kThreads), 0,
                        static_cast<hipStream_t>(stream), a, rows_out);
     return (int)hipGetLastError();

@@ -148,46 +148,62 @@ __global__ void __launch_bounds__(kThreads) gather_std_kernel(const float* __res
                                                               unsigned first_only, float eps) {
     using U = typename Unit<VEC>::type;
     constexpr int RPB = kThreads / LPR;
+    constexpr int RI = EPL <= 2 ? 2 : 1;           // independent rows per iteration (loads in flight)
     const int lane = threadIdx.x % LPR;
     const int rib = threadIdx.x / LPR;
     const int units = D / VEC;
     const float invD = 1.0f / (float)D;
-    for (long long row = (long long)blockIdx.x * RPB + rib; row < M; row += (long long)gridDim.x * RPB) {
-        const unsigned srow = mappo::source_row(map, first_only, (unsigned)row);
-        const U* xr = reinterpret_cast<const U*>(x + (long long)srow * D);
-        U xv[EPL];
-        float s = 0.f;
+    const long long stride = (long long)gridDim.x * RPB;
+    for (long long row0 = (long long)blockIdx.x * RPB + rib; row0 < M; row0 += stride * RI) {
+        U xv[RI][EPL];
+        float s[RI];
+        // issue the index lookups and row loads of all RI rows before touching any of them
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            int u = lane + e * LPR;
-            xv[e] = U(0.f);
-            if (u < units) xv[e] = __builtin_nontemporal_load(xr + u);
+        for (int i = 0; i < RI; ++i) {
+            const long long row = row0 + i * stride;
+            s[i] = 0.f;
+            const bool ok = row < M;
+            const unsigned srow = ok ? mappo::source_row(map, first_only, (unsigned)row) : 0u;
+            const U* xr = reinterpret_cast<const U*>(x + (long long)srow * D);
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) s += elem<VEC>(xv[e], k);
-        }
-        const float mu = group_sum<LPR>(s) * invD;
-        float q = 0.f;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            int u = lane + e * LPR;
-            if (u < units) {
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    float d = elem<VEC>(xv[e], k) - mu;
-                    q += d * d;
-                }
+            for (int e = 0; e < EPL; ++e) {
+                int u = lane + e * LPR;
+                xv[i][e] = U(0.f);
+                if (ok && u < units) xv[i][e] = __builtin_nontemporal_load(xr + u);
             }
         }
-        const float r = 1.0f / sqrtf(group_sum<LPR>(q) * invD + eps);
-        U* yr = reinterpret_cast<U*>(y + row * D);
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            int u = lane + e * LPR;
-            if (u < units) {
-                U o;
+        for (int i = 0; i < RI; ++i) {
+            const long long row = row0 + i * stride;
+            if (row >= M) break;
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) set_elem<VEC>(o, k, (elem<VEC>(xv[e], k) - mu) * r);
-                __builtin_nontemporal_store(o, yr + u);
+            for (int e = 0; e < EPL; ++e)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) s[i] += elem<VEC>(xv[i][e], k);
+            const float mu = group_sum<LPR>(s[i]) * invD;
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                int u = lane + e * LPR;
+                if (u < units) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        float d = elem<VEC>(xv[i][e], k) - mu;
+                        q += d * d;
+                    }
+                }
+            }
+            const float r = 1.0f / sqrtf(group_sum<LPR>(q) * invD + eps);
+            U* yr = reinterpret_cast<U*>(y + row * D);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                int u = lane + e * LPR;
+                if (u < units) {
+                    U o;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) set_elem<VEC>(o, k, (elem<VEC>(xv[i][e], k) - mu) * r);
+                    __builtin_nontemporal_store(o, yr + u);
+                }
             }
         }
     }

@@ -173,6 +173,7 @@ def main():
 
     from onpolicy.utils import dist as mdist
     if world > 1 or os.environ.get("MAPPO_FORCE_DIST", "0") == "1":
+        os.environ.setdefault("NCCL_DEBUG", "WARN")      # no version banner on stdout
         mdist.init_from_env(dev)
     lo, hi = mdist.shard_threads(wl["N"], rank, world)
     n_local = hi - lo
@@ -262,10 +263,21 @@ def main():
             out["cpu_baseline"] = cpu_baseline(wl)
             out["cpu_baseline"]["sample"] += "; GPU/CPU ratio on env-steps/s = %.0fx" % (
                 value / out["cpu_baseline"]["value"])
-        print(json.dumps(out))
+    else:
+        out = None
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if out is not None:
+        # RCCL writes a version banner to the C stdio stream; push that out first so that the JSON
+        # line is the LAST line this process prints
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

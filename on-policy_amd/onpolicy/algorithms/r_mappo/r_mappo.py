@@ -77,8 +77,11 @@ class R_MAPPO():
         self._obs_standardized = False
 
     # ------------------------------------------------------------------ losses
-    def _normalizer_update(self, return_batch):
+    def _normalizer_update(self, return_batch, moments=None):
         """ValueNorm / PopArt EMA update (reference r_mappo.py:65) from GLOBAL batch moments."""
+        if moments is not None:
+            self.value_normalizer.update(return_batch, batch_moments=moments)
+            return
         if not self.dp.active:
             self.value_normalizer.update(return_batch)
             return
@@ -163,12 +166,21 @@ class R_MAPPO():
         # In a data-parallel job each rank's loss is a mean over ITS minibatch; weighting it by
         # (local denominator / global denominator) makes the all-reduced gradient the gradient of
         # the global-batch mean.  Weights are exactly 1 for world size 1.
-        w_actor, w_critic = self.dp.loss_weights(
-            active_masks_batch, self._use_policy_active_masks, self._use_value_active_masks)
+        normalized = self._use_popart or self._use_valuenorm
+        norm_done = False
+        if self.dp.active:      # one small collective for the loss denominators and the normaliser moments
+            w_actor, w_critic, moments = self.dp.minibatch_stats(
+                active_masks_batch, return_batch, self._use_policy_active_masks, self._use_value_active_masks)
+            if normalized:
+                self._normalizer_update(return_batch, moments)
+                norm_done = True
+        else:
+            w_actor = w_critic = 1.0
 
         self.dp.zero_grad(self.policy.actor_optimizer, self.policy.critic_optimizer)
-        if (self._use_popart or self._use_valuenorm) and len(spans) > 1:
+        if normalized and not norm_done and len(spans) > 1:
             self._normalizer_update(return_batch)   # once per minibatch, before it is used (r_mappo.py:65-66)
+            norm_done = True
 
         single = len(spans) == 1
 
@@ -194,7 +206,7 @@ class R_MAPPO():
             else:
                 p_loss = per_sample.mean()
             v_loss = self._value_loss(values, value_preds_batch[lo:hi], return_batch[lo:hi], am,
-                                      update_normalizer=len(spans) == 1)
+                                      update_normalizer=not norm_done)
 
             # span weights: this span's share of the minibatch denominators (exactly 1 for one span)
             if len(spans) == 1:

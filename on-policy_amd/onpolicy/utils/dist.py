@@ -126,6 +126,22 @@ class DataParallel(object):
         w = (local / total).float()
         return (w[0] if policy_masked else w[1]), (w[0] if value_masked else w[1])
 
+    def minibatch_stats(self, active_masks, return_batch, policy_masked, value_masked):
+        """ONE collective for everything a minibatch needs globally before its loss is formed:
+        -> (w_actor, w_critic, (mean, mean_sq) of the returns over the global minibatch).
+        The loss weights are local / global denominators of the masked means (reference
+        r_mappo.py:135-139, 84-87); the moments feed the ValueNorm / PopArt update (r_mappo.py:65)."""
+        am = active_masks.detach()
+        ret = return_batch.detach()
+        local = torch.stack([am.sum().double(), torch.tensor(float(am.shape[0]), dtype=torch.float64, device=am.device),
+                             ret.sum().double(), (ret * ret).sum().double()])
+        total = local.clone()
+        self.all_reduce(total)
+        w = (local[:2] / total[:2]).float()
+        mean = (total[2] / total[1]).float().reshape(1)
+        mean_sq = (total[3] / total[1]).float().reshape(1)
+        return (w[0] if policy_masked else w[1]), (w[0] if value_masked else w[1]), (mean, mean_sq)
+
     def average_info(self, totals):
         """Logged scalars: mean over ranks of the per-rank means."""
         if self.active:

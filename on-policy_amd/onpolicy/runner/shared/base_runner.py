@@ -66,6 +66,12 @@ class Runner(object):
     :param config: (dict) Config dictionary containing parameters for training."""
 
     def __init__(self, config):
+        self._init_common(config)
+        self._init_learner()
+
+    def _init_common(self, config):
+        """Config unpacking, run / log / model directories and the scalar writer (reference
+        base_runner.py:17-66; the separated runner's are the same, runner/separated/base_runner.py:17-66)."""
         self.all_args = config['all_args']
         self.envs = config['envs']
         self.eval_envs = config['eval_envs']
@@ -108,6 +114,9 @@ class Runner(object):
             self.save_dir = str(os.path.join(str(self.run_dir), 'models'))
             os.makedirs(self.save_dir, exist_ok=True)
 
+    def _init_learner(self):
+        """One policy / trainer / HBM buffer shared by all agents (reference base_runner.py:68-108)."""
+        a = self.all_args
         if self.algorithm_name in ("mat", "mat_dec"):
             raise NotImplementedError("the MAT trainer is outside this implementation's scope")
         from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO as TrainAlgo

@@ -119,6 +119,9 @@ class SharedReplayBuffer(object):
         self.active_masks = torch.ones_like(self.masks)
 
         self.step = 0
+        # optional extra per-sample fields ([T, N, A, k] tensors) that the samplers gather after the
+        # 12 standard ones (the separated buffer's HAPPO ``factor`` is one)
+        self.extra_fields = {}
 
         # device workspaces of the GAE epilogue (tiny)
         rows = int(self._lib.mappo_gae_partial_rows(N * A))
@@ -303,16 +306,19 @@ class SharedReplayBuffer(object):
             flags |= _native.GAE_DENORM
         return flags
 
-    def compute_returns(self, next_value, value_normalizer=None):
+    def compute_returns(self, next_value, value_normalizer=None, _scan_denorm=True):
         """GAE / discounted returns over the whole buffer in one kernel launch
-        (reference shared_buffer.py:179-262).  ``next_value``: [N, A, 1] (or [N*A, 1]) array / tensor."""
+        (reference shared_buffer.py:179-262).  ``next_value``: [N, A, 1] (or [N*A, 1]) array / tensor.
+        ``_scan_denorm=False`` (used by SeparatedReplayBuffer for the one branch where the reference's
+        separated buffer does not de-normalise): identity D() in the scan; the fused advantages are
+        then marked stale so that they are recomputed with the normaliser."""
         if self.algo in ("mat", "mat_dec"):
             raise NotImplementedError("the MAT variants of compute_returns are outside this path")
         T, N, A = self.episode_length, self.n_rollout_threads, self.num_agents
         nv = self._dev(next_value).reshape(-1)
         if nv.numel() != N * A:
             raise ValueError("next_value has %d elements, expected %d" % (nv.numel(), N * A))
-        denorm = self._denorm_scalars(value_normalizer)
+        denorm = self._denorm_scalars(value_normalizer) if _scan_denorm else None
         p = _native.ptr
         # algorithmic bytes: r, v, m reads + returns write (16 B) + advantages write + active read
         # (+8 B) [+ bad_masks read 4 B] per (t, n, a) element  (SURVEY.md section 8d)
@@ -325,7 +331,7 @@ class SharedReplayBuffer(object):
         self._timed_end(ev)
         _native.check(code, "mappo_gae_f32")
         self._content_version += 1
-        self._adv_fresh = True
+        self._adv_fresh = bool(_scan_denorm) or not (self._use_popart or self._use_valuenorm)
         self._stats_fresh = False
 
     def normalized_advantages(self, value_normalizer=None, all_reduce=None):
@@ -389,6 +395,8 @@ class SharedReplayBuffer(object):
                 raise ValueError("advantages has the wrong number of elements")
         table.append(("advantages", adv, False))
         table.append(("available_actions", self.available_actions, False))
+        for name, tensor in self.extra_fields.items():
+            table.append((name, tensor, False))
         return table, stats
 
     supports_standardized_obs = True   # generators take standardize_obs=True (see feed_forward_generator)

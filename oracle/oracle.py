@@ -343,6 +343,109 @@ class OracleBuffer(object):
             yield tuple(out)
 
 
+class OracleSeparatedBuffer(object):
+    """Host restatement of the reference SeparatedReplayBuffer (separated_buffer.py:12-424): the
+    shared layout with one agent, fields exposed without the agent axis.  Differences restated:
+    the non-GAE proper-time-limits branch de-normalises only under PopArt (:146-151), the recurrent
+    sampler emits chunk-major rows (:372-404), ``factor`` rides along as a 13th element (:62,:225)."""
+
+    _VIEWS = ("share_obs", "obs", "rnn_states", "rnn_states_critic", "value_preds", "returns",
+              "available_actions", "actions", "action_log_probs", "rewards", "masks", "bad_masks", "active_masks")
+
+    def __init__(self, args, obs_space, share_obs_space, act_space):
+        self._inner = OracleBuffer(args, 1, obs_space, share_obs_space, act_space)
+        self.factor = None
+
+    def __getattr__(self, name):
+        if name in self._VIEWS:
+            a = getattr(self._inner, name)
+            return None if a is None else a[:, :, 0]
+        raise AttributeError(name)
+
+    def update_factor(self, factor):                                    # :62-63
+        self.factor = np.array(factor, dtype=np.float32)
+
+    def insert(self, *a, **k):
+        self._inner.insert(*[None if x is None else np.asarray(x)[:, None] for x in a],
+                           **{n: None if x is None else np.asarray(x)[:, None] for n, x in k.items()})
+
+    def after_update(self):
+        self._inner.after_update()
+
+    def compute_returns(self, next_value, value_normalizer=None):       # :122-167
+        b = self._inner
+        sigma, mu, dn = b._scalars(value_normalizer)
+        if not b._use_gae and b._use_proper_time_limits and not b._use_popart:
+            sigma, mu, dn = 1.0, 0.0, False                             # :149-151
+        ret, v = compute_returns(b.rewards, b.value_preds, np.asarray(next_value, dtype=np.float32), b.masks,
+                                 b.bad_masks, sigma=sigma, mu=mu, gamma=b.gamma, gae_lambda=b.gae_lambda,
+                                 use_gae=b._use_gae, use_proper_time_limits=b._use_proper_time_limits, denorm=dn)
+        b.returns[...] = ret
+        b.value_preds[...] = v
+
+    def _with_factor(self, gen, rows_of):
+        for sample in gen:
+            if self.factor is None:
+                yield sample
+            else:
+                yield sample + (rows_of(sample),)
+
+    def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None):   # :169-227
+        b = self._inner
+        T, N = b.rewards.shape[0:2]
+        adv = None if advantages is None else np.asarray(advantages, dtype=np.float32).reshape(T, N, 1, 1)
+        fields = b._fields(adv)
+        if self.factor is not None:
+            fields = fields + [("factor", self.factor.reshape(T, N, 1, -1))]
+        batch_size = N * T
+        if mini_batch_size is None:
+            assert batch_size >= num_mini_batch
+            mini_batch_size = batch_size // num_mini_batch
+        rand = torch.randperm(batch_size).numpy()
+        for i in range(num_mini_batch):
+            indices = rand[i * mini_batch_size:(i + 1) * mini_batch_size]
+            yield tuple(None if arr is None else
+                        gather_rows(arr.reshape(batch_size, -1), indices).reshape((len(indices),) + tuple(arr.shape[3:]))
+                        for _, arr in fields)
+
+    def _chunk_sampler(self, advantages, batches, L, chunk_major):
+        b = self._inner
+        T, N = b.rewards.shape[0:2]
+        adv = None if advantages is None else np.asarray(advantages, dtype=np.float32).reshape(T, N, 1, 1)
+        fields = b._fields(adv)
+        if self.factor is not None:
+            fields = fields + [("factor", self.factor.reshape(T, N, 1, -1))]
+        for indices in batches:
+            out = []
+            for name, arr in fields:
+                if arr is None:
+                    out.append(None)
+                    continue
+                first = name in ("rnn_states", "rnn_states_critic")
+                g = gather_chunks(arr, indices, L, first_only=first)          # rows l*mb + j
+                if chunk_major and not first:                                  # :372-404 -> rows j*L + l
+                    mb = len(indices)
+                    g = np.ascontiguousarray(g.reshape((L, mb) + g.shape[1:]).swapaxes(0, 1)).reshape(g.shape)
+                out.append(g)
+            yield tuple(out)
+
+    def recurrent_generator(self, advantages, num_mini_batch, data_chunk_length):              # :315-424
+        T, N = self._inner.rewards.shape[0:2]
+        data_chunks = N * T // data_chunk_length
+        mb = data_chunks // num_mini_batch
+        rand = torch.randperm(data_chunks).numpy()
+        batches = [rand[i * mb:(i + 1) * mb] for i in range(num_mini_batch)]
+        return self._chunk_sampler(advantages, batches, data_chunk_length, True)
+
+    def naive_recurrent_generator(self, advantages, num_mini_batch):                           # :229-313
+        T, N = self._inner.rewards.shape[0:2]
+        assert N >= num_mini_batch
+        per = N // num_mini_batch
+        perm = torch.randperm(N).numpy()
+        batches = [perm[s:s + per] for s in range(0, N, per)]
+        return self._chunk_sampler(advantages, batches, T, False)
+
+
 def _shape_of(space):
     """onpolicy/utils/util.py:31-38 + shared_buffer.py:48-52."""
     name = space.__class__.__name__

@@ -30,6 +30,7 @@ class FakeMPEVecEnv(object):
         return obs
 
     def step(self, actions):
+        actions = np.asarray(actions)        # the separated runner passes [envs][agents] lists
         assert actions.shape == (self.n, self.a, self.na) and np.all(actions.sum(-1) == 1)
         self.t += 1
         obs = self._obs()

@@ -61,20 +61,42 @@ class R_MAPPO():
         self._use_value_active_masks = args.use_value_active_masks
         self._use_policy_active_masks = args.use_policy_active_masks
 
-        assert (self._use_popart and self._use_valuenorm) == False, (
-            "self._use_popart and self._use_valuenorm can not be set True simultaneously")
-
-        if self._use_popart:
-            self.value_normalizer = self.policy.critic.v_out
-        elif self._use_valuenorm:
-            self.value_normalizer = ValueNorm(1, device=self.device)
-        else:
-            self.value_normalizer = None
+        self.value_normalizer = self._make_value_normalizer()
 
         # data parallelism over rollout threads; world size 1 unless torch.distributed is up
         self.dp = mdist.DataParallel(self.policy.actor, self.policy.critic, device)
         # set by train() while it feeds ppo_update with row-standardised observations
         self._obs_standardized = False
+
+    # ------------------------------------------------------------------ what HAPPO overrides
+    _use_factor = False          # minibatches may carry a 13th element (HAPPO factor); MAPPO ignores it
+    _updates_normalizer = True   # ppo_update feeds the returns to the value normaliser (r_mappo.py:65)
+
+    def _make_value_normalizer(self):
+        assert (self._use_popart and self._use_valuenorm) == False, (
+            "self._use_popart and self._use_valuenorm can not be set True simultaneously")
+        if self._use_popart:
+            return self.policy.critic.v_out
+        if self._use_valuenorm:
+            return ValueNorm(1, device=self.device)
+        return None
+
+    def _denormalize_advantages(self):
+        """Whether the advantages are returns - D(value_preds) (r_mappo.py:179-182) or the raw difference."""
+        return self._use_popart or self._use_valuenorm
+
+    def _value_targets(self, return_batch, update_normalizer):
+        """(target of the clipped error, target of the plain error), reference r_mappo.py:64-70."""
+        if self._use_popart or self._use_valuenorm:
+            if update_normalizer:
+                self._normalizer_update(return_batch)
+            target = self.value_normalizer.normalize(return_batch)
+        else:
+            target = return_batch
+        return target, target
+
+    def _ratio(self, action_log_probs, old_action_log_probs):
+        return torch.exp(action_log_probs - old_action_log_probs)          # r_mappo.py:129
 
     # ------------------------------------------------------------------ losses
     def _normalizer_update(self, return_batch, moments=None):
@@ -101,14 +123,9 @@ class R_MAPPO():
     def _value_loss(self, values, value_preds_batch, return_batch, active_masks_batch, update_normalizer):
         value_pred_clipped = value_preds_batch + (values - value_preds_batch).clamp(-self.clip_param,
                                                                                     self.clip_param)
-        if self._use_popart or self._use_valuenorm:
-            if update_normalizer:
-                self._normalizer_update(return_batch)
-            target = self.value_normalizer.normalize(return_batch)
-        else:
-            target = return_batch
-        error_clipped = target - value_pred_clipped
-        error_original = target - values
+        target_clipped, target_original = self._value_targets(return_batch, update_normalizer)
+        error_clipped = target_clipped - value_pred_clipped
+        error_original = target_original - values
 
         if self._use_huber_loss:
             value_loss_clipped = huber_loss(error_clipped, self.huber_delta)
@@ -154,6 +171,7 @@ class R_MAPPO():
         share_obs_batch, obs_batch, rnn_states_batch, rnn_states_critic_batch, actions_batch, \
             value_preds_batch, return_batch, masks_batch, active_masks_batch, old_action_log_probs_batch, \
             adv_targ, available_actions_batch = sample[:12]
+        factor_batch = check(sample[12]).to(**self.tpdv) if (self._use_factor and len(sample) > 12) else None
 
         old_action_log_probs_batch = check(old_action_log_probs_batch).to(**self.tpdv)
         adv_targ = check(adv_targ).to(**self.tpdv)
@@ -166,7 +184,7 @@ class R_MAPPO():
         # In a data-parallel job each rank's loss is a mean over ITS minibatch; weighting it by
         # (local denominator / global denominator) makes the all-reduced gradient the gradient of
         # the global-batch mean.  Weights are exactly 1 for world size 1.
-        normalized = self._use_popart or self._use_valuenorm
+        normalized = (self._use_popart or self._use_valuenorm) and self._updates_normalizer
         norm_done = False
         if self.dp.active:      # one small collective for the loss denominators and the normaliser moments
             w_actor, w_critic, moments = self.dp.minibatch_stats(
@@ -197,10 +215,13 @@ class R_MAPPO():
                 cut(available_actions_batch, lo, hi), am, **self._eval_kwargs())
 
             # clipped surrogate (r_mappo.py:129-139)
-            imp_weights = torch.exp(action_log_probs - old_action_log_probs_batch[lo:hi])
+            imp_weights = self._ratio(action_log_probs, old_action_log_probs_batch[lo:hi])
             surr1 = imp_weights * adv_targ[lo:hi]
             surr2 = torch.clamp(imp_weights, 1.0 - self.clip_param, 1.0 + self.clip_param) * adv_targ[lo:hi]
-            per_sample = -torch.sum(torch.min(surr1, surr2), dim=-1, keepdim=True)
+            surr = torch.min(surr1, surr2)
+            if factor_batch is not None:
+                surr = factor_batch[lo:hi] * surr                            # happo_trainer.py:137-141
+            per_sample = -torch.sum(surr, dim=-1, keepdim=True)
             if self._use_policy_active_masks:
                 p_loss = (per_sample * am).sum() / am.sum()
             else:
@@ -229,7 +250,7 @@ class R_MAPPO():
                 policy_loss = acc(policy_loss, p_loss, sw_actor)
                 dist_entropy = acc(dist_entropy, entropy, sw_actor)
             ratios.append(imp_weights.detach() if len(spans) > 1 else imp_weights)
-            del values, action_log_probs, entropy, surr1, surr2, per_sample, p_loss, v_loss
+            del values, action_log_probs, entropy, surr1, surr2, surr, per_sample, p_loss, v_loss
 
         imp_weights = ratios[0] if len(ratios) == 1 else torch.cat(ratios, 0)
 
@@ -256,13 +277,16 @@ class R_MAPPO():
         """Normalised advantages for the samplers (reference r_mappo.py:179-187)."""
         if hasattr(buffer, "normalized_advantages"):
             reduce_fn = self.dp.all_reduce if self.dp.active else None
-            return buffer.normalized_advantages(self.value_normalizer, all_reduce=reduce_fn)
+            if self._denormalize_advantages() == bool(self._use_popart or self._use_valuenorm):
+                return buffer.normalized_advantages(self.value_normalizer, all_reduce=reduce_fn)
+            return buffer.normalized_advantages(self.value_normalizer, all_reduce=reduce_fn,
+                                                denormalize=self._denormalize_advantages())
         # Foreign buffers that hold host arrays in the reference's format (e.g. the reference's own
         # SharedReplayBuffer): same arithmetic in torch on this trainer's device.
         returns = torch.as_tensor(np.asarray(buffer.returns[:-1]), dtype=torch.float32)
         value_preds = torch.as_tensor(np.asarray(buffer.value_preds[:-1]), dtype=torch.float32)
         active = torch.as_tensor(np.asarray(buffer.active_masks[:-1]), dtype=torch.float32)
-        if self._use_popart or self._use_valuenorm:
+        if self._denormalize_advantages():
             value_preds = self.value_normalizer.denormalize(value_preds.to(self.device)).cpu()
         adv = returns - value_preds
         on = active != 0.0

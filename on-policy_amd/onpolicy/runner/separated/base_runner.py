@@ -27,11 +27,15 @@ _SPAN_ELEMENTS = 1 << 28
 class Runner(_SharedRunner):
     def _init_learner(self):
         a = self.all_args
-        if self.algorithm_name in ("happo", "hatrpo", "mat", "mat_dec"):
-            raise NotImplementedError("algorithm %r is outside this implementation's scope (MAPPO / IPPO "
-                                      "family only)" % self.algorithm_name)
-        from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO as TrainAlgo
-        from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy as Policy
+        if self.algorithm_name in ("hatrpo", "mat", "mat_dec"):
+            raise NotImplementedError("algorithm %r is outside this implementation's scope (the PPO family: "
+                                      "mappo / rmappo / ippo / happo)" % self.algorithm_name)
+        if self.algorithm_name == "happo":
+            from onpolicy.algorithms.happo.happo_trainer import HAPPO as TrainAlgo
+            from onpolicy.algorithms.happo.policy import HAPPO_Policy as Policy
+        else:
+            from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO as TrainAlgo
+            from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy as Policy
         print("share_observation_space: ", self.envs.share_observation_space)
         print("observation_space: ", self.envs.observation_space)
         print("action_space: ", self.envs.action_space)

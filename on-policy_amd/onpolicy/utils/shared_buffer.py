@@ -131,6 +131,7 @@ class SharedReplayBuffer(object):
         self._adv_stats = torch.zeros(2, **f32)
         self._content_version = 0  # bumped by every method that writes buffer fields
         self._adv_fresh = False   # advantages/moments match the current returns & value_preds
+        self._adv_denormalized = False   # ... and were formed as returns - D(value_preds)
         self._stats_fresh = False
         self._events = None       # kernel name -> [(start, end, algorithmic bytes)], see profile_kernels
 
@@ -331,20 +332,28 @@ class SharedReplayBuffer(object):
         self._timed_end(ev)
         _native.check(code, "mappo_gae_f32")
         self._content_version += 1
-        self._adv_fresh = bool(_scan_denorm) or not (self._use_popart or self._use_valuenorm)
+        self._adv_fresh = True
+        self._adv_denormalized = denorm is not None      # what the fused advantages subtracted
         self._stats_fresh = False
 
-    def normalized_advantages(self, value_normalizer=None, all_reduce=None):
+    def normalized_advantages(self, value_normalizer=None, all_reduce=None, denormalize=None):
         """What the prologue of the reference's ``R_MAPPO.train`` computes (r_mappo.py:179-187), as an
         ``AdvantageHandle``.  Uses the advantages / moments the GAE launch already produced; if the
         buffer changed since, recomputes them with one ``mappo_advantages_f32`` launch.
         ``all_reduce``: optional callable applied in place to the float64 [3] moment sums
         (sum, sum of squares, count) -- data-parallel training passes an RCCL all-reduce here so that
-        mean / std are global-batch statistics on every rank."""
+        mean / std are global-batch statistics on every rank.
+        ``denormalize``: None follows the buffer's popart / valuenorm flags (MAPPO); False forces the raw
+        ``returns - value_preds`` (HAPPO under ValueNorm, happo_trainer.py:180-183)."""
         T, N, A = self.episode_length, self.n_rollout_threads, self.num_agents
         p = _native.ptr
-        if not self._adv_fresh:
-            denorm = self._denorm_scalars(value_normalizer)
+        flagged = bool(self._use_popart or self._use_valuenorm)
+        want = flagged if denormalize is None else bool(denormalize)
+        if want and not flagged:
+            raise ValueError("denormalize=True needs a buffer built with use_popart / use_valuenorm")
+        if not self._adv_fresh or self._adv_denormalized != want:
+            denorm = self._denorm_scalars(value_normalizer) if want else None
+            self._adv_denormalized = want
             code = self._lib.mappo_advantages_f32(p(self.returns), p(self.value_preds), p(denorm),
                                                   p(self.active_masks), p(self.advantages),
                                                   p(self._adv_partials), T, N * A, self._stream())

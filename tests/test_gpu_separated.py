@@ -111,7 +111,7 @@ def test_separated_mpe_runner(tmp_path, recurrent):
     args = make_args(env_name="MPE", episode_length=T, n_rollout_threads=N, num_env_steps=2 * T * N,
                      hidden_size=16, ppo_epoch=2, num_mini_batch=2, use_recurrent_policy=recurrent,
                      algorithm_name="rmappo" if recurrent else "mappo", data_chunk_length=4, log_interval=1,
-                     use_wandb=False, share_policy=False)
+                     use_wandb=False, share_policy=False, n_eval_rollout_threads=2)
     args.scenario_name = "fake_spread"
     envs = FakeMPEVecEnv(N, A, Do, na)
     torch.manual_seed(1)
@@ -166,3 +166,46 @@ def test_separated_mpe_runner(tmp_path, recurrent):
     runner.eval(0)
     lines = open(os.path.join(runner.log_dir, "scalars.jsonl")).read()
     assert "agent0/value_loss" in lines and "agent2/eval_average_episode_rewards" in lines
+
+
+@pytest.mark.parametrize("cname", ["mlp", "mlp_popart", "mlp_nonorm", "gru"])
+def test_happo_on_device_buffer_vs_reference(gold, cname):
+    """The reference's HAPPO.train on its SeparatedReplayBuffer (factor set) vs ours through the HBM
+    buffer: same CPU seed => same permutations; train_info / parameters within float32 tolerance
+    (the network maths runs through rocBLAS)."""
+    from test_happo_cpu import build_happo, check_happo_result, BUF
+    from onpolicy.utils.separated_buffer import SeparatedReplayBuffer
+    z = gold.npz("happo_cases")
+    key = "hap_%s_" % cname
+    meta, spec, args, spaces, policy, trainer = build_happo(gold, cname, device=DEV)
+    args.sampler_rng = "host"
+    buf = SeparatedReplayBuffer(args, *spaces, device=DEV)
+    for name in BUF:
+        dst = getattr(buf, name)
+        if dst.stride()[0] != 0:
+            dst.copy_(torch.from_numpy(z[key + "buf_" + name]))
+    buf.compute_returns(z[key + "next_value"], trainer.value_normalizer)
+    np.testing.assert_array_equal(buf.returns.cpu().numpy(), z[key + "returns"])
+    buf.update_factor(z[key + "factor"])
+    trainer.prep_training()
+    torch.manual_seed(21)
+    info = trainer.train(buf)
+    check_happo_result(z, key, meta, info, policy, trainer, rel=1e-3, atol=1e-4)
+
+
+def test_separated_runner_happo(tmp_path):
+    from onpolicy.runner.separated.mpe_runner import MPERunner
+    from onpolicy.algorithms.happo.happo_trainer import HAPPO
+    T, N, A, Do, na = 8, 4, 3, 6, 5
+    args = make_args(env_name="MPE", episode_length=T, n_rollout_threads=N, num_env_steps=2 * T * N, hidden_size=16,
+                     ppo_epoch=2, num_mini_batch=2, algorithm_name="happo", log_interval=1, use_wandb=False,
+                     share_policy=False)
+    args.scenario_name = "fake_spread"
+    torch.manual_seed(2)
+    runner = MPERunner({"all_args": args, "envs": FakeMPEVecEnv(N, A, Do, na), "eval_envs": None, "num_agents": A,
+                        "device": DEV, "run_dir": tmp_path})
+    assert all(isinstance(tr, HAPPO) for tr in runner.trainer)
+    runner.run()
+    factors = [b.factor for b in runner.buffer]
+    assert sum(bool((f == 1).all()) for f in factors) == 1          # only the first agent of the random order
+    assert all(bool(torch.isfinite(f).all()) for f in factors)

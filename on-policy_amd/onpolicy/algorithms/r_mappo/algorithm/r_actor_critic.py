@@ -93,7 +93,8 @@ class R_Critic(nn.Module, _DeviceMixin):
         self.base = _trunk(args, get_shape_from_obs_space(cent_obs_space))
         if self._recurrent:
             self.rnn = RNNLayer(self.hidden_size, self.hidden_size, self._recurrent_N, self._use_orthogonal)
-        head = PopArt(self.hidden_size, 1, device=device) if self._use_popart else TallLinear(self.hidden_size, 1)
+        # built and initialised on the host like every other layer; self.to(device) below moves it
+        head = PopArt(self.hidden_size, 1) if self._use_popart else TallLinear(self.hidden_size, 1)
         self.v_out = init(head, w_init, lambda b: nn.init.constant_(b, 0))
         self.to(device)
 

@@ -26,13 +26,17 @@ class PopArt(nn.Module):
         self.tpdv = dict(dtype=torch.float32, device=device)
         self.input_shape = input_shape
         self.output_shape = output_shape
-        self.weight = nn.Parameter(torch.empty(output_shape, input_shape, **self.tpdv))
-        self.bias = nn.Parameter(torch.empty(output_shape, **self.tpdv))
-        self.register_buffer("stddev", torch.ones(output_shape, **self.tpdv))
-        self.register_buffer("mean", torch.zeros(output_shape, **self.tpdv))
-        self.register_buffer("mean_sq", torch.zeros(output_shape, **self.tpdv))
-        self.register_buffer("debiasing_term", torch.tensor(0.0, **self.tpdv))
+        # parameters are drawn on the host (CPU generator, like every other layer here) and moved
+        # afterwards, so a seed gives the same initial head whatever the device
+        f32 = dict(dtype=torch.float32)
+        self.weight = nn.Parameter(torch.empty(output_shape, input_shape, **f32))
+        self.bias = nn.Parameter(torch.empty(output_shape, **f32))
+        self.register_buffer("stddev", torch.ones(output_shape, **f32))
+        self.register_buffer("mean", torch.zeros(output_shape, **f32))
+        self.register_buffer("mean_sq", torch.zeros(output_shape, **f32))
+        self.register_buffer("debiasing_term", torch.tensor(0.0, **f32))
         self.reset_parameters()
+        self.to(device)
 
     def reset_parameters(self):
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
@@ -46,7 +50,7 @@ class PopArt(nn.Module):
     def _as_tensor(self, x):
         if isinstance(x, np.ndarray):
             x = torch.from_numpy(x)
-        return x.to(**self.tpdv)
+        return x.to(dtype=torch.float32, device=self.weight.device)   # follows the module when it is moved
 
     def forward(self, input_vector):
         return F.linear(self._as_tensor(input_vector), self.weight, self.bias)

@@ -87,8 +87,8 @@ class SeparatedReplayBuffer(object):
             scan_denorm = False                      # :146-151: only PopArt de-normalises in this branch
         self._inner.compute_returns(next_value, value_normalizer, _scan_denorm=scan_denorm)
 
-    def normalized_advantages(self, value_normalizer=None, all_reduce=None):
-        return self._inner.normalized_advantages(value_normalizer, all_reduce)
+    def normalized_advantages(self, value_normalizer=None, all_reduce=None, denormalize=None):
+        return self._inner.normalized_advantages(value_normalizer, all_reduce, denormalize)
 
     # -- samplers: 12-tuples, or 13-tuples ending in factor once update_factor() has been called
     def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None, standardize_obs=False):

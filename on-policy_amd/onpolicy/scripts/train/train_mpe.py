@@ -44,9 +44,11 @@ def main(args):
     if all_args.algorithm_name == "rmappo":
         all_args.use_recurrent_policy = True
         all_args.use_naive_recurrent_policy = False
-    elif all_args.algorithm_name == "mappo":
+    elif all_args.algorithm_name in ("mappo", "happo"):     # happo: separated runner only (--share_policy false)
         all_args.use_recurrent_policy = False
         all_args.use_naive_recurrent_policy = False
+    elif all_args.algorithm_name == "ippo":
+        all_args.use_centralized_V = False
     else:
         raise NotImplementedError("algorithm %s is outside this implementation" % all_args.algorithm_name)
     assert (all_args.share_policy is True and all_args.scenario_name == 'simple_speaker_listener') is False, (
@@ -83,7 +85,7 @@ def main(args):
     if all_args.share_policy:
         from onpolicy.runner.shared.mpe_runner import MPERunner as Runner
     else:
-        raise NotImplementedError("separated (per-agent) policies are outside this implementation")
+        from onpolicy.runner.separated.mpe_runner import MPERunner as Runner
     runner = Runner(config)
     runner.run()
 

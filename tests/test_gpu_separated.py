@@ -209,3 +209,48 @@ def test_separated_runner_happo(tmp_path):
     factors = [b.factor for b in runner.buffer]
     assert sum(bool((f == 1).all()) for f in factors) == 1          # only the first agent of the random order
     assert all(bool(torch.isfinite(f).all()) for f in factors)
+
+
+@pytest.mark.parametrize("algo", ["happo", "rmappo"])
+def test_separated_smac_runner(tmp_path, algo):
+    """Per-agent buffers get the team-level mask logic of the SMAC runner (episode end, dead agents,
+    time-limit truncations) and the availability masks; HAPPO / recurrent MAPPO train on them."""
+    from onpolicy.runner.separated.smac_runner import SMACRunner
+    from fake_envs import FakeSMACVecEnv
+    T, N, A, Do, Ds, na = 8, 3, 4, 7, 9, 6
+    args = make_args(env_name="StarCraft2", episode_length=T, n_rollout_threads=N, num_env_steps=2 * T * N,
+                     hidden_size=16, ppo_epoch=1, num_mini_batch=1, use_recurrent_policy=(algo == "rmappo"),
+                     algorithm_name=algo, data_chunk_length=4, log_interval=1, use_wandb=False,
+                     use_proper_time_limits=True, share_policy=False, use_eval=True, n_eval_rollout_threads=2,
+                     eval_episodes=2, use_linear_lr_decay=True)
+    args.map_name = "fake"
+    envs = FakeSMACVecEnv(N, A, Do, Ds, na)
+    torch.manual_seed(1)
+    runner = SMACRunner({"all_args": args, "envs": envs, "eval_envs": FakeSMACVecEnv(2, A, Do, Ds, na, seed=3),
+                         "num_agents": A, "device": DEV, "run_dir": tmp_path})
+    runner.warmup()
+    for a, b in enumerate(runner.buffer):
+        np.testing.assert_array_equal(b.available_actions[0].cpu().numpy(), envs.log[0]["available_actions"][:, a])
+    for step in range(T):
+        out = runner.collect(step)
+        actions_env = np.stack([x.cpu().numpy() for x in out[1]], axis=1)
+        obs, share_obs, rewards, dones, infos, avail = envs.step(actions_env)
+        runner.insert((obs, share_obs, rewards, dones, infos, avail) + tuple(out))
+        rec = envs.log[-1]
+        dones_env = rec["dones"].all(1)
+        exp_masks = np.ones((N, A)); exp_masks[dones_env] = 0
+        exp_active = np.ones((N, A)); exp_active[rec["dones"]] = 0; exp_active[dones_env] = 1
+        exp_bad = np.array([[0.0 if i[a]["bad_transition"] else 1.0 for a in range(A)] for i in rec["infos"]])
+        for a, b in enumerate(runner.buffer):
+            np.testing.assert_array_equal(b.masks[step + 1, :, 0].cpu().numpy(), exp_masks[:, a])
+            np.testing.assert_array_equal(b.active_masks[step + 1, :, 0].cpu().numpy(), exp_active[:, a])
+            np.testing.assert_array_equal(b.bad_masks[step + 1, :, 0].cpu().numpy(), exp_bad[:, a])
+            np.testing.assert_array_equal(b.share_obs[step + 1].cpu().numpy(), rec["share_obs"][:, a])
+            np.testing.assert_array_equal(b.available_actions[step + 1].cpu().numpy(), rec["available_actions"][:, a])
+            np.testing.assert_array_equal(b.actions[step, :, 0].cpu().numpy(), rec["actions"][:, a])
+    runner.compute()
+    infos = runner.train()
+    assert len(infos) == A and all(np.isfinite(v) for info in infos for v in info.values())
+    runner.run()
+    lines = open(os.path.join(runner.log_dir, "scalars.jsonl")).read()
+    assert "agent3/dead_ratio" in lines and "eval_win_rate" in lines and "incre_win_rate" in lines

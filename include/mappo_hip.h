@@ -86,6 +86,24 @@ int mappo_gae_f32(const float* rewards, float* value_preds, const float* next_va
                   double* adv_partials, int T, int64_t C, double gamma, double gae_lambda,
                   unsigned flags, mappo_stream_t stream);
 
+/* Multi-agent-transformer branches of SharedReplayBuffer.compute_returns (shared_buffer.py:222-232
+ * with a value normaliser, :241-251 without; taken when args.algorithm_name is "mat" / "mat_dec",
+ * use_gae is set and use_proper_time_limits is not).  Same storage contract as mappo_gae_f32 with
+ * C = n_rollout_threads * num_agents columns ordered (thread, agent); differences:
+ *   advantages [T, C]  REQUIRED: advantages[t] = the GAE accumulator itself (:231,:250), which is
+ *                      what MATTrainer.train normalises (mat_trainer.py:160-164);
+ *   flags              MAPPO_GAE_DENORM: delta uses each agent's own D(v) (:223-229);
+ *                      0: delta uses the float32 mean over the env's num_agents agents of the raw
+ *                      value predictions, summed in numpy's pairwise order (:243-245), and
+ *                      returns[t] = gae + value_preds[t] of the agent itself (:251);
+ *                      num_agents <= 128 in this mode (MAPPO_E_TOO_MANY otherwise).
+ * adv_partials / active_masks as in mappo_gae_f32 (moments of the advantages written). */
+int mappo_gae_mat_f32(const float* rewards, float* value_preds, const float* next_value,
+                      const float* masks, float* returns, const float* denorm, float* advantages,
+                      const float* active_masks, double* adv_partials, int T, int64_t C,
+                      int num_agents, double gamma, double gae_lambda, unsigned flags,
+                      mappo_stream_t stream);
+
 /* Number of [.,3] float64 rows mappo_gae_f32 / mappo_advantages_f32 need in adv_partials
  * for C columns. */
 int64_t mappo_gae_partial_rows(int64_t C);

@@ -988,6 +988,113 @@ hipError_t launch_pipe(const GaeArgs& a, unsigned flags, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------- MAT kernel ----
+// The multi-agent-transformer branches of compute_returns (shared_buffer.py:222-232 with a value
+// normaliser, :241-248 without): GAE without time limits whose advantage output is the accumulator
+// itself (advantages[t] = gae, not returns - D(v)), and -- without a normaliser -- whose TD error
+// uses the mean over the env's agents of the value predictions.  One lane per column (n, a); the
+// lanes of one env each form the group mean redundantly (A adjacent floats, served by L1).
+
+// numpy's float32 add.reduce over a contiguous axis of n <= 128 elements (pairwise sum: plain loop
+// below 8, eight interleaved partial sums up to 128; numpy/core/src/umath/loops_utils.h -- the
+// recursive halving above 128 is not needed for agent counts and is rejected by the entry point).
+constexpr int kMaxMatAgents = 128;
+__device__ __forceinline__ float numpy_sum_f32(const float* a, int n) {
+    if (n < 8) {
+        float res = 0.f;
+        for (int i = 0; i < n; ++i) res = res + a[i];
+        return res;
+    }
+    {
+        float r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+        int i = 8;
+        for (; i < n - (n % 8); i += 8) {
+            r0 = r0 + a[i + 0];
+            r1 = r1 + a[i + 1];
+            r2 = r2 + a[i + 2];
+            r3 = r3 + a[i + 3];
+            r4 = r4 + a[i + 4];
+            r5 = r5 + a[i + 5];
+            r6 = r6 + a[i + 6];
+            r7 = r7 + a[i + 7];
+        }
+        float res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+        for (; i < n; ++i) res = res + a[i];
+        return res;
+    }
+    return 0.f;
+}
+
+template <bool DENORM>
+__global__ void __launch_bounds__(64) gae_mat_kernel(GaeArgs a, int A) {
+    const long long C = a.C;
+    const int T = a.T;
+    const long long col = (long long)blockIdx.x * 64 + threadIdx.x;
+    const bool live = col < C;
+    const bool has_act = a.active != nullptr;
+    float sigma = 1.f, mu = 0.f;
+    if (DENORM) {
+        sigma = a.denorm[0];
+        mu = a.denorm[1];
+    }
+    const float gamma = a.gamma, gl = a.gl, fA = (float)A;
+    double s1 = 0.0, s2 = 0.0, cnt = 0.0;
+    if (live) {
+        const long long g0 = (col / A) * A;  // first column of this env's agent group
+        float nv = a.next_value[col];
+        a.value_preds[(long long)T * C + col] = nv;  // shared_buffer.py:218
+        float next_term;                             // D(v_{t+1}) or mean_a v_{t+1}
+        if (DENORM) {
+            float s = nv * sigma;
+            next_term = s + mu;
+        } else {
+            next_term = numpy_sum_f32(a.next_value + g0, A) / fA;  // row T is being written: read the source
+        }
+        float g = 0.f;
+        for (int t = T - 1; t >= 0; --t) {
+            long long o = (long long)t * C + col;
+            float r = a.rewards[o], v0 = a.value_preds[o], m1 = a.masks[o + C];
+            float base = v0, cur_term;
+            if (DENORM) {
+                float s = v0 * sigma;
+                base = s + mu;  // value_t (:223)
+                cur_term = base;
+            } else {
+                cur_term = numpy_sum_f32(a.value_preds + (long long)t * C + g0, A) / fA;  // mean_v_t (:243)
+            }
+            float x = gamma * m1;  // :229 / :245: r + gamma * mask * next - cur
+            float y = x * next_term;
+            float z = r + y;
+            float delta = z - cur_term;
+            float c0 = gl * m1;  // :230 / :249
+            float carry = c0 * g;
+            g = delta + carry;
+            a.adv[o] = g;               // :231 / :250
+            a.returns[o] = g + base;    // :232 / :251
+            next_term = cur_term;
+            float am = has_act ? a.active[o] : 1.f;
+            if (am != 0.f) {
+                double d = (double)g;
+                s1 += d;
+                s2 += d * d;
+                cnt += 1.0;
+            }
+        }
+    }
+    zero_unowned_partials(a.partials, a.partial_rows);
+    if (a.partials != nullptr) {
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        cnt = wave_sum(cnt);
+        if (threadIdx.x == 0) {
+            double* p = a.partials + (long long)blockIdx.x * 3;
+            p[0] = s1;
+            p[1] = s2;
+            p[2] = cnt;
+        }
+    }
+}
+
 hipError_t launch_column(const GaeArgs& a, unsigned flags, hipStream_t stream) {
     const bool gae = flags & MAPPO_GAE_USE_GAE;
     const bool ptl = flags & MAPPO_GAE_PROPER_TIME_LIMITS;
@@ -1110,6 +1217,45 @@ extern "C" int mappo_gae_f32(const float* rewards, float* value_preds, const flo
         default: e = launch_column(a, flags, stream); break;
     }
     return (int)e;
+}
+
+extern "C" int mappo_gae_mat_f32(const float* rewards, float* value_preds, const float* next_value,
+                                 const float* masks, float* returns, const float* denorm,
+                                 float* advantages, const float* active_masks, double* adv_partials,
+                                 int T, int64_t C, int num_agents, double gamma, double gae_lambda,
+                                 unsigned flags, mappo_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!rewards || !value_preds || !next_value || !masks || !returns || !advantages) return MAPPO_E_NULL;
+    if ((flags & MAPPO_GAE_DENORM) && !denorm) return MAPPO_E_NULL;
+    if (flags & ~MAPPO_GAE_DENORM) return MAPPO_E_FLAGS;
+    if (T <= 0 || C <= 0 || num_agents <= 0 || C % num_agents != 0) return MAPPO_E_SHAPE;
+    if (!(flags & MAPPO_GAE_DENORM) && num_agents > kMaxMatAgents) return MAPPO_E_TOO_MANY;
+    const void* ptrs[] = {rewards, value_preds, next_value, masks, returns, denorm, advantages, active_masks};
+    for (const void* p : ptrs)
+        if (p && (reinterpret_cast<uintptr_t>(p) & 3u)) return MAPPO_E_ALIGN;
+    GaeArgs a;
+    a.rewards = rewards;
+    a.value_preds = value_preds;
+    a.next_value = next_value;
+    a.masks = masks;
+    a.bad = nullptr;
+    a.returns = returns;
+    a.denorm = (flags & MAPPO_GAE_DENORM) ? denorm : nullptr;
+    a.adv = advantages;
+    a.active = active_masks;
+    a.partials = adv_partials;
+    a.partial_rows = mappo_gae_partial_rows(C);
+    a.opts = 0;
+    a.T = T;
+    a.C = C;
+    a.gamma = (float)gamma;
+    a.gl = (float)(gamma * gae_lambda);
+    dim3 grid((unsigned)((C + 63) / 64)), block(64);
+    if (flags & MAPPO_GAE_DENORM)
+        hipLaunchKernelGGL((gae_mat_kernel<true>), grid, block, 0, stream, a, num_agents);
+    else
+        hipLaunchKernelGGL((gae_mat_kernel<false>), grid, block, 0, stream, a, num_agents);
+    return (int)hipGetLastError();
 }
 
 extern "C" int mappo_adv_reduce(const double* partials, int64_t rows, double* sums,

@@ -41,6 +41,8 @@ class Slab(ctypes.Structure):
 SIGNATURES = {
     "mappo_gae_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _i64,
                              ctypes.c_double, ctypes.c_double, ctypes.c_uint, _vp]),
+    "mappo_gae_mat_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _int,
+                                 ctypes.c_double, ctypes.c_double, ctypes.c_uint, _vp]),
     "mappo_gae_partial_rows": (_i64, [_i64]),
     "mappo_gae_set_variant": (_int, [_int]),
     "mappo_advantages_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]),

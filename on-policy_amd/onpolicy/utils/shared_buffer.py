@@ -132,6 +132,7 @@ class SharedReplayBuffer(object):
         self._content_version = 0  # bumped by every method that writes buffer fields
         self._adv_fresh = False   # advantages/moments match the current returns & value_preds
         self._adv_denormalized = False   # ... and were formed as returns - D(value_preds)
+        self._adv_is_gae = False         # ... or are the GAE accumulator of the MAT branches
         self._stats_fresh = False
         self._events = None       # kernel name -> [(start, end, algorithmic bytes)], see profile_kernels
 
@@ -313,14 +314,30 @@ class SharedReplayBuffer(object):
         ``_scan_denorm=False`` (used by SeparatedReplayBuffer for the one branch where the reference's
         separated buffer does not de-normalise): identity D() in the scan; the fused advantages are
         then marked stale so that they are recomputed with the normaliser."""
-        if self.algo in ("mat", "mat_dec"):
-            raise NotImplementedError("the MAT variants of compute_returns are outside this path")
         T, N, A = self.episode_length, self.n_rollout_threads, self.num_agents
         nv = self._dev(next_value).reshape(-1)
         if nv.numel() != N * A:
             raise ValueError("next_value has %d elements, expected %d" % (nv.numel(), N * A))
         denorm = self._denorm_scalars(value_normalizer) if _scan_denorm else None
         p = _native.ptr
+        if self.algo in ("mat", "mat_dec") and self._use_gae and not self._use_proper_time_limits:
+            # transformer branches (reference shared_buffer.py:222-232, :241-251): the advantages are the
+            # GAE accumulator itself and, without a normaliser, the TD error uses the agent-mean value
+            ev = self._timed("mappo_gae_mat_f32", 24 * T * N * A)
+            code = self._lib.mappo_gae_mat_f32(
+                p(self.rewards), p(self.value_preds), p(nv), p(self.masks), p(self.returns), p(denorm),
+                p(self.advantages), p(self.active_masks), p(self._adv_partials), T, N * A, A,
+                float(self.gamma), float(self.gae_lambda), _native.GAE_DENORM if denorm is not None else 0,
+                self._stream())
+            self._timed_end(ev)
+            _native.check(code, "mappo_gae_mat_f32")
+            self._content_version += 1
+            self._adv_fresh = True
+            self._adv_denormalized = bool(self._use_popart or self._use_valuenorm)   # = what MATTrainer reads
+            self._adv_is_gae = True
+            self._stats_fresh = False
+            return
+        self._adv_is_gae = False
         # algorithmic bytes: r, v, m reads + returns write (16 B) + advantages write + active read
         # (+8 B) [+ bad_masks read 4 B] per (t, n, a) element  (SURVEY.md section 8d)
         ev = self._timed("mappo_gae_f32", (24 + (4 if self._use_proper_time_limits else 0)) * T * N * A)
@@ -351,7 +368,10 @@ class SharedReplayBuffer(object):
         want = flagged if denormalize is None else bool(denormalize)
         if want and not flagged:
             raise ValueError("denormalize=True needs a buffer built with use_popart / use_valuenorm")
-        if not self._adv_fresh or self._adv_denormalized != want:
+        if self._adv_fresh and self._adv_is_gae and denormalize is None:
+            pass       # MAT: buffer.advantages is what the trainer normalises (mat_trainer.py:160-164)
+        elif not self._adv_fresh or self._adv_denormalized != want:
+            self._adv_is_gae = False
             denorm = self._denorm_scalars(value_normalizer) if want else None
             self._adv_denormalized = want
             code = self._lib.mappo_advantages_f32(p(self.returns), p(self.value_preds), p(denorm),
@@ -564,4 +584,24 @@ class SharedReplayBuffer(object):
                                packed=packed)
 
     def feed_forward_generator_transformer(self, advantages, num_mini_batch=None, mini_batch_size=None):
-        raise NotImplementedError("the MAT sampler is outside the MAPPO hot path (SURVEY.md section 8f)")
+        """Minibatches of whole (t, n) agent groups for the transformer policies (reference
+        shared_buffer.py:264-338): a permutation of the T*N env steps; every drawn step contributes its
+        A agents as consecutive rows, so a minibatch is [mb*A, dim] with row i*A + a.  Same fused row
+        gather as feed_forward_generator over source rows idx*A + a (computed on the device)."""
+        T, N, A = self.episode_length, self.n_rollout_threads, self.num_agents
+        batch_size = N * T
+        if mini_batch_size is None:
+            assert batch_size >= num_mini_batch, (
+                "PPO requires the number of processes ({}) "
+                "* number of steps ({}) = {} "
+                "to be greater than or equal to the number of PPO mini batches ({})."
+                "".format(N, T, batch_size, num_mini_batch))
+            mini_batch_size = batch_size // num_mini_batch
+        rand = self._randperm(batch_size)
+        table, stats = self._field_table(advantages)
+        packed = self._pack_records(table)
+        agents = torch.arange(A, device=self.device)
+        for i in range(num_mini_batch):
+            idx = rand[i * mini_batch_size:(i + 1) * mini_batch_size]
+            rows = (idx[:, None] * A + agents[None, :]).reshape(-1).contiguous()
+            yield self._gather(table, stats, rows, mini_batch_size * A, packed=packed)

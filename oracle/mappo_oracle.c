@@ -100,6 +100,74 @@ void orc_compute_returns(const float* rewards, float* value_preds, const float* 
     }
 }
 
+/* numpy's float32 add.reduce over a contiguous axis (pairwise summation,
+ * numpy/core/src/umath/loops_utils.h.src: <8 plain loop, <=128 eight partial sums, else halves). */
+static float np_pairwise_sum_f32(const float* a, int64_t n) {
+    if (n < 8) {
+        volatile float res = 0.0f;
+        for (int64_t i = 0; i < n; ++i) res = res + a[i];
+        return res;
+    }
+    if (n <= 128) {
+        volatile float r[8];
+        int64_t i;
+        for (i = 0; i < 8; ++i) r[i] = a[i];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] = r[j] + a[i + j];
+        volatile float p01 = r[0] + r[1], p23 = r[2] + r[3], p45 = r[4] + r[5], p67 = r[6] + r[7];
+        volatile float q0 = p01 + p23, q1 = p45 + p67;
+        volatile float res = q0 + q1;
+        for (; i < n; ++i) res = res + a[i];
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    volatile float lo = np_pairwise_sum_f32(a, n2), hi = np_pairwise_sum_f32(a + n2, n - n2);
+    return lo + hi;
+}
+
+/*
+ * The "mat" / "mat_dec" branches of SharedReplayBuffer.compute_returns
+ * (onpolicy/utils/shared_buffer.py:222-232 with a value normaliser, :241-251 without); columns are
+ * ordered (thread, agent) with A agents.  advantages[t] = gae.
+ */
+void orc_compute_returns_mat(const float* rewards, float* value_preds, const float* next_value,
+                             const float* masks, float* returns, float* advantages, float sigma,
+                             float mu, int T, int64_t C, int A, double gamma, double lam, int dn) {
+    const float g32 = (float)gamma;
+    const float gl32 = (float)(gamma * lam);
+    memcpy(value_preds + (int64_t)T * C, next_value, (size_t)C * sizeof(float)); /* :218 */
+    for (int64_t c = 0; c < C; ++c) {
+        const int64_t g0 = (c / A) * A;
+        volatile float gae = 0.0f;
+        for (int t = T - 1; t >= 0; --t) {
+            const int64_t o = (int64_t)t * C + c;
+            float next_term, cur_term, base;
+            if (dn) { /* :223-224 */
+                base = denorm(value_preds[o], sigma, mu, 1);
+                cur_term = base;
+                next_term = denorm(value_preds[o + C], sigma, mu, 1);
+            } else { /* :243-244: np.mean(value_preds[step], axis=-2) in float32 */
+                volatile float s0 = np_pairwise_sum_f32(value_preds + (int64_t)t * C + g0, A);
+                volatile float s1 = np_pairwise_sum_f32(value_preds + (int64_t)(t + 1) * C + g0, A);
+                cur_term = s0 / (float)A;
+                next_term = s1 / (float)A;
+                base = value_preds[o];
+            }
+            /* delta = r + gamma * mask * next - cur   (:229, :245) */
+            volatile float x = g32 * masks[o + C];
+            volatile float y = x * next_term;
+            volatile float z = rewards[o] + y;
+            volatile float delta = z - cur_term;
+            volatile float u = gl32 * masks[o + C]; /* :230, :249 */
+            volatile float carry = u * gae;
+            gae = delta + carry;
+            advantages[o] = gae;      /* :231, :250 */
+            returns[o] = gae + base;  /* :232, :251 */
+        }
+    }
+}
+
 /* onpolicy/algorithms/r_mappo/r_mappo.py:179-182: advantages = returns[:-1] - D(value_preds[:-1]) */
 void orc_advantages(const float* returns, const float* value_preds, float* adv, float sigma,
                     float mu, int denorm_on, int64_t n) {

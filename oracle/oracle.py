@@ -41,6 +41,10 @@ def lib():
                                           ctypes.c_float, ctypes.c_int, ctypes.c_int64,
                                           ctypes.c_double, ctypes.c_double, ctypes.c_uint]
         L.orc_compute_returns.restype = None
+        L.orc_compute_returns_mat.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, ctypes.c_float,
+                                              ctypes.c_float, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                              ctypes.c_double, ctypes.c_double, ctypes.c_int]
+        L.orc_compute_returns_mat.restype = None
         L.orc_advantages.argtypes = [_f32p, _f32p, _f32p, ctypes.c_float, ctypes.c_float,
                                      ctypes.c_int, ctypes.c_int64]
         L.orc_advantages.restype = None
@@ -100,6 +104,21 @@ def compute_returns(rewards, value_preds, next_value, masks, bad_masks=None, *, 
     lib().orc_compute_returns(_p(r), _p(v), _p(nv), _p(m), _p(b), _p(ret), float(sigma), float(mu),
                               T, C, float(gamma), float(gae_lambda), flags)
     return ret.reshape(shape1), v.reshape(shape1)
+
+
+def compute_returns_mat(rewards, value_preds, next_value, masks, *, num_agents, sigma=1.0, mu=0.0, gamma=0.99,
+                        gae_lambda=0.95, denorm=False):
+    """The mat / mat_dec branches of compute_returns (shared_buffer.py:222-232, :241-251) on
+    [T(+1), N, A, 1] arrays -> (returns [T+1, ...], value_preds [T+1, ...], advantages [T, ...])."""
+    T = rewards.shape[0]
+    C = int(np.prod(rewards.shape[1:]))
+    v = _c(value_preds).reshape(T + 1, C).copy()
+    ret = np.zeros((T + 1, C), dtype=np.float32)
+    adv = np.zeros((T, C), dtype=np.float32)
+    lib().orc_compute_returns_mat(_p(_c(rewards).reshape(T, C)), _p(v), _p(_c(next_value).reshape(C)),
+                                  _p(_c(masks).reshape(T + 1, C)), _p(ret), _p(adv), float(sigma), float(mu), T, C,
+                                  int(num_agents), float(gamma), float(gae_lambda), int(bool(denorm)))
+    return ret.reshape(value_preds.shape), v.reshape(value_preds.shape), adv.reshape(rewards.shape)
 
 
 def advantages(returns, value_preds, *, sigma=1.0, mu=0.0, denorm=False):
@@ -172,6 +191,7 @@ class OracleBuffer(object):
         self._use_popart = args.use_popart
         self._use_valuenorm = args.use_valuenorm
         self._use_proper_time_limits = args.use_proper_time_limits
+        self.algo = getattr(args, "algorithm_name", "mappo")
         self.num_agents = A = num_agents
         obs_shape = tuple(_shape_of(obs_space))
         share_shape = tuple(_shape_of(cent_obs_space))
@@ -265,6 +285,14 @@ class OracleBuffer(object):
     # -- shared_buffer.py:179-262
     def compute_returns(self, next_value, value_normalizer=None):
         sigma, mu, dn = self._scalars(value_normalizer)
+        if self.algo in ("mat", "mat_dec") and self._use_gae and not self._use_proper_time_limits:   # :222,:241
+            ret, v, adv = compute_returns_mat(self.rewards, self.value_preds, np.asarray(next_value, dtype=np.float32),
+                                              self.masks, num_agents=self.num_agents, sigma=sigma, mu=mu,
+                                              gamma=self.gamma, gae_lambda=self.gae_lambda, denorm=dn)
+            self.returns[...] = ret
+            self.value_preds[...] = v
+            self.advantages[...] = adv
+            return
         ret, v = compute_returns(self.rewards, self.value_preds, np.asarray(next_value, dtype=np.float32),
                                  self.masks, self.bad_masks, sigma=sigma, mu=mu, gamma=self.gamma,
                                  gae_lambda=self.gae_lambda, use_gae=self._use_gae,
@@ -282,6 +310,27 @@ class OracleBuffer(object):
              ("advantages", advantages),
              ("available_actions", None if self.available_actions is None else self.available_actions[:T])]
         return f
+
+    # -- shared_buffer.py:264-338: minibatches of whole (t, n) agent groups, agents consecutive
+    def feed_forward_generator_transformer(self, advantages, num_mini_batch=None, mini_batch_size=None):
+        T, N, A = self.rewards.shape[0:3]
+        batch_size = N * T
+        if mini_batch_size is None:
+            assert batch_size >= num_mini_batch
+            mini_batch_size = batch_size // num_mini_batch
+        rand = torch.randperm(batch_size).numpy()                                  # :284
+        sampler = [rand[i * mini_batch_size:(i + 1) * mini_batch_size] for i in range(num_mini_batch)]
+        fields = self._fields(advantages)
+        for indices in sampler:
+            out = []
+            for name, arr in fields:
+                if arr is None:
+                    out.append(None)
+                    continue
+                tail = arr.shape[3:]
+                g = gather_rows(arr.reshape(batch_size, -1), indices)              # [mb, A*D]
+                out.append(g.reshape((len(indices) * A,) + tuple(tail)))           # :315-331
+            yield tuple(out)
 
     # -- shared_buffer.py:340-400
     def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None):

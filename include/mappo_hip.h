@@ -256,6 +256,53 @@ int mappo_layernorm_bwd(const float* dy, const float* x, const float* mean, cons
                         const float* weight, float* dx, float* dweight, float* dbias, float* partials,
                         int64_t M, int D, mappo_stream_t stream);
 
+/* --------------------------------------------------------------- K7: fused PPO loss ----
+ * The clipped-surrogate loss of R_MAPPO.ppo_update for a Discrete action head, value and gradient in
+ * one pass over the rows of a minibatch (r_mappo.py:52-89 cal_value_loss, :119-153 policy loss and
+ * entropy; act.py:115-170 and distributions.py FixedCategorical for log-prob / entropy of the masked
+ * logits).  Per row i (all arrays float32, row-major):
+ *   logits [rows, n_actions]  raw outputs of the action head; available [rows, n_actions] (NULL = all
+ *   available; entries == 0 take logit -1e10 and receive zero gradient); actions [rows] (index as
+ *   float); old_logp, adv, active (NULL = 1), factor (NULL = 1; HAPPO, happo_trainer.py:137-141),
+ *   values, value_preds, returns [rows]; norm = {sigma, mu} of the value normaliser, the layout of
+ *   mappo_gae_f32's denorm: target = (returns - mu) / sigma (NULL = raw returns); inv_denoms = {1 / D_policy, 1 / D_value} device scalars -- the denominators of the
+ *   masked means (sum of active masks, or the row count) over the WHOLE minibatch (all spans, all
+ *   data-parallel ranks), so that the gradients of successive spans simply accumulate.
+ * Outputs: dlogits [rows, n_actions] = d(policy_loss - entropy_coef * entropy) / dlogits,
+ *          dvalues [rows] = d(value_loss_coef * value_loss) / dvalues (either may be NULL),
+ *          sums[4] += { sum w_p * (-surrogate), sum w_p * entropy, sum w_v * value_loss, sum ratio }
+ *          (float64, atomically accumulated: multiply by inv_denoms for the logged means).
+ * logits == NULL skips the actor half, values == NULL the critic half. */
+#define MAPPO_LOSS_HUBER               1u  /* args.use_huber_loss (else mse) */
+#define MAPPO_LOSS_CLIPPED_VALUE       2u  /* args.use_clipped_value_loss */
+#define MAPPO_LOSS_POLICY_ACTIVE_MASKS 4u  /* args.use_policy_active_masks */
+#define MAPPO_LOSS_VALUE_ACTIVE_MASKS  8u  /* args.use_value_active_masks */
+typedef struct mappo_ppo_loss {
+    const float* logits;
+    const float* available;
+    const float* actions;
+    const float* old_logp;
+    const float* adv;
+    const float* active;
+    const float* factor;
+    const float* values;
+    const float* value_preds;
+    const float* returns;
+    const float* norm;
+    const float* inv_denoms;
+    float* dlogits;
+    float* dvalues;
+    double* sums;
+    int64_t rows;
+    int n_actions;
+    float clip;
+    float huber_delta;
+    float entropy_coef;
+    float value_loss_coef;
+    unsigned flags;
+} mappo_ppo_loss_t;
+int mappo_ppo_loss_f32(const mappo_ppo_loss_t* args, mappo_stream_t stream);
+
 /* --------------------------------------------------------------------- misc ---- */
 int         mappo_abi_version(void);
 const char* mappo_build_info(void);        /* "gfx950 ..." static string */

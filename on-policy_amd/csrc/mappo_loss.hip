@@ -1,0 +1,175 @@
+// K7: the clipped-surrogate PPO loss of R_MAPPO.ppo_update for a Discrete action head, forward and
+// backward in one pass over the minibatch rows (reference onpolicy/algorithms/r_mappo/r_mappo.py:52-89
+// cal_value_loss, :119-153 policy loss / entropy; utils/distributions.py FixedCategorical;
+// utils/act.py:115-170 evaluate_actions).
+//
+// In the framework the loss is ~100 elementwise / reduction launches over [rows, 1] tensors per
+// minibatch span, each latency-bound.  Every term is a per-row function whose normalising denominators
+// (number of rows, sum of the active masks) are known before the forward pass, so the gradient of the
+// total loss w.r.t. the head's logits and the critic's values can be written in the same pass that
+// evaluates the loss: one thread per row, ~100 B of traffic per row.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mappo_hip.h"
+#include "mappo_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// huber_loss / mse_loss of onpolicy/utils/util.py:16-23 and their derivatives w.r.t. the error
+__device__ __forceinline__ float loss_of(float e, float delta, bool huber) {
+    if (!huber) return e * e / 2.f;
+    float ae = fabsf(e);
+    return ae <= delta ? e * e / 2.f : delta * (ae - delta / 2.f);
+}
+__device__ __forceinline__ float dloss_of(float e, float delta, bool huber) {
+    if (!huber) return e;
+    float ae = fabsf(e);
+    return ae <= delta ? e : (e > 0.f ? delta : -delta);
+}
+
+template <bool HAS_AVAIL>
+__global__ void __launch_bounds__(256) ppo_loss_kernel(mappo_ppo_loss_t a) {
+    const bool huber = a.flags & MAPPO_LOSS_HUBER;
+    const bool clipped_value = a.flags & MAPPO_LOSS_CLIPPED_VALUE;
+    const bool p_active = a.flags & MAPPO_LOSS_POLICY_ACTIVE_MASKS;
+    const bool v_active = a.flags & MAPPO_LOSS_VALUE_ACTIVE_MASKS;
+    const int na = a.n_actions;
+    const float inv_dp = a.inv_denoms[0], inv_dv = a.inv_denoms[1];
+    float nmean = 0.f, nstd = 1.f;
+    if (a.norm != nullptr) {  // {sigma, mu}
+        nstd = a.norm[0];
+        nmean = a.norm[1];
+    }
+    double s_policy = 0.0, s_entropy = 0.0, s_value = 0.0, s_ratio = 0.0;
+
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.rows;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float am = a.active != nullptr ? a.active[i] : 1.f;
+        // ---------------- actor: log-softmax over the (masked) logits, entropy, surrogate
+        if (a.logits != nullptr) {
+            const float* lg = a.logits + i * na;
+            const float* av = HAS_AVAIL ? a.available + i * na : nullptr;
+            float mx = -INFINITY;
+            for (int k = 0; k < na; ++k) {
+                float l = (HAS_AVAIL && av[k] == 0.f) ? -1e10f : lg[k];  // distributions.py: masked logits
+                mx = fmaxf(mx, l);
+            }
+            float se = 0.f;
+            for (int k = 0; k < na; ++k) {
+                float l = (HAS_AVAIL && av[k] == 0.f) ? -1e10f : lg[k];
+                se += expf(l - mx);
+            }
+            const float lse = mx + logf(se);
+            const int act = (int)a.actions[i];
+            float ent = 0.f, logp_a = 0.f;
+            for (int k = 0; k < na; ++k) {
+                float l = (HAS_AVAIL && av[k] == 0.f) ? -1e10f : lg[k];
+                float lp = l - lse;
+                float p = expf(lp);
+                ent -= p * lp;
+                if (k == act) logp_a = lp;
+            }
+            const float ratio = expf(logp_a - a.old_logp[i]);  // r_mappo.py:129
+            const float adv = a.adv[i];
+            const float lo = 1.f - a.clip, hi = 1.f + a.clip;
+            const float surr1 = ratio * adv;
+            const float surr2 = fminf(fmaxf(ratio, lo), hi) * adv;
+            float s = fminf(surr1, surr2);
+            const bool inside = ratio >= lo && ratio <= hi;
+            float ds_dratio = (inside || surr1 < surr2) ? adv : 0.f;  // min / clamp sub-gradients as autograd takes them
+            if (a.factor != nullptr) {                                 // happo_trainer.py:137-141
+                s *= a.factor[i];
+                ds_dratio *= a.factor[i];
+            }
+            const float wp = p_active ? am : 1.f;
+            s_policy += (double)(-s * wp);
+            s_entropy += (double)(ent * wp);
+            s_ratio += (double)ratio;
+            if (a.dlogits != nullptr) {
+                // d/dl_j of [ -s - c_ent * H ] * wp / D_p;  dlogp_a/dl_j = [j == a] - p_j,  dH/dl_j = -p_j (logp_j + H)
+                const float g_logp = -ds_dratio * ratio;
+                const float scale = wp * inv_dp;
+                float* dl = a.dlogits + i * na;
+                for (int k = 0; k < na; ++k) {
+                    bool masked = HAS_AVAIL && av[k] == 0.f;
+                    float l = masked ? -1e10f : lg[k];
+                    float lp = l - lse;
+                    float p = expf(lp);
+                    float g = g_logp * ((k == act ? 1.f : 0.f) - p) + a.entropy_coef * p * (lp + ent);
+                    dl[k] = masked ? 0.f : g * scale;  // torch.where routes no gradient to masked logits
+                }
+            }
+        }
+        // ---------------- critic: clipped value loss against the (normalised) return
+        if (a.values != nullptr) {
+            const float v = a.values[i], vp = a.value_preds[i];
+            const float target = a.norm != nullptr ? (a.returns[i] - nmean) / nstd : a.returns[i];
+            const float d = v - vp;
+            const float vpc = vp + fminf(fmaxf(d, -a.clip), a.clip);  // r_mappo.py:62-63
+            const float e_c = target - vpc, e_o = target - v;
+            const float l_c = loss_of(e_c, a.huber_delta, huber), l_o = loss_of(e_o, a.huber_delta, huber);
+            const float g_o = -dloss_of(e_o, a.huber_delta, huber);
+            const float g_c = (d >= -a.clip && d <= a.clip) ? -dloss_of(e_c, a.huber_delta, huber) : 0.f;
+            float vl = l_o, g = g_o;
+            if (clipped_value) {  // torch.max: the larger branch, both halves on a tie
+                if (l_c > l_o) {
+                    vl = l_c;
+                    g = g_c;
+                } else if (l_c == l_o) {
+                    g = 0.5f * (g_o + g_c);
+                }
+            }
+            const float wv = v_active ? am : 1.f;
+            s_value += (double)(vl * wv);
+            if (a.dvalues != nullptr) a.dvalues[i] = a.value_loss_coef * g * wv * inv_dv;
+        }
+    }
+
+    __shared__ double red[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    s_policy = wave_sum_d(s_policy);
+    s_entropy = wave_sum_d(s_entropy);
+    s_value = wave_sum_d(s_value);
+    s_ratio = wave_sum_d(s_ratio);
+    if (lane == 0) {
+        red[wave][0] = s_policy;
+        red[wave][1] = s_entropy;
+        red[wave][2] = s_value;
+        red[wave][3] = s_ratio;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && a.sums != nullptr) {
+        double t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        atomicAdd(a.sums + threadIdx.x, t);
+    }
+}
+
+}  // namespace
+
+extern "C" int mappo_ppo_loss_f32(const mappo_ppo_loss_t* args, mappo_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!args) return MAPPO_E_NULL;
+    mappo_ppo_loss_t a = *args;
+    if (!a.inv_denoms) return MAPPO_E_NULL;
+    if (!a.logits && !a.values) return MAPPO_E_NULL;
+    if (a.logits && (!a.actions || !a.old_logp || !a.adv)) return MAPPO_E_NULL;
+    if (a.values && (!a.value_preds || !a.returns)) return MAPPO_E_NULL;
+    if (a.rows <= 0 || (a.logits && a.n_actions <= 0)) return MAPPO_E_SHAPE;
+    if (a.flags & ~15u) return MAPPO_E_FLAGS;
+    long long blocks = (a.rows + 255) / 256;
+    if (blocks > mappo::kCUs * 8) blocks = mappo::kCUs * 8;
+    if (a.logits && a.available)
+        hipLaunchKernelGGL((ppo_loss_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL((ppo_loss_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    return (int)hipGetLastError();
+}

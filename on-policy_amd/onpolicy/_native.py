@@ -37,6 +37,17 @@ class Slab(ctypes.Structure):
     _fields_ = [("src", _vp), ("dst", _vp), ("count", _i64)]
 
 
+class PPOLoss(ctypes.Structure):
+    """struct mappo_ppo_loss (include/mappo_hip.h)."""
+    _fields_ = [(n, _vp) for n in ("logits", "available", "actions", "old_logp", "adv", "active", "factor", "values",
+                                   "value_preds", "returns", "norm", "inv_denoms", "dlogits", "dvalues", "sums")] + \
+               [("rows", _i64), ("n_actions", ctypes.c_int), ("clip", ctypes.c_float),
+                ("huber_delta", ctypes.c_float), ("entropy_coef", ctypes.c_float),
+                ("value_loss_coef", ctypes.c_float), ("flags", ctypes.c_uint)]
+
+
+LOSS_HUBER, LOSS_CLIPPED_VALUE, LOSS_POLICY_ACTIVE_MASKS, LOSS_VALUE_ACTIVE_MASKS = 1, 2, 4, 8
+
 # symbol -> (restype, argtypes); must list every function include/mappo_hip.h declares
 SIGNATURES = {
     "mappo_gae_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _i64,
@@ -61,6 +72,7 @@ SIGNATURES = {
     "mappo_act_layernorm_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),
     "mappo_layernorm_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, ctypes.c_float, _vp]),
     "mappo_layernorm_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]),
+    "mappo_ppo_loss_f32": (_int, [ctypes.POINTER(PPOLoss), _vp]),
     "mappo_abi_version": (_int, []),
     "mappo_build_info": (ctypes.c_char_p, []),
     "mappo_error_string": (ctypes.c_char_p, [_int]),

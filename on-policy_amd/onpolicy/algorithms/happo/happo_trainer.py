@@ -31,6 +31,9 @@ class HAPPO(R_MAPPO):
     def _denormalize_advantages(self):
         return bool(self._use_popart)
 
+    def _fused_loss_allowed(self):
+        return not self._use_popart       # the self-updating normaliser has side effects per normalize() call
+
     def _value_targets(self, return_batch, update_normalizer):
         if self._use_popart or self._use_valuenorm:
             if self._use_popart and self.dp.active:

@@ -58,6 +58,14 @@ class R_MAPPOPolicy:
         values = self.critic(cent_obs, rnn_states_critic, masks, obs_standardized=obs_standardized)[0]
         return values, action_log_probs, dist_entropy
 
+    def evaluate_logits(self, cent_obs, obs, rnn_states_actor, rnn_states_critic, masks, obs_standardized=False,
+                        need_actor=True):
+        """-> (values, logits of the Discrete action head or None): the inputs of the fused PPO loss."""
+        logits = self.actor.evaluate_logits(obs, rnn_states_actor, masks, obs_standardized=obs_standardized) \
+            if need_actor else None
+        values = self.critic(cent_obs, rnn_states_critic, masks, obs_standardized=obs_standardized)[0]
+        return values, logits
+
     def act(self, obs, rnn_states_actor, masks, available_actions=None, deterministic=False):
         actions, _, rnn_states_actor = self.actor(obs, rnn_states_actor, masks, available_actions, deterministic)
         return actions, rnn_states_actor

@@ -78,6 +78,13 @@ class R_Actor(nn.Module, _DeviceMixin):
             active_masks=active_masks if self._use_policy_active_masks else None)
 
 
+    def evaluate_logits(self, obs, rnn_states, masks, obs_standardized=False):
+        """Raw outputs of the Discrete action head for the fused PPO loss (K7), [B, n_actions]."""
+        obs, rnn_states, masks = self._to_device(obs, rnn_states, masks)
+        feats, _ = self._features(obs, rnn_states, masks, obs_standardized)
+        return self.act.action_out.linear(feats)
+
+
 class R_Critic(nn.Module, _DeviceMixin):
     def __init__(self, args, cent_obs_space, device=torch.device("cpu")):
         super(R_Critic, self).__init__()

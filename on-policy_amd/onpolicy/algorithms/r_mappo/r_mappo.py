@@ -28,6 +28,7 @@ from onpolicy.utils.util import get_gard_norm, huber_loss, mse_loss
 from onpolicy.utils.valuenorm import ValueNorm
 from onpolicy.algorithms.utils.util import check
 from onpolicy.utils import dist as mdist
+from onpolicy.algorithms.utils import fused_loss
 
 
 class R_MAPPO():
@@ -67,6 +68,8 @@ class R_MAPPO():
         self.dp = mdist.DataParallel(self.policy.actor, self.policy.critic, device)
         # set by train() while it feeds ppo_update with row-standardised observations
         self._obs_standardized = False
+        # Discrete head on a HIP device: loss + gradient in one kernel (K7) instead of the framework ops
+        self._fused_loss = fused_loss.supported(self.policy, device) and self._fused_loss_allowed()
 
     # ------------------------------------------------------------------ what HAPPO overrides
     _use_factor = False          # minibatches may carry a 13th element (HAPPO factor); MAPPO ignores it
@@ -80,6 +83,9 @@ class R_MAPPO():
         if self._use_valuenorm:
             return ValueNorm(1, device=self.device)
         return None
+
+    def _fused_loss_allowed(self):
+        return True
 
     def _denormalize_advantages(self):
         """Whether the advantages are returns - D(value_preds) (r_mappo.py:179-182) or the raw difference."""
@@ -207,7 +213,14 @@ class R_MAPPO():
 
         value_loss = policy_loss = dist_entropy = None
         ratios = []
-        for lo, hi in spans:
+        fused = self._fused_loss and adv_targ.is_cuda and actions_batch is not None
+        if fused:
+            value_loss, policy_loss, dist_entropy, imp_weights = self._fused_spans(
+                spans, cut, (share_obs_batch, obs_batch, rnn_states_batch, rnn_states_critic_batch, actions_batch,
+                             value_preds_batch, return_batch, masks_batch, active_masks_batch,
+                             old_action_log_probs_batch, adv_targ, available_actions_batch, factor_batch),
+                w_actor, w_critic, normalized and not norm_done, update_actor)
+        for lo, hi in ([] if fused else spans):
             am = active_masks_batch[lo:hi]
             values, action_log_probs, entropy = self.policy.evaluate_actions(
                 cut(share_obs_batch, lo, hi), cut(obs_batch, lo, hi), cut(rnn_states_batch, lo, hi),
@@ -252,7 +265,8 @@ class R_MAPPO():
             ratios.append(imp_weights.detach() if len(spans) > 1 else imp_weights)
             del values, action_log_probs, entropy, surr1, surr2, surr, per_sample, p_loss, v_loss
 
-        imp_weights = ratios[0] if len(ratios) == 1 else torch.cat(ratios, 0)
+        if not fused:
+            imp_weights = ratios[0] if len(ratios) == 1 else torch.cat(ratios, 0)
 
         self.dp.all_reduce_grads()  # no-op for world size 1
 
@@ -268,6 +282,48 @@ class R_MAPPO():
         self.policy.critic_optimizer.step()
 
         return value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights
+
+    def _fused_spans(self, spans, cut, tensors, w_actor, w_critic, update_normalizer, update_actor):
+        """The span loop of ppo_update through the fused loss kernel (K7): per span one forward to the
+        head's logits / the critic's values, one ``mappo_ppo_loss_f32`` launch that evaluates the loss and
+        its gradient, one backward from those gradients.  -> (value_loss, policy_loss, dist_entropy,
+        mean ratio) as device scalars."""
+        share_obs, obs, rnn_a, rnn_c, actions, value_preds, returns, masks, active, old_logp, adv, avail, factor = tensors
+        dev, rows = adv.device, adv.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        actions = check(actions).to(**f32)
+        avail = None if avail is None else check(avail).to(**f32)
+        n_rows = torch.full((), float(rows), **f32)
+        active_total = active.sum()
+        inv_local = 1.0 / torch.stack([active_total if self._use_policy_active_masks else n_rows,
+                                       active_total if self._use_value_active_masks else n_rows])
+        # data-parallel weights are local / global denominators, so this is 1 / the GLOBAL denominators
+        inv = (inv_local * torch.stack([torch.as_tensor(w_actor, **f32).reshape(()),
+                                        torch.as_tensor(w_critic, **f32).reshape(())])).contiguous()
+        sums = torch.zeros(4, dtype=torch.float64, device=dev)
+        normalized = self._use_popart or self._use_valuenorm
+        for lo, hi in spans:
+            values, logits = self.policy.evaluate_logits(
+                cut(share_obs, lo, hi), cut(obs, lo, hi), cut(rnn_a, lo, hi), cut(rnn_c, lo, hi), cut(masks, lo, hi),
+                **self._eval_kwargs())
+            if update_normalizer:       # reference order: forward, normaliser update, loss (r_mappo.py:120-66)
+                self._normalizer_update(returns)
+                update_normalizer = False
+            norm = self.value_normalizer.denorm_scalars().to(**f32).contiguous() if normalized else None
+            dlogits, dvalues = fused_loss.ppo_loss(
+                logits, cut(avail, lo, hi), cut(actions, lo, hi), old_logp[lo:hi], adv[lo:hi], active[lo:hi],
+                None if factor is None else factor[lo:hi], values, value_preds[lo:hi], returns[lo:hi], norm, inv,
+                sums, clip=self.clip_param, huber_delta=self.huber_delta, entropy_coef=self.entropy_coef,
+                value_loss_coef=self.value_loss_coef, use_huber=self._use_huber_loss,
+                use_clipped_value_loss=self._use_clipped_value_loss,
+                policy_active_masks=self._use_policy_active_masks, value_active_masks=self._use_value_active_masks)
+            if update_actor:
+                torch.autograd.backward([logits, values], [dlogits, dvalues])
+            else:
+                values.backward(dvalues)
+            del values, logits, dlogits, dvalues
+        means = sums.float()
+        return means[2] * inv_local[1], means[0] * inv_local[0], means[1] * inv_local[0], means[3] / n_rows
 
     def _eval_kwargs(self):
         return {"obs_standardized": True} if self._obs_standardized else {}

@@ -244,7 +244,20 @@ int mappo_slab_copy(const mappo_slab_t* slabs, int n_slabs, mappo_stream_t strea
  * two for the `Linear -> act -> LayerNorm` blocks of mlp.py:17-22.  `x` is the PRE-activation in
  * both directions (the backward recomputes act(x)); dx is the gradient w.r.t. the pre-activation.
  */
+/* mappo_bias_act_layernorm_fwd/_bwd: additionally the bias add of the preceding Linear,
+ * y = LayerNorm(act(x + pre_bias)) with pre_bias [D] (NULL = 0): the GEMM runs without a bias and the
+ * backward returns dpre_bias [D] = column sums of dx, i.e. the Linear's bias gradient, for free --
+ * otherwise a separate pass over the [M, D] gradient (mlp.py:17-22 `nn.Linear` + `nn.LayerNorm`).
+ * `partials` is 3 * mappo_layernorm_max_blocks() * D floats when dpre_bias is requested (D <= 1024,
+ * dx required), 2 * ... otherwise. */
 int mappo_layernorm_max_blocks(void);
+int mappo_bias_act_layernorm_fwd(const float* x, const float* pre_bias, const float* weight, const float* bias,
+                                 float* y, float* mean, float* rstd, int64_t M, int D, float eps, int act,
+                                 mappo_stream_t stream);
+int mappo_bias_act_layernorm_bwd(const float* dy, const float* x, const float* pre_bias, const float* mean,
+                                 const float* rstd, const float* weight, float* dx, float* dweight, float* dbias,
+                                 float* dpre_bias, float* partials, int64_t M, int D, int act,
+                                 mappo_stream_t stream);
 int mappo_act_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y, float* mean,
                             float* rstd, int64_t M, int D, float eps, int act, mappo_stream_t stream);
 int mappo_act_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,

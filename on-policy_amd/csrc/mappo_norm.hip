@@ -65,7 +65,8 @@ __device__ __forceinline__ float act_grad(float z, float a) {
 
 // ------------------------------------------------------------------------ forward ----
 template <int VEC, int LPR, int EPL, int ACT>
-__global__ void __launch_bounds__(kThreads) ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ void __launch_bounds__(kThreads) ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pre,
+                                                          const float* __restrict__ w,
                                                           const float* __restrict__ b, float* __restrict__ y,
                                                           float* __restrict__ mean, float* __restrict__ rstd,
                                                           long long M, int D, float eps) {
@@ -76,15 +77,17 @@ __global__ void __launch_bounds__(kThreads) ln_fwd_kernel(const float* __restric
     const int units = D / VEC;
     const float invD = 1.0f / (float)D;
 
-    U wv[EPL], bv[EPL];
+    U wv[EPL], bv[EPL], pv[EPL];   // LayerNorm weight / bias, bias of the preceding Linear (or 0)
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
         int u = lane + e * LPR;
         wv[e] = U(0.f);
         bv[e] = U(0.f);
+        pv[e] = U(0.f);
         if (u < units) {
             wv[e] = reinterpret_cast<const U*>(w)[u];
             bv[e] = reinterpret_cast<const U*>(b)[u];
+            if (pre != nullptr) pv[e] = reinterpret_cast<const U*>(pre)[u];
         }
     }
     for (long long row = (long long)blockIdx.x * RPB + rib; row < M; row += (long long)gridDim.x * RPB) {
@@ -97,10 +100,9 @@ __global__ void __launch_bounds__(kThreads) ln_fwd_kernel(const float* __restric
             xv[e] = U(0.f);
             if (u < units) {
                 xv[e] = xr[u];
-                if (ACT != 0) {
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) set_elem<VEC>(xv[e], k, act_fwd<ACT>(elem<VEC>(xv[e], k)));
-                }
+                for (int k = 0; k < VEC; ++k)
+                    set_elem<VEC>(xv[e], k, act_fwd<ACT>(elem<VEC>(xv[e], k) + elem<VEC>(pv[e], k)));
             }
 #pragma unroll
             for (int k = 0; k < VEC; ++k) s += elem<VEC>(xv[e], k);
@@ -215,23 +217,29 @@ __global__ void __launch_bounds__(kThreads) ln_bwd_kernel(const float* __restric
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ w, float* __restrict__ dx,
                                                           float* __restrict__ pw, float* __restrict__ pb,
-                                                          long long M, int D) {
+                                                          long long M, int D, const float* __restrict__ pre,
+                                                          float* __restrict__ pp) {
     using U = typename Unit<VEC>::type;
     constexpr int RPB = kThreads / LPR;
-    extern __shared__ float red[];                 // [2][RPB][D]
+    extern __shared__ float red[];                 // [2 or 3][RPB][D]
     const int lane = threadIdx.x % LPR;
     const int rib = threadIdx.x / LPR;
     const int units = D / VEC;
     const float invD = 1.0f / (float)D;
 
-    U wv[EPL], aw[EPL], ab[EPL];
+    U wv[EPL], aw[EPL], ab[EPL], pv[EPL], ap[EPL];   // ap: column sums of dx = gradient of the Linear bias `pre`
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
         int u = lane + e * LPR;
         wv[e] = U(0.f);
         aw[e] = U(0.f);
         ab[e] = U(0.f);
-        if (u < units) wv[e] = reinterpret_cast<const U*>(w)[u];
+        pv[e] = U(0.f);
+        ap[e] = U(0.f);
+        if (u < units) {
+            wv[e] = reinterpret_cast<const U*>(w)[u];
+            if (pre != nullptr) pv[e] = reinterpret_cast<const U*>(pre)[u];
+        }
     }
     for (long long row = (long long)blockIdx.x * RPB + rib; row < M; row += (long long)gridDim.x * RPB) {
         const U* xr = reinterpret_cast<const U*>(x + row * D);
@@ -250,7 +258,7 @@ __global__ void __launch_bounds__(kThreads) ln_bwd_kernel(const float* __restric
                 U dv = gr[u];
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
-                    float zin = elem<VEC>(xv, k);
+                    float zin = elem<VEC>(xv, k) + elem<VEC>(pv[e], k);
                     float av = act_fwd<ACT>(zin);
                     if (ACT != 0) set_elem<VEC>(ag[e], k, act_grad<ACT>(zin, av));
                     float h = (av - mu) * r;
@@ -275,9 +283,11 @@ __global__ void __launch_bounds__(kThreads) ln_bwd_kernel(const float* __restric
                 if (u < units) {
                     U o;
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k)
-                        set_elem<VEC>(o, k, r * (elem<VEC>(gv[e], k) - m1 - elem<VEC>(xh[e], k) * m2) *
-                                               elem<VEC>(ag[e], k));
+                    for (int k = 0; k < VEC; ++k) {
+                        float v = r * (elem<VEC>(gv[e], k) - m1 - elem<VEC>(xh[e], k) * m2) * elem<VEC>(ag[e], k);
+                        set_elem<VEC>(o, k, v);
+                        set_elem<VEC>(ap[e], k, elem<VEC>(ap[e], k) + v);
+                    }
                     dr[u] = o;
                 }
             }
@@ -297,6 +307,17 @@ __global__ void __launch_bounds__(kThreads) ln_bwd_kernel(const float* __restric
             }
         }
     }
+    float* rp = red + (size_t)2 * RPB * D;
+    if (NEED_DX && pp != nullptr) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            int u = lane + e * LPR;
+            if (u < units) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) rp[(size_t)rib * D + u * VEC + k] = elem<VEC>(ap[e], k);
+            }
+        }
+    }
     __syncthreads();
     for (int c = threadIdx.x; c < D; c += kThreads) {
         float sw = 0.f, sb = 0.f;
@@ -307,6 +328,12 @@ __global__ void __launch_bounds__(kThreads) ln_bwd_kernel(const float* __restric
         }
         pw[(size_t)blockIdx.x * D + c] = sw;
         pb[(size_t)blockIdx.x * D + c] = sb;
+        if (NEED_DX && pp != nullptr) {
+            float sp = 0.f;
+#pragma unroll 4
+            for (int q = 0; q < RPB; ++q) sp += rp[(size_t)q * D + c];
+            pp[(size_t)blockIdx.x * D + c] = sp;
+        }
     }
 }
 
@@ -400,27 +427,29 @@ int mappo::gather_standardize(const float* src, float* dst, int width, long long
 
 extern "C" int mappo_layernorm_max_blocks(void) { return mappo::kCUs * 8; }
 
-extern "C" int mappo_act_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y,
-                                       float* mean, float* rstd, int64_t M, int D, float eps, int act,
-                                       mappo_stream_t stream_) {
+extern "C" int mappo_bias_act_layernorm_fwd(const float* x, const float* pre_bias, const float* weight,
+                                            const float* bias, float* y, float* mean, float* rstd, int64_t M,
+                                            int D, float eps, int act, mappo_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!x || !weight || !bias || !y || !mean || !rstd) return MAPPO_E_NULL;
     if (M <= 0 || D <= 0) return MAPPO_E_SHAPE;
     Shape s = pick_shape(x, y, D);
-    if (s.vec == 4 && !(mappo::aligned_to(weight, 16) && mappo::aligned_to(bias, 16))) s = pick_shape((void*)1, (void*)1, D);
+    if (s.vec == 4 && !(mappo::aligned_to(weight, 16) && mappo::aligned_to(bias, 16) &&
+                        (!pre_bias || mappo::aligned_to(pre_bias, 16))))
+        s = pick_shape((void*)1, (void*)1, D);
     if (s.epl == 0) return MAPPO_E_SHAPE;
     dim3 grid(ln_grid(M, s.lpr)), block(kThreads);
     if (act < 0 || act > 2) return MAPPO_E_FLAGS;
 #define LN_LAUNCH_FWD(V, L, E)                                                                   \
     if (s.vec == V && s.lpr == L && s.epl == E) {                                                \
         if (act == 0)                                                                            \
-            hipLaunchKernelGGL((ln_fwd_kernel<V, L, E, 0>), grid, block, 0, stream, x, weight, bias, y, mean, \
+            hipLaunchKernelGGL((ln_fwd_kernel<V, L, E, 0>), grid, block, 0, stream, x, pre_bias, weight, bias, y, mean, \
                                rstd, (long long)M, D, eps);                                      \
         else if (act == 1)                                                                       \
-            hipLaunchKernelGGL((ln_fwd_kernel<V, L, E, 1>), grid, block, 0, stream, x, weight, bias, y, mean, \
+            hipLaunchKernelGGL((ln_fwd_kernel<V, L, E, 1>), grid, block, 0, stream, x, pre_bias, weight, bias, y, mean, \
                                rstd, (long long)M, D, eps);                                      \
         else                                                                                     \
-            hipLaunchKernelGGL((ln_fwd_kernel<V, L, E, 2>), grid, block, 0, stream, x, weight, bias, y, mean, \
+            hipLaunchKernelGGL((ln_fwd_kernel<V, L, E, 2>), grid, block, 0, stream, x, pre_bias, weight, bias, y, mean, \
                                rstd, (long long)M, D, eps);                                      \
         return (int)hipGetLastError();                                                           \
     }
@@ -429,32 +458,43 @@ extern "C" int mappo_act_layernorm_fwd(const float* x, const float* weight, cons
     return MAPPO_E_SHAPE;
 }
 
+extern "C" int mappo_act_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y,
+                                       float* mean, float* rstd, int64_t M, int D, float eps, int act,
+                                       mappo_stream_t stream) {
+    return mappo_bias_act_layernorm_fwd(x, nullptr, weight, bias, y, mean, rstd, M, D, eps, act, stream);
+}
+
 extern "C" int mappo_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y,
                                    float* mean, float* rstd, int64_t M, int D, float eps,
                                    mappo_stream_t stream) {
-    return mappo_act_layernorm_fwd(x, weight, bias, y, mean, rstd, M, D, eps, 0, stream);
+    return mappo_bias_act_layernorm_fwd(x, nullptr, weight, bias, y, mean, rstd, M, D, eps, 0, stream);
 }
 
-extern "C" int mappo_act_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
-                                       const float* weight, float* dx, float* dweight, float* dbias,
-                                       float* partials, int64_t M, int D, int act, mappo_stream_t stream_) {
+extern "C" int mappo_bias_act_layernorm_bwd(const float* dy, const float* x, const float* pre_bias,
+                                            const float* mean, const float* rstd, const float* weight, float* dx,
+                                            float* dweight, float* dbias, float* dpre_bias, float* partials,
+                                            int64_t M, int D, int act, mappo_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!dy || !x || !mean || !rstd || !weight || !dweight || !dbias || !partials) return MAPPO_E_NULL;
+    if (dpre_bias && !dx) return MAPPO_E_NULL;        // the Linear-bias gradient is the column sum of dx
     if (M <= 0 || D <= 0) return MAPPO_E_SHAPE;
+    if (dpre_bias && D > 1024) return MAPPO_E_SHAPE;  // third LDS partial: keep the workgroup within 64 KB
     Shape s = pick_shape(x, dy, D);
-    if (s.vec == 4 && !(mappo::aligned_to(weight, 16) && (!dx || mappo::aligned_to(dx, 16))))
+    if (s.vec == 4 && !(mappo::aligned_to(weight, 16) && (!dx || mappo::aligned_to(dx, 16)) &&
+                        (!pre_bias || mappo::aligned_to(pre_bias, 16))))
         s = pick_shape((void*)1, (void*)1, D);
     if (s.epl == 0) return MAPPO_E_SHAPE;
     const int nblk = ln_grid(M, s.lpr);
     float* pw = partials;
     float* pb = partials + (size_t)mappo::kCUs * 8 * D;
-    const size_t lds = (size_t)2 * (kThreads / s.lpr) * D * sizeof(float);
+    float* pp = dpre_bias ? partials + (size_t)2 * mappo::kCUs * 8 * D : nullptr;
+    const size_t lds = (size_t)(dpre_bias ? 3 : 2) * (kThreads / s.lpr) * D * sizeof(float);
     dim3 grid(nblk), block(kThreads);
     bool launched = false;
     if (act < 0 || act > 2) return MAPPO_E_FLAGS;
 #define LN_BWD_ONE(V, L, E, DX, A)                                                               \
     hipLaunchKernelGGL((ln_bwd_kernel<V, L, E, DX, A>), grid, block, lds, stream, dy, x, mean, rstd, weight, \
-                       dx, pw, pb, (long long)M, D)
+                       dx, pw, pb, (long long)M, D, pre_bias, pp)
 #define LN_LAUNCH_BWD(V, L, E)                                                                   \
     if (!launched && s.vec == V && s.lpr == L && s.epl == E) {                                   \
         if (dx) {                                                                                \
@@ -475,11 +515,22 @@ extern "C" int mappo_act_layernorm_bwd(const float* dy, const float* x, const fl
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(ln_reduce_kernel, dim3((D + 63) / 64), dim3(kReduceThreads), 0, stream, pw, pb, dweight,
                        dbias, nblk, D);
+    if (dpre_bias)
+        hipLaunchKernelGGL(ln_reduce_kernel, dim3((D + 63) / 64), dim3(kReduceThreads), 0, stream, pp, pp,
+                           dpre_bias, dpre_bias, nblk, D);
     return (int)hipGetLastError();
+}
+
+extern "C" int mappo_act_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                                       const float* weight, float* dx, float* dweight, float* dbias,
+                                       float* partials, int64_t M, int D, int act, mappo_stream_t stream) {
+    return mappo_bias_act_layernorm_bwd(dy, x, nullptr, mean, rstd, weight, dx, dweight, dbias, nullptr, partials,
+                                        M, D, act, stream);
 }
 
 extern "C" int mappo_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                                    const float* weight, float* dx, float* dweight, float* dbias,
                                    float* partials, int64_t M, int D, mappo_stream_t stream) {
-    return mappo_act_layernorm_bwd(dy, x, mean, rstd, weight, dx, dweight, dbias, partials, M, D, 0, stream);
+    return mappo_bias_act_layernorm_bwd(dy, x, nullptr, mean, rstd, weight, dx, dweight, dbias, nullptr, partials,
+                                        M, D, 0, stream);
 }

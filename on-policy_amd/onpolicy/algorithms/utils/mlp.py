@@ -74,7 +74,10 @@ class MLPBase(nn.Module):
         linear, act, norm = first[0], first[1], first[2]
         w_eff = linear.weight * self.feature_norm.weight
         b_eff = linear.bias + linear.weight @ self.feature_norm.bias
-        h = norm.forward_act(tall_linear(x, w_eff, b_eff), act)
+        if isinstance(norm, FusedLayerNorm) and norm.fuses_bias(x, act, linear.out_features):
+            h = norm.forward_act(tall_linear(x, w_eff, None), act, pre_bias=b_eff)   # bias add in the LN kernel
+        else:
+            h = norm.forward_act(tall_linear(x, w_eff, b_eff), act)
         for layer in self.mlp.fc2:
             h = layer(h)
         return h

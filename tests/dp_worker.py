@@ -33,9 +33,9 @@ def full_arrays(N, dims):
     return arrays
 
 
-def run_update(N_global, lo, hi, args_over):
-    """compute_returns + train on rollout threads [lo, hi) of the global case."""
-    from oracle import oracle
+def run_update(N_global, lo, hi, args_over, device=None):
+    """compute_returns + train on rollout threads [lo, hi) of the global case.  ``device`` None: host
+    OracleBuffer + CPU trainer; a HIP device: the HBM buffer and the trainer (fused loss) on it."""
     from helpers import load_into
     from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy
     from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO
@@ -44,30 +44,44 @@ def run_update(N_global, lo, hi, args_over):
     shard = {k: (v[:, lo:hi] if k != "next_value" else v[lo:hi]) for k, v in arrays.items()}
     torch.manual_seed(1)
     np.random.seed(1)
-    policy = R_MAPPOPolicy(args, *spaces)
-    trainer = R_MAPPO(args, policy)
-    buf = oracle.OracleBuffer(args, dims[1], *spaces)
+    if device is None:
+        from oracle import oracle
+        policy = R_MAPPOPolicy(args, *spaces)
+        trainer = R_MAPPO(args, policy)
+        buf = oracle.OracleBuffer(args, dims[1], *spaces)
+    else:
+        from onpolicy.utils.shared_buffer import SharedReplayBuffer
+        args.sampler_rng = "host"
+        policy = R_MAPPOPolicy(args, *spaces, device=device)
+        trainer = R_MAPPO(args, policy, device=device)
+        buf = SharedReplayBuffer(args, dims[1], *spaces, device=device)
     load_into(buf, shard)
     buf.compute_returns(shard["next_value"], trainer.value_normalizer)
     trainer.prep_training()
     torch.manual_seed(100)
     info = trainer.train(buf)
-    sd = {"actor." + k: v.clone() for k, v in policy.actor.state_dict().items()}
-    sd.update({"critic." + k: v.clone() for k, v in policy.critic.state_dict().items()})
+    sd = {"actor." + k: v.detach().cpu().clone() for k, v in policy.actor.state_dict().items()}
+    sd.update({"critic." + k: v.detach().cpu().clone() for k, v in policy.critic.state_dict().items()})
     if trainer.value_normalizer is not None and hasattr(trainer.value_normalizer, "running_mean"):
-        sd["vn.mean"] = trainer.value_normalizer.running_mean.clone()
-        sd["vn.sq"] = trainer.value_normalizer.running_mean_sq.clone()
+        sd["vn.mean"] = trainer.value_normalizer.running_mean.cpu().clone()
+        sd["vn.sq"] = trainer.value_normalizer.running_mean_sq.cpu().clone()
     return info, sd, trainer.dp.world_size
 
 
-def worker(rank, world, port, N_global, args_over, out_dir):
+def worker(rank, world, port, N_global, args_over, out_dir, device=None):
+    """``device``: None = CPU ranks; "cuda:0" = every rank on GPU 0 with the gloo backend (RCCL refuses
+    duplicate devices), which exercises the device buffer + fused loss under data parallelism."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(1)
     from onpolicy.utils import dist as mdist
-    mdist.init_from_env(torch.device("cpu"))
+    if device is not None:
+        os.environ["MAPPO_DIST_BACKEND"] = "gloo"
+        device = torch.device(device)
+        torch.cuda.set_device(device)
+    mdist.init_from_env(torch.device("cpu") if device is None else device)
     assert dist.get_backend() == "gloo"
     lo, hi = mdist.shard_threads(N_global, rank, world)
-    info, sd, ws = run_update(N_global, lo, hi, args_over)
+    info, sd, ws = run_update(N_global, lo, hi, args_over, device)
     assert ws == world
     torch.save({"info": info, "sd": sd, "span": (lo, hi)}, os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()

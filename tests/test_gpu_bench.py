@@ -60,3 +60,36 @@ def test_two_ranks_on_one_gpu_strong_scaling_path():
     assert d["config"]["threads_per_gpu"] == 32 and d["config"]["n_rollout_threads"] == 64
     assert "cpu_baseline" not in d
     assert all(abs(v) < 1e6 for v in d["train_info"].values())
+
+
+@pytest.mark.parametrize("args_over", [dict(), dict(use_policy_active_masks=False, use_valuenorm=False, use_huber_loss=False)],
+                         ids=["default", "unmasked_nonorm_mse"])
+def test_two_rank_device_update_equals_single_process(tmp_path, args_over):
+    """Data parallelism on the device path (HBM buffer, fused loss with global denominators, flat gradient
+    bucket): two ranks sharing GPU 0 over gloo, each with half of the rollout threads, must end with identical
+    replicas that match the single-process update on the whole buffer (num_mini_batch = 1)."""
+    import numpy as np
+    import torch
+    import torch.multiprocessing as mp
+    import dp_worker
+    from test_data_parallel_cpu import _free_port
+    N, world, port = 6, 2, _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=dp_worker.worker, args=(r, world, port, N, args_over, str(tmp_path), "cuda:0"))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    ranks = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=False) for r in range(world)]
+    for k in ranks[0]["sd"]:
+        assert torch.equal(ranks[0]["sd"][k], ranks[1]["sd"][k]), k
+    info, sd, ws = dp_worker.run_update(N, 0, N, args_over, torch.device("cuda", 0))
+    assert ws == 1
+    for k in sd:
+        np.testing.assert_allclose(ranks[0]["sd"][k].numpy(), sd[k].numpy(), rtol=2e-4, atol=5e-6, err_msg=k)
+    for k in ("actor_grad_norm", "critic_grad_norm"):
+        assert ranks[0]["info"][k] == pytest.approx(info[k], rel=1e-3, abs=1e-6)
+    for k in ("value_loss", "policy_loss", "dist_entropy", "ratio"):     # mean over ranks of per-rank means
+        assert ranks[0]["info"][k] == pytest.approx(ranks[1]["info"][k], rel=1e-6, abs=1e-9)

@@ -151,3 +151,51 @@ class FakeChooseVecEnv(object):
 
     def close(self):
         pass
+
+
+class TinyEnv(object):
+    """One multi-agent env (not vectorised) for the VecEnv wrapper tests.  ``share=True`` speaks the SMAC
+    protocol (obs, share_obs, rewards, dones, infos, available_actions), otherwise the MPE one.
+    ``choose=True``: ``reset(choose)`` returns zeros when the flag is False (Hanabi protocol)."""
+
+    def __init__(self, seed, n_agents=2, obs_dim=3, horizon=3, share=False, choose=False):
+        self.a, self.do, self.h, self.share, self.choose = n_agents, obs_dim, horizon, share, choose
+        self.observation_space = [Box((obs_dim,)) for _ in range(n_agents)]
+        self.share_observation_space = [Box((obs_dim * n_agents,)) for _ in range(n_agents)]
+        self.action_space = [Discrete(4) for _ in range(n_agents)]
+        self.rng = np.random.default_rng(seed)
+        self.t = 0
+        self.resets = 0
+
+    def _obs(self):
+        obs = self.rng.standard_normal((self.a, self.do)).astype(np.float32)
+        if not self.share:
+            return obs
+        return obs, np.tile(obs.reshape(1, -1), (self.a, 1)), np.ones((self.a, 4), np.float32)
+
+    def reset(self, choose=True):
+        if self.choose and not choose:
+            z = np.zeros((self.a, self.do), np.float32)
+            return (z, np.zeros((self.a, self.do * self.a), np.float32), np.zeros((self.a, 4), np.float32)) \
+                if self.share else z
+        self.t = 0
+        self.resets += 1
+        out = self._obs()
+        if self.share:
+            out[0][0, 0] = 1000.0 + self.resets      # marks observations that come from a reset
+        else:
+            out[0, 0] = 1000.0 + self.resets
+        return out
+
+    def step(self, action):
+        self.t += 1
+        rewards = np.full((self.a, 1), float(np.sum(action)) + self.t, dtype=np.float32)
+        dones = np.full(self.a, self.t >= self.h)
+        infos = [{"t": self.t} for _ in range(self.a)]
+        if self.share:
+            obs, share_obs, avail = self._obs()
+            return obs, share_obs, rewards, dones, infos, avail
+        return self._obs(), rewards, dones, infos
+
+    def close(self):
+        pass

@@ -102,6 +102,9 @@ class Runner(object):
         self.log_interval = a.log_interval
         self.model_dir = a.model_dir
 
+        if self.use_render:      # reference base_runner.py:48-52
+            self.gif_dir = str(os.path.join(str(config["run_dir"]), 'gifs'))
+            os.makedirs(self.gif_dir, exist_ok=True)
         if self.use_wandb and getattr(wandb, "run", None) is not None:
             self.save_dir = str(wandb.run.dir)
             self.run_dir = str(wandb.run.dir)

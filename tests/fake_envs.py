@@ -199,3 +199,42 @@ class TinyEnv(object):
 
     def close(self):
         pass
+
+
+class FakeFootballVecEnv(object):
+    """DummyVecEnv protocol of the football wrapper: reset() -> obs [N, A, Do]; step(list of [A] int arrays) ->
+    obs, rewards [N, A, 1], dones [N, A], infos (one dict per env)."""
+
+    def __init__(self, n_threads, n_agents, obs_dim, n_actions, horizon=5, seed=0):
+        self.n, self.a, self.do, self.na, self.h = n_threads, n_agents, obs_dim, n_actions, horizon
+        self.observation_space = [Box((obs_dim,)) for _ in range(n_agents)]
+        self.share_observation_space = [Box((obs_dim,)) for _ in range(n_agents)]
+        self.action_space = [Discrete(n_actions) for _ in range(n_agents)]
+        self.rng = np.random.default_rng(seed)
+        self.left = np.full(n_threads, horizon)
+        self.log = []
+
+    def reset(self):
+        self.left[:] = self.h
+        obs = self.rng.standard_normal((self.n, self.a, self.do)).astype(np.float32)
+        self.log.append(dict(kind="reset", obs=obs))
+        return obs
+
+    def step(self, actions):
+        assert len(actions) == self.n and all(np.asarray(a).shape == (self.a,) for a in actions)
+        act = np.stack([np.asarray(a) for a in actions]).astype(np.int64)
+        assert act.min() >= 0 and act.max() < self.na
+        self.left -= 1
+        self.left[1] -= 1 if self.left[1] > 0 else 0          # env 1 finishes twice as fast
+        done_env = self.left <= 0
+        obs = self.rng.standard_normal((self.n, self.a, self.do)).astype(np.float32)
+        rewards = self.rng.standard_normal((self.n, self.a, 1)).astype(np.float32)
+        dones = np.repeat(done_env[:, None], self.a, axis=1)
+        infos = [{"score_reward": int(i % 2), "max_steps": self.h, "steps_left": int(max(self.left[i], 0))}
+                 for i in range(self.n)]
+        self.left[done_env] = self.h
+        self.log.append(dict(kind="step", obs=obs, rewards=rewards, dones=dones, actions=act))
+        return obs, rewards, dones, infos
+
+    def close(self):
+        pass

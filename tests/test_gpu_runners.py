@@ -151,3 +151,42 @@ def test_naive_recurrent_trainer_on_device():
     trainer.prep_training()
     info = trainer.train(buf)
     assert all(np.isfinite(v) for v in info.values()), info
+
+
+@pytest.mark.parametrize("recurrent", [False, True])
+def test_football_runner(tmp_path, recurrent):
+    from onpolicy.runner.shared.football_runner import FootballRunner
+    from fake_envs import FakeFootballVecEnv
+    T, N, A, Do, na = 6, 4, 3, 9, 7
+    args = make_args(env_name="Football", episode_length=T, n_rollout_threads=N, num_env_steps=3 * T * N,
+                     hidden_size=16, ppo_epoch=2, num_mini_batch=2, use_recurrent_policy=recurrent,
+                     algorithm_name="rmappo" if recurrent else "mappo", data_chunk_length=3, log_interval=T * N,
+                     save_interval=T * N, eval_interval=T * N, use_eval=True, n_eval_rollout_threads=2,
+                     eval_episodes=3, use_wandb=False)
+    envs = FakeFootballVecEnv(N, A, Do, na)
+    torch.manual_seed(1)
+    runner = FootballRunner({"all_args": args, "envs": envs, "eval_envs": FakeFootballVecEnv(2, A, Do, na, seed=5),
+                             "num_agents": A, "device": torch.device("cuda", 0), "run_dir": tmp_path})
+    runner.warmup()
+    b = runner.buffer
+    np.testing.assert_array_equal(b.obs[0].cpu().numpy(), envs.log[0]["obs"])
+    np.testing.assert_array_equal(b.share_obs[0].cpu().numpy(), envs.log[0]["obs"])
+    for step in range(T):
+        out = runner.collect(step)
+        obs, rewards, dones, infos = envs.step(out[5])
+        runner.insert((obs, rewards, dones, infos) + tuple(out[:5]))
+        rec = envs.log[-1]
+        np.testing.assert_array_equal(b.obs[step + 1].cpu().numpy(), rec["obs"])
+        np.testing.assert_array_equal(b.share_obs[step + 1].cpu().numpy(), rec["obs"])
+        np.testing.assert_array_equal(b.actions[step, :, :, 0].cpu().numpy(), rec["actions"])
+        np.testing.assert_array_equal(b.masks[step + 1, :, :, 0].cpu().numpy(), 1.0 - rec["dones"])
+        if recurrent:
+            assert float(b.rnn_states[step + 1][torch.as_tensor(rec["dones"])].abs().sum()) == 0.0
+    assert len(runner.env_infos["goal"]) >= 2 and set(runner.env_infos) == {"goal", "win_rate", "steps"}
+    runner.compute()
+    info = runner.train()
+    assert all(np.isfinite(v) for v in info.values())
+    runner.run()
+    lines = [json.loads(l) for l in open(os.path.join(runner.log_dir, "scalars.jsonl"))]
+    tags = {r["tag"] for r in lines}
+    assert {"value_loss", "goal", "win_rate", "eval_goal", "eval_win_rate", "eval_step"} <= tags

@@ -36,8 +36,12 @@ __device__ __forceinline__ float dloss_of(float e, float delta, bool huber) {
     return ae <= delta ? e : (e > 0.f ? delta : -delta);
 }
 
-template <bool HAS_AVAIL>
+// STAGED: the [256, n_actions] logits / availability tile of a workgroup goes through LDS with coalesced
+// global accesses (a thread's own row is n_actions floats at a stride of n_actions: 20-byte pieces for the
+// 5 actions of MPE), and the gradient tile goes back the same way.  Rows sit at an odd word stride in LDS.
+template <bool HAS_AVAIL, bool STAGED>
 __global__ void __launch_bounds__(256) ppo_loss_kernel(mappo_ppo_loss_t a) {
+    extern __shared__ float lds[];
     const bool huber = a.flags & MAPPO_LOSS_HUBER;
     const bool clipped_value = a.flags & MAPPO_LOSS_CLIPPED_VALUE;
     const bool p_active = a.flags & MAPPO_LOSS_POLICY_ACTIVE_MASKS;
@@ -50,14 +54,30 @@ __global__ void __launch_bounds__(256) ppo_loss_kernel(mappo_ppo_loss_t a) {
         nmean = a.norm[1];
     }
     double s_policy = 0.0, s_entropy = 0.0, s_value = 0.0, s_ratio = 0.0;
+    const int stride = na | 1;
+    float* s_lg = lds;
+    float* s_av = lds + 256 * stride;
 
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.rows;
-         i += (long long)gridDim.x * blockDim.x) {
-        const float am = a.active != nullptr ? a.active[i] : 1.f;
+    for (long long base = (long long)blockIdx.x * 256; base < a.rows; base += (long long)gridDim.x * 256) {
+        const long long i = base + threadIdx.x;
+        const bool live = i < a.rows;
+        if (STAGED && a.logits != nullptr) {
+            const long long left = a.rows - base;
+            const int tile = (int)(left < 256 ? left : 256) * na;
+            const float* gl = a.logits + base * na;
+            const float* ga = HAS_AVAIL ? a.available + base * na : nullptr;
+            for (int e = threadIdx.x; e < tile; e += 256) {
+                int r = e / na, k = e - r * na;
+                s_lg[r * stride + k] = gl[e];
+                if (HAS_AVAIL) s_av[r * stride + k] = ga[e];
+            }
+            __syncthreads();
+        }
+        const float am = (live && a.active != nullptr) ? a.active[i] : 1.f;
         // ---------------- actor: log-softmax over the (masked) logits, entropy, surrogate
-        if (a.logits != nullptr) {
-            const float* lg = a.logits + i * na;
-            const float* av = HAS_AVAIL ? a.available + i * na : nullptr;
+        if (live && a.logits != nullptr) {
+            const float* lg = STAGED ? s_lg + threadIdx.x * stride : a.logits + i * na;
+            const float* av = !HAS_AVAIL ? nullptr : STAGED ? s_av + threadIdx.x * stride : a.available + i * na;
             float mx = -INFINITY;
             for (int k = 0; k < na; ++k) {
                 float l = (HAS_AVAIL && av[k] == 0.f) ? -1e10f : lg[k];  // distributions.py: masked logits
@@ -98,7 +118,7 @@ __global__ void __launch_bounds__(256) ppo_loss_kernel(mappo_ppo_loss_t a) {
                 // d/dl_j of [ -s - c_ent * H ] * wp / D_p;  dlogp_a/dl_j = [j == a] - p_j,  dH/dl_j = -p_j (logp_j + H)
                 const float g_logp = -ds_dratio * ratio;
                 const float scale = wp * inv_dp;
-                float* dl = a.dlogits + i * na;
+                float* dl = STAGED ? s_lg + threadIdx.x * stride : a.dlogits + i * na;  // in place: read, then written
                 for (int k = 0; k < na; ++k) {
                     bool masked = HAS_AVAIL && av[k] == 0.f;
                     float l = masked ? -1e10f : lg[k];
@@ -109,8 +129,19 @@ __global__ void __launch_bounds__(256) ppo_loss_kernel(mappo_ppo_loss_t a) {
                 }
             }
         }
+        if (STAGED && a.logits != nullptr && a.dlogits != nullptr) {
+            __syncthreads();
+            const long long left = a.rows - base;
+            const int tile = (int)(left < 256 ? left : 256) * na;
+            float* gd = a.dlogits + base * na;
+            for (int e = threadIdx.x; e < tile; e += 256) {
+                int r = e / na, k = e - r * na;
+                gd[e] = s_lg[r * stride + k];
+            }
+        }
+        if (STAGED && a.logits != nullptr) __syncthreads();   // the tile is free for the next iteration
         // ---------------- critic: clipped value loss against the (normalised) return
-        if (a.values != nullptr) {
+        if (live && a.values != nullptr) {
             const float v = a.values[i], vp = a.value_preds[i];
             const float target = a.norm != nullptr ? (a.returns[i] - nmean) / nstd : a.returns[i];
             const float d = v - vp;
@@ -167,9 +198,16 @@ extern "C" int mappo_ppo_loss_f32(const mappo_ppo_loss_t* args, mappo_stream_t s
     if (a.flags & ~15u) return MAPPO_E_FLAGS;
     long long blocks = (a.rows + 255) / 256;
     if (blocks > mappo::kCUs * 8) blocks = mappo::kCUs * 8;
-    if (a.logits && a.available)
-        hipLaunchKernelGGL((ppo_loss_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
-    else
-        hipLaunchKernelGGL((ppo_loss_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    const bool avail = a.logits && a.available;
+    const size_t lds = a.logits ? (size_t)(avail ? 2 : 1) * 256 * (a.n_actions | 1) * sizeof(float) : 0;
+    const bool staged = a.logits && lds <= 48 * 1024;
+    dim3 grid((unsigned)blocks), block(256);
+    if (staged) {
+        if (avail) hipLaunchKernelGGL((ppo_loss_kernel<true, true>), grid, block, lds, stream, a);
+        else hipLaunchKernelGGL((ppo_loss_kernel<false, true>), grid, block, lds, stream, a);
+    } else {
+        if (avail) hipLaunchKernelGGL((ppo_loss_kernel<true, false>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((ppo_loss_kernel<false, false>), grid, block, 0, stream, a);
+    }
     return (int)hipGetLastError();
 }

@@ -48,7 +48,7 @@ def _torch_loss(logits, avail, actions, old_logp, adv, active, factor, values, v
 
 @pytest.mark.parametrize("na,with_avail,with_factor,with_norm", [(5, False, False, True), (5, True, True, False),
                                                                   (19, True, False, True), (1, False, False, False),
-                                                                  (38, False, True, True)])
+                                                                  (38, False, True, True), (40, True, False, True)])   # 40 + mask: too wide for the LDS-staged variant
 def test_fused_loss_matches_autograd(na, with_avail, with_factor, with_norm):
     from onpolicy.algorithms.utils import fused_loss
     R = 10007

@@ -42,6 +42,14 @@ WORKLOADS = {
                       "--gain", "0.01"],
                recurrent=False,
                label="synthetic MPE simple_spread x8 agents, T=400 N=4096 A=8, mappo MLP h64, ppo_epoch=10, 1 minibatch"),
+    # the north-star shapes with the recurrent policy ("run both mappo and rmappo")
+    "ns_rnn": dict(T=400, N=4096, A=8, Do=48, Ds=384, na=5, cpu_sample_N=32,
+                   flags=["--algorithm_name", "rmappo", "--hidden_size", "64", "--layer_N", "1", "--use_ReLU",
+                          "--ppo_epoch", "10", "--num_mini_batch", "1", "--data_chunk_length", "10", "--lr", "7e-4",
+                          "--critic_lr", "7e-4", "--gain", "0.01"],
+                   recurrent=True,
+                   label="synthetic MPE simple_spread x8 agents, T=400 N=4096 A=8, rmappo GRU h64 chunk 10, "
+                         "ppo_epoch=10, 1 minibatch"),
     # BASELINE.json configs[1]
     "cfg2": dict(T=200, N=1024, A=5, Do=30, Ds=150, na=5, cpu_sample_N=64,
                  flags=["--algorithm_name", "mappo", "--hidden_size", "64", "--layer_N", "1", "--use_ReLU",

@@ -159,17 +159,24 @@ class R_MAPPO():
     MAX_TENSOR_ELEMENTS = 1 << 30
 
     def _row_spans(self, sample):
+        """-> (spans, chunk_len).  Feed-forward minibatches (chunk_len None) are cut into row spans
+        [lo, hi); recurrent ones ([L * mb, ...] sequence fields with row l * mb + j and [mb, ...] RNN states)
+        into spans of whole chunks j in [lo, hi), every span keeping all L steps of its chunks."""
         rows = sample[10].shape[0] if sample[10] is not None else sample[5].shape[0]
         widest = max(int(np.prod(t.shape[1:])) for t in (sample[0], sample[1]) if t is not None)
         cap = max(1, self.MAX_TENSOR_ELEMENTS // max(1, widest))
+        recurrent = sample[2] is not None and sample[2].shape[0] != rows
         if rows <= cap:
-            return [(0, rows)]
-        if sample[2] is not None and sample[2].shape[0] != rows:
-            raise RuntimeError("a recurrent minibatch of %d rows x %d features exceeds what PyTorch-ROCm can "
-                               "index; raise --num_mini_batch" % (rows, widest))
-        n = -(-rows // cap)
-        step = -(-rows // n)
-        return [(lo, min(rows, lo + step)) for lo in range(0, rows, step)]
+            return [(0, rows)], None
+        if recurrent:
+            mb = sample[2].shape[0]
+            chunk_len = rows // mb
+            units, cap = mb, max(1, cap // chunk_len)
+        else:
+            chunk_len, units = None, rows
+        n = -(-units // cap)
+        step = -(-units // n)
+        return [(lo, min(units, lo + step)) for lo in range(0, units, step)], chunk_len
 
     def ppo_update(self, sample, update_actor=True):
         """One actor step and one critic step on a minibatch (reference r_mappo.py:91-169).
@@ -185,7 +192,7 @@ class R_MAPPO():
         return_batch = check(return_batch).to(**self.tpdv)
         active_masks_batch = check(active_masks_batch).to(**self.tpdv)
 
-        spans = self._row_spans(sample)
+        spans, chunk_len = self._row_spans(sample)
         rows = adv_targ.shape[0]
         # In a data-parallel job each rank's loss is a mean over ITS minibatch; weighting it by
         # (local denominator / global denominator) makes the all-reduced gradient the gradient of
@@ -208,8 +215,16 @@ class R_MAPPO():
 
         single = len(spans) == 1
 
+        n_chunks = rows // chunk_len if chunk_len else None
+
         def cut(x, lo, hi):
-            return x if (x is None or single) else x[lo:hi]
+            """The part of a minibatch tensor that belongs to span [lo, hi)."""
+            if x is None or single:
+                return x
+            if chunk_len is None or x.shape[0] == n_chunks:        # row spans / per-chunk RNN states
+                return x[lo:hi]
+            tail = x.shape[1:]                                      # [L * mb, ...] with row l * mb + j
+            return x.reshape(chunk_len, n_chunks, *tail)[:, lo:hi].reshape(chunk_len * (hi - lo), *tail)
 
         value_loss = policy_loss = dist_entropy = None
         ratios = []
@@ -221,32 +236,33 @@ class R_MAPPO():
                              old_action_log_probs_batch, adv_targ, available_actions_batch, factor_batch),
                 w_actor, w_critic, normalized and not norm_done, update_actor)
         for lo, hi in ([] if fused else spans):
-            am = active_masks_batch[lo:hi]
+            am = cut(active_masks_batch, lo, hi)
             values, action_log_probs, entropy = self.policy.evaluate_actions(
                 cut(share_obs_batch, lo, hi), cut(obs_batch, lo, hi), cut(rnn_states_batch, lo, hi),
                 cut(rnn_states_critic_batch, lo, hi), cut(actions_batch, lo, hi), cut(masks_batch, lo, hi),
                 cut(available_actions_batch, lo, hi), am, **self._eval_kwargs())
 
             # clipped surrogate (r_mappo.py:129-139)
-            imp_weights = self._ratio(action_log_probs, old_action_log_probs_batch[lo:hi])
-            surr1 = imp_weights * adv_targ[lo:hi]
-            surr2 = torch.clamp(imp_weights, 1.0 - self.clip_param, 1.0 + self.clip_param) * adv_targ[lo:hi]
+            adv_span = cut(adv_targ, lo, hi)
+            imp_weights = self._ratio(action_log_probs, cut(old_action_log_probs_batch, lo, hi))
+            surr1 = imp_weights * adv_span
+            surr2 = torch.clamp(imp_weights, 1.0 - self.clip_param, 1.0 + self.clip_param) * adv_span
             surr = torch.min(surr1, surr2)
             if factor_batch is not None:
-                surr = factor_batch[lo:hi] * surr                            # happo_trainer.py:137-141
+                surr = cut(factor_batch, lo, hi) * surr                            # happo_trainer.py:137-141
             per_sample = -torch.sum(surr, dim=-1, keepdim=True)
             if self._use_policy_active_masks:
                 p_loss = (per_sample * am).sum() / am.sum()
             else:
                 p_loss = per_sample.mean()
-            v_loss = self._value_loss(values, value_preds_batch[lo:hi], return_batch[lo:hi], am,
+            v_loss = self._value_loss(values, cut(value_preds_batch, lo, hi), cut(return_batch, lo, hi), am,
                                       update_normalizer=not norm_done)
 
             # span weights: this span's share of the minibatch denominators (exactly 1 for one span)
             if len(spans) == 1:
                 sw_actor = sw_critic = 1.0
             else:
-                frac_rows = float(hi - lo) / rows
+                frac_rows = float(am.shape[0]) / rows
                 frac_active = am.sum() / active_masks_batch.sum()
                 sw_actor = frac_active if self._use_policy_active_masks else frac_rows
                 sw_critic = frac_active if self._use_value_active_masks else frac_rows
@@ -311,8 +327,8 @@ class R_MAPPO():
                 update_normalizer = False
             norm = self.value_normalizer.denorm_scalars().to(**f32).contiguous() if normalized else None
             dlogits, dvalues = fused_loss.ppo_loss(
-                logits, cut(avail, lo, hi), cut(actions, lo, hi), old_logp[lo:hi], adv[lo:hi], active[lo:hi],
-                None if factor is None else factor[lo:hi], values, value_preds[lo:hi], returns[lo:hi], norm, inv,
+                logits, cut(avail, lo, hi), cut(actions, lo, hi), cut(old_logp, lo, hi), cut(adv, lo, hi),
+                cut(active, lo, hi), cut(factor, lo, hi), values, cut(value_preds, lo, hi), cut(returns, lo, hi), norm, inv,
                 sums, clip=self.clip_param, huber_delta=self.huber_delta, entropy_coef=self.entropy_coef,
                 value_loss_coef=self.value_loss_coef, use_huber=self._use_huber_loss,
                 use_clipped_value_loss=self._use_clipped_value_loss,

@@ -103,15 +103,17 @@ def test_train_matches_reference(gold, cname):
         np.testing.assert_allclose(got, z[key + "final_norm"], rtol=1e-5, atol=1e-9)
 
 
-def test_row_span_microbatching_is_equivalent(gold):
-    """Minibatches too large for PyTorch-ROCm's 32-bit row kernels are evaluated in row spans with
-    gradient accumulation; that must give the same update as one pass (float32 summation order
-    aside)."""
+@pytest.mark.parametrize("cname", ["mlp", "gru"])
+def test_row_span_microbatching_is_equivalent(gold, cname):
+    """Minibatches too large for PyTorch-ROCm's 32-bit row kernels are evaluated in spans with gradient
+    accumulation -- row spans for feed-forward minibatches, spans of whole chunks (all L steps of a chunk
+    stay together) for recurrent ones; that must give the same update as one pass (float32 summation
+    order aside)."""
     z = gold.npz("trainer_cases")
-    key = "trn_mlp_"
+    key = "trn_%s_" % cname
     results = []
-    for cap in (1 << 30, 200):     # 200 elements / 11 features -> spans of 18 rows
-        meta, spec, args, spaces, policy, trainer = _build(gold, "mlp")
+    for cap in (1 << 30, 200):     # 200 elements / 11 features -> spans of 18 rows (3 chunks of 5 steps)
+        meta, spec, args, spaces, policy, trainer = _build(gold, cname)
         trainer.MAX_TENSOR_ELEMENTS = cap
         buf = oracle.OracleBuffer(args, spec["A"], *spaces)
         for name in ("share_obs", "obs", "rnn_states", "rnn_states_critic", "actions", "value_preds", "masks",

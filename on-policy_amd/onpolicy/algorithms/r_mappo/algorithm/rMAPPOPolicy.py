@@ -26,7 +26,10 @@ class R_MAPPOPolicy:
         self.critic_optimizer = self._adam(self.critic, self.critic_lr)
 
     def _adam(self, net, lr):
-        return torch.optim.Adam(net.parameters(), lr=lr, eps=self.opti_eps, weight_decay=self.weight_decay)
+        # reference rMAPPOPolicy.py:31-37: torch.optim.Adam(lr, eps=opti_eps, weight_decay).  On the GPU the
+        # single-kernel ("fused") implementation of the same update replaces ~14 launches per step
+        fused = {"fused": True} if torch.device(self.device).type == "cuda" else {}
+        return torch.optim.Adam(net.parameters(), lr=lr, eps=self.opti_eps, weight_decay=self.weight_decay, **fused)
 
     def lr_decay(self, episode, episodes):
         update_linear_schedule(self.actor_optimizer, episode, episodes, self.lr)

@@ -338,34 +338,30 @@ __global__ void __launch_bounds__(kThreads) ln_bwd_kernel(const float* __restric
 }
 
 // Column sums of the per-workgroup partials: 64 columns x 16 row groups per workgroup, fixed order.
+// blockIdx.y selects the array (weight / bias / Linear-bias partials), so one launch reduces all of them.
 constexpr int kReduceThreads = 1024;
-__global__ void __launch_bounds__(kReduceThreads) ln_reduce_kernel(const float* __restrict__ pw,
-                                                                    const float* __restrict__ pb,
-                                                                    float* __restrict__ dw, float* __restrict__ db,
-                                                                    int nblk, int D) {
-    __shared__ float sw[16][64], sb[16][64];
+struct ReduceArgs {
+    const float* src[3];
+    float* dst[3];
+};
+__global__ void __launch_bounds__(kReduceThreads) ln_reduce_kernel(ReduceArgs a, int nblk, int D) {
+    __shared__ float sm[16][64];
+    const float* __restrict__ src = blockIdx.y == 0 ? a.src[0] : blockIdx.y == 1 ? a.src[1] : a.src[2];
+    float* __restrict__ dst = blockIdx.y == 0 ? a.dst[0] : blockIdx.y == 1 ? a.dst[1] : a.dst[2];
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
-    float aw = 0.f, ab = 0.f;
+    float acc = 0.f;
     if (c < D) {
 #pragma unroll 8
-        for (int q = g; q < nblk; q += 16) {
-            aw += pw[(size_t)q * D + c];
-            ab += pb[(size_t)q * D + c];
-        }
+        for (int q = g; q < nblk; q += 16) acc += src[(size_t)q * D + c];
     }
-    sw[g][cl] = aw;
-    sb[g][cl] = ab;
+    sm[g][cl] = acc;
     __syncthreads();
     if (g == 0 && c < D) {
-        float tw = 0.f, tb = 0.f;
+        float t = 0.f;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            tw += sw[q][cl];
-            tb += sb[q][cl];
-        }
-        dw[c] = tw;
-        db[c] = tb;
+        for (int q = 0; q < 16; ++q) t += sm[q][cl];
+        dst[c] = t;
     }
 }
 
@@ -513,11 +509,15 @@ extern "C" int mappo_bias_act_layernorm_bwd(const float* dy, const float* x, con
     if (!launched) return MAPPO_E_SHAPE;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(ln_reduce_kernel, dim3((D + 63) / 64), dim3(kReduceThreads), 0, stream, pw, pb, dweight,
-                       dbias, nblk, D);
-    if (dpre_bias)
-        hipLaunchKernelGGL(ln_reduce_kernel, dim3((D + 63) / 64), dim3(kReduceThreads), 0, stream, pp, pp,
-                           dpre_bias, dpre_bias, nblk, D);
+    ReduceArgs ra;
+    ra.src[0] = pw;
+    ra.src[1] = pb;
+    ra.src[2] = pp;
+    ra.dst[0] = dweight;
+    ra.dst[1] = dbias;
+    ra.dst[2] = dpre_bias;
+    hipLaunchKernelGGL(ln_reduce_kernel, dim3((D + 63) / 64, dpre_bias ? 3 : 2), dim3(kReduceThreads), 0, stream, ra,
+                       nblk, D);
     return (int)hipGetLastError();
 }
 

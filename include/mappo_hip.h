@@ -316,6 +316,26 @@ typedef struct mappo_ppo_loss {
 } mappo_ppo_loss_t;
 int mappo_ppo_loss_f32(const mappo_ppo_loss_t* args, mappo_stream_t stream);
 
+/* --------------------------------------------------------------- K8: GRU cell gates ----
+ * Everything of one GRU step that is not a GEMM (reference onpolicy/algorithms/utils/rnn.py:7-80 runs
+ * nn.GRU; PyTorch cell, gates stacked r|z|n), reading / writing the per-sequence buffers in place:
+ *   r = sigmoid(gi_r + b_ir + gh_r + b_hr), z = sigmoid(gi_z + b_iz + gh_z + b_hz),
+ *   n = tanh(gi_n + b_in + r * (gh_n + b_hn)), h' = n + z * (hm - n)
+ * mappo_gru_cell_fwd: gi, gh [B, 3H] (input / hidden projections without bias), hm [B, H] (previous state,
+ *   already multiplied by this step's mask), b_ih, b_hh [3H]; writes h_out [B, H] = h', optionally
+ *   hm_next [B, H] = h' * mask_next[row] (mask_next [B]: the next step's episode-boundary mask, rnn.py:43-77;
+ *   NULL mask = 1) and ws [B, 4H] = {r, z, n, gh_n + b_hn} for the backward.
+ * mappo_gru_cell_bwd: g = dout + carry * mask_next (dout [B, H] = d loss / d h' from the layers above, carry
+ *   [B, H] = d loss / d hm of the next step, either may be NULL); writes dgi, dgh [B, 3H] (gradients of the
+ *   two projections; their column sums are the bias gradients) and dhx [B, H] = g * z, the direct part of
+ *   d loss / d hm (the caller adds dgh W_hh). */
+int mappo_gru_cell_fwd(const float* gi, const float* gh, const float* hm, const float* b_ih, const float* b_hh,
+                       const float* mask_next, float* h_out, float* hm_next, float* ws, int64_t B, int H,
+                       mappo_stream_t stream);
+int mappo_gru_cell_bwd(const float* dout, const float* carry, const float* mask_next, const float* ws,
+                       const float* hm, float* dgi, float* dgh, float* dhx, int64_t B, int H,
+                       mappo_stream_t stream);
+
 /* --------------------------------------------------------------------- misc ---- */
 int         mappo_abi_version(void);
 const char* mappo_build_info(void);        /* "gfx950 ..." static string */

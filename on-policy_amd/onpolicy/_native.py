@@ -75,6 +75,8 @@ SIGNATURES = {
     "mappo_bias_act_layernorm_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, ctypes.c_float, _int, _vp]),
     "mappo_bias_act_layernorm_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int,
                                             _vp]),
+    "mappo_gru_cell_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]),
+    "mappo_gru_cell_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]),
     "mappo_ppo_loss_f32": (_int, [ctypes.POINTER(PPOLoss), _vp]),
     "mappo_abi_version": (_int, []),
     "mappo_build_info": (ctypes.c_char_p, []),

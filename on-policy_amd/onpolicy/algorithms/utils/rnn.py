@@ -20,7 +20,74 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .fused_norm import FusedLayerNorm
-from .tall_linear import tall_linear
+from .tall_linear import tall_linear, splitk_weight_grad, column_sums
+
+
+class _GRUSequenceFn(torch.autograd.Function):
+    """One GRU layer over a whole chunk on HIP tensors: gi_all [L, B, 3H] (input projection of all steps, no
+    bias), h0 [B, H], masks [L, B, 1] -> out [L, B, H].  Per step: one GEMM for the hidden projection and
+    one ``mappo_gru_cell_fwd`` launch (K8) that writes h_t into ``out[t]`` and the masked state of the next
+    step in place; the backward mirrors it with ``mappo_gru_cell_bwd`` + one GEMM per step, and forms the
+    recurrent weight gradient and both bias gradients ONCE over all L * B rows (split-K) instead of per
+    step.  Nothing is stacked, unbound or accumulated by autograd."""
+
+    @staticmethod
+    def forward(ctx, gi_all, h0, masks, w_hh, b_ih, b_hh):
+        from onpolicy import _native
+        lib, p = _native.lib(), _native.ptr
+        L, B, G = gi_all.shape
+        H = G // 3
+        gi_all, masks = gi_all.contiguous(), masks.contiguous()
+        b_ih, b_hh, w_hh = b_ih.contiguous(), b_hh.contiguous(), w_hh.contiguous()
+        dev = gi_all.device
+        stream = _native.stream_of(dev)
+        hm_all = torch.empty(L, B, H, dtype=torch.float32, device=dev)
+        out = torch.empty(L, B, H, dtype=torch.float32, device=dev)
+        need_ws = any(ctx.needs_input_grad)
+        ws_all = torch.empty(L, B, 4 * H, dtype=torch.float32, device=dev) if need_ws else None
+        torch.mul(h0, masks[0], out=hm_all[0])
+        w_t = w_hh.t()
+        for t in range(L):
+            gh = torch.mm(hm_all[t], w_t)
+            last = t + 1 == L
+            _native.check(lib.mappo_gru_cell_fwd(p(gi_all[t]), p(gh), p(hm_all[t]), p(b_ih), p(b_hh),
+                                                 None if last else p(masks[t + 1]), p(out[t]),
+                                                 None if last else p(hm_all[t + 1]),
+                                                 p(ws_all[t]) if need_ws else None, B, H, stream),
+                          "mappo_gru_cell_fwd")
+        if need_ws:
+            ctx.save_for_backward(hm_all, masks, w_hh, ws_all)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from onpolicy import _native
+        lib, p = _native.lib(), _native.ptr
+        hm_all, masks, w_hh, ws_all = ctx.saved_tensors
+        L, B, H = hm_all.shape
+        dev = hm_all.device
+        stream = _native.stream_of(dev)
+        dout = dout.contiguous()
+        dgi_all = torch.empty(L, B, 3 * H, dtype=torch.float32, device=dev)
+        dgh_all = torch.empty(L, B, 3 * H, dtype=torch.float32, device=dev)
+        dhx = torch.empty(B, H, dtype=torch.float32, device=dev)
+        carry = None
+        for t in range(L - 1, -1, -1):
+            last = t + 1 == L
+            _native.check(lib.mappo_gru_cell_bwd(p(dout[t]), p(carry), None if last else p(masks[t + 1]),
+                                                 p(ws_all[t]), p(hm_all[t]), p(dgi_all[t]), p(dgh_all[t]), p(dhx),
+                                                 B, H, stream), "mappo_gru_cell_bwd")
+            carry = torch.addmm(dhx, dgh_all[t], w_hh)            # d loss / d hm[t]
+        dh0 = carry * masks[0] if ctx.needs_input_grad[1] else None
+        flat_gh = dgh_all.view(L * B, 3 * H)
+        dw = splitk_weight_grad(flat_gh, hm_all.view(L * B, H)) if ctx.needs_input_grad[3] else None
+        db_ih = column_sums(dgi_all.view(L * B, 3 * H)) if ctx.needs_input_grad[4] else None
+        db_hh = column_sums(flat_gh) if ctx.needs_input_grad[5] else None
+        return dgi_all, dh0, None, dw, db_ih, db_hh
+
+
+# MAPPO_GRU_SEQUENCE=0 falls back to aten::_thnn_fused_gru_cell driven step by step through autograd
+_SEQUENCE_KERNELS = __import__("os").environ.get("MAPPO_GRU_SEQUENCE", "1") != "0"
 
 
 class RNNLayer(nn.Module):
@@ -69,6 +136,11 @@ class RNNLayer(nn.Module):
         finals = []
         for k in range(self._recurrent_N):
             w_ih, w_hh, b_ih, b_hh = self._layer_weights(k)
+            if fused and _SEQUENCE_KERNELS:     # K8: whole chunk through the in-place cell kernels
+                gi_all = tall_linear(layer_in.reshape(L * B, -1), w_ih, None).view(L, B, -1)
+                layer_in = _GRUSequenceFn.apply(gi_all, h0[:, k], masks, w_hh, b_ih, b_hh)
+                finals.append(layer_in[-1])
+                continue
             if fused:       # biases are added inside the fused cell
                 gi_all = tall_linear(layer_in.reshape(L * B, -1), w_ih, None).view(L, B, -1)
             else:

@@ -18,6 +18,33 @@ _MIN_ROWS = 1 << 16      # below this the library GEMM is fine
 _SLAB_ROWS = 4096        # rows per slab (R)
 
 
+def splitk_weight_grad(dy, x):
+    """dy^T @ x for tall [M, N], [M, K] matrices as a batched GEMM over row slabs + a sum over slabs."""
+    M, N = dy.shape
+    K = x.shape[1]
+    S = M // _SLAB_ROWS
+    main = S * _SLAB_ROWS
+    if S == 0:
+        return dy.t() @ x
+    dw = torch.bmm(dy[:main].view(S, _SLAB_ROWS, N).transpose(1, 2), x[:main].view(S, _SLAB_ROWS, K)).sum(0)
+    if main < M:
+        dw = dw + dy[main:].t() @ x[main:]
+    return dw
+
+
+def column_sums(dy):
+    """dy.sum(0) for a tall [M, N] matrix in two stages (slab sums, then over slabs)."""
+    M, N = dy.shape
+    S = M // _SLAB_ROWS
+    main = S * _SLAB_ROWS
+    if S == 0:
+        return dy.sum(0)
+    db = dy[:main].view(S, _SLAB_ROWS, N).sum(1).sum(0)
+    if main < M:
+        db = db + dy[main:].sum(0)
+    return db
+
+
 class _TallLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -29,22 +56,10 @@ class _TallLinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
-        M, N = dy.shape
-        K = x.shape[1]
         dx = dy @ weight if ctx.needs_input_grad[0] else None
-        S = M // _SLAB_ROWS
-        main = S * _SLAB_ROWS
-        dw = db = None
-        if ctx.needs_input_grad[1]:
-            # [S, N, R] x [S, R, K] -> [S, N, K] -> sum over slabs
-            dw = torch.bmm(dy[:main].view(S, _SLAB_ROWS, N).transpose(1, 2),
-                           x[:main].view(S, _SLAB_ROWS, K)).sum(0)
-            if main < M:
-                dw = dw + dy[main:].t() @ x[main:]
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy[:main].view(S, _SLAB_ROWS, N).sum(1).sum(0)
-            if main < M:
-                db = db + dy[main:].sum(0)
+        # [S, N, R] x [S, R, K] -> [S, N, K] -> sum over slabs
+        dw = splitk_weight_grad(dy, x) if ctx.needs_input_grad[1] else None
+        db = column_sums(dy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db
 
 

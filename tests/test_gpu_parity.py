@@ -683,8 +683,16 @@ def test_gru_layer_device_vs_cpu():
     for the rollout (one step) and the update (L-step chunks with mask resets) call shapes."""
     from onpolicy.algorithms.utils.rnn import RNNLayer
     torch.manual_seed(2)
-    H, R, L, B = 64, 1, 10, 70000
+    for H, R, L, B in [(64, 1, 10, 70000), (30, 2, 4, 1000)]:      # (30: 4-byte access path; 2 stacked layers)
+        _gru_case(RNNLayer, H, R, L, B)
+
+
+def _gru_case(RNNLayer, H, R, L, B):
     cpu = RNNLayer(H, H, R, True)
+    with torch.no_grad():
+        for name, prm in cpu.rnn.named_parameters():
+            if "bias" in name:
+                prm.normal_(0.0, 0.3)       # the reference initialises them to 0; exercise their placement
     gpu = RNNLayer(H, H, R, True).to(_dev())
     gpu.load_state_dict(cpu.state_dict())
     x = torch.randn(L * B, H)

@@ -254,7 +254,8 @@ def main():
                     "launch_ms": round(ms, 5), "launches": launches, "algorithmic_bytes": int(nbytes)}
 
         out = {
-            "metric": "env-steps/sec through GAE+ppo_update, 4096 threads×8 agents×400 steps",
+            # BASELINE.json's metric (quoted on the north star); other workloads name their own shape
+            "metric": "env-steps/sec through GAE+ppo_update, %d threads×%d agents×%d steps" % (wl["N"], wl["A"], wl["T"]),
             "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": opt.steps,
             "warmup": opt.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

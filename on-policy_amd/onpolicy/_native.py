@@ -103,6 +103,8 @@ def lib():
             fn = getattr(L, name)  # AttributeError here = header / library mismatch
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get("MAPPO_GAE_VARIANT"):      # tuning hook (tools/): kernel variant + option bits
+            L.mappo_gae_set_variant(int(os.environ["MAPPO_GAE_VARIANT"]))
         if L.mappo_abi_version() != 1:
             raise NativeError("libmappo_hip.so ABI version %d, expected 1" % L.mappo_abi_version())
         _lib = L

@@ -381,6 +381,9 @@ class R_MAPPO():
             hasattr(self.policy, "can_fold_input_norm") and self.policy.can_fold_input_norm()
         gen_kwargs = {"standardize_obs": True} if fold else {}
 
+        if hasattr(buffer, "plan_epochs"):
+            buffer.plan_epochs(self.ppo_epoch)      # lets the sampler draw the next permutation ahead
+
         keys = ('value_loss', 'policy_loss', 'dist_entropy', 'actor_grad_norm', 'critic_grad_norm', 'ratio')
         totals = torch.zeros(len(keys), dtype=torch.float32, device=self.device)
 

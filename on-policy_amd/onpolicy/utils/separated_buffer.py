@@ -90,6 +90,9 @@ class SeparatedReplayBuffer(object):
     def normalized_advantages(self, value_normalizer=None, all_reduce=None, denormalize=None):
         return self._inner.normalized_advantages(value_normalizer, all_reduce, denormalize)
 
+    def plan_epochs(self, n_epochs):
+        self._inner.plan_epochs(n_epochs)
+
     # -- samplers: 12-tuples, or 13-tuples ending in factor once update_factor() has been called
     def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None, standardize_obs=False):
         return self._inner.feed_forward_generator(self._adv(advantages), num_mini_batch, mini_batch_size,

@@ -120,7 +120,7 @@ class SharedReplayBuffer(object):
 
         self.step = 0
         self._prefetch_perms = self.device.type == "cuda" and os.environ.get("MAPPO_PREFETCH_PERM", "1") != "0"
-        self._perm_stream, self._perm_ready = None, {}
+        self._perm_stream, self._perm_ready, self._perm_plan = None, {}, 0
         # optional extra per-sample fields ([T, N, A, k] tensors) that the samplers gather after the
         # 12 standard ones (the separated buffer's HAPPO ``factor`` is one)
         self.extra_fields = {}
@@ -398,10 +398,6 @@ class SharedReplayBuffer(object):
         if self._sampler_rng == "host":
             # the reference's draw (shared_buffer.py:360,415,511): CPU generator, then upload
             return torch.randperm(n).to(self.device, non_blocking=True)
-        if not self._prefetch_perms:
-            return torch.randperm(n, device=self.device)
-        # device draw: the radix-sort passes of the NEXT permutation of this size run on a side stream
-        # while the current epoch trains, instead of in front of it (ppo_epoch permutations per train())
         cur = torch.cuda.current_stream(self.device)
         ready = self._perm_ready.pop(n, None)
         if ready is None:
@@ -410,14 +406,24 @@ class SharedReplayBuffer(object):
             perm, done = ready
             cur.wait_event(done)
             perm.record_stream(cur)
-        if self._perm_stream is None:
-            self._perm_stream = torch.cuda.Stream(device=self.device)
-        with torch.cuda.stream(self._perm_stream):
-            nxt = torch.randperm(n, device=self.device)
-            done = torch.cuda.Event()
-            done.record(self._perm_stream)
-        self._perm_ready = {n: (nxt, done)}       # at most one spare permutation is kept
+        # device draw: while more epochs are planned (plan_epochs), the radix-sort passes of the NEXT
+        # permutation run on a side stream during the current epoch instead of in front of the next one
+        self._perm_plan -= 1
+        if self._prefetch_perms and self._perm_plan > 0:
+            if self._perm_stream is None:
+                self._perm_stream = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(self._perm_stream):
+                nxt = torch.randperm(n, device=self.device)
+                done = torch.cuda.Event()
+                done.record(self._perm_stream)
+            self._perm_ready = {n: (nxt, done)}       # at most one spare permutation is kept
         return perm
+
+    def plan_epochs(self, n_epochs):
+        """The trainer announces how many sampler passes follow (``ppo_epoch``): all but the last draw
+        the next permutation ahead.  Nothing is drawn ahead without a plan, so no sort ever overlaps
+        work of the next rollout / ``compute_returns``."""
+        self._perm_plan = int(n_epochs)
 
     def _field_table(self, advantages):
         """(name, source tensor whose rows are gathered, trailing shape, first_only, adv mode)."""

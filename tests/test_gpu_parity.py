@@ -273,11 +273,13 @@ def test_gather_fused_normalisation_and_device_rng():
     assert np.array_equal(np.sort(allidx), np.arange(B))
     # later epochs use permutations that were drawn ahead on the side stream: each is a fresh, complete one
     epochs = [allidx]
+    buf.plan_epochs(3)
     for _ in range(3):
         order = torch.cat([smp[9].reshape(-1).long() for smp in buf.feed_forward_generator(handle, 4)]).cpu().numpy()
         assert np.array_equal(np.sort(order), np.arange(B))
         assert all(not np.array_equal(order, prev) for prev in epochs)
         epochs.append(order)
+    assert not buf._perm_ready                  # the last planned epoch draws nothing ahead
 
 
 def test_gather_wide_odd_rows_vs_oracle():

@@ -336,6 +336,14 @@ int mappo_gru_cell_bwd(const float* dout, const float* carry, const float* mask_
                        const float* hm, float* dgi, float* dgh, float* dhx, int64_t B, int H,
                        mappo_stream_t stream);
 
+/* mappo_gru_step_fwd: a whole forward GRU step for H = 64 (MAPPO_E_SHAPE otherwise) -- the hidden projection
+ * hm W_hh^T runs on the f32 MFMA inside the kernel with W_hh [3H, H] held in LDS, so the [B, 3H] projection
+ * never goes through HBM and no separate skinny GEMM is launched.  Same buffers and semantics as
+ * mappo_gru_cell_fwd without `gh`. */
+int mappo_gru_step_fwd(const float* gi, const float* hm, const float* w_hh, const float* b_ih, const float* b_hh,
+                       const float* mask_next, float* h_out, float* hm_next, float* ws, int64_t B, int H,
+                       mappo_stream_t stream);
+
 /* --------------------------------------------------------------------- misc ---- */
 int         mappo_abi_version(void);
 const char* mappo_build_info(void);        /* "gfx950 ..." static string */

@@ -180,3 +180,134 @@ extern "C" int mappo_gru_cell_bwd(const float* dout, const float* carry, const f
                            ws, hm, dgi, dgh, dhx, (long long)B, H);
     return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------- fused step (H = 64) ----
+// The hidden projection of a forward step is a [B, 64] x [64, 192] GEMM whose output is consumed immediately
+// by the gate arithmetic above.  As a library call this skinny GEMM runs far from any roofline (159 us for
+// 268 MB of traffic at B = 262 144) and the [B, 192] intermediate makes a round trip through HBM.  For H = 64
+// the whole forward step is one kernel: W_hh (48 KB) sits in LDS, a wave owns 32 rows, the products run on
+// the f32 MFMA (v_mfma_f32_32x32x2_f32: exact f32, k-ordered fma chain) and the gates are evaluated on the
+// accumulators.  (The mirror-image backward kernel was tried and was slower than cell kernel + library
+// GEMM: its operands are row-per-lane, so every global access touched 64 different lines; it is not kept.)
+//
+// MFMA operand maps (cdna_hip_programming.md): A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31],
+// C/D[row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)][col = lane & 31].  The two k slots of an instruction
+// are fed with k = kk and k = 32 + kk (half-wave h takes the h-th half of the reduction range), so a lane keeps
+// 32 CONTIGUOUS floats of its row as A operands.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kH = 64, kG = 192;
+
+__global__ void __launch_bounds__(256) gru_step_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ hm,
+                                                           const float* __restrict__ w_hh,
+                                                           const float* __restrict__ b_ih,
+                                                           const float* __restrict__ b_hh,
+                                                           const float* __restrict__ mask_next,
+                                                           float* __restrict__ h_out, float* __restrict__ hm_next,
+                                                           float* __restrict__ ws, long long B) {
+    __shared__ float Wl[kH * kG];  // Wl[k][j] = W_hh[j][k]
+    for (int e = threadIdx.x; e < kH * kG; e += 256) {
+        int j = e / kH, k = e - j * kH;
+        Wl[k * kG + j] = w_hh[e];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    // biases of this lane's two hidden units (c and 32 + c)
+    float bir[2], biz[2], bin[2], bhr[2], bhz[2], bhn[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        int u = 32 * s + c;
+        bir[s] = b_ih[u];
+        biz[s] = b_ih[kH + u];
+        bin[s] = b_ih[2 * kH + u];
+        bhr[s] = b_hh[u];
+        bhz[s] = b_hh[kH + u];
+        bhn[s] = b_hh[2 * kH + u];
+    }
+    const long long ntiles = (B + 31) / 32;
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+        const long long row0 = tile * 32;
+        long long rowA = row0 + c;
+        if (rowA >= B) rowA = B - 1;
+        float a[32];
+        const v4* ap = reinterpret_cast<const v4*>(hm + rowA * kH + 32 * h);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            v4 t = ap[q];
+            a[4 * q + 0] = t[0];
+            a[4 * q + 1] = t[1];
+            a[4 * q + 2] = t[2];
+            a[4 * q + 3] = t[3];
+        }
+        f32x16 acc[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            const float* wrow = Wl + (32 * h + kk) * kG + c;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], wrow[32 * t], acc[t], 0, 0, 0);
+        }
+        // gates on the accumulators: lane holds columns c and 32 + c of r | z | n for 16 rows.  All loads are
+        // issued unconditionally on clamped rows (a branch per row would serialise 16 memory round trips);
+        // only the stores are predicated.
+        float gr[16][2], gz[16][2], gn[16][2], hx[16][2], mk[16];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            long long row = row0 + (v & 3) + 8 * (v >> 2) + 4 * h;
+            if (row >= B) row = B - 1;
+            mk[v] = mask_next != nullptr ? mask_next[row] : 1.f;
+            const float* gir = gi + row * kG;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int u = 32 * s + c;
+                gr[v][s] = gir[u];
+                gz[v][s] = gir[kH + u];
+                gn[v][s] = gir[2 * kH + u];
+                hx[v][s] = hm[row * kH + u];
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const long long row = row0 + (v & 3) + 8 * (v >> 2) + 4 * h;
+            const bool ok = row < B;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int u = 32 * s + c;
+                const float rr = sigmoidf_(gr[v][s] + bir[s] + acc[s][v] + bhr[s]);
+                const float zz = sigmoidf_(gz[v][s] + biz[s] + acc[2 + s][v] + bhz[s]);
+                const float qq = acc[4 + s][v] + bhn[s];
+                const float nn = tanhf(gn[v][s] + bin[s] + rr * qq);
+                const float hh = nn + zz * (hx[v][s] - nn);
+                if (ok) {
+                    h_out[row * kH + u] = hh;
+                    if (hm_next != nullptr) hm_next[row * kH + u] = hh * mk[v];
+                    if (ws != nullptr) {
+                        float* w = ws + row * 4 * kH;
+                        w[u] = rr;
+                        w[kH + u] = zz;
+                        w[2 * kH + u] = nn;
+                        w[3 * kH + u] = qq;
+                    }
+                }
+            }
+        }
+    }
+}
+
+extern "C" int mappo_gru_step_fwd(const float* gi, const float* hm, const float* w_hh, const float* b_ih,
+                                  const float* b_hh, const float* mask_next, float* h_out, float* hm_next,
+                                  float* ws, int64_t B, int H, mappo_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!gi || !hm || !w_hh || !b_ih || !b_hh || !h_out) return MAPPO_E_NULL;
+    if (B <= 0 || H != kH) return MAPPO_E_SHAPE;
+    if (!all16({gi, hm, w_hh, h_out, hm_next, ws})) return MAPPO_E_ALIGN;
+    long long blocks = ((B + 31) / 32 + 3) / 4;
+    if (blocks > mappo::kCUs * 2) blocks = mappo::kCUs * 2;
+    hipLaunchKernelGGL(gru_step_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, gi, hm, w_hh, b_ih, b_hh,
+                       mask_next, h_out, hm_next, ws, (long long)B);
+    return (int)hipGetLastError();
+}

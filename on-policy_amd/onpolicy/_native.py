@@ -77,6 +77,7 @@ SIGNATURES = {
                                             _vp]),
     "mappo_gru_cell_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]),
     "mappo_gru_cell_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]),
+    "mappo_gru_step_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]),
     "mappo_ppo_loss_f32": (_int, [ctypes.POINTER(PPOLoss), _vp]),
     "mappo_abi_version": (_int, []),
     "mappo_build_info": (ctypes.c_char_p, []),

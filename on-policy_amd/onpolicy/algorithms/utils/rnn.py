@@ -47,14 +47,18 @@ class _GRUSequenceFn(torch.autograd.Function):
         ws_all = torch.empty(L, B, 4 * H, dtype=torch.float32, device=dev) if need_ws else None
         torch.mul(h0, masks[0], out=hm_all[0])
         w_t = w_hh.t()
+        whole_step = _FUSED_STEP and H == 64        # hidden projection on the MFMA inside the step kernel
         for t in range(L):
-            gh = torch.mm(hm_all[t], w_t)
             last = t + 1 == L
-            _native.check(lib.mappo_gru_cell_fwd(p(gi_all[t]), p(gh), p(hm_all[t]), p(b_ih), p(b_hh),
-                                                 None if last else p(masks[t + 1]), p(out[t]),
-                                                 None if last else p(hm_all[t + 1]),
-                                                 p(ws_all[t]) if need_ws else None, B, H, stream),
-                          "mappo_gru_cell_fwd")
+            nxt = (None, None) if last else (p(masks[t + 1]), p(hm_all[t + 1]))
+            wst = p(ws_all[t]) if need_ws else None
+            if whole_step:
+                _native.check(lib.mappo_gru_step_fwd(p(gi_all[t]), p(hm_all[t]), p(w_hh), p(b_ih), p(b_hh), nxt[0],
+                                                     p(out[t]), nxt[1], wst, B, H, stream), "mappo_gru_step_fwd")
+            else:
+                gh = torch.mm(hm_all[t], w_t)
+                _native.check(lib.mappo_gru_cell_fwd(p(gi_all[t]), p(gh), p(hm_all[t]), p(b_ih), p(b_hh), nxt[0],
+                                                     p(out[t]), nxt[1], wst, B, H, stream), "mappo_gru_cell_fwd")
         if need_ws:
             ctx.save_for_backward(hm_all, masks, w_hh, ws_all)
         return out
@@ -73,10 +77,10 @@ class _GRUSequenceFn(torch.autograd.Function):
         dhx = torch.empty(B, H, dtype=torch.float32, device=dev)
         carry = None
         for t in range(L - 1, -1, -1):
-            last = t + 1 == L
-            _native.check(lib.mappo_gru_cell_bwd(p(dout[t]), p(carry), None if last else p(masks[t + 1]),
-                                                 p(ws_all[t]), p(hm_all[t]), p(dgi_all[t]), p(dgh_all[t]), p(dhx),
-                                                 B, H, stream), "mappo_gru_cell_bwd")
+            mk = None if t + 1 == L else p(masks[t + 1])
+            _native.check(lib.mappo_gru_cell_bwd(p(dout[t]), p(carry), mk, p(ws_all[t]), p(hm_all[t]),
+                                                 p(dgi_all[t]), p(dgh_all[t]), p(dhx), B, H, stream),
+                          "mappo_gru_cell_bwd")
             carry = torch.addmm(dhx, dgh_all[t], w_hh)            # d loss / d hm[t]
         dh0 = carry * masks[0] if ctx.needs_input_grad[1] else None
         flat_gh = dgh_all.view(L * B, 3 * H)
@@ -88,6 +92,9 @@ class _GRUSequenceFn(torch.autograd.Function):
 
 # MAPPO_GRU_SEQUENCE=0 falls back to aten::_thnn_fused_gru_cell driven step by step through autograd
 _SEQUENCE_KERNELS = __import__("os").environ.get("MAPPO_GRU_SEQUENCE", "1") != "0"
+# MAPPO_GRU_FUSED_STEP=0 keeps the forward hidden projection a library GEMM next to the K8 cell kernel
+# (default for H = 64: one kernel per step with the projection on the f32 MFMA)
+_FUSED_STEP = __import__("os").environ.get("MAPPO_GRU_FUSED_STEP", "1") != "0"
 
 
 class RNNLayer(nn.Module):

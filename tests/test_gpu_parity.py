@@ -685,8 +685,15 @@ def test_gru_layer_device_vs_cpu():
     for the rollout (one step) and the update (L-step chunks with mask resets) call shapes."""
     from onpolicy.algorithms.utils.rnn import RNNLayer
     torch.manual_seed(2)
+    from onpolicy.algorithms.utils import rnn as rnn_mod
     for H, R, L, B in [(64, 1, 10, 70000), (30, 2, 4, 1000)]:      # (30: 4-byte access path; 2 stacked layers)
         _gru_case(RNNLayer, H, R, L, B)
+    # H = 64 takes the one-kernel forward step (MFMA hidden projection); check the cell-kernel + GEMM form too
+    old, rnn_mod._FUSED_STEP = rnn_mod._FUSED_STEP, False
+    try:
+        _gru_case(RNNLayer, 64, 1, 5, 33333)
+    finally:
+        rnn_mod._FUSED_STEP = old
 
 
 def _gru_case(RNNLayer, H, R, L, B):

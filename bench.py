@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s
 
 WORKLOADS = {
     # north star: simple_spread generalised to 8 agents, flags of train_mpe_spread.sh
-    "ns": dict(T=400, N=4096, A=8, Do=48, Ds=384, na=5, cpu_sample_N=64,
+    "ns": dict(T=400, N=4096, A=8, Do=48, Ds=384, na=5, cpu_sample_N=128,
                flags=["--algorithm_name", "mappo", "--hidden_size", "64", "--layer_N", "1", "--use_ReLU",
                       "--ppo_epoch", "10", "--num_mini_batch", "1", "--lr", "7e-4", "--critic_lr", "7e-4",
                       "--gain", "0.01"],

@@ -85,8 +85,12 @@ class _GRUSequenceFn(torch.autograd.Function):
         dh0 = carry * masks[0] if ctx.needs_input_grad[1] else None
         flat_gh = dgh_all.view(L * B, 3 * H)
         dw = splitk_weight_grad(flat_gh, hm_all.view(L * B, H)) if ctx.needs_input_grad[3] else None
-        db_ih = column_sums(dgi_all.view(L * B, 3 * H)) if ctx.needs_input_grad[4] else None
-        db_hh = column_sums(flat_gh) if ctx.needs_input_grad[5] else None
+        # the r and z thirds of dgh equal those of dgi, so their bias gradients are shared; only the n third
+        # (dn * r instead of dn) needs its own column sums
+        db_ih = db_hh = None
+        if ctx.needs_input_grad[4] or ctx.needs_input_grad[5]:
+            db_ih = column_sums(dgi_all.view(L * B, 3 * H))
+            db_hh = torch.cat([db_ih[:2 * H], column_sums(flat_gh[:, 2 * H:])])
         return dgi_all, dh0, None, dw, db_ih, db_hh
 
 

@@ -39,7 +39,7 @@ def column_sums(dy):
     main = S * _SLAB_ROWS
     if S == 0:
         return dy.sum(0)
-    db = dy[:main].view(S, _SLAB_ROWS, N).sum(1).sum(0)
+    db = dy[:main].unflatten(0, (S, _SLAB_ROWS)).sum(1).sum(0)      # also for column slices (strided rows)
     if main < M:
         db = db + dy[main:].sum(0)
     return db

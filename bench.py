@@ -165,6 +165,8 @@ def main():
     ap.add_argument("--threads", type=int, default=None, help="override the global n_rollout_threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sampler-rng", default="device", choices=["device", "host"])
+    ap.add_argument("--no-gemm-tuning", action="store_true",
+                    help="leave GEMM kernel selection to the library heuristic (onpolicy/utils/gemm_tuning.py)")
     opt = ap.parse_args()
 
     wl = dict(WORKLOADS[opt.workload])
@@ -199,6 +201,8 @@ def main():
     buf = SharedReplayBuffer(args, wl["A"], *spaces, device=dev)
     next_value = fill_synthetic(buf, wl, seed=1234 + rank)
     trainer.prep_training()
+    from onpolicy.utils import gemm_tuning
+    tuned = (not opt.no_gemm_tuning) and gemm_tuning.enable()
 
     def step():
         buf.compute_returns(next_value, trainer.value_normalizer)
@@ -212,6 +216,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if tuned:
+        step()      # untimed: any GEMM shape without a stored winner is tuned here, never in the timed region
     for _ in range(opt.warmup):
         step()
     buf.profile_kernels(True)
@@ -262,7 +268,7 @@ def main():
             "config": {"workload": wl["label"], "T": wl["T"], "n_rollout_threads": wl["N"],
                        "threads_per_gpu": n_local, "agents": wl["A"], "obs_dim": wl["Do"],
                        "share_obs_dim": wl["Ds"], "actions": wl["na"], "ppo_epoch": args.ppo_epoch,
-                       "num_mini_batch": args.num_mini_batch, "sampler_rng": opt.sampler_rng,
+                       "num_mini_batch": args.num_mini_batch, "gemm_tuning": bool(tuned), "sampler_rng": opt.sampler_rng,
                        "parallelism": "dp%d over rollout threads" % world},
             "roofline": roof("mappo_gae_f32"),
             "roofline_gather": roof("mappo_gather_chunks" if wl["recurrent"] else "mappo_gather_rows"),

@@ -73,6 +73,9 @@ def main(args):
     except Exception:
         pass
 
+    from onpolicy.utils import gemm_tuning
+    gemm_tuning.enable()          # best GEMM kernel per shape (PyTorch TunableOp), winners cached per user
+
     torch.manual_seed(all_args.seed)
     torch.cuda.manual_seed_all(all_args.seed)
     np.random.seed(all_args.seed)

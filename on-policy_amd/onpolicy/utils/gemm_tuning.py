@@ -1,0 +1,42 @@
+"""GEMM kernel selection for the tall, skinny matrix products of the MAPPO update.
+
+The Linear layers of the actor / critic see [10^6..10^7, 48..384] x [.., 64] products.  PyTorch-ROCm's default
+pick (hipBLASLt's heuristic) is 15-35 % slower on these shapes than the best kernel the two BLAS libraries
+offer (e.g. 1151 -> 925 us for the 384 -> 64 critic layer at 2.6 M rows, 358 -> 243 us for the 64 -> 64 layers).
+PyTorch's own TunableOp benchmarks the candidates the first time a shape is seen and remembers the winner;
+this module switches it on, pre-loads the winners for the shapes of the shipped workloads
+(``tuned_gemms_gfx950.csv``: north star at 1 / 2 / 4 / 8 GPUs, SMAC, Hanabi shapes) so that no tuning is needed
+for them, and keeps whatever gets tuned later in a per-user cache file (one per device ordinal).
+
+The maths is unchanged (float32 GEMMs; only the tile configuration / summation order differs).
+``MAPPO_GEMM_TUNING=0`` disables it; ``MAPPO_GEMM_TUNING_CACHE`` moves the cache directory.
+"""
+import os
+import tempfile
+
+import torch
+
+SHIPPED = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tuned_gemms_gfx950.csv")
+
+
+def enable(tune_new=True):
+    """Turn TunableOp on for this process.  -> True if it is active."""
+    if os.environ.get("MAPPO_GEMM_TUNING", "1") == "0" or not torch.cuda.is_available():
+        return False
+    t = torch.cuda.tunable
+    t.enable(True)
+    t.tuning_enable(bool(tune_new))
+    t.set_max_tuning_duration(30)        # ms per candidate
+    t.set_max_tuning_iterations(5)
+    cache = os.environ.get("MAPPO_GEMM_TUNING_CACHE") or os.path.join(tempfile.gettempdir(), "mappo_amd_gemm_tuning")
+    os.makedirs(cache, exist_ok=True)
+    t.set_filename(os.path.join(cache, "tunableop_results.csv"), insert_device_ordinal=True)
+    for path in (SHIPPED, t.get_filename()):
+        if os.path.exists(path):
+            t.read_file(path)            # ignored (with a warning) if it was made by other library versions
+    return True
+
+
+def results():
+    """The (op, shape, solution, time) tuples TunableOp currently holds."""
+    return torch.cuda.tunable.get_results() if torch.cuda.is_available() else ()

@@ -18,7 +18,9 @@ def _run(extra_env=None, args=()):
     env.update(extra_env or {})
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--threads", "64", "--steps", "1",
-                          "--warmup", "1", "--no-cpu-baseline", "--sampler-rng", "host"] + list(args),
+                          "--warmup", "1", "--no-cpu-baseline", "--sampler-rng", "host"]
+                         + ([] if "--gemm-tuning" in args else ["--no-gemm-tuning"])
+                         + [a for a in args if a != "--gemm-tuning"],
                          capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -93,3 +95,24 @@ def test_two_rank_device_update_equals_single_process(tmp_path, args_over):
         assert ranks[0]["info"][k] == pytest.approx(info[k], rel=1e-3, abs=1e-6)
     for k in ("value_loss", "policy_loss", "dist_entropy", "ratio"):     # mean over ranks of per-rank means
         assert ranks[0]["info"][k] == pytest.approx(ranks[1]["info"][k], rel=1e-6, abs=1e-9)
+
+
+def test_gemm_tuning_preloads_shipped_winners(tmp_path):
+    """onpolicy.utils.gemm_tuning: TunableOp comes up with the shipped winners for the bench shapes loaded (no
+    tuning needed for them), and a bench run with it reports gemm_tuning = true."""
+    import torch
+    from onpolicy.utils import gemm_tuning
+    assert os.path.exists(gemm_tuning.SHIPPED)
+    os.environ["MAPPO_GEMM_TUNING_CACHE"] = str(tmp_path)
+    try:
+        assert gemm_tuning.enable(tune_new=False)
+        keys = {r[1] for r in gemm_tuning.results()}
+        assert "tn_64_2621440_384_ld_384_384_64" in keys          # critic 384 -> 64 layer at the north-star span
+        a = torch.randn(4096, 64, device="cuda")
+        w = torch.randn(64, 64, device="cuda")
+        torch.testing.assert_close(a @ w, (a.double() @ w.double()).float(), rtol=1e-4, atol=1e-4)
+    finally:
+        torch.cuda.tunable.enable(False)
+        os.environ.pop("MAPPO_GEMM_TUNING_CACHE", None)
+    out = _run({"MAPPO_GEMM_TUNING_CACHE": str(tmp_path)}, args=("--gemm-tuning",))
+    assert out["config"]["gemm_tuning"] is True

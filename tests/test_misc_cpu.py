@@ -98,3 +98,18 @@ def test_action_heads_shapes_and_consistency(space, act_dim):
     probs = layer.get_probs(x) if space.__class__.__name__ != "Box" else None
     if space.__class__.__name__ == "Discrete":
         torch.testing.assert_close(probs.sum(-1), torch.ones(10), rtol=1e-5, atol=1e-6)
+
+
+def test_gemm_tuning_is_a_no_op_without_a_gpu(monkeypatch):
+    """onpolicy.utils.gemm_tuning.enable() must not touch anything on a CPU-only host, honours its off switch,
+    and the shipped winners file is a TunableOp CSV for gfx950."""
+    import torch
+    from onpolicy.utils import gemm_tuning
+    if not torch.cuda.is_available():
+        assert gemm_tuning.enable() is False
+        assert tuple(gemm_tuning.results()) == ()
+    monkeypatch.setenv("MAPPO_GEMM_TUNING", "0")
+    assert gemm_tuning.enable() is False
+    lines = open(gemm_tuning.SHIPPED).read().splitlines()
+    assert lines[0].startswith("Validator,PT_VERSION") and any("gfx950" in l for l in lines[:6])
+    assert sum(l.startswith("Gemm") for l in lines) > 50

@@ -47,7 +47,9 @@ class _GRUSequenceFn(torch.autograd.Function):
         ws_all = torch.empty(L, B, 4 * H, dtype=torch.float32, device=dev) if need_ws else None
         torch.mul(h0, masks[0], out=hm_all[0])
         w_t = w_hh.t()
-        whole_step = _FUSED_STEP and H == 64        # hidden projection on the MFMA inside the step kernel
+        # hidden projection on the MFMA inside the step kernel: measured ahead of (tuned) library GEMM + cell kernel
+        # from ~130 k rows per step upwards (1397 vs 1441 ms on ns_rnn at 262 k rows; 132 vs 128 ms on smac at 102 k)
+        whole_step = _FUSED_STEP and H == 64 and B >= _FUSED_STEP_MIN_ROWS
         for t in range(L):
             last = t + 1 == L
             nxt = (None, None) if last else (p(masks[t + 1]), p(hm_all[t + 1]))
@@ -99,6 +101,7 @@ _SEQUENCE_KERNELS = __import__("os").environ.get("MAPPO_GRU_SEQUENCE", "1") != "
 # MAPPO_GRU_FUSED_STEP=0 keeps the forward hidden projection a library GEMM next to the K8 cell kernel
 # (default for H = 64: one kernel per step with the projection on the f32 MFMA)
 _FUSED_STEP = __import__("os").environ.get("MAPPO_GRU_FUSED_STEP", "1") != "0"
+_FUSED_STEP_MIN_ROWS = 1 << 17
 
 
 class RNNLayer(nn.Module):

@@ -686,14 +686,15 @@ def test_gru_layer_device_vs_cpu():
     from onpolicy.algorithms.utils.rnn import RNNLayer
     torch.manual_seed(2)
     from onpolicy.algorithms.utils import rnn as rnn_mod
-    for H, R, L, B in [(64, 1, 10, 70000), (30, 2, 4, 1000)]:      # (30: 4-byte access path; 2 stacked layers)
+    for H, R, L, B in [(64, 1, 6, 140001), (30, 2, 4, 1000)]:      # (64 at > 131 k rows: one-kernel forward step; 30: 4-byte path, 2 layers)
         _gru_case(RNNLayer, H, R, L, B)
-    # H = 64 takes the one-kernel forward step (MFMA hidden projection); check the cell-kernel + GEMM form too
-    old, rnn_mod._FUSED_STEP = rnn_mod._FUSED_STEP, False
+    # below the row threshold H = 64 runs cell kernel + library GEMM; also force the one-kernel step on few rows
+    _gru_case(RNNLayer, 64, 1, 5, 33333)
+    old, rnn_mod._FUSED_STEP_MIN_ROWS = rnn_mod._FUSED_STEP_MIN_ROWS, 0
     try:
-        _gru_case(RNNLayer, 64, 1, 5, 33333)
+        _gru_case(RNNLayer, 64, 1, 3, 1001)
     finally:
-        rnn_mod._FUSED_STEP = old
+        rnn_mod._FUSED_STEP_MIN_ROWS = old
 
 
 def _gru_case(RNNLayer, H, R, L, B):

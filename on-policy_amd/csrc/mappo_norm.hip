@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(kThreads) ln_fwd_kernel(const float* __restric
             int u = lane + e * LPR;
             xv[e] = U(0.f);
             if (u < units) {
-                xv[e] = xr[u];
+                xv[e] = __builtin_nontemporal_load(xr + u);
 #pragma unroll
                 for (int k = 0; k < VEC; ++k)
                     set_elem<VEC>(xv[e], k, act_fwd<ACT>(elem<VEC>(xv[e], k) + elem<VEC>(pv[e], k)));
@@ -254,8 +254,8 @@ __global__ void __launch_bounds__(kThreads) ln_bwd_kernel(const float* __restric
             gv[e] = U(0.f);
             ag[e] = U(1.f);
             if (u < units) {
-                U xv = xr[u];
-                U dv = gr[u];
+                U xv = __builtin_nontemporal_load(xr + u);
+                U dv = __builtin_nontemporal_load(gr + u);
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
                     float zin = elem<VEC>(xv, k) + elem<VEC>(pv[e], k);

@@ -28,6 +28,18 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _gemm_tuning_stays_local(monkeypatch):
+    """The train scripts switch PyTorch's GEMM autotuner on (onpolicy/utils/gemm_tuning.py); in the test session
+    that would tune every small shape of every later test.  Tests that want it set MAPPO_GEMM_TUNING=1
+    themselves; whatever a test enabled is switched off again afterwards."""
+    monkeypatch.setenv("MAPPO_GEMM_TUNING", os.environ.get("MAPPO_TEST_GEMM_TUNING", "0"))
+    yield
+    import torch
+    if torch.cuda.is_available() and torch.cuda.tunable.is_enabled():
+        torch.cuda.tunable.enable(False)
+
+
 @pytest.fixture(scope="session")
 def gold():
     class G(object):

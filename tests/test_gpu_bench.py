@@ -104,6 +104,7 @@ def test_gemm_tuning_preloads_shipped_winners(tmp_path):
     from onpolicy.utils import gemm_tuning
     assert os.path.exists(gemm_tuning.SHIPPED)
     os.environ["MAPPO_GEMM_TUNING_CACHE"] = str(tmp_path)
+    os.environ["MAPPO_GEMM_TUNING"] = "1"        # the session default for tests is off (conftest.py)
     try:
         assert gemm_tuning.enable(tune_new=False)
         keys = {r[1] for r in gemm_tuning.results()}
@@ -114,5 +115,5 @@ def test_gemm_tuning_preloads_shipped_winners(tmp_path):
     finally:
         torch.cuda.tunable.enable(False)
         os.environ.pop("MAPPO_GEMM_TUNING_CACHE", None)
-    out = _run({"MAPPO_GEMM_TUNING_CACHE": str(tmp_path)}, args=("--gemm-tuning",))
+    out = _run({"MAPPO_GEMM_TUNING_CACHE": str(tmp_path), "MAPPO_GEMM_TUNING": "1"}, args=("--gemm-tuning",))
     assert out["config"]["gemm_tuning"] is True

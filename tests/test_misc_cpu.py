@@ -105,6 +105,7 @@ def test_gemm_tuning_is_a_no_op_without_a_gpu(monkeypatch):
     and the shipped winners file is a TunableOp CSV for gfx950."""
     import torch
     from onpolicy.utils import gemm_tuning
+    monkeypatch.setenv("MAPPO_GEMM_TUNING", "1")
     if not torch.cuda.is_available():
         assert gemm_tuning.enable() is False
         assert tuple(gemm_tuning.results()) == ()

@@ -190,3 +190,49 @@ def test_football_runner(tmp_path, recurrent):
     lines = [json.loads(l) for l in open(os.path.join(runner.log_dir, "scalars.jsonl"))]
     tags = {r["tag"] for r in lines}
     assert {"value_loss", "goal", "win_rate", "eval_goal", "eval_win_rate", "eval_step"} <= tags
+
+
+@pytest.mark.parametrize("kind", ["Box", "MultiDiscrete", "MultiBinary"])
+def test_other_action_spaces_on_the_device_buffer(kind):
+    """Non-Discrete action heads (continuous, multi-discrete, multi-binary; reference utils/act.py:10-42,
+    utils/util.py:40-52 for the stored action width): rollout actions go into the HBM buffer with the right
+    width, there is no availability mask, and the update takes the framework loss path (the fused loss is for
+    Discrete heads) through compute_returns / the samplers / train."""
+    from helpers import Box
+    from test_misc_cpu import _MultiDiscrete, _MultiBinary
+    from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy
+    from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO
+    from onpolicy.utils.shared_buffer import SharedReplayBuffer
+    space, width = {"Box": (Box((3,)), 3), "MultiDiscrete": (_MultiDiscrete([3, 4]), 2),
+                    "MultiBinary": (_MultiBinary(4), 4)}[kind]
+    T, N, A, Do, Ds = 6, 5, 2, 7, 14
+    dev = torch.device("cuda", 0)
+    args = make_args(episode_length=T, n_rollout_threads=N, hidden_size=16, ppo_epoch=2, num_mini_batch=2)
+    torch.manual_seed(3)
+    policy = R_MAPPOPolicy(args, Box((Do,)), Box((Ds,)), space, device=dev)
+    trainer = R_MAPPO(args, policy, device=dev)
+    assert not trainer._fused_loss
+    buf = SharedReplayBuffer(args, A, Box((Do,)), Box((Ds,)), space, device=dev)
+    assert buf.available_actions is None and tuple(buf.actions.shape) == (T, N, A, width)
+    rng = np.random.default_rng(0)
+    buf.obs[0] = torch.as_tensor(rng.standard_normal((N, A, Do)), dtype=torch.float32)
+    buf.share_obs[0] = torch.as_tensor(rng.standard_normal((N, A, Ds)), dtype=torch.float32)
+    trainer.prep_rollout()
+    flat = lambda x: x.reshape(N * A, *x.shape[2:])
+    for step in range(T):
+        with torch.no_grad():
+            v, a, lp, ha, hc = policy.get_actions(flat(buf.share_obs[step]), flat(buf.obs[step]),
+                                                  flat(buf.rnn_states[step]), flat(buf.rnn_states_critic[step]),
+                                                  flat(buf.masks[step]))
+        per_env = lambda x: x.reshape(N, A, *x.shape[1:])
+        buf.insert(rng.standard_normal((N, A, Ds)).astype(np.float32), rng.standard_normal((N, A, Do)).astype(np.float32),
+                   per_env(ha), per_env(hc), per_env(a), per_env(lp), per_env(v),
+                   rng.standard_normal((N, A, 1)).astype(np.float32), np.ones((N, A, 1), np.float32))
+    with torch.no_grad():
+        nv = policy.get_values(flat(buf.share_obs[-1]), flat(buf.rnn_states_critic[-1]), flat(buf.masks[-1]))
+    buf.compute_returns(nv.reshape(N, A, 1), trainer.value_normalizer)
+    trainer.prep_training()
+    info = trainer.train(buf)
+    assert all(np.isfinite(v) for v in info.values()), info
+    sample = next(iter(buf.feed_forward_generator(None, 2)))
+    assert sample[11] is None and tuple(sample[4].shape) == (T * N * A // 2, width)

@@ -208,6 +208,10 @@ class SharedReplayBuffer(object):
         keep, slabs = [], []
         for dst, value in pairs:
             src = self._dev(value)
+            if src.numel() != dst.numel() and src.numel() * dst.shape[-1] == dst.numel():
+                # numpy assignment semantics of the reference (shared_buffer.py:107-121): a [.., 1] value is
+                # broadcast over the last axis, e.g. the summed log-prob of a continuous action over act_dim
+                src = src.reshape(*dst.shape[:-1], 1).expand(dst.shape).contiguous()
             if src.numel() != dst.numel():
                 raise ValueError("cannot write %d elements into a buffer slab of %d (shape %s)"
                                  % (src.numel(), dst.numel(), tuple(dst.shape)))

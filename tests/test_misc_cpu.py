@@ -114,3 +114,19 @@ def test_gemm_tuning_is_a_no_op_without_a_gpu(monkeypatch):
     lines = open(gemm_tuning.SHIPPED).read().splitlines()
     assert lines[0].startswith("Validator,PT_VERSION") and any("gfx950" in l for l in lines[:6])
     assert sum(l.startswith("Gemm") for l in lines) > 50
+
+
+def test_multi_discrete_space_drives_the_action_head():
+    """onpolicy.utils.multi_discrete.MultiDiscrete (reference utils/multi_discrete.py) is recognised by name by the
+    action head and the shape helpers."""
+    from onpolicy.utils.multi_discrete import MultiDiscrete
+    from onpolicy.utils.util import get_shape_from_act_space
+    space = MultiDiscrete([[0, 4], [0, 1], [0, 2]])
+    assert space.shape == 3 and space.n == 9 and space.contains([4, 1, 2]) and not space.contains([5, 0, 0])
+    np.random.seed(0)
+    assert all(space.contains(space.sample()) for _ in range(50))
+    assert get_shape_from_act_space(space) == 3
+    layer = ACTLayer(space, 8, True, 0.01)
+    actions, logp = layer(torch.randn(6, 8))
+    assert actions.shape == (6, 3) and logp.shape == (6, 3)
+    assert bool((actions[:, 0] <= 4).all()) and bool((actions[:, 1] <= 1).all()) and bool((actions[:, 2] <= 2).all())

@@ -26,7 +26,8 @@ _AGENT_SIZE = 0.15
 
 
 class VecSimpleSpread(object):
-    def __init__(self, n_threads, num_agents=3, num_landmarks=None, episode_length=25, seed=1):
+    def __init__(self, n_threads, num_agents=3, num_landmarks=None, episode_length=25, seed=1, auto_reset=True):
+        self.auto_reset = auto_reset      # finished worlds restart inside step(), as the vec-env workers do
         self.n, self.a = int(n_threads), int(num_agents)
         self.l = int(num_landmarks) if num_landmarks is not None else self.a
         self.world_length = int(episode_length)
@@ -96,7 +97,8 @@ class VecSimpleSpread(object):
         done_env = self.t >= self.world_length
         dones = np.repeat(done_env[:, None], self.a, 1)
         infos = [[{"individual_reward": float(per_agent[i, j])} for j in range(self.a)] for i in range(self.n)]
-        self._reset_worlds(done_env)                                           # auto-reset like the vec-env workers
+        if self.auto_reset:
+            self._reset_worlds(done_env)
         return self._obs(), rewards, dones, infos
 
     def close(self):

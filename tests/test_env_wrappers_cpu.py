@@ -91,15 +91,62 @@ def test_external_env_tree_is_a_fallback(tmp_path, monkeypatch):
     ext = tmp_path / "envs"
     (ext / "starcraft2").mkdir(parents=True)
     (ext / "starcraft2" / "__init__.py").write_text("NAME = 'external smac'\n")
-    (ext / "mpe").mkdir()
-    (ext / "mpe" / "MPE_env.py").write_text("def MPEEnv(args):\n    return 'external mpe'\n")
+    # an external MPE tree in the reference's layout: scenarios.load(name).Scenario + environment.MultiAgentEnv
+    (ext / "mpe" / "scenarios").mkdir(parents=True)
+    (ext / "mpe" / "scenarios" / "__init__.py").write_text(
+        "import types\n"
+        "def load(name):\n"
+        "    m = types.SimpleNamespace()\n"
+        "    class Scenario:\n"
+        "        def make_world(self, args): return 'world of ' + name\n"
+        "        reset_world = reward = observation = info = None\n"
+        "    m.Scenario = Scenario\n"
+        "    return m\n")
+    (ext / "mpe" / "environment.py").write_text(
+        "def MultiAgentEnv(world, *callbacks):\n    return 'external env: ' + world\n")
     (ext / "env_wrappers.py").write_text("raise RuntimeError('must not shadow the package module')\n")
-    code = ("import onpolicy.envs.starcraft2 as s, onpolicy.envs.env_wrappers as w, onpolicy.envs.mpe.MPE_env as m, "
-            "onpolicy.envs.mpe.simple_spread as ss; print(s.NAME, m.MPEEnv(None), hasattr(w, 'DummyVecEnv'), "
-            "hasattr(ss, 'VecSimpleSpread'))")
+    code = ("import types, onpolicy.envs.starcraft2 as s, onpolicy.envs.env_wrappers as w, onpolicy.envs.mpe.MPE_env as m, "
+            "onpolicy.envs.mpe.simple_spread as ss; a = types.SimpleNamespace(scenario_name='simple_reference'); "
+            "print(s.NAME, '|', m.MPEEnv(a), '|', hasattr(w, 'DummyVecEnv'), hasattr(ss, 'VecSimpleSpread'))")
     import os
     from conftest import ROOT
     env = dict(os.environ, MAPPO_ENVS_PATH=str(ext), PYTHONPATH=os.path.join(str(ROOT), "on-policy_amd"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=str(ROOT))
     assert out.returncode == 0, out.stderr[-1500:]
-    assert out.stdout.strip() == "external smac external mpe True True"
+    assert out.stdout.strip() == "external smac | external env: world of simple_reference.py | True True"
+
+
+def test_mpe_env_factory_with_vec_wrappers():
+    """MPEEnv(args) single worlds behind DummyVecEnv / SubprocVecEnv give the [N, A, .] batches the MPE runner
+    expects and restart after episode_length steps; same seeds => same trajectories in both wrappers."""
+    from types import SimpleNamespace
+    from onpolicy.envs.mpe.MPE_env import MPEEnv
+    args = SimpleNamespace(scenario_name="simple_spread", num_agents=3, num_landmarks=3, episode_length=4)
+
+    def make(rank):
+        def init():
+            env = MPEEnv(args)
+            env.seed(100 + rank)
+            return env
+        return init
+    n = 3
+    dummy, sub = W.DummyVecEnv([make(i) for i in range(n)]), W.SubprocVecEnv([make(i) for i in range(n)])
+    try:
+        o1, o2 = dummy.reset(), sub.reset()
+        assert o1.shape == (n, 3, 18) and o1.dtype == np.float32
+        np.testing.assert_array_equal(o1, o2)
+        rng = np.random.default_rng(0)
+        for t in range(1, 7):
+            act = np.eye(5)[rng.integers(0, 5, (n, 3))]
+            r1, r2 = dummy.step(act), sub.step(act)
+            obs, rew, done, info = r1
+            assert obs.shape == (n, 3, 18) and rew.shape == (n, 3, 1) and done.shape == (n, 3)
+            assert bool(done.all()) == (t == 4)                 # episode_length 4, then a fresh episode
+            for a, b in zip(r1[:3], r2[:3]):
+                np.testing.assert_array_equal(a, b)
+            assert "individual_reward" in info[0][0]
+    finally:
+        dummy.close()
+        sub.close()
+    with pytest.raises(NotImplementedError):
+        MPEEnv(SimpleNamespace(scenario_name="simple_reference", num_agents=2, episode_length=4))

@@ -414,12 +414,28 @@ class OracleSeparatedBuffer(object):
     def update_factor(self, factor):                                    # :62-63
         self.factor = np.array(factor, dtype=np.float32)
 
-    def insert(self, *a, **k):
-        self._inner.insert(*[None if x is None else np.asarray(x)[:, None] for x in a],
-                           **{n: None if x is None else np.asarray(x)[:, None] for n, x in k.items()})
+    @property
+    def step(self):
+        return self._inner.step
 
-    def after_update(self):
+    @staticmethod
+    def _with_agent_axis(a, k):
+        lift = lambda x: None if x is None else np.asarray(x)[:, None]
+        return [lift(x) for x in a], {n: lift(x) for n, x in k.items()}
+
+    def insert(self, *a, **k):                                          # :65-83
+        a, k = self._with_agent_axis(a, k)
+        self._inner.insert(*a, **k)
+
+    def chooseinsert(self, *a, **k):                                    # :85-103
+        a, k = self._with_agent_axis(a, k)
+        self._inner.chooseinsert(*a, **k)
+
+    def after_update(self):                                             # :105-114
         self._inner.after_update()
+
+    def chooseafter_update(self):                                       # :116-120
+        self._inner.chooseafter_update()
 
     def compute_returns(self, next_value, value_normalizer=None):       # :122-167
         b = self._inner

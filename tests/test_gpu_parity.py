@@ -731,3 +731,23 @@ def _gru_case(RNNLayer, H, R, L, B):
         b = gpu(xr.to(_dev()), hr.to(_dev()), mr.to(_dev()))
     torch.testing.assert_close(b[0].cpu(), a[0], rtol=1e-4, atol=2e-5)
     torch.testing.assert_close(b[1].cpu(), a[1], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("kind,mode", [("shared", "insert"), ("shared", "chooseinsert"), ("separated", "insert"),
+                                       ("separated", "chooseinsert")])
+def test_storage_vs_reference_fixtures(gold, kind, mode):
+    """insert / chooseinsert / after_update / chooseafter_update through the slab kernel (K2) against the contents
+    the reference's own buffers hold after the same seeded stream (oracle/make_golden_storage.py)."""
+    from storage_replay import FIELDS as STORED, replay
+    z = gold.npz("storage_cases")
+    T, N, A, Do, Ds, na, H = [int(x) for x in z["dims"]]
+    args = make_args(episode_length=T, n_rollout_threads=N, hidden_size=H, use_recurrent_policy=True)
+    if kind == "shared":
+        buf, lead = _buffer(args, A, Do=Do, Ds=Ds, na=na), (N, A)
+    else:
+        from onpolicy.utils.separated_buffer import SeparatedReplayBuffer
+        buf, lead = SeparatedReplayBuffer(args, Box((Do,)), Box((Ds,)), Discrete(na), device=_dev()), (N,)
+    replay(buf, mode, lead, z["dims"])
+    assert buf.step == int(z["%s_%s_step" % (kind, mode)])
+    for name in STORED:
+        np.testing.assert_array_equal(getattr(buf, name).cpu().numpy(), z["%s_%s_%s" % (kind, mode, name)], err_msg=name)

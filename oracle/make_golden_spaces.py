@@ -36,7 +36,9 @@ class MultiBinary(object):
 
 # (MultiBinary is not generated: the reference's ACTLayer passes available_actions to Bernoulli.forward, act.py:87,
 # which takes no such argument -- its rollout path raises TypeError)
-SPACES = {"box": lambda: mg.Box((3,)), "multidiscrete": lambda: MultiDiscrete([[0, 2], [0, 3]])}
+SPACES = {"box": lambda: mg.Box((3,)), "multidiscrete": lambda: MultiDiscrete([[0, 2], [0, 3]]),
+          # image observations: CNNBase trunk (algorithms/utils/cnn.py) for actor and critic, Discrete head
+          "cnn": lambda: mg.Discrete(4)}
 BUF = ("share_obs", "obs", "rnn_states", "rnn_states_critic", "actions", "value_preds", "masks", "bad_masks",
        "active_masks", "action_log_probs", "rewards")
 
@@ -48,7 +50,8 @@ def main():
         args = mg.make_args(episode_length=T, n_rollout_threads=N, hidden_size=16, layer_N=1, ppo_epoch=2,
                             num_mini_batch=2, algorithm_name="mappo")
         act_space = make_space()
-        spaces = mg.Box((Do,)), mg.Box((Ds,)), act_space
+        spaces = (mg.Box((Do,)), mg.Box((Ds,)), act_space) if cname != "cnn" else \
+            (mg.Box((3, 9, 9)), mg.Box((3, 9, 9)), act_space)
         torch.manual_seed(1)
         np.random.seed(1)
         policy = ref.R_MAPPOPolicy(args, *spaces)
@@ -58,7 +61,7 @@ def main():
         _sd(key + "init_critic.", policy.critic, out)
         rng = np.random.default_rng(99)
         buf = ref.SharedReplayBuffer(args, A, *spaces)
-        assert buf.available_actions is None
+        assert (buf.available_actions is None) == (cname != "cnn")
         next_value = mg.fill_buffer(buf, rng)
         # actions and their log-probs from the reference policy itself, stored the way the runners store them
         B = N * A
@@ -67,17 +70,19 @@ def main():
         torch.manual_seed(7)
         with torch.no_grad():
             for t in range(T):
+                avail = None if buf.available_actions is None else flat(buf.available_actions[t])
                 _, a, lp, _, _ = policy.get_actions(flat(buf.share_obs[t]), flat(buf.obs[t]), flat(buf.rnn_states[t]),
-                                                    flat(buf.rnn_states_critic[t]), flat(buf.masks[t]))
+                                                    flat(buf.rnn_states_critic[t]), flat(buf.masks[t]), avail)
                 buf.actions[t] = a.numpy().reshape(N, A, -1)
                 buf.action_log_probs[t] = lp.numpy().reshape(N, A, -1)       # [., 1] broadcasts for Box
             ev = policy.evaluate_actions(flat(buf.share_obs[0]), flat(buf.obs[0]), flat(buf.rnn_states[0]),
                                          flat(buf.rnn_states_critic[0]), flat(buf.actions[0]), flat(buf.masks[0]),
-                                         None, flat(buf.active_masks[0]))
+                                         None if buf.available_actions is None else flat(buf.available_actions[0]),
+                                         flat(buf.active_masks[0]))
         out[key + "eval_values"] = ev[0].numpy().copy()
         out[key + "eval_logp"] = ev[1].numpy().copy()
         out[key + "eval_entropy"] = np.array(float(ev[2]), dtype=np.float32)
-        for name in BUF:
+        for name in BUF + (("available_actions",) if buf.available_actions is not None else ()):
             out[key + "buf_" + name] = getattr(buf, name).copy()
         out[key + "next_value"] = next_value
         buf.compute_returns(next_value, trainer.value_normalizer)

@@ -1,11 +1,11 @@
-"""Continuous (Box) and MultiDiscrete action heads through policy + trainer against fixtures produced by the
+"""Continuous (Box) and MultiDiscrete action heads, and image observations (CNNBase), through policy + trainer against fixtures produced by the
 reference's R_MAPPOPolicy / R_MAPPO on the same seeds (oracle/make_golden_spaces.py): identical initial
 parameters, evaluate_actions outputs, train_info and final parameters within float32 tolerance."""
 import numpy as np
 import pytest
 import torch
 
-from helpers import Box, make_args
+from helpers import Box, Discrete, make_args
 from oracle import oracle
 from test_misc_cpu import _MultiDiscrete
 
@@ -17,13 +17,16 @@ BUF = ("share_obs", "obs", "rnn_states", "rnn_states_critic", "actions", "value_
 
 
 def _space(cname):
+    if cname == "cnn":
+        return Discrete(4)
     return Box((3,)) if cname == "box" else _MultiDiscrete([3, 4])       # sub-action ranges [0, 2] and [0, 3]
 
 
 def build_space_case(gold, cname, device=torch.device("cpu")):
     meta = gold.meta("space_cases")[cname]
     args = make_args(episode_length=meta["T"], n_rollout_threads=meta["N"], **meta["args"])
-    spaces = Box((meta["Do"],)), Box((meta["Ds"],)), _space(cname)
+    spaces = (Box((meta["Do"],)), Box((meta["Ds"],)), _space(cname)) if cname != "cnn" else \
+        (Box((3, 9, 9)), Box((3, 9, 9)), _space(cname))
     torch.manual_seed(1)
     np.random.seed(1)
     policy = R_MAPPOPolicy(args, *spaces, device=device)
@@ -42,7 +45,7 @@ def check_final(z, key, meta, info, policy, rel=2e-4, atol=2e-5):
             np.testing.assert_allclose(sd[k].cpu().numpy(), z[prefix + k], rtol=1e-4, atol=atol, err_msg=prefix + k)
 
 
-@pytest.mark.parametrize("cname", ["box", "multidiscrete"])
+@pytest.mark.parametrize("cname", ["box", "multidiscrete", "cnn"])
 def test_other_action_heads_match_reference(gold, cname):
     z = gold.npz("space_cases")
     key = "spc_%s_" % cname
@@ -53,8 +56,8 @@ def test_other_action_heads_match_reference(gold, cname):
         for k, v in sd.items():
             np.testing.assert_array_equal(v.numpy(), z[prefix + k], err_msg=prefix + k)
     buf = oracle.OracleBuffer(args, meta["A"], *spaces)
-    assert buf.actions.shape[-1] == meta["act_width"] and buf.available_actions is None
-    for name in BUF:
+    assert buf.actions.shape[-1] == meta["act_width"] and (buf.available_actions is None) == (cname != "cnn")
+    for name in BUF + (("available_actions",) if cname == "cnn" else ()):
         getattr(buf, name)[...] = z[key + "buf_" + name]
     B = meta["N"] * meta["A"]
     flat = lambda x: x[0].reshape(B, *x.shape[3:])
@@ -62,7 +65,8 @@ def test_other_action_heads_match_reference(gold, cname):
     with torch.no_grad():
         values, logp, ent = policy.evaluate_actions(flat(buf.share_obs), flat(buf.obs), flat(buf.rnn_states),
                                                     flat(buf.rnn_states_critic), flat(buf.actions), flat(buf.masks),
-                                                    None, flat(buf.active_masks))
+                                                    None if cname != "cnn" else flat(buf.available_actions),
+                                                    flat(buf.active_masks))
     tol = dict(rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(values.numpy(), z[key + "eval_values"], **tol)
     np.testing.assert_allclose(logp.numpy(), z[key + "eval_logp"], **tol)

@@ -9,7 +9,7 @@ from test_action_spaces_cpu import BUF, build_space_case, check_final
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("cname", ["box", "multidiscrete"])
+@pytest.mark.parametrize("cname", ["box", "multidiscrete", "cnn"])
 def test_other_action_heads_on_device_vs_reference(gold, cname):
     from onpolicy.utils.shared_buffer import SharedReplayBuffer
     dev = torch.device("cuda", 0)
@@ -18,7 +18,7 @@ def test_other_action_heads_on_device_vs_reference(gold, cname):
     meta, args, spaces, policy, trainer = build_space_case(gold, cname, device=dev)
     args.sampler_rng = "host"
     buf = SharedReplayBuffer(args, meta["A"], *spaces, device=dev)
-    for name in BUF:
+    for name in BUF + (("available_actions",) if cname == "cnn" else ()):
         dst = getattr(buf, name)
         if dst.stride()[0] != 0:
             dst.copy_(torch.from_numpy(z[key + "buf_" + name]))

@@ -88,10 +88,10 @@ def test_fused_loss_matches_autograd(na, with_avail, with_factor, with_norm):
             value_active_masks=v_active, **hp)
         tag = (use_huber, use_clipped, p_active, v_active)
         s = sums.cpu().numpy()
-        assert s[0] * float(inv[0]) == pytest.approx(float(pl), rel=2e-5, abs=1e-6), tag
-        assert s[1] * float(inv[0]) == pytest.approx(float(ent), rel=2e-5, abs=1e-6), tag
-        assert s[2] * float(inv[1]) == pytest.approx(float(vl), rel=2e-5, abs=1e-6), tag
-        assert s[3] / R == pytest.approx(float(ratio.mean()), rel=2e-5), tag
+        assert s[0] * float(inv[0]) == pytest.approx(float(pl.detach()), rel=2e-5, abs=1e-6), tag
+        assert s[1] * float(inv[0]) == pytest.approx(float(ent.detach()), rel=2e-5, abs=1e-6), tag
+        assert s[2] * float(inv[1]) == pytest.approx(float(vl.detach()), rel=2e-5, abs=1e-6), tag
+        assert s[3] / R == pytest.approx(float(ratio.detach().mean()), rel=2e-5), tag
         scale = float(logits.grad.abs().max())
         np.testing.assert_allclose(dlogits.cpu().numpy(), logits.grad.cpu().numpy(), rtol=2e-4, atol=2e-6 * max(scale, 1e-3) + 1e-10,
                                    err_msg=str(tag))

@@ -38,7 +38,13 @@ class MultiBinary(object):
 # which takes no such argument -- its rollout path raises TypeError)
 SPACES = {"box": lambda: mg.Box((3,)), "multidiscrete": lambda: MultiDiscrete([[0, 2], [0, 3]]),
           # image observations: CNNBase trunk (algorithms/utils/cnn.py) for actor and critic, Discrete head
-          "cnn": lambda: mg.Discrete(4)}
+          "cnn": lambda: mg.Discrete(4),
+          # whole-trajectory sampler (--use_naive_recurrent_policy) and a 2-layer GRU with xavier init and no
+          # input LayerNorm: flag combinations the main trainer fixtures do not reach
+          "naive_gru": lambda: mg.Discrete(5), "gru2_xavier": lambda: mg.Discrete(5)}
+EXTRA_ARGS = {"naive_gru": dict(use_naive_recurrent_policy=True, algorithm_name="rmappo"),
+              "gru2_xavier": dict(use_recurrent_policy=True, recurrent_N=2, use_orthogonal=False,
+                                  use_feature_normalization=False, data_chunk_length=4, algorithm_name="rmappo")}
 BUF = ("share_obs", "obs", "rnn_states", "rnn_states_critic", "actions", "value_preds", "masks", "bad_masks",
        "active_masks", "action_log_probs", "rewards")
 
@@ -47,8 +53,9 @@ def main():
     out, meta = {}, {}
     T, N, A, Do, Ds = 8, 4, 2, 6, 10
     for cname, make_space in SPACES.items():
-        args = mg.make_args(episode_length=T, n_rollout_threads=N, hidden_size=16, layer_N=1, ppo_epoch=2,
-                            num_mini_batch=2, algorithm_name="mappo")
+        base_args = dict(hidden_size=16, layer_N=1, ppo_epoch=2, num_mini_batch=2, algorithm_name="mappo")
+        base_args.update(EXTRA_ARGS.get(cname, {}))
+        args = mg.make_args(episode_length=T, n_rollout_threads=N, **base_args)
         act_space = make_space()
         spaces = (mg.Box((Do,)), mg.Box((Ds,)), act_space) if cname != "cnn" else \
             (mg.Box((3, 9, 9)), mg.Box((3, 9, 9)), act_space)
@@ -61,7 +68,7 @@ def main():
         _sd(key + "init_critic.", policy.critic, out)
         rng = np.random.default_rng(99)
         buf = ref.SharedReplayBuffer(args, A, *spaces)
-        assert (buf.available_actions is None) == (cname != "cnn")
+        assert (buf.available_actions is None) == (cname in ("box", "multidiscrete"))
         next_value = mg.fill_buffer(buf, rng)
         # actions and their log-probs from the reference policy itself, stored the way the runners store them
         B = N * A
@@ -94,7 +101,7 @@ def main():
         _sd(key + "final_actor.", policy.actor, out)
         _sd(key + "final_critic.", policy.critic, out)
         meta[cname] = dict(T=T, N=N, A=A, Do=Do, Ds=Ds, act_width=int(buf.actions.shape[-1]), train_info=info,
-                           args=dict(hidden_size=16, layer_N=1, ppo_epoch=2, num_mini_batch=2, algorithm_name="mappo"))
+                           args=base_args)
     np.savez_compressed(os.path.join(mg.GOLD, "space_cases.npz"), **out)
     with open(os.path.join(mg.GOLD, "space_cases.json"), "w") as f:
         json.dump(meta, f, indent=1)

@@ -16,9 +16,12 @@ BUF = ("share_obs", "obs", "rnn_states", "rnn_states_critic", "actions", "value_
        "active_masks", "action_log_probs", "rewards")
 
 
+DISCRETE = {"cnn": 4, "naive_gru": 5, "gru2_xavier": 5}      # cases with a Discrete head (+ availability masks)
+
+
 def _space(cname):
-    if cname == "cnn":
-        return Discrete(4)
+    if cname in DISCRETE:
+        return Discrete(DISCRETE[cname])
     return Box((3,)) if cname == "box" else _MultiDiscrete([3, 4])       # sub-action ranges [0, 2] and [0, 3]
 
 
@@ -45,7 +48,7 @@ def check_final(z, key, meta, info, policy, rel=2e-4, atol=2e-5):
             np.testing.assert_allclose(sd[k].cpu().numpy(), z[prefix + k], rtol=1e-4, atol=atol, err_msg=prefix + k)
 
 
-@pytest.mark.parametrize("cname", ["box", "multidiscrete", "cnn"])
+@pytest.mark.parametrize("cname", ["box", "multidiscrete", "cnn", "naive_gru", "gru2_xavier"])
 def test_other_action_heads_match_reference(gold, cname):
     z = gold.npz("space_cases")
     key = "spc_%s_" % cname
@@ -56,8 +59,8 @@ def test_other_action_heads_match_reference(gold, cname):
         for k, v in sd.items():
             np.testing.assert_array_equal(v.numpy(), z[prefix + k], err_msg=prefix + k)
     buf = oracle.OracleBuffer(args, meta["A"], *spaces)
-    assert buf.actions.shape[-1] == meta["act_width"] and (buf.available_actions is None) == (cname != "cnn")
-    for name in BUF + (("available_actions",) if cname == "cnn" else ()):
+    assert buf.actions.shape[-1] == meta["act_width"] and (buf.available_actions is None) == (cname not in DISCRETE)
+    for name in BUF + (("available_actions",) if cname in DISCRETE else ()):
         getattr(buf, name)[...] = z[key + "buf_" + name]
     B = meta["N"] * meta["A"]
     flat = lambda x: x[0].reshape(B, *x.shape[3:])
@@ -65,7 +68,7 @@ def test_other_action_heads_match_reference(gold, cname):
     with torch.no_grad():
         values, logp, ent = policy.evaluate_actions(flat(buf.share_obs), flat(buf.obs), flat(buf.rnn_states),
                                                     flat(buf.rnn_states_critic), flat(buf.actions), flat(buf.masks),
-                                                    None if cname != "cnn" else flat(buf.available_actions),
+                                                    None if cname not in DISCRETE else flat(buf.available_actions),
                                                     flat(buf.active_masks))
     tol = dict(rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(values.numpy(), z[key + "eval_values"], **tol)

@@ -4,12 +4,12 @@ import numpy as np
 import pytest
 import torch
 
-from test_action_spaces_cpu import BUF, build_space_case, check_final
+from test_action_spaces_cpu import BUF, DISCRETE, build_space_case, check_final
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("cname", ["box", "multidiscrete", "cnn"])
+@pytest.mark.parametrize("cname", ["box", "multidiscrete", "cnn", "naive_gru", "gru2_xavier"])
 def test_other_action_heads_on_device_vs_reference(gold, cname):
     from onpolicy.utils.shared_buffer import SharedReplayBuffer
     dev = torch.device("cuda", 0)
@@ -18,7 +18,7 @@ def test_other_action_heads_on_device_vs_reference(gold, cname):
     meta, args, spaces, policy, trainer = build_space_case(gold, cname, device=dev)
     args.sampler_rng = "host"
     buf = SharedReplayBuffer(args, meta["A"], *spaces, device=dev)
-    for name in BUF + (("available_actions",) if cname == "cnn" else ()):
+    for name in BUF + (("available_actions",) if cname in DISCRETE else ()):
         dst = getattr(buf, name)
         if dst.stride()[0] != 0:
             dst.copy_(torch.from_numpy(z[key + "buf_" + name]))

@@ -23,6 +23,9 @@ import os
 import sys
 import time
 
+# the host driver only supports dmabuf IPC: RCCL's buffer registration across ranks needs this (no-op if exported)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (os.path.join(ROOT, "on-policy_amd"), ROOT):
     if p not in sys.path:

@@ -38,6 +38,7 @@ def init_from_env(device=None):
     forced = os.environ.get("MAPPO_FORCE_DIST", "0") == "1"
     if (world <= 1 and not forced) or (dist.is_available() and dist.is_initialized()):
         return world
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (required by RCCL on these hosts)
     os.environ.setdefault("RANK", "0")
     os.environ.setdefault("MASTER_PORT", "29533")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -24,16 +24,25 @@ def enable(tune_new=True):
     if os.environ.get("MAPPO_GEMM_TUNING", "1") == "0" or not torch.cuda.is_available():
         return False
     t = torch.cuda.tunable
-    t.enable(True)
-    t.tuning_enable(bool(tune_new))
-    t.set_max_tuning_duration(30)        # ms per candidate
-    t.set_max_tuning_iterations(5)
-    cache = os.environ.get("MAPPO_GEMM_TUNING_CACHE") or os.path.join(tempfile.gettempdir(), "mappo_amd_gemm_tuning")
-    os.makedirs(cache, exist_ok=True)
-    t.set_filename(os.path.join(cache, "tunableop_results.csv"), insert_device_ordinal=True)
-    for path in (SHIPPED, t.get_filename()):
-        if os.path.exists(path):
-            t.read_file(path)            # ignored (with a warning) if it was made by other library versions
+    try:
+        t.enable(True)
+        t.tuning_enable(bool(tune_new))
+        t.set_max_tuning_duration(30)        # ms per candidate
+        t.set_max_tuning_iterations(5)
+        cache = os.environ.get("MAPPO_GEMM_TUNING_CACHE") or \
+            os.path.join(tempfile.gettempdir(), "mappo_amd_gemm_tuning")
+        os.makedirs(cache, exist_ok=True)
+        t.set_filename(os.path.join(cache, "tunableop_results.csv"), insert_device_ordinal=True)
+        for path in (SHIPPED, t.get_filename()):
+            if os.path.exists(path):
+                t.read_file(path)            # ignored (with a warning) if it was made by other library versions
+    except Exception as e:                   # kernel selection is an optimisation: never fail a run over it
+        print("gemm_tuning: not enabled (%s: %s)" % (type(e).__name__, e))
+        try:
+            t.enable(False)
+        except Exception:
+            pass
+        return False
     return True
 
 

@@ -12,28 +12,36 @@ class MultiDiscrete(object):
     no-op of each sub-action."""
 
     def __init__(self, array_of_param_array):
-        self.low = np.array([x[0] for x in array_of_param_array])
-        self.high = np.array([x[1] for x in array_of_param_array])
-        self.num_discrete_space = self.low.shape[0]
-        self.n = np.sum(self.high) + 2
+        bounds = np.asarray(array_of_param_array, dtype=np.int64).reshape(-1, 2)
+        self.low, self.high = bounds[:, 0].copy(), bounds[:, 1].copy()
 
-    def sample(self):
-        """One uniformly drawn value per sub-action."""
-        u = np.random.rand(self.num_discrete_space)
-        return [int(x) for x in np.floor((self.high - self.low + 1.0) * u + self.low)]
-
-    def contains(self, x):
-        x = np.array(x)
-        return len(x) == self.num_discrete_space and bool((x >= self.low).all()) and bool((x <= self.high).all())
+    @property
+    def num_discrete_space(self):
+        return int(self.low.shape[0])
 
     @property
     def shape(self):
+        """Number of sub-actions (an int, as the reference has it -- not a tuple)."""
         return self.num_discrete_space
 
+    @property
+    def n(self):
+        return int(self.high.sum()) + 2
+
+    def sample(self):
+        """One uniformly drawn value per sub-action (numpy's global generator, like the reference)."""
+        span = self.high - self.low + 1
+        return [int(lo + np.floor(u * s)) for lo, s, u in zip(self.low, span, np.random.rand(len(span)))]
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.low.shape and bool(np.all((x >= self.low) & (x <= self.high)))
+
     def __repr__(self):
-        return "MultiDiscrete" + str(self.num_discrete_space)
+        return "MultiDiscrete%d" % self.num_discrete_space
 
     def __eq__(self, other):
-        return np.array_equal(self.low, other.low) and np.array_equal(self.high, other.high)
+        return isinstance(other, MultiDiscrete) and np.array_equal(self.low, other.low) \
+            and np.array_equal(self.high, other.high)
 
     __hash__ = None

@@ -284,14 +284,17 @@ __global__ void __launch_bounds__(kThreads) pack_records_kernel(RecArgs a) {
     }
 }
 
-constexpr int kRecPerThread = 2;    // records per thread per pass (independent loads in flight)
-
+// Records are read by q4 = rw / 4 adjacent lanes, one 16-byte piece each, so that one wave instruction fetches
+// whole records (a lane walking its record with q4 successive loads touched the record's cache line q4 times:
+// 4.5 GB of fetches for 0.63 GB of records at the north star, PMC FETCH_SIZE).  Rounds of kThreads / q4 records
+// are issued back to back until the LDS tile is full, so every lane has several independent loads in flight.
 __global__ void __launch_bounds__(kThreads) gather_records_kernel(RecArgs a, unsigned long long rows_out) {
     __shared__ float tile[kThreads * kRecMaxWidth];
     const unsigned rw = a.rw, q4 = rw / 4;
-    // rows per pass: limited by the LDS tile (kThreads * kRecMaxWidth floats)
-    const unsigned per_thread = (kRecPerThread * rw <= (unsigned)kRecMaxWidth) ? kRecPerThread : 1;
-    const unsigned pass_rows = kThreads * per_thread;
+    const unsigned per_round = kThreads / q4;                     // records fetched by one round of loads
+    const unsigned rounds = (kThreads * kRecMaxWidth / rw) / per_round;
+    const unsigned pass_rows = per_round * rounds;                // rows per pass: what the LDS tile holds
+    const unsigned sub = threadIdx.x / q4, piece = threadIdx.x - sub * q4;
     float mean = 0.f, den = 1.f;
     if (a.stats) {
         mean = a.stats[0];
@@ -299,14 +302,15 @@ __global__ void __launch_bounds__(kThreads) gather_records_kernel(RecArgs a, uns
     }
     for (unsigned long long row0 = (unsigned long long)blockIdx.x * pass_rows; row0 < rows_out;
          row0 += (unsigned long long)gridDim.x * pass_rows) {
-        for (unsigned p = 0; p < per_thread; ++p) {
-            const unsigned lr = threadIdx.x + p * kThreads;         // local row inside the pass
-            const unsigned long long j = row0 + lr;
-            if (j < rows_out) {
-                const unsigned srow = mappo::source_row(a.map, 0u, (unsigned)j);
-                const f32x4* rec = reinterpret_cast<const f32x4*>(a.records + (unsigned long long)srow * rw);
-                f32x4* mine = reinterpret_cast<f32x4*>(tile + lr * rw);
-                for (unsigned q = 0; q < q4; ++q) mine[q] = __builtin_nontemporal_load(rec + q);
+        if (sub < per_round) {
+            for (unsigned r = 0; r < rounds; ++r) {
+                const unsigned lr = r * per_round + sub;            // local row inside the pass
+                const unsigned long long j = row0 + lr;
+                if (j < rows_out) {
+                    const unsigned srow = mappo::source_row(a.map, 0u, (unsigned)j);
+                    const f32x4* rec = reinterpret_cast<const f32x4*>(a.records + (unsigned long long)srow * rw);
+                    reinterpret_cast<f32x4*>(tile + lr * rw)[piece] = __builtin_nontemporal_load(rec + piece);
+                }
             }
         }
         __syncthreads();

@@ -486,7 +486,9 @@ class SharedReplayBuffer(object):
             off += width
         if not fields:
             return None, 0, {}
-        rw = (off + 3) // 4 * 4
+        rw = 4
+        while rw < off:          # 16 / 32 / 64 / 128-byte records: a record never straddles more lines than needed
+            rw *= 2
         rows = T * N * A
         # the packed fields only change when the buffer is written -- by this class's kernels
         # (_content_version) or by in-place torch ops on the field tensors (tensor._version): within

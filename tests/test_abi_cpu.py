@@ -35,6 +35,28 @@ def test_struct_layouts_match_header():
     # struct mappo_field: 2 pointers + 4 int32 = 32 bytes; struct mappo_slab: 2 pointers + int64 = 24
     assert ctypes.sizeof(_native.Field) == 32
     assert ctypes.sizeof(_native.Slab) == 24
+    # struct mappo_record_field: 2 pointers + 4 int32; struct mappo_ppo_loss: 15 pointers, int64, int, 4 floats,
+    # unsigned -- field order as in the header
+    assert ctypes.sizeof(_native.RecordField) == 32
+    assert ctypes.sizeof(_native.PPOLoss) == 15 * 8 + 8 + 4 + 4 * 4 + 4
+    src = open(HEADER).read()
+    body = src[src.index("typedef struct mappo_ppo_loss {"):src.index("} mappo_ppo_loss_t;")]
+    declared = re.findall(r"\b(\w+);", body)
+    assert declared == [name for name, _ in _native.PPOLoss._fields_]
+
+
+def test_new_entry_points_validate_arguments():
+    lib = _native.lib()
+    assert lib.mappo_gae_mat_f32(None, None, None, None, None, None, None, None, None, 4, 4, 2, 0.99, 0.95, 0, None) == -1
+    assert lib.mappo_ppo_loss_f32(None, None) == -1
+    loss = _native.PPOLoss()                       # all-NULL struct: inv_denoms missing
+    assert lib.mappo_ppo_loss_f32(ctypes.byref(loss), None) == -1
+    assert lib.mappo_gru_cell_fwd(None, None, None, None, None, None, None, None, None, 4, 64, None) == -1
+    assert lib.mappo_gru_cell_bwd(None, None, None, None, None, None, None, None, 4, 64, None) == -1
+    assert lib.mappo_gru_step_fwd(None, None, None, None, None, None, None, None, None, 4, 64, None) == -1
+    assert lib.mappo_bias_act_layernorm_fwd(None, None, None, None, None, None, None, 4, 64, 1e-5, 1, None) == -1
+    assert lib.mappo_bias_act_layernorm_bwd(None, None, None, None, None, None, None, None, None, None, None, 4, 64, 1,
+                                            None) == -1
 
 
 def test_argument_validation_without_device():

@@ -90,3 +90,15 @@ def test_missing_library_is_loud(monkeypatch, tmp_path):
     monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_native.NativeError, match="no CPU fallback"):
         _native.lib()
+
+
+def test_header_is_plain_c():
+    """include/mappo_hip.h must be consumable from C (the cgo / JNI / ctypes side of an integration) and C++."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    for lang, std in (("c", "c99"), ("c++", "c++17")):
+        out = subprocess.run(["gcc", "-fsyntax-only", "-x", lang, "-std=" + std, "-Wall", "-Werror", HEADER],
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr

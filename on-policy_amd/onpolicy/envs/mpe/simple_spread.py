@@ -74,7 +74,9 @@ class VecSimpleSpread(object):
         d = np.sqrt(((self.pos[:, :, None, :] - self.landmarks[:, None, :, :]) ** 2).sum(-1))  # [n, a, l]
         cover = -d.min(1).sum(-1)                                                               # [n]
         dd = np.sqrt(((self.pos[:, :, None, :] - self.pos[:, None, :, :]) ** 2).sum(-1))
-        hits = (dd < 2 * _AGENT_SIZE) & ~np.eye(self.a, dtype=bool)
+        # the reference's loop runs over ALL agents, the agent itself included (scenarios/simple_spread.py:78-81:
+        # is_collision(agent, agent) is true), so every agent carries a constant -1; kept for identical rewards
+        hits = dd < 2 * _AGENT_SIZE
         per_agent = cover[:, None] - hits.sum(-1)                                               # [n, a]
         return per_agent
 

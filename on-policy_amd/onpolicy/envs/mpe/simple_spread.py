@@ -7,7 +7,8 @@ row f2).  This module exists so that BASELINE.json's configs[0] (MPE simple_spre
 It follows the published MPE dynamics (Lowe et al. 2017; the reference vendors them under
 onpolicy/envs/mpe/{core,environment}.py and scenarios/simple_spread.py): point-mass agents with
 damping 0.25, dt 0.1, action sensitivity 5, soft contact forces, shared reward
--sum_landmarks min_agents dist - collisions.  All ``n_threads`` worlds advance in one set of array
+-sum_landmarks min_agents dist - collisions; trajectories are pinned to the reference's own environment by
+tests/test_mpe_env_cpu.py (fixtures: oracle/make_golden_mpe.py).  All ``n_threads`` worlds advance in one set of array
 operations, so a rollout step costs one numpy pass instead of ``n_threads`` pipe round trips.
 
 VecEnv protocol (reference onpolicy/envs/env_wrappers.py:235-298): ``reset() -> obs [N, A, Do]``,

@@ -82,7 +82,9 @@ class Runner(_SharedRunner):
     def train(self):
         """Sequential update in random agent order with the HAPPO factor bookkeeping
         (reference base_runner.py:135-183)."""
-        train_infos = [None] * self.num_agents
+        # like the reference, the infos are returned in UPDATE order (base_runner.py:178 appends), so
+        # log_train's "agent%i/" prefix counts positions in this round's random order, not agent ids
+        train_infos = []
         factor = torch.ones(self.episode_length, self.n_rollout_threads, 1, dtype=torch.float32,
                             device=self.buffer[0].device)
         for agent_id in torch.randperm(self.num_agents).tolist():
@@ -90,7 +92,7 @@ class Runner(_SharedRunner):
             tr.prep_training()
             b.update_factor(factor)
             old_logp = self._buffer_log_probs(agent_id)
-            train_infos[agent_id] = tr.train(b)
+            train_infos.append(tr.train(b))
             new_logp = self._buffer_log_probs(agent_id)
             factor = factor * torch.prod(torch.exp(new_logp - old_logp), dim=-1, keepdim=True)
             b.after_update()

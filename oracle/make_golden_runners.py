@@ -74,6 +74,8 @@ def main():
         "mpe_rnn": dict(env="MPE", runner=MPERunner, T=8, N=4, A=3, Do=6, na=5,
                         args=dict(algorithm_name="rmappo", use_recurrent_policy=True, hidden_size=16, ppo_epoch=2,
                                   num_mini_batch=2, data_chunk_length=4)),
+        # (no football case: the reference's FootballRunner.insert passes rnn_states= to a buffer method whose
+        #  parameter is rnn_states_actor, football_runner.py:132-142 vs shared_buffer.py:90 -- it raises TypeError)
         "smac_rnn": dict(env="StarCraft2", runner=SMACRunner, T=8, N=3, A=4, Do=7, Ds=9, na=6,
                          args=dict(algorithm_name="rmappo", use_recurrent_policy=True, hidden_size=16, ppo_epoch=1,
                                    num_mini_batch=1, data_chunk_length=4, use_proper_time_limits=True)),

@@ -27,12 +27,15 @@ for name in ("wandb", "imageio", "tensorboardX"):
     sys.modules.setdefault(name, types.ModuleType(name))
 
 
+LOGGED = []      # (main_tag, {key: value}, step) of every add_scalars call of the reference runners
+
+
 class _Writer(object):
     def __init__(self, *a, **k):
         pass
 
-    def add_scalars(self, *a, **k):
-        pass
+    def add_scalars(self, main_tag, tag_scalar_dict, global_step=None):
+        LOGGED.append((main_tag, {k: float(v) for k, v in tag_scalar_dict.items()}, global_step))
 
 
 sys.modules["tensorboardX"].SummaryWriter = _Writer
@@ -55,9 +58,13 @@ def params(out, key, policy):
         out[key + "critic." + k] = v.detach().numpy().copy()
 
 
-def config(args, envs, A, run_dir):
-    return {"all_args": args, "envs": envs, "eval_envs": None, "num_agents": A, "device": torch.device("cpu"),
+def config(args, envs, A, run_dir, eval_envs=None):
+    return {"all_args": args, "envs": envs, "eval_envs": eval_envs, "num_agents": A, "device": torch.device("cpu"),
             "run_dir": Path(run_dir)}
+
+
+def logged_since(mark):
+    return [[tag, vals, step] for tag, vals, step in LOGGED[mark:]]
 
 
 def main():
@@ -83,14 +90,16 @@ def main():
     for cname, sp in specs.items():
         T, N, A = sp["T"], sp["N"], sp["A"]
         args = mg.make_args(env_name=sp["env"], episode_length=T, n_rollout_threads=N, num_env_steps=T * N,
-                            use_wandb=False, **sp["args"])
+                            use_wandb=False, use_eval=True, n_eval_rollout_threads=2, eval_episodes=4, **sp["args"])
         args.scenario_name = args.map_name = "fake"
         smac = sp["env"] == "StarCraft2"
         envs = fake_envs.FakeSMACVecEnv(N, A, sp["Do"], sp["Ds"], sp["na"]) if smac \
             else fake_envs.FakeMPEVecEnv(N, A, sp["Do"], sp["na"])
+        eval_envs = fake_envs.FakeSMACVecEnv(2, A, sp["Do"], sp["Ds"], sp["na"], seed=3) if smac \
+            else fake_envs.FakeMPEVecEnv(2, A, sp["Do"], sp["na"], seed=3)
         torch.manual_seed(1)
         np.random.seed(1)
-        runner = sp["runner"](config(args, envs, A, os.path.join(tmp, cname)))
+        runner = sp["runner"](config(args, envs, A, os.path.join(tmp, cname), eval_envs))
         key = "run_%s_" % cname
         params(out, key + "init_", runner.policy)
         torch.manual_seed(5)
@@ -111,10 +120,12 @@ def main():
         dump(out, key + "rollout_", runner, True)
         torch.manual_seed(9)
         info = runner.train()
-        meta[cname] = dict(spec={k: v for k, v in sp.items() if k != "runner"},
-                           train_info={k: float(v) for k, v in info.items()})
         dump(out, key + "after_", runner, True)
         params(out, key + "final_", runner.policy)
+        mark = len(LOGGED)
+        runner.eval(777)                      # deterministic policy on the eval envs; what it logs is the result
+        meta[cname] = dict(spec={k: v for k, v in sp.items() if k != "runner"},
+                           train_info={k: float(v) for k, v in info.items()}, eval_logged=logged_since(mark))
 
     # ---- separated policies (one policy / trainer / buffer per agent, HAPPO factor bookkeeping in train())
     from onpolicy.runner.separated.mpe_runner import MPERunner as SepMPERunner
@@ -177,14 +188,18 @@ def main():
     envs = fake_envs.FakeChooseVecEnv(N, A, Do, Ds, na)
     torch.manual_seed(1)
     np.random.seed(1)
-    runner = HanabiRunner(config(args, envs, A, os.path.join(tmp, "hanabi")))
+    args.n_eval_rollout_threads = 3
+    runner = HanabiRunner(config(args, envs, A, os.path.join(tmp, "hanabi"),
+                                 fake_envs.FakeChooseVecEnv(3, A, Do, Ds, na, seed=4)))
     params(out, "run_hanabi_init_", runner.policy)
     torch.manual_seed(5)
     runner.run()
     dump(out, "run_hanabi_after_", runner, True)
     params(out, "run_hanabi_final_", runner.policy)
+    mark = len(LOGGED)
+    runner.eval(888)
     meta["hanabi"] = dict(spec=dict(T=T, N=N, A=A, Do=Do, Ds=Ds, na=na), true_total_num_steps=int(runner.true_total_num_steps),
-                          env_steps=int(envs.steps), games=int(envs.games))
+                          env_steps=int(envs.steps), games=int(envs.games), eval_logged=logged_since(mark))
     np.savez_compressed(os.path.join(mg.GOLD, "runner_cases.npz"), **out)
     with open(os.path.join(mg.GOLD, "runner_cases.json"), "w") as f:
         json.dump(meta, f, indent=1)

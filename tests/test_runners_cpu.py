@@ -23,9 +23,23 @@ def host_buffer(monkeypatch):
     monkeypatch.setattr(base, "SharedReplayBuffer", HostSharedBuffer)
 
 
-def _config(args, envs, A, tmp_path):
-    return {"all_args": args, "envs": envs, "eval_envs": None, "num_agents": A, "device": torch.device("cpu"),
+def _config(args, envs, A, tmp_path, eval_envs=None):
+    return {"all_args": args, "envs": envs, "eval_envs": eval_envs, "num_agents": A, "device": torch.device("cpu"),
             "run_dir": tmp_path}
+
+
+def _check_eval(runner, step, expected):
+    """runner.eval(step) must log what the reference runner logged (tag, value) for the same policy and eval envs."""
+    import json
+    path = os.path.join(runner.log_dir, "scalars.jsonl")
+    before = len(open(path).read().splitlines()) if os.path.exists(path) else 0
+    runner.eval(step)
+    got = [json.loads(l) for l in open(path).read().splitlines()[before:]]
+    assert [g["tag"] for g in got] == [e[0] for e in expected]
+    for g, (tag, vals, at) in zip(got, expected):
+        assert g["step"] == at
+        for k, v in vals.items():
+            assert g[k] == pytest.approx(v, rel=2e-4, abs=2e-6), (tag, g[k], v)
 
 
 def _check_params(z, prefix, policy, exact=False):
@@ -57,13 +71,15 @@ def test_rollout_and_update_match_reference_runner(gold, host_buffer, tmp_path, 
     T, N, A = sp["T"], sp["N"], sp["A"]
     smac = sp["env"] == "StarCraft2"
     args = make_args(env_name=sp["env"], episode_length=T, n_rollout_threads=N, num_env_steps=T * N, use_wandb=False,
-                     **sp["args"])
+                     use_eval=True, n_eval_rollout_threads=2, eval_episodes=4, **sp["args"])
     args.scenario_name = args.map_name = "fake"
     envs = fake_envs.FakeSMACVecEnv(N, A, sp["Do"], sp["Ds"], sp["na"]) if smac \
         else fake_envs.FakeMPEVecEnv(N, A, sp["Do"], sp["na"])
+    eval_envs = fake_envs.FakeSMACVecEnv(2, A, sp["Do"], sp["Ds"], sp["na"], seed=3) if smac \
+        else fake_envs.FakeMPEVecEnv(2, A, sp["Do"], sp["na"], seed=3)
     torch.manual_seed(1)
     np.random.seed(1)
-    runner = (SMACRunner if smac else MPERunner)(_config(args, envs, A, tmp_path))
+    runner = (SMACRunner if smac else MPERunner)(_config(args, envs, A, tmp_path, eval_envs))
     key = "run_%s_" % cname
     _check_params(z, key + "init_", runner.policy, exact=True)
     torch.manual_seed(5)
@@ -87,6 +103,7 @@ def test_rollout_and_update_match_reference_runner(gold, host_buffer, tmp_path, 
         assert info[k] == pytest.approx(v, rel=5e-4, abs=5e-6), (k, info[k], v)
     _check_buffer(z, key + "after_", runner.buffer)
     _check_params(z, key + "final_", runner.policy)
+    _check_eval(runner, 777, meta["eval_logged"])
 
 
 def test_hanabi_turn_loop_matches_reference_runner(gold, host_buffer, tmp_path):
@@ -98,10 +115,12 @@ def test_hanabi_turn_loop_matches_reference_runner(gold, host_buffer, tmp_path):
                      ppo_epoch=2, num_mini_batch=1, algorithm_name="mappo", log_interval=1000, save_interval=1000,
                      use_wandb=False)
     args.hanabi_name = "fake"
+    args.n_eval_rollout_threads = 3
     envs = fake_envs.FakeChooseVecEnv(N, A, sp["Do"], sp["Ds"], sp["na"])
     torch.manual_seed(1)
     np.random.seed(1)
-    runner = HanabiRunner(_config(args, envs, A, tmp_path))
+    runner = HanabiRunner(_config(args, envs, A, tmp_path, fake_envs.FakeChooseVecEnv(3, A, sp["Do"], sp["Ds"], sp["na"],
+                                                                                     seed=4)))
     _check_params(z, "run_hanabi_init_", runner.policy, exact=True)
     torch.manual_seed(5)
     runner.run()
@@ -109,6 +128,7 @@ def test_hanabi_turn_loop_matches_reference_runner(gold, host_buffer, tmp_path):
     assert envs.steps == meta["env_steps"] and envs.games == meta["games"]
     _check_buffer(z, "run_hanabi_after_", runner.buffer)
     _check_params(z, "run_hanabi_final_", runner.policy)
+    _check_eval(runner, 888, meta["eval_logged"])
 
 
 @pytest.fixture

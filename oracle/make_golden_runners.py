@@ -142,14 +142,16 @@ def main():
     for cname, sp in sep_specs.items():
         T, N, A = sp["T"], sp["N"], sp["A"]
         args = mg.make_args(env_name=sp["env"], episode_length=T, n_rollout_threads=N, num_env_steps=T * N,
-                            use_wandb=False, **sp["args"])
+                            use_wandb=False, use_eval=True, n_eval_rollout_threads=2, eval_episodes=4, **sp["args"])
         args.scenario_name = args.map_name = "fake"
         smac = sp["env"] == "StarCraft2"
         envs = fake_envs.FakeSMACVecEnv(N, A, sp["Do"], sp["Ds"], sp["na"]) if smac \
             else fake_envs.FakeMPEVecEnv(N, A, sp["Do"], sp["na"])
+        eval_envs = fake_envs.FakeSMACVecEnv(2, A, sp["Do"], sp["Ds"], sp["na"], seed=3) if smac \
+            else fake_envs.FakeMPEVecEnv(2, A, sp["Do"], sp["na"], seed=3)
         torch.manual_seed(1)
         np.random.seed(1)
-        runner = sp["runner"](config(args, envs, A, os.path.join(tmp, cname)))
+        runner = sp["runner"](config(args, envs, A, os.path.join(tmp, cname), eval_envs))
         key = "run_%s_" % cname
         for a in range(A):
             params(out, key + "init%d_" % a, runner.policy[a])
@@ -176,8 +178,17 @@ def main():
         for a in range(A):
             out[key + "factor%d" % a] = np.array(runner.buffer[a].factor, dtype=np.float32)
             params(out, key + "final%d_" % a, runner.policy[a])
+        mark = len(LOGGED)
+        try:
+            runner.eval(555)
+            logged = logged_since(mark)
+        except ValueError:
+            # the reference's separated SMAC eval concatenates per-thread lists and fails when a thread has not
+            # finished an episode by the time eval_episodes is reached (smac_runner.py:220); no fixture then
+            logged = None
         meta[cname] = dict(spec={k: v for k, v in sp.items() if k != "runner"},
-                           train_info=[{k: float(v) for k, v in info.items()} for info in infos_train])
+                           train_info=[{k: float(v) for k, v in info.items()} for info in infos_train],
+                           eval_logged=logged)
 
     # ---- Hanabi: the whole turn-based loop for a few episodes
     T, N, A, Do, Ds, na = 6, 5, 3, 9, 12, 7

@@ -149,13 +149,15 @@ def test_separated_runners_match_reference(gold, host_separated_buffer, tmp_path
     T, N, A = sp["T"], sp["N"], sp["A"]
     smac = sp["env"] == "StarCraft2"
     args = make_args(env_name=sp["env"], episode_length=T, n_rollout_threads=N, num_env_steps=T * N, use_wandb=False,
-                     **sp["args"])
+                     use_eval=True, n_eval_rollout_threads=2, eval_episodes=4, **sp["args"])
     args.scenario_name = args.map_name = "fake"
     envs = fake_envs.FakeSMACVecEnv(N, A, sp["Do"], sp["Ds"], sp["na"]) if smac \
         else fake_envs.FakeMPEVecEnv(N, A, sp["Do"], sp["na"])
+    eval_envs = fake_envs.FakeSMACVecEnv(2, A, sp["Do"], sp["Ds"], sp["na"], seed=3) if smac \
+        else fake_envs.FakeMPEVecEnv(2, A, sp["Do"], sp["na"], seed=3)
     torch.manual_seed(1)
     np.random.seed(1)
-    runner = (SMACRunner if smac else MPERunner)(_config(args, envs, A, tmp_path))
+    runner = (SMACRunner if smac else MPERunner)(_config(args, envs, A, tmp_path, eval_envs))
     key = "run_%s_" % cname
     for a in range(A):
         _check_params(z, key + "init%d_" % a, runner.policy[a], exact=True)
@@ -183,3 +185,7 @@ def test_separated_runners_match_reference(gold, host_separated_buffer, tmp_path
             assert infos_train[a][k] == pytest.approx(v, rel=5e-4, abs=5e-6), (a, k, infos_train[a][k], v)
         np.testing.assert_allclose(runner.buffer[a].factor.numpy(), z[key + "factor%d" % a], rtol=2e-4, atol=2e-6)
         _check_params(z, key + "final%d_" % a, runner.policy[a])
+    if meta["eval_logged"] is not None:       # None: the reference's own eval failed on this case (see the generator)
+        _check_eval(runner, 555, meta["eval_logged"])
+    else:
+        runner.eval(555)

@@ -193,7 +193,7 @@ def main():
     # ---- Hanabi: the whole turn-based loop for a few episodes
     T, N, A, Do, Ds, na = 6, 5, 3, 9, 12, 7
     args = mg.make_args(env_name="Hanabi", episode_length=T, n_rollout_threads=N, num_env_steps=4 * T * N,
-                        hidden_size=16, ppo_epoch=2, num_mini_batch=1, algorithm_name="mappo", log_interval=1000,
+                        hidden_size=16, ppo_epoch=2, num_mini_batch=1, algorithm_name="mappo", use_linear_lr_decay=True, log_interval=1000,
                         save_interval=1000, use_wandb=False)
     args.hanabi_name = "fake"
     envs = fake_envs.FakeChooseVecEnv(N, A, Do, Ds, na)

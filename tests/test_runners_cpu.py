@@ -112,7 +112,7 @@ def test_hanabi_turn_loop_matches_reference_runner(gold, host_buffer, tmp_path):
     sp = meta["spec"]
     T, N, A = sp["T"], sp["N"], sp["A"]
     args = make_args(env_name="Hanabi", episode_length=T, n_rollout_threads=N, num_env_steps=4 * T * N, hidden_size=16,
-                     ppo_epoch=2, num_mini_batch=1, algorithm_name="mappo", log_interval=1000, save_interval=1000,
+                     ppo_epoch=2, num_mini_batch=1, algorithm_name="mappo", use_linear_lr_decay=True, log_interval=1000, save_interval=1000,
                      use_wandb=False)
     args.hanabi_name = "fake"
     args.n_eval_rollout_threads = 3

@@ -162,7 +162,7 @@ def cpu_baseline(wl):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="ns", choices=sorted(WORKLOADS))
     ap.add_argument("--threads", type=int, default=None, help="override the global n_rollout_threads")

@@ -150,3 +150,39 @@ def test_mpe_env_factory_with_vec_wrappers():
         sub.close()
     with pytest.raises(NotImplementedError):
         MPEEnv(SimpleNamespace(scenario_name="simple_reference", num_agents=2, episode_length=4))
+
+
+@pytest.mark.parametrize("name,share,choose", [
+    ("DummyVecEnv", False, False), ("SubprocVecEnv", False, False), ("ShareDummyVecEnv", True, False),
+    ("ShareSubprocVecEnv", True, False), ("ChooseDummyVecEnv", True, True), ("ChooseSubprocVecEnv", True, True),
+    ("ChooseSimpleDummyVecEnv", False, True), ("ChooseSimpleSubprocVecEnv", False, True)])
+def test_wrappers_match_reference_outputs(gold, name, share, choose):
+    """Every array a reset / step of the reference's wrapper class returns on the tiny env with seeded actions
+    (oracle/make_golden_wrappers.py) -- auto-reset timing, choose-resets, stacking -- reproduced bit for bit."""
+    z = gold.npz("wrapper_cases")
+
+    def flatten(x, prefix, out):
+        if isinstance(x, (tuple, list)) and not (len(x) and isinstance(x[0], dict)) and not isinstance(x, np.ndarray):
+            for i, y in enumerate(x):
+                flatten(y, prefix + "_%d" % i, out)
+        else:
+            arr = np.asarray(x)
+            if arr.dtype != object:
+                out[prefix] = arr
+    got = {}
+    n = 3
+    venv = getattr(W, name)([functools.partial(TinyEnv, seed=10 + i, share=share, choose=choose) for i in range(n)])
+    try:
+        rng = np.random.default_rng(0)
+        flatten(venv.reset(np.array([True, False, True])) if choose else venv.reset(), name + "_reset", got)
+        for t in range(7):
+            actions = rng.integers(0, 4, size=(n, 2, 1))
+            flatten(venv.step(actions), name + "_step%d" % t, got)
+            if choose and t == 3:
+                flatten(venv.reset(np.array([False, True, True])), name + "_reset_mid", got)
+    finally:
+        venv.close()
+    expected = sorted(k for k in z.files if k.startswith(name + "_"))
+    assert sorted(got) == expected
+    for k in expected:
+        np.testing.assert_array_equal(got[k], z[k], err_msg=k)

@@ -1,10 +1,11 @@
 """Environment side of the package.  Provided here: the VecEnv wrappers (``env_wrappers``), duck-typed
-spaces (``spaces``) and a vectorised MPE ``simple_spread`` (``mpe.simple_spread``).  The simulators themselves
-(SMAC, Hanabi, football, the other MPE scenarios) are out of scope.
+spaces (``spaces``), a vectorised MPE ``simple_spread`` (``mpe.simple_spread``) and Hanabi as a batched native
+stepper (``hanabi``).  The other simulators (SMAC, football, the other MPE scenarios) are out of scope (SURVEY.md
+section 8).
 
 To run against env packages that follow the reference's layout -- e.g. the reference's own
 ``onpolicy/envs`` directory -- list their directories in ``MAPPO_ENVS_PATH`` (``os.pathsep``-separated):
-sub-modules that are not found here (``onpolicy.envs.starcraft2``, ``onpolicy.envs.hanabi``, ...) are then
+sub-modules that are not found here (``onpolicy.envs.starcraft2``, ``onpolicy.envs.football``, ...) are then
 looked up there, under the same import names the reference's train scripts use.
 """
 import os as _os

@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Train script for Hanabi (turn-based runner) -- flags and flow of the reference's
 onpolicy/scripts/train/train_hanabi_forward.py (parse_args :61-69, env factories :16-58, runner :158-162).
-``onpolicy.envs.hanabi`` must come from an external env tree (``MAPPO_ENVS_PATH``).
+The env is the in-tree batched stepper (``onpolicy.envs.hanabi``): all rollout threads advance in one native
+call (``HanabiBatchVecEnv``).  ``--use_subproc_envs`` builds the reference's layout instead -- one ``HanabiEnv``
+per thread behind ``ChooseSubprocVecEnv`` / ``ChooseDummyVecEnv``; both give identical games for the same seeds.
 
     python -m onpolicy.scripts.train.train_hanabi_forward --env_name Hanabi --hanabi_name Hanabi-Full --num_agents 2 ...
 """
@@ -13,6 +15,13 @@ from onpolicy.scripts.train import _launch
 
 
 def make_env(all_args, n_threads, seed_of_rank):
+    if all_args.env_name != "Hanabi":
+        raise NotImplementedError("Can not support the " + all_args.env_name + " environment.")
+    assert 1 < all_args.num_agents < 6, "num_agents can be only between 2-5."
+    if not all_args.use_subproc_envs:
+        from onpolicy.envs.hanabi.batch import HanabiBatchVecEnv
+        return HanabiBatchVecEnv(all_args, [seed_of_rank(rank) for rank in range(n_threads)])
+
     def get_env_fn(rank):
         def init_env():
             if all_args.env_name != "Hanabi":
@@ -31,6 +40,9 @@ def make_env(all_args, n_threads, seed_of_rank):
 def parse_args(args, parser):
     parser.add_argument('--hanabi_name', type=str, default='Hanabi-Very-Small', help="Which env to run on")
     parser.add_argument('--num_agents', type=int, default=2, help="number of players")
+    parser.add_argument('--use_subproc_envs', action='store_true', default=False,
+                        help="one HanabiEnv per rollout thread behind the Choose* VecEnv wrappers (reference layout) "
+                             "instead of the batched stepper")
     return parser.parse_known_args(args)[0]
 
 

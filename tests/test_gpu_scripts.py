@@ -1,5 +1,6 @@
-"""-m gpu: the SMAC / football / Hanabi train scripts end to end against tiny fake single-env classes placed in an
-external env tree (MAPPO_ENVS_PATH) -- flags, VecEnv wrappers, runner choice, logging and checkpoints."""
+"""-m gpu: the SMAC / football train scripts end to end against tiny fake single-env classes placed in an external env
+tree (MAPPO_ENVS_PATH), and the Hanabi train script on the in-tree engine (batched stepper and one env per thread)
+-- flags, VecEnv wrappers, runner choice, logging and checkpoints."""
 import json
 import os
 import sys
@@ -64,49 +65,11 @@ class FootballEnv(object):
                 np.full(self.a, done), info)
     def close(self): pass
 '''
-HANABI_ENV = '''
-import numpy as np
-from onpolicy.envs.spaces import Box, Discrete
-class HanabiEnv(object):
-    """One acting player per step; reset(choose) -> obs [Do], share_obs [Ds], available_actions [na]."""
-    def __init__(self, args, seed):
-        self.a, self.do, self.ds, self.na = args.num_agents, 9, 12, 7
-        self.observation_space = [Box(shape=(self.do,)) for _ in range(self.a)]
-        self.share_observation_space = [Box(shape=(self.ds,)) for _ in range(self.a)]
-        self.action_space = [Discrete(self.na) for _ in range(self.a)]
-        self.rng = np.random.default_rng(seed)
-        self.left = 0
-    def seed(self, s): pass
-    def _emit(self):
-        av = (self.rng.random(self.na) < 0.5).astype(np.float32); av[0] = 1
-        self.av = av
-        return self.rng.standard_normal(self.do).astype(np.float32), self.rng.standard_normal(self.ds).astype(np.float32), av
-    def reset(self, choose=True):
-        if not choose:
-            return np.zeros(self.do, np.float32), np.zeros(self.ds, np.float32), np.zeros(self.na, np.float32)
-        self.left = 6
-        return self._emit()
-    def step(self, action):
-        a = int(np.asarray(action).reshape(-1)[0])
-        if a == -1:
-            return (np.zeros(self.do, np.float32), np.zeros(self.ds, np.float32), np.zeros((self.a, 1), np.float32),
-                    None, {}, np.zeros(self.na, np.float32))
-        assert self.av[a] == 1
-        self.left -= 1
-        done = self.left <= 0
-        obs, share, av = self._emit()
-        if done:
-            av = np.zeros(self.na, np.float32)
-        return obs, share, np.full((self.a, 1), 0.5, np.float32), done, ({"score": 3} if done else {}), av
-    def close(self): pass
-'''
-
-
 @pytest.fixture
 def env_tree(tmp_path, monkeypatch):
     ext = tmp_path / "ext_envs"
     for pkg, files in (("starcraft2", {"StarCraft2_Env.py": SMAC_ENV, "smac_maps.py": SMAC_MAPS}),
-                       ("football", {"Football_Env.py": FOOTBALL_ENV}), ("hanabi", {"Hanabi_Env.py": HANABI_ENV})):
+                       ("football", {"Football_Env.py": FOOTBALL_ENV})):
         (ext / pkg).mkdir(parents=True)
         (ext / pkg / "__init__.py").write_text("")
         for name, body in files.items():
@@ -118,8 +81,7 @@ def env_tree(tmp_path, monkeypatch):
     envs._extend(envs.__path__)
     yield ext
     envs.__path__[:] = before
-    for mod in [m for m in sys.modules if m.startswith(("onpolicy.envs.starcraft2", "onpolicy.envs.football",
-                                                        "onpolicy.envs.hanabi"))]:
+    for mod in [m for m in sys.modules if m.startswith(("onpolicy.envs.starcraft2", "onpolicy.envs.football"))]:
         del sys.modules[mod]
 
 
@@ -154,11 +116,16 @@ def test_train_football_script(env_tree):
     assert os.path.exists(os.path.join(runner.save_dir, "actor.pt"))
 
 
-def test_train_hanabi_script(env_tree):
+@pytest.mark.parametrize("layout", [[], ["--use_subproc_envs"]])
+def test_train_hanabi_script(tmp_path, monkeypatch, layout):
+    """Real games (in-tree engine): HanabiBatchVecEnv by default, ChooseSubprocVecEnv over HanabiEnv on request."""
     from onpolicy.scripts.train import train_hanabi_forward
-    runner = train_hanabi_forward.main(["--env_name", "Hanabi", "--hanabi_name", "fake", "--num_agents", "2",
+    monkeypatch.setenv("MAPPO_RESULTS_DIR", str(tmp_path / "results"))
+    runner = train_hanabi_forward.main(["--env_name", "Hanabi", "--hanabi_name", "Hanabi-Very-Small", "--num_agents", "2",
                                         "--algorithm_name", "mappo", "--n_rollout_threads", "2", "--episode_length", "6",
                                         "--num_env_steps", "48", "--ppo_epoch", "2", "--hidden_size", "16",
-                                        "--use_wandb", "--log_interval", "1", "--n_training_threads", "1"])
+                                        "--use_wandb", "--log_interval", "1", "--n_training_threads", "1"] + layout)
+    assert type(runner.envs).__name__ == ("ChooseSubprocVecEnv" if layout else "HanabiBatchVecEnv")
     assert runner.true_total_num_steps > 0
     assert {"value_loss", "average_score"} <= _tags(runner)
+    runner.envs.close()

@@ -24,6 +24,26 @@ def _cases(gold):
     return z, [c.split("|") for c in z["cases"]]
 
 
+@pytest.fixture
+def cpu_launch(monkeypatch, tmp_path):
+    """Lets the train / eval scripts run here: host buffer stand-in, CPU device (threads set as the real device_of
+    does), results under tmp_path."""
+    import torch
+    import onpolicy.runner.shared.base_runner as base
+    from host_buffer import HostSharedBuffer
+    from onpolicy.scripts.train import _launch
+
+    def device_of(all_args):
+        torch.set_num_threads(all_args.n_training_threads)
+        return torch.device("cpu")
+    threads = torch.get_num_threads()
+    monkeypatch.setattr(base, "SharedReplayBuffer", HostSharedBuffer)
+    monkeypatch.setattr(_launch, "device_of", device_of)
+    monkeypatch.setenv("MAPPO_RESULTS_DIR", str(tmp_path / "results"))
+    yield
+    torch.set_num_threads(threads)
+
+
 def _args(game, players, all_obs):
     return types.SimpleNamespace(hanabi_name=game, num_agents=int(players), use_obs_instead_of_state=bool(all_obs))
 
@@ -170,18 +190,13 @@ def test_missing_library_is_loud(monkeypatch, tmp_path):
 
 
 @pytest.mark.parametrize("game,players", [("Hanabi-Very-Small", 2), ("Hanabi-Small", 3)])
-def test_train_script_plays_real_games(monkeypatch, tmp_path, game, players):
+def test_train_script_plays_real_games(cpu_launch, game, players):
     """train_hanabi_forward end to end on the real engine (host buffer stand-in, CPU): the batched stepper and the
     reference layout (one HanabiEnv per thread behind the Choose* wrappers) play the same games, so the two runs log
     the same scores and end with the same parameters."""
     import json
     import torch
-    import onpolicy.runner.shared.base_runner as base
-    from host_buffer import HostSharedBuffer
-    from onpolicy.scripts.train import _launch, train_hanabi_forward
-    monkeypatch.setattr(base, "SharedReplayBuffer", HostSharedBuffer)
-    monkeypatch.setattr(_launch, "device_of", lambda all_args: torch.device("cpu"))
-    monkeypatch.setenv("MAPPO_RESULTS_DIR", str(tmp_path / "results"))
+    from onpolicy.scripts.train import train_hanabi_forward
     argv = ["--env_name", "Hanabi", "--hanabi_name", game, "--num_agents", str(players), "--algorithm_name", "mappo",
             "--n_rollout_threads", "3", "--episode_length", "8", "--num_env_steps", "96", "--ppo_epoch", "2",
             "--hidden_size", "16", "--use_wandb", "--log_interval", "1", "--n_training_threads", "1", "--use_eval",
@@ -201,3 +216,23 @@ def test_train_script_plays_real_games(monkeypatch, tmp_path, game, players):
         runner.eval_envs.close()
     assert len(runs[0][0]) >= 4 and runs[0][0] == runs[1][0] and runs[0][2] == runs[1][2]
     assert torch.equal(runs[0][1], runs[1][1])
+
+
+def test_eval_script_scores_a_saved_policy(cpu_launch):
+    """scripts/eval/eval_hanabi.py: restore the checkpoint a training run saved and average the score of
+    deterministic games (reference scripts/eval/eval_hanabi.py + HanabiRunner.eval_100k)."""
+    from onpolicy.scripts.eval import eval_hanabi
+    from onpolicy.scripts.train import train_hanabi_forward
+    common = ["--env_name", "Hanabi", "--hanabi_name", "Hanabi-Very-Small", "--num_agents", "2", "--algorithm_name",
+              "mappo", "--n_rollout_threads", "2", "--hidden_size", "16", "--use_wandb", "--n_training_threads", "1"]
+    trained = train_hanabi_forward.main(common + ["--episode_length", "8", "--num_env_steps", "32", "--ppo_epoch", "1"])
+    model_dir = str(trained.save_dir)
+    assert os.path.exists(os.path.join(model_dir, "actor.pt"))
+    with pytest.raises(AssertionError, match="use_eval"):
+        eval_hanabi.main(common + ["--model_dir", model_dir])
+    with pytest.raises(AssertionError, match="model_dir"):
+        eval_hanabi.main(common + ["--use_eval"])
+    argv = common + ["--use_eval", "--model_dir", model_dir, "--n_eval_rollout_threads", "4", "--eval_games", "12"]
+    score = eval_hanabi.main(argv)
+    assert 0.0 <= score <= 5.0
+    assert eval_hanabi.main(argv) == score              # deterministic policy, seeded tables

@@ -85,9 +85,99 @@ CASES = [
 ]
 
 
+# rule sets the named games never use, driven through the reference's pyhanabi classes directly
+RULE_CASES = [
+    # name, config (HanabiGame parameters, hanabi_game.cc:31-49), steps, skill
+    ("seer3", dict(colors=3, ranks=4, players=3, hand_size=3, max_information_tokens=5, max_life_tokens=2,
+                   observation_type=2, seed=21), 160, 0.9),
+    ("random_start4", dict(colors=4, ranks=5, players=4, max_information_tokens=6, max_life_tokens=3,
+                           observation_type=1, random_start_player=1, seed=22), 200, 0.9),
+    ("tall_hands2", dict(colors=5, ranks=5, players=2, hand_size=4, max_information_tokens=2, max_life_tokens=5,
+                         observation_type=1, seed=23), 200, 0.8),
+    ("two_ranks5", dict(colors=5, ranks=2, players=5, hand_size=2, max_information_tokens=4, max_life_tokens=1,
+                        observation_type=0, seed=24), 150, 0.9),
+    ("no_tokens3", dict(colors=2, ranks=3, players=3, hand_size=2, max_information_tokens=0, max_life_tokens=2,
+                        observation_type=1, random_start_player=1, seed=25), 120, 0.7),
+]
+
+
+def play_rule_case(pyhanabi, config, steps, skill, rng):
+    game = pyhanabi.HanabiGame(config)
+    encoder = pyhanabi.ObservationEncoder(game, pyhanabi.ObservationEncoderType.CANONICAL)
+    P, h = game.num_players(), game.hand_size()
+    rec = dict(views=[], own=[], legal=[], to_move=[], actions=[], scores=[], status=[], resets=[])
+
+    def new_state():
+        state = game.new_initial_state()
+        while state.cur_player() == pyhanabi.CHANCE_PLAYER_ID:
+            state.deal_random_card()
+        return state
+
+    def snapshot(state):
+        obs = [state.observation(p) for p in range(P)]
+        rec["views"].append([encoder.encode(o) for o in obs])
+        rec["own"].append([encoder.encodeownhand(o) for o in obs])
+        legal = np.zeros(game.max_moves(), dtype=np.uint8)
+        legal[[game.get_move_uid(m) for m in obs[state.cur_player()].legal_moves()]] = 1
+        rec["legal"].append(legal)
+        rec["to_move"].append(state.cur_player())
+        return legal
+
+    state = new_state()
+    legal = snapshot(state)
+    ends = set()
+    for t in range(steps):
+        moves = np.nonzero(legal)[0]
+        a = None
+        if rng.random() < skill:
+            me, fireworks = state.cur_player(), state.fireworks()
+            for i, card in enumerate(state.player_hands()[me]):
+                if card.rank() == fireworks[card.color()]:
+                    a = h + i
+                    break
+            if a is None:
+                safe = [u for u in moves if not (h <= u < 2 * h)]
+                a = int(rng.choice(safe)) if safe else None
+        if a is None:
+            a = int(rng.choice(moves))
+        state.apply_move(game.get_move(a))
+        while state.cur_player() == pyhanabi.CHANCE_PLAYER_ID:
+            state.deal_random_card()
+        rec["actions"].append(a)
+        rec["scores"].append(state.score())
+        rec["status"].append(state.end_of_game_status().value)
+        legal = snapshot(state)
+        if state.is_terminal():
+            ends.add(state.end_of_game_status().name)
+            rec["resets"].append(t)
+            state = new_state()
+            legal = snapshot(state)
+    return rec, game, encoder, ends
+
+
 def main():
     HanabiEnv = load_reference_env()
     out, names = {}, []
+    from onpolicy.envs.hanabi import pyhanabi
+    rule_names = []
+    for name, config, steps, skill in RULE_CASES:
+        rec, game, encoder, ends = play_rule_case(pyhanabi, config, steps, skill, np.random.default_rng(config["seed"]))
+        key = "rules_" + name
+        out[key + "_config"] = np.array([config.get(k, d) for k, d in (
+            ("colors", 5), ("ranks", 5), ("players", 2), ("hand_size", 0), ("max_information_tokens", 8),
+            ("max_life_tokens", 3), ("observation_type", 1), ("random_start_player", 0), ("seed", 0))])
+        out[key + "_dims"] = np.array([game.max_moves(), encoder.shape()[0], encoder.ownhandshape()[0], game.hand_size()])
+        for k in ("views", "own", "legal"):
+            arr = np.asarray(rec[k])
+            assert np.array_equal(arr, arr.astype(np.uint8))
+            out["%s_%s" % (key, k)] = arr.astype(np.uint8)
+        for k in ("to_move", "actions", "scores", "status", "resets"):
+            out["%s_%s" % (key, k)] = np.asarray(rec[k], dtype=np.int32)
+        rule_names.append(name)
+        print("%-16s episodes %2d  best score %2d  first movers %s  endings %s" % (
+            name, len(rec["resets"]), max(rec["scores"]), sorted(set(rec["to_move"][i + 1] for i in rec["resets"])),
+            sorted(ends)))
+    out["rule_cases"] = np.array(rule_names)
     for name, game, players, all_obs, seed, steps, skill in CASES:
         args = types.SimpleNamespace(hanabi_name=game, num_agents=players, use_obs_instead_of_state=all_obs)
         env = HanabiEnv(args, seed)

@@ -90,6 +90,55 @@ def test_env_replays_reference_games_exactly(gold):
     assert endings == {1, 2, 3}          # out of life tokens, out of cards, completed fireworks
 
 
+def test_rule_sets_outside_the_named_games_match_the_reference_engine(gold):
+    """Seer observations, random start player, non-default hand sizes / token counts / rank counts: every player's
+    encoded view, own-hand vector, the legal moves, the player to move, score and end-of-game status after each move,
+    against the reference's HanabiGame / HanabiState / ObservationEncoder played with the same seed and actions."""
+    z = gold.npz("hanabi_cases")
+    keys = ("colors", "ranks", "players", "hand_size", "max_information_tokens", "max_life_tokens",
+            "observation_type", "random_start_player")
+    first_movers = set()
+    for name in z["rule_cases"]:
+        k = "rules_%s_" % name
+        config = [int(v) for v in z[k + "config"]]
+        rules, seed = dict(zip(keys, config[:8])), config[8]
+        b = hb.HanabiBatch(rules, [seed])
+        n_moves, obs_len, own_len, hand = (int(v) for v in z[k + "dims"])
+        assert (b.num_moves, b.obs_len, b.own_hand_len) == (n_moves, obs_len, own_len)
+        views, own, legal, to_move = z[k + "views"], z[k + "own"], z[k + "legal"], z[k + "to_move"]
+        resets = set(int(t) for t in z[k + "resets"])
+        row = 0
+
+        def check(what):
+            b.encode()
+            assert int(b.to_move[0]) == int(to_move[row]), "%s: player to move at %s" % (name, what)
+            assert np.array_equal(b.available_actions[0], legal[row]), "%s: legal moves at %s" % (name, what)
+            for p in range(b.players):
+                got_view, got_own = b.player_view(0, p)
+                assert np.array_equal(got_view, views[row, p]), "%s: view of player %d at %s" % (name, p, what)
+                assert np.array_equal(got_own, own[row, p]), "%s: own hand of player %d at %s" % (name, p, what)
+            assert np.array_equal(b.obs[0, :obs_len], views[row, to_move[row]])
+
+        b.reset()
+        check("the first deal")
+        first_movers.add((str(name), int(b.to_move[0])))
+        for t, a in enumerate(z[k + "actions"]):
+            b.step([int(a)])
+            row += 1
+            check("move %d" % t)
+            state = b.table_state(0)
+            assert state["score"] == int(z[k + "scores"][t]) == int(b.scores[0])
+            assert state["end_of_game"] == int(z[k + "status"][t]) and bool(b.status[0]) == (state["end_of_game"] != 0)
+            if t in resets:
+                assert b.status[0] == 1
+                b.reset()
+                row += 1
+                check("the deal after move %d" % t)
+                first_movers.add((str(name), int(b.to_move[0])))
+        assert row + 1 == len(views)
+    assert len({m for n, m in first_movers if n == "random_start4"}) >= 3      # the start player really is drawn
+
+
 def test_batched_vec_env_equals_one_env_per_thread(gold):
     """HanabiBatchVecEnv (one native call for all threads) == the per-env protocol of ChooseDummyVecEnv over
     HanabiEnv objects, including threads that sit a step out (action -1) and selective resets."""

@@ -106,3 +106,128 @@ class VecSimpleSpread(object):
 
     def close(self):
         pass
+
+
+class _LazyInfos(object):
+    """``infos[i][j]['individual_reward']`` of the reference protocol, materialised from the device only if somebody
+    looks (the runner reads the last step's infos once per log interval)."""
+
+    def __init__(self, per_agent):
+        self._per_agent, self._rows = per_agent, None
+
+    def _materialise(self):
+        if self._rows is None:
+            self._rows = [[{"individual_reward": float(v)} for v in row] for row in self._per_agent.cpu().tolist()]
+        return self._rows
+
+    def __len__(self):
+        return self._per_agent.shape[0]
+
+    def __iter__(self):
+        return iter(self._materialise())
+
+    def __getitem__(self, i):
+        return self._materialise()[i]
+
+
+class TorchSimpleSpread(object):
+    """The same worlds as ``VecSimpleSpread`` held as tensors on ``device``: with the policy, the rollout buffer and
+    the env on the GPU, a rollout step moves nothing over PCIe.  State is float64 like
+    the reference's numpy physics; observations and rewards leave as float32.
+
+    ``device_resident = True`` tells the runner to hand over the integer action tensor [N, A, 1] as it comes out of
+    the policy (one-hot [N, A, 5] arrays are accepted as well) and to expect tensors back: obs [N, A, Do] float32,
+    rewards [N, A, 1] float32, dones [N, A] bool, infos (lazy)."""
+    device_resident = True
+
+    def __init__(self, n_threads, num_agents=3, num_landmarks=None, episode_length=25, seed=1, auto_reset=True,
+                 device="cpu"):
+        import torch
+        self._torch = torch
+        self.auto_reset = auto_reset
+        self.device = torch.device(device)
+        self.n, self.a = int(n_threads), int(num_agents)
+        self.l = int(num_landmarks) if num_landmarks is not None else self.a
+        self.world_length = int(episode_length)
+        self.rng = torch.Generator(device=self.device)
+        self.rng.manual_seed(int(seed))
+        obs_dim = 4 + 2 * self.l + 4 * (self.a - 1)
+        self.observation_space = [Box(shape=(obs_dim,)) for _ in range(self.a)]
+        self.share_observation_space = [Box(shape=(obs_dim * self.a,)) for _ in range(self.a)]
+        self.action_space = [Discrete(5) for _ in range(self.a)]
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self.pos = torch.zeros(self.n, self.a, 2, **f64)
+        self.vel = torch.zeros(self.n, self.a, 2, **f64)
+        self.landmarks = torch.zeros(self.n, self.l, 2, **f64)
+        self.t = torch.zeros(self.n, dtype=torch.int64, device=self.device)
+        self._others = ~torch.eye(self.a, dtype=torch.bool, device=self.device)
+        # action index -> force direction (environment.py: u[0] += a[1] - a[2], u[1] += a[3] - a[4])
+        self._directions = torch.tensor([[0, 0], [1, 0], [-1, 0], [0, 1], [0, -1]], **f64) * _SENSITIVITY
+
+    def _uniform(self, *shape):
+        torch = self._torch
+        return torch.rand(*shape, generator=self.rng, dtype=torch.float64, device=self.device) * 2 - 1
+
+    def _reset_worlds(self, which):
+        """Branch-free (no host sync): fresh positions are drawn for every world and kept where ``which`` is set."""
+        torch = self._torch
+        w = which.view(-1, 1, 1)
+        self.pos = torch.where(w, self._uniform(self.n, self.a, 2), self.pos)
+        self.vel = torch.where(w, torch.zeros_like(self.vel), self.vel)
+        self.landmarks = torch.where(w, self._uniform(self.n, self.l, 2), self.landmarks)
+        self.t = torch.where(which, torch.zeros_like(self.t), self.t)
+
+    def _obs(self):
+        torch = self._torch
+        n, a = self.n, self.a
+        rel_land = (self.landmarks[:, None, :, :] - self.pos[:, :, None, :]).reshape(n, a, -1)
+        rel_other = self.pos[:, None, :, :] - self.pos[:, :, None, :]
+        rel_other = rel_other[:, self._others].reshape(n, a, (a - 1) * 2)
+        comm = torch.zeros(n, a, (a - 1) * 2, dtype=torch.float64, device=self.device)
+        return torch.cat([self.vel, self.pos, rel_land, rel_other, comm], -1).to(torch.float32)
+
+    def _collision_forces(self):
+        torch = self._torch
+        delta = self.pos[:, :, None, :] - self.pos[:, None, :, :]
+        dist = torch.sqrt((delta ** 2).sum(-1))
+        pen = torch.logaddexp(torch.zeros_like(dist), -(dist - 2 * _AGENT_SIZE) / _CONTACT_MARGIN) * _CONTACT_MARGIN
+        f = _CONTACT_FORCE * delta / dist[..., None] * pen[..., None]
+        f = torch.where(self._others[None, :, :, None], f, torch.zeros_like(f))       # no self force (0 / 0 there)
+        return torch.nan_to_num(f, nan=0.0, posinf=0.0, neginf=0.0).sum(2)
+
+    def _reward(self):
+        torch = self._torch
+        d = torch.sqrt(((self.pos[:, :, None, :] - self.landmarks[:, None, :, :]) ** 2).sum(-1))
+        cover = -d.min(1).values.sum(-1)
+        dd = torch.sqrt(((self.pos[:, :, None, :] - self.pos[:, None, :, :]) ** 2).sum(-1))
+        hits = dd < 2 * _AGENT_SIZE            # the agent itself included, as in the reference (see VecSimpleSpread)
+        return cover[:, None] - hits.sum(-1)
+
+    def reset(self):
+        torch = self._torch
+        self._reset_worlds(torch.ones(self.n, dtype=torch.bool, device=self.device))
+        return self._obs()
+
+    def step(self, actions):
+        torch = self._torch
+        actions = torch.as_tensor(actions, device=self.device)
+        if actions.shape == (self.n, self.a, 5):                         # one-hot (the host protocol)
+            a = actions.to(torch.float64)
+            u = torch.stack([a[..., 1] - a[..., 2], a[..., 3] - a[..., 4]], -1) * _SENSITIVITY
+        else:                                                            # action indices straight from the policy
+            assert actions.shape in ((self.n, self.a, 1), (self.n, self.a)), tuple(actions.shape)
+            u = self._directions[actions.reshape(self.n, self.a).long()]
+        force = u + self._collision_forces()
+        self.vel = self.vel * (1 - _DAMPING) + force * _DT
+        self.pos = self.pos + self.vel * _DT
+        self.t = self.t + 1
+        per_agent = self._reward()
+        rewards = per_agent.sum(-1, keepdim=True).expand(self.n, self.a).unsqueeze(-1).to(torch.float32)
+        done_env = self.t >= self.world_length
+        dones = done_env[:, None].expand(self.n, self.a)
+        if self.auto_reset:
+            self._reset_worlds(done_env)
+        return self._obs(), rewards, dones, _LazyInfos(per_agent)
+
+    def close(self):
+        pass

@@ -35,6 +35,8 @@ class MPERunner(Runner):
         """Centralised critic input: every agent sees the concatenation of all observations."""
         if self.use_centralized_V:
             share = obs.reshape(n_threads, -1)
+            if torch.is_tensor(share):       # device-resident env: a broadcast view, materialised by the K2 slab write
+                return share.unsqueeze(1).expand(-1, self.num_agents, -1)
             return np.expand_dims(share, 1).repeat(self.num_agents, axis=1)
         return obs
 
@@ -95,12 +97,18 @@ class MPERunner(Runner):
         action_log_probs = self._per_env(action_log_prob)
         rnn_states = self._per_env(rnn_states)
         rnn_states_critic = self._per_env(rnn_states_critic)
-        actions_env = _one_hot_actions(self.envs.action_space[0], _t2n(actions))   # the one D2H copy
+        if getattr(self.envs, "device_resident", False):
+            actions_env = actions            # env state lives on the device: the action indices never leave it
+        else:
+            actions_env = _one_hot_actions(self.envs.action_space[0], _t2n(actions))   # the one D2H copy
         return values, actions, action_log_probs, rnn_states, rnn_states_critic, actions_env
 
     def insert(self, data):
         obs, rewards, dones, infos, values, actions, action_log_probs, rnn_states, rnn_states_critic = data
-        alive = torch.as_tensor(~np.asarray(dones, dtype=bool), dtype=torch.float32, device=self.buffer.device)
+        if torch.is_tensor(dones):
+            alive = (~dones).to(dtype=torch.float32, device=self.buffer.device)
+        else:
+            alive = torch.as_tensor(~np.asarray(dones, dtype=bool), dtype=torch.float32, device=self.buffer.device)
         masks = alive.unsqueeze(-1)                                         # 0 where the episode ended
         # finished agents restart from a zero RNN state (reference mpe_runner.py:128-129)
         rnn_states = rnn_states * alive.view(*alive.shape, 1, 1)

@@ -3,7 +3,8 @@
 onpolicy/scripts/train/train_mpe.py (main :64, parse_args :52-61, env factories :16-49): same flags,
 same algorithm-name -> recurrent-flag rewrite, same config dict handed to ``MPERunner``.
 
-Differences: simple_spread comes from the in-tree vectorised implementation (no gym / subprocess workers);
+Differences: simple_spread comes from the in-tree vectorised implementation (no gym / subprocess workers;
+``--use_device_env`` keeps the training worlds on the GPU next to policy and buffer);
 other scenarios are built per worker from an external env tree (MAPPO_ENVS_PATH); wandb / setproctitle are optional.
 Example (BASELINE.json configs[0]):
     python -m onpolicy.scripts.train.train_mpe --env_name MPE --scenario_name simple_spread \\
@@ -16,8 +17,12 @@ from onpolicy.config import get_config
 from onpolicy.scripts.train import _launch
 
 
-def make_train_env(all_args, n_threads=None, seed_offset=0):
+def make_train_env(all_args, n_threads=None, seed_offset=0, device=None):
     n = all_args.n_rollout_threads if n_threads is None else n_threads
+    if all_args.scenario_name == "simple_spread" and device is not None:    # worlds held on the device (row f1)
+        from onpolicy.envs.mpe.simple_spread import TorchSimpleSpread
+        return TorchSimpleSpread(n, all_args.num_agents, all_args.num_landmarks, all_args.episode_length,
+                                 seed=all_args.seed + seed_offset, device=device)
     if all_args.scenario_name == "simple_spread":       # built in, all worlds advanced by one numpy pass
         from onpolicy.envs.mpe.simple_spread import VecSimpleSpread
         return VecSimpleSpread(n, all_args.num_agents, all_args.num_landmarks, all_args.episode_length,
@@ -40,6 +45,9 @@ def parse_args(args, parser):
     parser.add_argument('--scenario_name', type=str, default='simple_spread', help="Which scenario to run on")
     parser.add_argument("--num_landmarks", type=int, default=3)
     parser.add_argument('--num_agents', type=int, default=2, help="number of players")
+    parser.add_argument('--use_device_env', action='store_true', default=False,
+                        help="simple_spread with the training worlds held as tensors on the policy's device "
+                             "(shared-policy runner): no per-step host round trip")
     return parser.parse_known_args(args)[0]
 
 
@@ -51,9 +59,12 @@ def main(args):
     device = _launch.device_of(all_args)
     run_dir = _launch.new_run_dir(all_args, all_args.scenario_name)
     _launch.seed_everything(all_args)
-    envs = make_train_env(all_args)
+    shared = all_args.share_policy and all_args.algorithm_name != "happo"
+    if all_args.use_device_env and not (shared and all_args.scenario_name == "simple_spread"):
+        raise NotImplementedError("--use_device_env: simple_spread with the shared-policy runner only")
+    envs = make_train_env(all_args, device=device if all_args.use_device_env else None)
     eval_envs = make_train_env(all_args, all_args.n_eval_rollout_threads, 50000) if all_args.use_eval else None
-    if all_args.share_policy and all_args.algorithm_name != "happo":
+    if shared:
         from onpolicy.runner.shared.mpe_runner import MPERunner as Runner
     else:
         from onpolicy.runner.separated.mpe_runner import MPERunner as Runner

@@ -11,7 +11,7 @@ import pytest
 REF_SCRIPTS = "/root/reference/onpolicy/scripts/train"
 EXTERNAL = ("onpolicy.envs.starcraft2", "onpolicy.envs.football")
 # flags of ours that the reference does not have (script -> names)
-EXTRA_FLAGS = {"train_hanabi_forward.py": {"use_subproc_envs": False}}
+EXTRA_FLAGS = {"train_hanabi_forward.py": {"use_subproc_envs": False}, "train_mpe.py": {"use_device_env": False}}
 # runner modules the reference's scripts name but the reference itself does not contain
 ABSENT_IN_REFERENCE = ("onpolicy.runner.separated.hanabi_runner_forward", "onpolicy.runner.separated.football_runner")
 

@@ -138,11 +138,11 @@ class RNNLayer(nn.Module):
     def _run(self, x, h0, masks):
         """x [L, B, in], h0 [B, R, H], masks [L, B, 1] -> (y [L, B, H], h_last [B, R, H]).
 
-        On HIP tensors the gate arithmetic of a step is ONE fused kernel (aten::_thnn_fused_gru_cell,
-        forward and backward) fed by two GEMMs whose weight gradients use the split-K form of
-        ``tall_linear`` (they reduce over the 10^5-row batch); time steps are taken apart with
-        ``unbind`` / ``stack`` so that autograd does one scatter per tensor instead of one per step.
-        CPU tensors use the explicit cell below (same formulas)."""
+        On HIP tensors a layer runs through ``_GRUSequenceFn`` (K8: in-place cell kernels, one hidden GEMM per
+        step or, from 131 k rows per step, the projection inside the step kernel; weight / bias gradients once
+        over all L * B rows).  ``MAPPO_GRU_SEQUENCE=0`` selects the older device path instead -- aten's fused GRU
+        cell driven step by step through autograd, time steps taken apart with ``unbind`` / ``stack``.  CPU
+        tensors use the explicit cell above (same formulas)."""
         L, B = x.size(0), x.size(1)
         fused = x.is_cuda
         mask_steps = masks.unbind(0)

@@ -172,7 +172,10 @@ class HanabiBatchVecEnv(object):
     """All rollout threads of the turn-based Hanabi runner in one native batch (see the module docstring).
     ``seeds[i]`` is what the reference's train script passes to env i (train_hanabi_forward.py:24-26)."""
 
-    def __init__(self, all_args, seeds):
+    def __init__(self, all_args, seeds, copy=True):
+        """``copy=False`` returns the batch's own arrays (overwritten by the next reset / step) instead of fresh
+        ones -- for callers that, like the turn-based runner, copy what they keep anyway."""
+        self._out = (lambda a: a.copy()) if copy else (lambda a: a)
         rules = rules_for(all_args.hanabi_name, all_args.num_agents)
         share = SHARE_ALL_PLAYERS if all_args.use_obs_instead_of_state else SHARE_OWN_HAND
         self.batch = HanabiBatch(rules, seeds, share)
@@ -188,7 +191,7 @@ class HanabiBatchVecEnv(object):
         choose = np.ones(b.n, dtype=bool) if reset_choose is None else np.asarray(reset_choose, dtype=bool)
         b.reset(choose)
         b.encode(choose)
-        return b.obs.copy(), b.share_obs.copy(), b.available_actions.copy()
+        return self._out(b.obs), self._out(b.share_obs), self._out(b.available_actions)
 
     def step(self, actions):
         b = self.batch
@@ -198,7 +201,7 @@ class HanabiBatchVecEnv(object):
         rewards = np.repeat(b.rewards[:, None, None], b.players, axis=1)
         dones = _DONE_OF_STATUS[b.status]
         infos = [{"score": int(s)} for s in b.scores]
-        return b.obs.copy(), b.share_obs.copy(), rewards, dones, infos, b.available_actions.copy()
+        return self._out(b.obs), self._out(b.share_obs), rewards, dones, infos, self._out(b.available_actions)
 
     def close(self):
         self.batch.close()

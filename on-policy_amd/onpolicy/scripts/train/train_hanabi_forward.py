@@ -20,7 +20,8 @@ def make_env(all_args, n_threads, seed_of_rank):
     assert 1 < all_args.num_agents < 6, "num_agents can be only between 2-5."
     if not all_args.use_subproc_envs:
         from onpolicy.envs.hanabi.batch import HanabiBatchVecEnv
-        return HanabiBatchVecEnv(all_args, [seed_of_rank(rank) for rank in range(n_threads)])
+        # the runner copies every row it keeps, so the stepper's own arrays are handed out as they are
+        return HanabiBatchVecEnv(all_args, [seed_of_rank(rank) for rank in range(n_threads)], copy=False)
 
     def get_env_fn(rank):
         def init_env():

@@ -118,21 +118,23 @@ class HanabiRunner(Runner):
                 self.reset_choose = np.ones(n, dtype=bool)
                 break
 
+            # rows of the envs that move: a plain slice (views, no gather) when every env does, else their indices
+            sel = slice(None) if choose.all() else np.flatnonzero(choose)
+            obs_c, share_c, avail_c = self.use_obs[sel], self.use_share_obs[sel], self.use_available_actions[sel]
             self.trainer.prep_rollout()
             value, action, action_log_prob, rnn_state, rnn_state_critic = self.trainer.policy.get_actions(
-                self.use_share_obs[choose], self.use_obs[choose], turn.rnn_states[choose, agent_id],
-                turn.rnn_states_critic[choose, agent_id], turn.masks[choose, agent_id],
-                self.use_available_actions[choose])
+                share_c, obs_c, turn.rnn_states[sel, agent_id], turn.rnn_states_critic[sel, agent_id],
+                turn.masks[sel, agent_id], avail_c)
             action_np = _t2n(action)
-            turn.obs[choose, agent_id] = self.use_obs[choose]
-            turn.share_obs[choose, agent_id] = self.use_share_obs[choose]
-            turn.available_actions[choose, agent_id] = self.use_available_actions[choose]
-            turn.values[choose, agent_id] = _t2n(value)
-            turn.actions[choose, agent_id] = action_np
-            env_actions[choose] = action_np
-            turn.action_log_probs[choose, agent_id] = _t2n(action_log_prob)
-            turn.rnn_states[choose, agent_id] = _t2n(rnn_state)
-            turn.rnn_states_critic[choose, agent_id] = _t2n(rnn_state_critic)
+            turn.obs[sel, agent_id] = obs_c
+            turn.share_obs[sel, agent_id] = share_c
+            turn.available_actions[sel, agent_id] = avail_c
+            turn.values[sel, agent_id] = _t2n(value)
+            turn.actions[sel, agent_id] = action_np
+            env_actions[sel] = action_np
+            turn.action_log_probs[sel, agent_id] = _t2n(action_log_prob)
+            turn.rnn_states[sel, agent_id] = _t2n(rnn_state)
+            turn.rnn_states_critic[sel, agent_id] = _t2n(rnn_state_critic)
 
             obs, share_obs, rewards, dones, infos, available_actions = self.envs.step(env_actions)
             self.true_total_num_steps += int(choose.sum())
@@ -143,13 +145,17 @@ class HanabiRunner(Runner):
 
             # the acting player collects what accumulated since its previous move; everybody accrues
             # the new reward (the reward of buffer step 0 is discarded by the shift in run())
-            turn.rewards[choose, agent_id] = turn.rewards_since_last_action[choose, agent_id]
-            turn.rewards_since_last_action[choose, agent_id] = 0.0
-            turn.rewards_since_last_action[choose] += rewards[choose]
+            turn.rewards[sel, agent_id] = turn.rewards_since_last_action[sel, agent_id]
+            turn.rewards_since_last_action[sel, agent_id] = 0.0
+            turn.rewards_since_last_action[sel] += rewards[sel]
 
             done = np.asarray(dones) == True   # noqa: E712  (dones may hold None for idle envs)
             alive = np.asarray(dones) == False  # noqa: E712
             self.reset_choose[done] = True
+            turn.masks[alive, agent_id] = 1.0                 # running games: the current player stays live
+            turn.active_masks[alive, agent_id] = 1.0
+            if not done.any():
+                continue
             # finished games: nobody may act, states restart, players after the current one are inactive
             self.use_available_actions[done] = 0.0
             turn.masks[done] = 0.0
@@ -163,13 +169,9 @@ class HanabiRunner(Runner):
             turn.values[done, rest] = 0.0
             turn.obs[done, rest] = 0.0
             turn.share_obs[done, rest] = 0.0
-            # running games: the current player stays live
-            turn.masks[alive, agent_id] = 1.0
-            turn.active_masks[alive, agent_id] = 1.0
-
-            for d, info in zip(dones, infos):
-                if d and 'score' in info.keys():
-                    self.scores.append(info['score'])
+            for i in np.flatnonzero(done):
+                if 'score' in infos[i].keys():
+                    self.scores.append(infos[i]['score'])
 
     def train(self):
         self.trainer.prep_training()

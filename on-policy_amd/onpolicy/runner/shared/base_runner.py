@@ -117,13 +117,18 @@ class Runner(object):
             self.save_dir = str(os.path.join(str(self.run_dir), 'models'))
             os.makedirs(self.save_dir, exist_ok=True)
 
+    _mat = False          # True when the learner is the Multi-Agent Transformer (set by _init_learner)
+
     def _init_learner(self):
         """One policy / trainer / HBM buffer shared by all agents (reference base_runner.py:68-108)."""
         a = self.all_args
-        if self.algorithm_name in ("mat", "mat_dec"):
-            raise NotImplementedError("the MAT trainer is outside this implementation's scope")
-        from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO as TrainAlgo
-        from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy as Policy
+        self._mat = self.algorithm_name in ("mat", "mat_dec")
+        if self._mat:
+            from onpolicy.algorithms.mat.mat_trainer import MATTrainer as TrainAlgo
+            from onpolicy.algorithms.mat.algorithm.transformer_policy import TransformerPolicy as Policy
+        else:
+            from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO as TrainAlgo
+            from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy as Policy
 
         share_observation_space = self.envs.share_observation_space[0] if self.use_centralized_V \
             else self.envs.observation_space[0]
@@ -131,11 +136,12 @@ class Runner(object):
         print("share_obs_space: ", self.envs.share_observation_space)
         print("act_space: ", self.envs.action_space)
 
+        extra = (self.num_agents,) if self._mat else ()       # the transformer is built for a fixed team size
         self.policy = Policy(a, self.envs.observation_space[0], share_observation_space,
-                             self.envs.action_space[0], device=self.device)
+                             self.envs.action_space[0], *extra, device=self.device)
         if self.model_dir is not None:
             self.restore(self.model_dir)
-        self.trainer = TrainAlgo(a, self.policy, device=self.device)
+        self.trainer = TrainAlgo(a, self.policy, *extra, device=self.device)
         self.buffer = SharedReplayBuffer(a, self.num_agents, self.envs.observation_space[0],
                                          share_observation_space, self.envs.action_space[0],
                                          device=self.device if torch.device(self.device).type == "cuda" else None)
@@ -168,9 +174,10 @@ class Runner(object):
         """Bootstrap value of the last state, then returns / advantages for the whole rollout."""
         self.trainer.prep_rollout()
         b = self.buffer
-        next_values = self.trainer.policy.get_values(self._rows(b.share_obs[-1]),
-                                                     self._rows(b.rnn_states_critic[-1]),
-                                                     self._rows(b.masks[-1]))
+        inputs = [self._rows(b.share_obs[-1]), self._rows(b.rnn_states_critic[-1]), self._rows(b.masks[-1])]
+        if self._mat:                     # the transformer's critic reads the observations (base_runner.py:124-128)
+            inputs.insert(1, self._rows(b.obs[-1]))
+        next_values = self.trainer.policy.get_values(*inputs)
         b.compute_returns(self._per_env(next_values), self.trainer.value_normalizer)
 
     def train(self):
@@ -181,11 +188,15 @@ class Runner(object):
         return train_infos
 
     def save(self, episode=0):
-        """actor.pt / critic.pt state dicts, the reference's checkpoint format."""
+        """actor.pt / critic.pt state dicts (transformer_<episode>.pt for MAT), the reference's checkpoint format."""
+        if self._mat:
+            return self.policy.save(self.save_dir, episode)
         torch.save(self.trainer.policy.actor.state_dict(), str(self.save_dir) + "/actor.pt")
         torch.save(self.trainer.policy.critic.state_dict(), str(self.save_dir) + "/critic.pt")
 
     def restore(self, model_dir):
+        if self._mat:
+            return self.policy.restore(model_dir)
         self.policy.actor.load_state_dict(torch.load(str(model_dir) + '/actor.pt', map_location=self.device))
         if not self.all_args.use_render:
             self.policy.critic.load_state_dict(torch.load(str(model_dir) + '/critic.pt', map_location=self.device))

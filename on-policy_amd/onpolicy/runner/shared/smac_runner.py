@@ -123,8 +123,9 @@ class SMACRunner(Runner):
         eval_masks = np.ones((n, self.num_agents, 1), dtype=np.float32)
         while True:
             self.trainer.prep_rollout()
+            critic_input = [np.concatenate(eval_share_obs)] if self._mat else []     # smac_runner.py:176-182
             eval_actions, eval_rnn_states = self.trainer.policy.act(
-                np.concatenate(eval_obs), np.concatenate(eval_rnn_states), np.concatenate(eval_masks),
+                *critic_input, np.concatenate(eval_obs), np.concatenate(eval_rnn_states), np.concatenate(eval_masks),
                 np.concatenate(eval_available_actions), deterministic=True)
             eval_actions = np.array(np.split(_t2n(eval_actions), n))
             eval_rnn_states = np.array(np.split(_t2n(eval_rnn_states), n))

@@ -18,11 +18,14 @@ def apply_algorithm_flags(all_args, allowed=("rmappo", "mappo", "ippo")):
     if name == "rmappo":
         all_args.use_recurrent_policy = True
         all_args.use_naive_recurrent_policy = False
-    elif name in ("mappo", "happo"):
+    elif name in ("mappo", "happo", "mat", "mat_dec"):
         all_args.use_recurrent_policy = False
         all_args.use_naive_recurrent_policy = False
     elif name == "ippo":
         all_args.use_centralized_V = False
+    if name == "mat_dec":          # decentralised actor variant of MAT (train_smac.py:151-153)
+        all_args.dec_actor = True
+        all_args.share_actor = True
     return all_args
 
 

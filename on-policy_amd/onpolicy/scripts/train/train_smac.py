@@ -77,7 +77,7 @@ def num_agents_of(all_args):
 
 
 def main(args):
-    all_args = _launch.apply_algorithm_flags(parse_args(args, get_config()), ("rmappo", "mappo", "ippo", "happo"))
+    all_args = _launch.apply_algorithm_flags(parse_args(args, get_config()), ("rmappo", "mappo", "ippo", "happo", "mat", "mat_dec"))
     device = _launch.device_of(all_args)
     run_dir = _launch.new_run_dir(all_args, all_args.map_name)
     _launch.seed_everything(all_args)

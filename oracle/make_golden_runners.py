@@ -52,6 +52,10 @@ def dump(out, key, runner, with_avail):
 
 
 def params(out, key, policy):
+    if hasattr(policy, "transformer"):          # MAT: one network
+        for k, v in policy.transformer.state_dict().items():
+            out[key + "transformer." + k] = v.detach().numpy().copy()
+        return
     for k, v in policy.actor.state_dict().items():
         out[key + "actor." + k] = v.detach().numpy().copy()
     for k, v in policy.critic.state_dict().items():
@@ -86,6 +90,12 @@ def main():
         "smac_rnn": dict(env="StarCraft2", runner=SMACRunner, T=8, N=3, A=4, Do=7, Ds=9, na=6,
                          args=dict(algorithm_name="rmappo", use_recurrent_policy=True, hidden_size=16, ppo_epoch=1,
                                    num_mini_batch=1, data_chunk_length=4, use_proper_time_limits=True)),
+        # Multi-Agent Transformer through the same SMAC runner (base_runner.py:66-93, :124-128; smac_runner.py:176-182)
+        "smac_mat": dict(env="StarCraft2", runner=SMACRunner, T=8, N=3, A=4, Do=7, Ds=9, na=6,
+                         args=dict(algorithm_name="mat", n_embd=16, n_head=2, n_block=1, ppo_epoch=2, num_mini_batch=2)),
+        "smac_mat_dec": dict(env="StarCraft2", runner=SMACRunner, T=8, N=3, A=4, Do=7, Ds=9, na=6,
+                             args=dict(algorithm_name="mat_dec", dec_actor=True, share_actor=True, n_embd=16, n_head=1,
+                                       n_block=1, ppo_epoch=1, num_mini_batch=1)),
     }
     for cname, sp in specs.items():
         T, N, A = sp["T"], sp["N"], sp["A"]

@@ -53,6 +53,9 @@ class HostSharedBuffer(object):
         for sample in gen:
             yield tuple(None if x is None else torch.from_numpy(np.ascontiguousarray(x)) for x in sample)
 
+    def feed_forward_generator_transformer(self, advantages, num_mini_batch=None, mini_batch_size=None):
+        return self._wrap(self._o.feed_forward_generator_transformer(_np(advantages), num_mini_batch, mini_batch_size))
+
     def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None):
         return self._wrap(self._o.feed_forward_generator(_np(advantages), num_mini_batch, mini_batch_size))
 
@@ -93,6 +96,9 @@ class HostSeparatedBuffer(object):
         self._o.compute_returns(_np(next_value).reshape(self.n_rollout_threads, 1), value_normalizer)
 
     _wrap = HostSharedBuffer._wrap
+
+    def feed_forward_generator_transformer(self, advantages, num_mini_batch=None, mini_batch_size=None):
+        return self._wrap(self._o.feed_forward_generator_transformer(_np(advantages), num_mini_batch, mini_batch_size))
 
     def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None):
         return self._wrap(self._o.feed_forward_generator(_np(advantages), num_mini_batch, mini_batch_size))

@@ -43,7 +43,9 @@ def _check_eval(runner, step, expected):
 
 
 def _check_params(z, prefix, policy, exact=False):
-    for net, mod in (("actor.", policy.actor), ("critic.", policy.critic)):
+    nets = (("transformer.", policy.transformer),) if hasattr(policy, "transformer") else \
+        (("actor.", policy.actor), ("critic.", policy.critic))
+    for net, mod in nets:
         for k, v in mod.state_dict().items():
             ref = z[prefix + net + k]
             if exact:
@@ -62,7 +64,7 @@ def _check_buffer(z, prefix, buf):
             np.testing.assert_allclose(got, ref, err_msg=name, **TOL)
 
 
-@pytest.mark.parametrize("cname", ["mpe_mlp", "mpe_rnn", "smac_rnn"])
+@pytest.mark.parametrize("cname", ["mpe_mlp", "mpe_rnn", "smac_rnn", "smac_mat", "smac_mat_dec"])
 def test_rollout_and_update_match_reference_runner(gold, host_buffer, tmp_path, cname):
     from onpolicy.runner.shared.mpe_runner import MPERunner
     from onpolicy.runner.shared.smac_runner import SMACRunner

@@ -53,12 +53,9 @@ class SelfAttention(nn.Module):
     def __init__(self, n_embd, n_head, n_agent, masked=False):
         super(SelfAttention, self).__init__()
         assert n_embd % n_head == 0
-        self.masked = masked
-        self.n_head = n_head
-        self.key = init_(nn.Linear(n_embd, n_embd))
-        self.query = init_(nn.Linear(n_embd, n_embd))
-        self.value = init_(nn.Linear(n_embd, n_embd))
-        self.proj = init_(nn.Linear(n_embd, n_embd))
+        self.masked, self.n_head = masked, n_head
+        for name in ("key", "query", "value", "proj"):          # construction order fixes the init random stream
+            setattr(self, name, init_(nn.Linear(n_embd, n_embd)))
         # part of the reference's state dict; causality itself is handled by the attention kernel
         self.register_buffer("mask", torch.tril(torch.ones(n_agent + 1, n_agent + 1))
                              .view(1, 1, n_agent + 1, n_agent + 1))
@@ -84,30 +81,29 @@ class SelfAttention(nn.Module):
 class EncodeBlock(nn.Module):
     def __init__(self, n_embd, n_head, n_agent):
         super(EncodeBlock, self).__init__()
-        self.ln1 = nn.LayerNorm(n_embd)
-        self.ln2 = nn.LayerNorm(n_embd)
+        self.ln1, self.ln2 = nn.LayerNorm(n_embd), nn.LayerNorm(n_embd)
         self.attn = SelfAttention(n_embd, n_head, n_agent, masked=False)
         self.mlp = _two_layer(n_embd)
 
     def forward(self, x):
-        x = self.ln1(x + self.attn(x, x, x))
-        return self.ln2(x + self.mlp(x))
+        """Post-norm residual block: agents attend to each other without a mask."""
+        attended = self.ln1(x + self.attn(x, x, x))
+        return self.ln2(attended + self.mlp(attended))
 
 
 class DecodeBlock(nn.Module):
     def __init__(self, n_embd, n_head, n_agent):
         super(DecodeBlock, self).__init__()
-        self.ln1 = nn.LayerNorm(n_embd)
-        self.ln2 = nn.LayerNorm(n_embd)
-        self.ln3 = nn.LayerNorm(n_embd)
-        self.attn1 = SelfAttention(n_embd, n_head, n_agent, masked=True)
-        self.attn2 = SelfAttention(n_embd, n_head, n_agent, masked=True)
+        self.ln1, self.ln2, self.ln3 = (nn.LayerNorm(n_embd) for _ in range(3))
+        self.attn1 = SelfAttention(n_embd, n_head, n_agent, masked=True)      # over the action tokens
+        self.attn2 = SelfAttention(n_embd, n_head, n_agent, masked=True)      # encoder rows query the action stream
         self.mlp = _two_layer(n_embd)
 
     def forward(self, x, rep_enc):
-        x = self.ln1(x + self.attn1(x, x, x))
-        x = self.ln2(rep_enc + self.attn2(key=x, value=x, query=rep_enc))
-        return self.ln3(x + self.mlp(x))
+        """All positions at once; both attentions are causal over the agent order."""
+        tokens = self.ln1(x + self.attn1(x, x, x))
+        mixed = self.ln2(rep_enc + self.attn2(key=tokens, value=tokens, query=rep_enc))
+        return self.ln3(mixed + self.mlp(mixed))
 
     def step(self, x, rep_enc, cache):
         """One new position: x, rep_enc [B, 1, D]; ``cache`` holds this block's keys / values of the earlier ones."""
@@ -117,9 +113,9 @@ class DecodeBlock(nn.Module):
                 k, v = torch.cat([cache[name][0], k], 2), torch.cat([cache[name][1], v], 2)
             cache[name] = (k, v)
             return k, v
-        x = self.ln1(x + self.attn1.attend(x, *extend("self", self.attn1, x), causal=False))
-        x = self.ln2(rep_enc + self.attn2.attend(rep_enc, *extend("cross", self.attn2, x), causal=False))
-        return self.ln3(x + self.mlp(x))
+        tokens = self.ln1(x + self.attn1.attend(x, *extend("self", self.attn1, x), causal=False))
+        mixed = self.ln2(rep_enc + self.attn2.attend(rep_enc, *extend("cross", self.attn2, tokens), causal=False))
+        return self.ln3(mixed + self.mlp(mixed))
 
 
 class Encoder(nn.Module):

@@ -15,71 +15,65 @@ from onpolicy.utils.util import get_gard_norm, huber_loss, mse_loss
 from onpolicy.utils.valuenorm import ValueNorm
 
 
+_HYPER = ("clip_param", "ppo_epoch", "num_mini_batch", "data_chunk_length", "value_loss_coef", "entropy_coef",
+          "max_grad_norm", "huber_delta", "dec_actor")
+_SWITCHES = {"_use_recurrent_policy": "use_recurrent_policy", "_use_naive_recurrent": "use_naive_recurrent_policy",
+             "_use_max_grad_norm": "use_max_grad_norm", "_use_clipped_value_loss": "use_clipped_value_loss",
+             "_use_huber_loss": "use_huber_loss", "_use_valuenorm": "use_valuenorm",
+             "_use_value_active_masks": "use_value_active_masks", "_use_policy_active_masks": "use_policy_active_masks"}
+
+
+def _masked_mean(x, weights, use_weights):
+    return (x * weights).sum() / weights.sum() if use_weights else x.mean()
+
+
 class MATTrainer(object):
     def __init__(self, args, policy, num_agents, device=torch.device("cpu")):
-        self.device = device
+        self.policy, self.num_agents, self.device = policy, num_agents, device
         self.tpdv = dict(dtype=torch.float32, device=device)
-        self.policy = policy
-        self.num_agents = num_agents
-        for name in ("clip_param", "ppo_epoch", "num_mini_batch", "data_chunk_length", "value_loss_coef",
-                     "entropy_coef", "max_grad_norm", "huber_delta", "dec_actor"):
+        for name in _HYPER:
             setattr(self, name, getattr(args, name))
-        self._use_recurrent_policy = args.use_recurrent_policy
-        self._use_naive_recurrent = args.use_naive_recurrent_policy
-        self._use_max_grad_norm = args.use_max_grad_norm
-        self._use_clipped_value_loss = args.use_clipped_value_loss
-        self._use_huber_loss = args.use_huber_loss
-        self._use_valuenorm = args.use_valuenorm
-        self._use_value_active_masks = args.use_value_active_masks
-        self._use_policy_active_masks = args.use_policy_active_masks
+        for attr, flag in _SWITCHES.items():
+            setattr(self, attr, getattr(args, flag))
         self.value_normalizer = ValueNorm(1, device=self.device) if self._use_valuenorm else None
 
     def cal_value_loss(self, values, value_preds_batch, return_batch, active_masks_batch):
-        value_pred_clipped = value_preds_batch + (values - value_preds_batch).clamp(-self.clip_param, self.clip_param)
+        """Clipped value loss against the (normalised) returns; the normaliser is updated with this minibatch first."""
         if self._use_valuenorm:
             self.value_normalizer.update(return_batch)
             target = self.value_normalizer.normalize(return_batch)
         else:
             target = return_batch
-        error_clipped, error_original = target - value_pred_clipped, target - values
-        loss_of = (lambda e: huber_loss(e, self.huber_delta)) if self._use_huber_loss else mse_loss
-        value_loss = loss_of(error_original)
+        per_sample = (lambda e: huber_loss(e, self.huber_delta)) if self._use_huber_loss else mse_loss
+        loss = per_sample(target - values)
         if self._use_clipped_value_loss:
-            value_loss = torch.max(value_loss, loss_of(error_clipped))
-        if self._use_value_active_masks:
-            return (value_loss * active_masks_batch).sum() / active_masks_batch.sum()
-        return value_loss.mean()
+            near_old = value_preds_batch + (values - value_preds_batch).clamp(-self.clip_param, self.clip_param)
+            loss = torch.max(loss, per_sample(target - near_old))
+        return _masked_mean(loss, active_masks_batch, self._use_value_active_masks)
+
+    def _surrogate(self, action_log_probs, old_action_log_probs, adv_targ, active_masks):
+        ratio = torch.exp(action_log_probs - old_action_log_probs)
+        clipped = torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)
+        objective = torch.min(ratio * adv_targ, clipped * adv_targ).sum(dim=-1, keepdim=True)
+        return _masked_mean(-objective, active_masks, self._use_policy_active_masks), ratio
 
     def ppo_update(self, sample):
-        share_obs_batch, obs_batch, rnn_states_batch, rnn_states_critic_batch, actions_batch, value_preds_batch, \
-            return_batch, masks_batch, active_masks_batch, old_action_log_probs_batch, adv_targ, \
-            available_actions_batch = sample[:12]
-        old_action_log_probs_batch = check(old_action_log_probs_batch).to(**self.tpdv)
-        adv_targ = check(adv_targ).to(**self.tpdv)
-        value_preds_batch = check(value_preds_batch).to(**self.tpdv)
-        return_batch = check(return_batch).to(**self.tpdv)
-        active_masks_batch = check(active_masks_batch).to(**self.tpdv)
-
+        """One minibatch: joint loss = surrogate - entropy bonus + value loss, one backward, one Adam step.
+        -> (value_loss, grad_norm, policy_loss, dist_entropy, grad_norm, importance weights), the reference's tuple."""
+        share_obs, obs, rnn_a, rnn_c, actions, value_preds, returns, masks, active, old_logp, adv, avail = sample[:12]
+        old_logp, adv, value_preds, returns, active = (check(x).to(**self.tpdv)
+                                                       for x in (old_logp, adv, value_preds, returns, active))
         values, action_log_probs, dist_entropy = self.policy.evaluate_actions(
-            share_obs_batch, obs_batch, rnn_states_batch, rnn_states_critic_batch, actions_batch, masks_batch,
-            available_actions_batch, active_masks_batch)
-        imp_weights = torch.exp(action_log_probs - old_action_log_probs_batch)
-        surr1 = imp_weights * adv_targ
-        surr2 = torch.clamp(imp_weights, 1.0 - self.clip_param, 1.0 + self.clip_param) * adv_targ
-        surrogate = -torch.sum(torch.min(surr1, surr2), dim=-1, keepdim=True)
-        if self._use_policy_active_masks:
-            policy_loss = (surrogate * active_masks_batch).sum() / active_masks_batch.sum()
-        else:
-            policy_loss = surrogate.mean()
-        value_loss = self.cal_value_loss(values, value_preds_batch, return_batch, active_masks_batch)
+            share_obs, obs, rnn_a, rnn_c, actions, masks, avail, active)
+        policy_loss, imp_weights = self._surrogate(action_log_probs, old_logp, adv, active)
+        value_loss = self.cal_value_loss(values, value_preds, returns, active)
         loss = policy_loss - dist_entropy * self.entropy_coef + value_loss * self.value_loss_coef
 
         self.policy.optimizer.zero_grad()
         loss.backward()
-        if self._use_max_grad_norm:
-            grad_norm = nn.utils.clip_grad_norm_(self.policy.transformer.parameters(), self.max_grad_norm)
-        else:
-            grad_norm = get_gard_norm(self.policy.transformer.parameters())
+        params = self.policy.transformer.parameters()
+        grad_norm = nn.utils.clip_grad_norm_(params, self.max_grad_norm) if self._use_max_grad_norm \
+            else get_gard_norm(params)
         self.policy.optimizer.step()
         return value_loss, grad_norm, policy_loss, dist_entropy, grad_norm, imp_weights
 

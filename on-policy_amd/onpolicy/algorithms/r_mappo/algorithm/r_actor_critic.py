@@ -73,9 +73,10 @@ class R_Actor(nn.Module, _DeviceMixin):
         obs, rnn_states, action, masks, available_actions, active_masks = self._to_device(
             obs, rnn_states, action, masks, available_actions, active_masks)
         feats, _ = self._features(obs, rnn_states, masks, obs_standardized)
-        return self.act.evaluate_actions(
-            feats, action, available_actions,
-            active_masks=active_masks if self._use_policy_active_masks else None)
+        # "hatrpo": the trust-region trainer also needs the distribution's parameters (r_actor_critic.py:102-108)
+        evaluate = self.act.evaluate_actions_trpo if self.algo == "hatrpo" else self.act.evaluate_actions
+        return evaluate(feats, action, available_actions,
+                        active_masks=active_masks if self._use_policy_active_masks else None)
 
 
     def evaluate_logits(self, obs, rnn_states, masks, obs_standardized=False):

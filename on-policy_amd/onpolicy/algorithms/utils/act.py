@@ -5,7 +5,7 @@ forward :44, get_probs :91, evaluate_actions :115); the space is recognised by c
 import torch
 import torch.nn as nn
 
-from .distributions import Bernoulli, Categorical, DiagGaussian
+from .distributions import Bernoulli, Categorical, DiagGaussian, FixedCategorical
 
 
 def _masked_mean(x, active_masks, squeeze=True):
@@ -67,6 +67,38 @@ class ACTLayer(nn.Module):
         if self.mixed_action or self.multi_discrete:
             return torch.cat([head(x).probs for head in self.action_outs], -1)
         return self._single(x, available_actions).probs
+
+    def evaluate_actions_trpo(self, x, action, available_actions=None, active_masks=None):
+        """What the trust-region trainer needs besides log-probs and entropy (reference act.py:180-235):
+        -> (action_log_probs, dist_entropy, mean, std, normalised logits).  ``mean`` / ``std`` carry gradients for
+        Box heads only; categorical heads report theirs as NaN like ``torch.distributions.Categorical`` and are
+        compared through their normalised logits instead (``None`` for Box heads)."""
+        if self.mixed_action:
+            raise NotImplementedError("the trust-region update is not defined for the mixed action head")
+        if self.multi_discrete:
+            log_probs, ents, means, stds, logits = [], [], [], [], []
+            for head, act in zip(self.action_outs, torch.transpose(action, 0, 1)):
+                dist = head(x)
+                log_probs.append(dist.log_probs(act))
+                ents.append(_masked_mean(dist.entropy(), active_masks))
+                means.append(dist.mean)
+                stds.append(dist.stddev)
+                logits.append(dist.logits)
+            # the reference averages the per-head entropies through a fresh tensor, i.e. without gradient
+            return (torch.cat(log_probs, -1), torch.stack(ents).detach().mean(), torch.cat(means, -1),
+                    torch.cat(stds, -1), torch.cat(logits, -1))
+        dist = self._single(x, available_actions)
+        categorical = isinstance(dist, FixedCategorical)
+        ent = dist.entropy()
+        if active_masks is None:
+            entropy = ent.mean()
+        elif categorical:
+            entropy = _masked_mean(ent, active_masks)
+        else:
+            # the reference multiplies the [B] entropies by the [B, 1] masks (act.py:231), a [B, B] outer product
+            # whose normalised sum is just the sum of the entropies; logged only -- computed here without the product
+            entropy = ent.sum()
+        return dist.log_probs(action), entropy, dist.mean, dist.stddev, (dist.logits if categorical else None)
 
     def evaluate_actions(self, x, action, available_actions=None, active_masks=None):
         if self.mixed_action:

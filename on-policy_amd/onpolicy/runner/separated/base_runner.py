@@ -27,10 +27,13 @@ _SPAN_ELEMENTS = 1 << 28
 class Runner(_SharedRunner):
     def _init_learner(self):
         a = self.all_args
-        if self.algorithm_name in ("hatrpo", "mat", "mat_dec"):
-            raise NotImplementedError("algorithm %r is outside this implementation's scope (the PPO family: "
-                                      "mappo / rmappo / ippo / happo)" % self.algorithm_name)
-        if self.algorithm_name == "happo":
+        if self.algorithm_name in ("mat", "mat_dec"):
+            raise NotImplementedError("algorithm %r needs the shared-policy runner (one transformer for the team)"
+                                      % self.algorithm_name)
+        if self.algorithm_name == "hatrpo":
+            from onpolicy.algorithms.hatrpo.hatrpo_trainer import HATRPO as TrainAlgo
+            from onpolicy.algorithms.hatrpo.policy import HATRPO_Policy as Policy
+        elif self.algorithm_name == "happo":
             from onpolicy.algorithms.happo.happo_trainer import HAPPO as TrainAlgo
             from onpolicy.algorithms.happo.policy import HAPPO_Policy as Policy
         else:

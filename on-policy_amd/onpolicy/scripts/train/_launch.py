@@ -18,7 +18,7 @@ def apply_algorithm_flags(all_args, allowed=("rmappo", "mappo", "ippo")):
     if name == "rmappo":
         all_args.use_recurrent_policy = True
         all_args.use_naive_recurrent_policy = False
-    elif name in ("mappo", "happo", "mat", "mat_dec"):
+    elif name in ("mappo", "happo", "hatrpo", "mat", "mat_dec"):
         all_args.use_recurrent_policy = False
         all_args.use_naive_recurrent_policy = False
     elif name == "ippo":

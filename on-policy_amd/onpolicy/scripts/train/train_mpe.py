@@ -53,13 +53,13 @@ def parse_args(args, parser):
 
 def main(args):
     all_args = parse_args(args, get_config())
-    _launch.apply_algorithm_flags(all_args, ("rmappo", "mappo", "ippo", "happo"))   # happo: --share_policy false only
+    _launch.apply_algorithm_flags(all_args, ("rmappo", "mappo", "ippo", "happo", "hatrpo"))   # happo / hatrpo: separated runner
     assert (all_args.share_policy is True and all_args.scenario_name == 'simple_speaker_listener') is False, (
         "The simple_speaker_listener scenario can not use shared policy. Please check the config.py.")
     device = _launch.device_of(all_args)
     run_dir = _launch.new_run_dir(all_args, all_args.scenario_name)
     _launch.seed_everything(all_args)
-    shared = all_args.share_policy and all_args.algorithm_name != "happo"
+    shared = all_args.share_policy and all_args.algorithm_name not in ("happo", "hatrpo")
     if all_args.use_device_env and not (shared and all_args.scenario_name == "simple_spread"):
         raise NotImplementedError("--use_device_env: simple_spread with the shared-policy runner only")
     envs = make_train_env(all_args, device=device if all_args.use_device_env else None)

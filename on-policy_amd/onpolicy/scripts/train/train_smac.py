@@ -77,14 +77,14 @@ def num_agents_of(all_args):
 
 
 def main(args):
-    all_args = _launch.apply_algorithm_flags(parse_args(args, get_config()), ("rmappo", "mappo", "ippo", "happo", "mat", "mat_dec"))
+    all_args = _launch.apply_algorithm_flags(parse_args(args, get_config()), ("rmappo", "mappo", "ippo", "happo", "hatrpo", "mat", "mat_dec"))
     device = _launch.device_of(all_args)
     run_dir = _launch.new_run_dir(all_args, all_args.map_name)
     _launch.seed_everything(all_args)
     envs = make_env(all_args, all_args.n_rollout_threads, lambda rank: all_args.seed + rank * 1000)
     eval_envs = make_env(all_args, all_args.n_eval_rollout_threads,
                          lambda rank: all_args.seed * 50000 + rank * 10000) if all_args.use_eval else None
-    if all_args.share_policy and all_args.algorithm_name != "happo":
+    if all_args.share_policy and all_args.algorithm_name not in ("happo", "hatrpo"):
         from onpolicy.runner.shared.smac_runner import SMACRunner as Runner
     else:
         from onpolicy.runner.separated.smac_runner import SMACRunner as Runner

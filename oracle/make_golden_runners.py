@@ -147,6 +147,10 @@ def main():
         "sep_smac_happo": dict(env="StarCraft2", runner=SepSMACRunner, T=8, N=3, A=4, Do=7, Ds=9, na=6,
                                args=dict(algorithm_name="happo", hidden_size=16, ppo_epoch=1, num_mini_batch=1,
                                          use_proper_time_limits=True, share_policy=False)),
+        # trust-region updates; one minibatch per agent, so that the result does not depend on the permutation drawn
+        # after the reference's throw-away actor has advanced the random stream (hatrpo_trainer.py:222-225)
+        "sep_smac_hatrpo": dict(env="StarCraft2", runner=SepSMACRunner, T=8, N=3, A=4, Do=7, Ds=9, na=6,
+                                args=dict(algorithm_name="hatrpo", hidden_size=16, num_mini_batch=1, share_policy=False)),
     }
     SEP_FIELDS = tuple(f for f in FIELDS)
     for cname, sp in sep_specs.items():

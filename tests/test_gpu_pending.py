@@ -94,3 +94,36 @@ def test_train_mpe_with_device_resident_worlds(tmp_path, monkeypatch, algo):
     tags = {json.loads(l)["tag"] for l in open(os.path.join(runner.log_dir, "scalars.jsonl"))}
     assert {"value_loss", "average_episode_rewards", "agent0/individual_rewards"} <= tags
     assert torch.isfinite(runner.buffer.rewards).all() and float(runner.buffer.masks.min()) == 0.0
+
+
+@pytest.mark.parametrize("cname", ["mlp", "mlp_popart", "mlp_nonorm", "gru", "rejected"])
+def test_hatrpo_on_device_buffer_vs_reference(gold, cname):
+    """tests/test_hatrpo_cpu.py on the HBM separated buffer with the networks on the GPU."""
+    from test_hatrpo_cpu import BUF
+    from onpolicy.algorithms.hatrpo.hatrpo_trainer import HATRPO
+    from onpolicy.algorithms.hatrpo.policy import HATRPO_Policy
+    from onpolicy.utils.separated_buffer import SeparatedReplayBuffer
+    z, meta = gold.npz("hatrpo_cases"), gold.meta("hatrpo_cases")[cname]
+    spec, key = meta["spec"], "hat_%s_" % cname
+    args = make_args(episode_length=spec["T"], n_rollout_threads=spec["N"], sampler_rng="host", **spec["args"])
+    spaces = Box((spec["Do"],)), Box((spec["Ds"],)), Discrete(spec["act"][1])
+    torch.manual_seed(1)
+    np.random.seed(1)
+    policy = HATRPO_Policy(args, *spaces, device=DEV)
+    trainer = HATRPO(args, policy, device=DEV)
+    buf = SeparatedReplayBuffer(args, *spaces, device=DEV)
+    for name in BUF:
+        dst = getattr(buf, name)
+        if dst.stride()[0] != 0:
+            dst.copy_(torch.from_numpy(z[key + "buf_" + name]))
+    buf.compute_returns(z[key + "next_value"], trainer.value_normalizer)
+    np.testing.assert_array_equal(buf.returns.cpu().numpy(), z[key + "returns"])
+    buf.update_factor(z[key + "factor"])
+    trainer.prep_training()
+    torch.manual_seed(21)
+    info = trainer.train(buf)
+    for k, v in meta["train_info"].items():
+        assert info[k] == pytest.approx(v, rel=1e-2, abs=1e-4), (k, info[k], v)
+    for prefix, module in ((key + "final_actor.", policy.actor), (key + "final_critic.", policy.critic)):
+        for k, v in module.state_dict().items():
+            np.testing.assert_allclose(v.cpu().numpy(), z[prefix + k], rtol=1e-2, atol=5e-4, err_msg=prefix + k)

@@ -140,7 +140,7 @@ def host_separated_buffer(monkeypatch):
     monkeypatch.setattr(base, "SeparatedReplayBuffer", HostSeparatedBuffer)
 
 
-@pytest.mark.parametrize("cname", ["sep_mpe_mlp", "sep_smac_happo"])
+@pytest.mark.parametrize("cname", ["sep_mpe_mlp", "sep_smac_happo", "sep_smac_hatrpo"])
 def test_separated_runners_match_reference(gold, host_separated_buffer, tmp_path, cname):
     """Per-agent policies / trainers / buffers, random update order, factor bookkeeping
     (reference runner/separated/base_runner.py:135-183) with MAPPO and with HAPPO trainers."""

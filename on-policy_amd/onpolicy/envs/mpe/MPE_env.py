@@ -33,8 +33,24 @@ class SimpleSpreadEnv(object):
         obs, rewards, dones, infos = self._world.step(np.asarray(action_n, dtype=np.float64)[None])
         return obs[0], rewards[0], dones[0], infos[0]
 
-    def render(self, mode="human"):
-        raise NotImplementedError("rendering needs the reference's pyglet-based environment (MAPPO_ENVS_PATH)")
+    def render(self, mode="human", size=350):
+        """``rgb_array``: [frame], one uint8 [size, size, 3] image of the world rasterised in numpy -- agents blue,
+        landmarks dark grey, view [-1.5, 1.5]^2 centred on the origin (the reference draws the same entities
+        through pyglet, environment.py:219-301, one viewer per env when ``shared_viewer``).  ``human`` needs a
+        display and the reference's renderer (MAPPO_ENVS_PATH)."""
+        if mode != "rgb_array":
+            raise NotImplementedError("on-screen rendering needs the reference's pyglet-based environment "
+                                      "(MAPPO_ENVS_PATH); use --save_gifs / mode='rgb_array'")
+        w = self._world
+        frame = np.full((size, size, 3), 255, dtype=np.uint8)
+        span = 1.5
+        ys, xs = np.mgrid[0:size, 0:size]
+        wx = (xs + 0.5) / size * 2 * span - span
+        wy = span - (ys + 0.5) / size * 2 * span              # image rows grow downwards
+        for centres, radius, colour in ((w.landmarks[0], 0.05, (64, 64, 64)), (w.pos[0], 0.15, (89, 89, 217))):
+            for cx, cy in centres:
+                frame[(wx - cx) ** 2 + (wy - cy) ** 2 <= radius ** 2] = colour
+        return [frame]
 
     def close(self):
         pass

@@ -187,5 +187,4 @@ class MPERunner(Runner):
                 print("eval average episode rewards of agent%i: " % agent_id
                       + str(np.mean(np.sum(episode_rewards[:, :, agent_id], axis=0))))
         if self.all_args.save_gifs:
-            import imageio
-            imageio.mimsave(str(self.gif_dir) + '/render.gif', all_frames, duration=self.all_args.ifi)
+            self._save_frames(all_frames)

@@ -201,6 +201,19 @@ class Runner(object):
         if not self.all_args.use_render:
             self.policy.critic.load_state_dict(torch.load(str(model_dir) + '/critic.pt', map_location=self.device))
 
+    def _save_frames(self, frames):
+        """render.gif through imageio when it is installed, else the raw frames as render.npz."""
+        try:
+            import imageio
+        except ImportError:
+            path = str(self.gif_dir) + '/render.npz'
+            np.savez_compressed(path, frames=np.asarray(frames), ifi=self.all_args.ifi)
+            print("imageio is not installed: frames written to " + path)
+            return path
+        path = str(self.gif_dir) + '/render.gif'
+        imageio.mimsave(path, frames, duration=self.all_args.ifi)
+        return path
+
     def _log_scalar(self, key, value, step):
         if self.use_wandb:
             wandb.log({key: value}, step=step)

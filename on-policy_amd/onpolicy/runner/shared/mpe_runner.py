@@ -180,5 +180,4 @@ class MPERunner(Runner):
                     envs.render('human')
             print("average episode rewards is: " + str(np.mean(np.sum(np.array(episode_rewards), axis=0))))
         if self.all_args.save_gifs:
-            import imageio
-            imageio.mimsave(str(self.gif_dir) + '/render.gif', all_frames, duration=self.all_args.ifi)
+            self._save_frames(all_frames)

@@ -115,3 +115,70 @@ def test_train_script_with_device_resident_worlds(monkeypatch, tmp_path, algo):
             train_mpe.main(argv + ["--use_device_env", "--share_policy"])        # store_false: separated runner
     finally:
         torch.set_num_threads(threads)
+
+
+def test_rasterised_frames_show_the_entities():
+    from onpolicy.envs.mpe.MPE_env import SimpleSpreadEnv
+    env = SimpleSpreadEnv(num_agents=2, num_landmarks=1, episode_length=5, seed=0)
+    env.reset()
+    env._world.pos[0] = [[0.0, 0.0], [1.0, -1.0]]
+    env._world.landmarks[0] = [[-1.0, 1.0]]
+    (frame,) = env.render("rgb_array", size=300)
+    assert frame.shape == (300, 300, 3) and frame.dtype == np.uint8
+    px = lambda x, y: tuple(int(v) for v in frame[int((1.5 - y) / 3 * 300), int((x + 1.5) / 3 * 300)])   # noqa: E731
+    assert px(0.0, 0.0) == (89, 89, 217) and px(1.0, -1.0) == (89, 89, 217)      # agents
+    assert px(-1.0, 1.0) == (64, 64, 64)                                         # landmark
+    assert px(-1.0, -1.0) == (255, 255, 255) and px(0.0, 0.3) == (255, 255, 255)  # background, outside the agent disc
+    with pytest.raises(NotImplementedError, match="rgb_array"):
+        env.render("human")
+
+
+@pytest.mark.parametrize("shared", [True, False])
+def test_render_script_records_a_saved_policy(monkeypatch, tmp_path, shared):
+    """scripts/render/render_mpe.py: checkpoints of a short training run, replayed deterministically with frames
+    recorded (render.npz here: imageio is not installed)."""
+    import os
+    import torch
+    import onpolicy.runner.shared.base_runner as base
+    import onpolicy.runner.separated.base_runner as sep_base
+    from host_buffer import HostSharedBuffer
+    from onpolicy.scripts.render import render_mpe
+    from onpolicy.scripts.train import _launch, train_mpe
+    threads = torch.get_num_threads()
+
+    def device_of(all_args):
+        torch.set_num_threads(all_args.n_training_threads)
+        return torch.device("cpu")
+    monkeypatch.setattr(base, "SharedReplayBuffer", HostSharedBuffer)
+    monkeypatch.setattr(_launch, "device_of", device_of)
+    monkeypatch.setenv("MAPPO_RESULTS_DIR", str(tmp_path / "results"))
+    common = ["--env_name", "MPE", "--scenario_name", "simple_spread", "--num_agents", "2", "--num_landmarks", "2",
+              "--algorithm_name", "mappo", "--episode_length", "6", "--hidden_size", "16", "--use_wandb",
+              "--n_training_threads", "1"] + ([] if shared else ["--share_policy"])
+    try:
+        if shared:
+            trained = train_mpe.main(common + ["--n_rollout_threads", "2", "--num_env_steps", "24", "--ppo_epoch", "1"])
+        else:       # the separated runner needs per-agent HBM buffers to train; checkpoints of fresh policies do here
+            from oracle import oracle
+            monkeypatch.setattr(sep_base, "SeparatedReplayBuffer",
+                                lambda a, o, s, act, device=None: oracle.OracleSeparatedBuffer(a, o, s, act))
+            from onpolicy.runner.separated.mpe_runner import MPERunner
+            from onpolicy.envs.mpe.simple_spread import VecSimpleSpread
+            from onpolicy.config import get_config
+            args = train_mpe.parse_args(common + ["--n_rollout_threads", "2"], get_config())
+            _launch.apply_algorithm_flags(args, ("mappo",))
+            trained = MPERunner({"all_args": args, "envs": VecSimpleSpread(2, 2, 2, 6), "eval_envs": None,
+                                 "num_agents": 2, "device": torch.device("cpu"), "run_dir": tmp_path / "sep"})
+            trained.save()
+        argv = common + ["--n_rollout_threads", "1", "--use_render", "--save_gifs", "--render_episodes", "2",
+                         "--ifi", "0.0", "--model_dir", str(trained.save_dir)]
+        with pytest.raises(AssertionError, match="1 env"):
+            render_mpe.main(common + ["--n_rollout_threads", "2", "--use_render", "--model_dir", str(trained.save_dir)])
+        with pytest.raises(AssertionError, match="model_dir"):
+            render_mpe.main(common + ["--n_rollout_threads", "1", "--use_render"])
+        runner = render_mpe.main(argv)
+        frames = np.load(os.path.join(runner.gif_dir, "render.npz"))["frames"]
+        assert frames.shape == (2 * (1 + 6), 350, 350, 3) and frames.dtype == np.uint8
+        assert (frames[0] != frames[3]).any()                       # the agents move
+    finally:
+        torch.set_num_threads(threads)

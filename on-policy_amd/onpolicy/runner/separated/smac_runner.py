@@ -7,152 +7,125 @@ it; only the integer actions leave the GPU.  The team-level mask logic (episode 
 truncations) is the shared runner's.
 """
 import time
-from functools import reduce
 
 import numpy as np
 import torch
 
 from onpolicy.runner.separated.base_runner import Runner, _t2n
-from onpolicy.runner.shared.smac_runner import _SMAC_NAMES
+from onpolicy.runner.shared import _smac_common as common
 
 
 class SMACRunner(Runner):
     def __init__(self, config):
         super(SMACRunner, self).__init__(config)
 
+    # ------------------------------------------------------------------ training loop
     def run(self):
         self.warmup()
-        start = time.time()
-        episodes = int(self.num_env_steps) // self.episode_length // self.n_rollout_threads
-        last_battles_game = np.zeros(self.n_rollout_threads, dtype=np.float32)
-        last_battles_won = np.zeros(self.n_rollout_threads, dtype=np.float32)
+        started = time.time()
+        T, N = self.episode_length, self.n_rollout_threads
+        episodes = int(self.num_env_steps) // T // N
+        battles = common.BattleLog(N)
         infos = []
         for episode in range(episodes):
             if self.use_linear_lr_decay:
                 for tr in self.trainer:     # the reference calls .policy on the list here (smac_runner.py:27)
                     tr.policy.lr_decay(episode, episodes)
-            for step in range(self.episode_length):
-                values, actions, action_log_probs, rnn_states, rnn_states_critic = self.collect(step)
-                actions_env = np.stack([_t2n(a) for a in actions], axis=1)              # [N, A, act_dim]
-                obs, share_obs, rewards, dones, infos, available_actions = self.envs.step(actions_env)
-                self.insert((obs, share_obs, rewards, dones, infos, available_actions, values, actions,
-                             action_log_probs, rnn_states, rnn_states_critic))
+            for step in range(T):
+                outputs = self.collect(step)
+                team_actions = np.stack([_t2n(a) for a in outputs[1]], axis=1)            # [N, A, act_dim]
+                env_out = self.envs.step(team_actions)
+                infos = env_out[4]
+                self.insert(tuple(env_out) + tuple(outputs))
             self.compute()
             train_infos = self.train()
 
-            total_num_steps = (episode + 1) * self.episode_length * self.n_rollout_threads
+            steps_done = (episode + 1) * T * N
             if episode % self.save_interval == 0 or episode == episodes - 1:
                 self.save()
             if episode % self.log_interval == 0:
-                end = time.time()
-                print("\n Map {} Algo {} Exp {} updates {}/{} episodes, total num timesteps {}/{}, FPS {}.\n"
-                      .format(getattr(self.all_args, "map_name", "?"), self.algorithm_name, self.experiment_name,
-                              episode, episodes, total_num_steps, self.num_env_steps,
-                              int(total_num_steps / (end - start))))
-                if self.env_name in _SMAC_NAMES:
-                    won, game, d_won, d_game = [], [], [], []
-                    for i, info in enumerate(infos):
-                        if 'battles_won' in info[0].keys():
-                            won.append(info[0]['battles_won'])
-                            d_won.append(info[0]['battles_won'] - last_battles_won[i])
-                        if 'battles_game' in info[0].keys():
-                            game.append(info[0]['battles_game'])
-                            d_game.append(info[0]['battles_game'] - last_battles_game[i])
-                    incre_win_rate = np.sum(d_won) / np.sum(d_game) if np.sum(d_game) > 0 else 0.0
+                print(common.progress_line(self.all_args, self.algorithm_name, self.experiment_name, episode, episodes,
+                                           steps_done, self.num_env_steps, time.time() - started))
+                if self.env_name in common.SMAC_ENV_NAMES:
+                    incre_win_rate = battles.incremental_win_rate(infos)
                     print("incre win rate is {}.".format(incre_win_rate))
-                    self._log_scalar("incre_win_rate", incre_win_rate, total_num_steps)
-                    last_battles_game, last_battles_won = game, won
+                    self._log_scalar("incre_win_rate", incre_win_rate, steps_done)
                 for agent_id, b in enumerate(self.buffer):
                     # sic: the reference divides by num_agents times the entries of ONE agent's masks
                     # (smac_runner.py:96), so the logged value is not a ratio of this agent's steps
-                    n_entries = self.num_agents * reduce(lambda x, y: x * y, list(b.active_masks.shape))
-                    train_infos[agent_id]['dead_ratio'] = 1 - float(b.active_masks.sum()) / n_entries
-                self.log_train(train_infos, total_num_steps)
+                    entries = self.num_agents * common.mask_entries(b.active_masks)
+                    train_infos[agent_id]['dead_ratio'] = 1 - float(b.active_masks.sum()) / entries
+                self.log_train(train_infos, steps_done)
             if episode % self.eval_interval == 0 and self.use_eval:
-                self.eval(total_num_steps)
+                self.eval(steps_done)
 
     def warmup(self):
         obs, share_obs, available_actions = self.envs.reset()
-        if not self.use_centralized_V:
-            share_obs = obs
-        f32 = torch.float32
+        first = dict(obs=obs, share_obs=share_obs if self.use_centralized_V else obs,
+                     available_actions=available_actions)
         for agent_id, b in enumerate(self.buffer):
-            b.share_obs[0] = torch.as_tensor(np.ascontiguousarray(share_obs[:, agent_id]), dtype=f32)
-            b.obs[0] = torch.as_tensor(np.ascontiguousarray(obs[:, agent_id]), dtype=f32)
-            b.available_actions[0] = torch.as_tensor(np.ascontiguousarray(available_actions[:, agent_id]), dtype=f32)
+            for name, value in first.items():
+                getattr(b, name)[0] = torch.as_tensor(np.ascontiguousarray(value[:, agent_id]), dtype=torch.float32)
 
     @torch.no_grad()
     def collect(self, step):
-        """-> per-agent lists of device tensors."""
-        out = ([], [], [], [], [])
+        """-> (values, actions, action_log_probs, rnn_states, rnn_states_critic), each a per-agent list of device
+        tensors [N, ...]."""
+        per_output = ([], [], [], [], [])
         for tr, b in zip(self.trainer, self.buffer):
             tr.prep_rollout()
-            result = tr.policy.get_actions(b.share_obs[step], b.obs[step], b.rnn_states[step],
-                                           b.rnn_states_critic[step], b.masks[step], b.available_actions[step])
-            for lst, x in zip(out, result):
-                lst.append(x)
-        return out
+            outputs = tr.policy.get_actions(b.share_obs[step], b.obs[step], b.rnn_states[step],
+                                            b.rnn_states_critic[step], b.masks[step], b.available_actions[step])
+            for bucket, x in zip(per_output, outputs):
+                bucket.append(x)
+        return per_output
 
     def insert(self, data):
         obs, share_obs, rewards, dones, infos, available_actions, \
             values, actions, action_log_probs, rnn_states, rnn_states_critic = data
-        dev = self.buffer[0].device
-        dones = np.asarray(dones, dtype=bool)
-        dones_env = np.all(dones, axis=1)                                   # the whole team is done
-        env_alive = torch.as_tensor(~dones_env, dtype=torch.float32, device=dev)
-
-        masks = np.ones((self.n_rollout_threads, self.num_agents, 1), dtype=np.float32)
-        masks[dones_env] = 0.0
-        active_masks = np.ones((self.n_rollout_threads, self.num_agents, 1), dtype=np.float32)
-        active_masks[dones] = 0.0                                            # dead agents ...
-        active_masks[dones_env] = 1.0                                        # ... revive with the reset
-        bad_masks = np.array([[[0.0] if info[agent_id]['bad_transition'] else [1.0]
-                               for agent_id in range(self.num_agents)] for info in infos], dtype=np.float32)
-        if not self.use_centralized_V:
-            share_obs = obs
+        team_done, masks, active_masks, bad_masks = common.team_masks(dones, infos, self.num_agents)
+        keep = torch.as_tensor(~team_done, dtype=torch.float32, device=self.buffer[0].device).view(-1, 1, 1)
+        critic_obs = share_obs if self.use_centralized_V else obs
         rewards = np.asarray(rewards, dtype=np.float32)
         for a, b in enumerate(self.buffer):
-            b.insert(share_obs[:, a], obs[:, a], rnn_states[a] * env_alive.view(-1, 1, 1),
-                     rnn_states_critic[a] * env_alive.view(-1, 1, 1), actions[a], action_log_probs[a], values[a],
-                     rewards[:, a], masks[:, a], bad_masks[:, a], active_masks[:, a], available_actions[:, a])
+            b.insert(critic_obs[:, a], obs[:, a], rnn_states[a] * keep, rnn_states_critic[a] * keep, actions[a],
+                     action_log_probs[a], values[a], rewards[:, a], masks[:, a], bad_masks[:, a], active_masks[:, a],
+                     available_actions[:, a])
 
     @torch.no_grad()
     def eval(self, total_num_steps):
-        n = self.n_eval_rollout_threads
-        eval_battles_won, eval_episode = 0, 0
-        eval_episode_rewards = [[] for _ in range(n)]
-        one_episode_rewards = [[] for _ in range(n)]
-        eval_obs, eval_share_obs, eval_available_actions = self.eval_envs.reset()
-        eval_rnn_states = np.zeros((n, self.num_agents, self.recurrent_N, self.hidden_size), dtype=np.float32)
-        eval_masks = np.ones((n, self.num_agents, 1), dtype=np.float32)
-        while True:
-            collected = []
+        """Deterministic policies on the eval envs until ``eval_episodes`` episodes have finished (reference
+        smac_runner.py:178-253: returns are collected per thread and concatenated)."""
+        n, A = self.n_eval_rollout_threads, self.num_agents
+        finished, won = 0, 0
+        episode_returns = [[] for _ in range(n)]
+        running = [[] for _ in range(n)]
+        obs, _, available_actions = self.eval_envs.reset()
+        rnn_states = np.zeros((n, A, self.recurrent_N, self.hidden_size), dtype=np.float32)
+        masks = np.ones((n, A, 1), dtype=np.float32)
+        while finished < self.all_args.eval_episodes:
+            team_actions = []
             for a, tr in enumerate(self.trainer):
                 tr.prep_rollout()
-                act, state = tr.policy.act(eval_obs[:, a], eval_rnn_states[:, a], eval_masks[:, a],
-                                           eval_available_actions[:, a], deterministic=True)
-                eval_rnn_states[:, a] = _t2n(state)
-                collected.append(_t2n(act))
-            eval_actions = np.array(collected).transpose(1, 0, 2)
-            eval_obs, eval_share_obs, eval_rewards, eval_dones, eval_infos, eval_available_actions = \
-                self.eval_envs.step(eval_actions)
+                action, state = tr.policy.act(obs[:, a], rnn_states[:, a], masks[:, a], available_actions[:, a],
+                                              deterministic=True)
+                rnn_states[:, a] = _t2n(state)
+                team_actions.append(_t2n(action))
+            obs, _, rewards, dones, infos, available_actions = self.eval_envs.step(
+                np.array(team_actions).transpose(1, 0, 2))
             for i in range(n):
-                one_episode_rewards[i].append(eval_rewards[i])
-            eval_dones_env = np.all(eval_dones, axis=1)
-            eval_rnn_states[eval_dones_env] = 0.0
-            eval_masks = np.ones((n, self.num_agents, 1), dtype=np.float32)
-            eval_masks[eval_dones_env] = 0.0
-            for i in range(n):
-                if eval_dones_env[i]:
-                    eval_episode += 1
-                    eval_episode_rewards[i].append(np.sum(one_episode_rewards[i], axis=0))
-                    one_episode_rewards[i] = []
-                    if eval_infos[i][0]['won']:
-                        eval_battles_won += 1
-            if eval_episode >= self.all_args.eval_episodes:
-                rewards = np.concatenate([r for r in eval_episode_rewards if len(r) > 0])
-                self.log_env({'eval_average_episode_rewards': rewards}, total_num_steps)
-                eval_win_rate = eval_battles_won / eval_episode
-                print("eval win rate is {}.".format(eval_win_rate))
-                self._log_scalar("eval_win_rate", eval_win_rate, total_num_steps)
-                break
+                running[i].append(rewards[i])
+            team_done = np.all(dones, axis=1)
+            rnn_states[team_done] = 0.0
+            masks = np.ones((n, A, 1), dtype=np.float32)
+            masks[team_done] = 0.0
+            for i in np.flatnonzero(team_done):
+                finished += 1
+                episode_returns[i].append(np.sum(running[i], axis=0))
+                running[i] = []
+                won += bool(infos[i][0]['won'])
+        returns = np.concatenate([r for r in episode_returns if len(r) > 0])
+        self.log_env({'eval_average_episode_rewards': returns}, total_num_steps)
+        eval_win_rate = won / finished
+        print("eval win rate is {}.".format(eval_win_rate))
+        self._log_scalar("eval_win_rate", eval_win_rate, total_num_steps)

@@ -10,95 +10,57 @@ kernel.
 """
 import math
 
-import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from onpolicy.utils.running_moments import DebiasedMoments
 
-class PopArt(nn.Module):
+
+class PopArt(DebiasedMoments, nn.Module):
+    _first_moment, _second_moment = "mean", "mean_sq"
+
     def __init__(self, input_shape, output_shape, norm_axes=1, beta=0.99999, epsilon=1e-5,
                  device=torch.device("cpu")):
-        super(PopArt, self).__init__()
-        self.beta = beta
-        self.epsilon = epsilon
-        self.norm_axes = norm_axes
+        nn.Module.__init__(self)
+        self.beta, self.epsilon, self.norm_axes = beta, epsilon, norm_axes
+        self.input_shape, self.output_shape = input_shape, output_shape
         self.tpdv = dict(dtype=torch.float32, device=device)
-        self.input_shape = input_shape
-        self.output_shape = output_shape
         # parameters are drawn on the host (CPU generator, like every other layer here) and moved
         # afterwards, so a seed gives the same initial head whatever the device
-        f32 = dict(dtype=torch.float32)
-        self.weight = nn.Parameter(torch.empty(output_shape, input_shape, **f32))
-        self.bias = nn.Parameter(torch.empty(output_shape, **f32))
-        self.register_buffer("stddev", torch.ones(output_shape, **f32))
-        self.register_buffer("mean", torch.zeros(output_shape, **f32))
-        self.register_buffer("mean_sq", torch.zeros(output_shape, **f32))
-        self.register_buffer("debiasing_term", torch.tensor(0.0, **f32))
+        self.weight = nn.Parameter(torch.empty(output_shape, input_shape, dtype=torch.float32))
+        self.bias = nn.Parameter(torch.empty(output_shape, dtype=torch.float32))
+        self.register_buffer("stddev", torch.ones(output_shape, dtype=torch.float32))
+        for name, shape in (("mean", output_shape), ("mean_sq", output_shape), ("debiasing_term", ())):
+            self.register_buffer(name, torch.zeros(shape, dtype=torch.float32))
         self.reset_parameters()
         self.to(device)
 
     def reset_parameters(self):
+        """nn.Linear's default initialisation of the head, zero statistics."""
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
-        fan_in, _ = nn.init._calculate_fan_in_and_fan_out(self.weight)
-        bound = 1 / math.sqrt(fan_in)
+        bound = 1 / math.sqrt(nn.init._calculate_fan_in_and_fan_out(self.weight)[0])
         nn.init.uniform_(self.bias, -bound, bound)
-        self.mean.zero_()
-        self.mean_sq.zero_()
-        self.debiasing_term.zero_()
-
-    def _as_tensor(self, x):
-        if isinstance(x, np.ndarray):
-            x = torch.from_numpy(x)
-        return x.to(dtype=torch.float32, device=self.weight.device)   # follows the module when it is moved
+        self.zero_moments()
 
     def forward(self, input_vector):
         return F.linear(self._as_tensor(input_vector), self.weight, self.bias)
 
+    def debiased_mean_var(self):
+        return self._mean_var()
+
     @torch.no_grad()
     def update(self, input_vector, batch_moments=None):
-        old_mean, old_var = self.debiased_mean_var()
-        old_stddev = torch.sqrt(old_var)
-        if batch_moments is None:
-            x = self._as_tensor(input_vector)
-            axes = tuple(range(self.norm_axes))
-            batch_mean = x.mean(dim=axes)
-            batch_sq_mean = (x ** 2).mean(dim=axes)
-        else:
-            batch_mean, batch_sq_mean = batch_moments
-        self.mean.mul_(self.beta).add_(batch_mean * (1.0 - self.beta))
-        self.mean_sq.mul_(self.beta).add_(batch_sq_mean * (1.0 - self.beta))
-        self.debiasing_term.mul_(self.beta).add_(1.0 * (1.0 - self.beta))
+        """Move the statistics, then rescale the head so that its de-normalised output is unchanged:
+        w' = w sigma / sigma',  b' = (sigma b + mu - mu') / sigma'."""
+        old_mean, old_var = self._mean_var()
+        old_sigma = torch.sqrt(old_var)
+        self._fold_in(input_vector, batch_moments, self.beta)
         self.stddev.copy_((self.mean_sq - self.mean ** 2).sqrt().clamp(min=1e-4))
-        new_mean, new_var = self.debiased_mean_var()
-        new_stddev = torch.sqrt(new_var)
+        new_mean, new_var = self._mean_var()
+        new_sigma = torch.sqrt(new_var)
         # Rebind .data instead of writing in place: the forward pass of the current minibatch has
         # already saved the old weights for its backward (update() runs between forward and
         # backward, r_mappo.py:65), and those saved tensors must stay untouched.
-        self.weight.data = self.weight.data * (old_stddev / new_stddev).unsqueeze(-1)
-        self.bias.data = (old_stddev * self.bias.data + old_mean - new_mean) / new_stddev
-
-    def debiased_mean_var(self):
-        debias = self.debiasing_term.clamp(min=self.epsilon)
-        mean = self.mean / debias
-        mean_sq = self.mean_sq / debias
-        var = (mean_sq - mean ** 2).clamp(min=1e-2)
-        return mean, var
-
-    def denorm_scalars(self):
-        mean, var = self.debiased_mean_var()
-        return torch.stack([torch.sqrt(var).reshape(()), mean.reshape(())])
-
-    def normalize(self, input_vector):
-        x = self._as_tensor(input_vector)
-        mean, var = self.debiased_mean_var()
-        lead = (None,) * self.norm_axes
-        return (x - mean[lead]) / torch.sqrt(var)[lead]
-
-    def denormalize(self, input_vector):
-        as_numpy = isinstance(input_vector, np.ndarray)
-        x = self._as_tensor(input_vector)
-        mean, var = self.debiased_mean_var()
-        lead = (None,) * self.norm_axes
-        out = x * torch.sqrt(var)[lead] + mean[lead]
-        return out.cpu().numpy() if as_numpy else out
+        self.weight.data = self.weight.data * (old_sigma / new_sigma).unsqueeze(-1)
+        self.bias.data = (old_sigma * self.bias.data + old_mean - new_mean) / new_sigma

@@ -1,0 +1,79 @@
+"""Debiased exponential moving moments -- the statistics behind both value normalisers of the reference
+(``ValueNorm``, onpolicy/utils/valuenorm.py:32-79, and the ``PopArt`` head, onpolicy/algorithms/utils/popart.py:49-98
+use the same arithmetic under different attribute names):
+
+    m1 <- w m1 + (1 - w) E[x],   m2 <- w m2 + (1 - w) E[x^2],   d <- w d + (1 - w)
+    mean = m1 / max(d, eps),     var = max(m2 / max(d, eps) - mean^2, 1e-2)
+
+``DebiasedMoments`` is a mix-in for an ``nn.Module`` that owns three buffers (their names are class attributes, so the
+state dicts keep the reference's keys); it provides the update, (de)normalisation with numpy-in / numpy-out and
+tensor-in / tensor-out, and ``denorm_scalars()`` -- the [sigma, mu] device tensor the GAE kernel reads without a
+host sync.  ``update`` accepts batch moments that were all-reduced across GPUs in place of a local batch.
+"""
+import numpy as np
+import torch
+
+_VAR_FLOOR = 1e-2
+
+
+class DebiasedMoments(object):
+    _first_moment = "running_mean"
+    _second_moment = "running_mean_sq"
+    _debias = "debiasing_term"
+
+    # -- storage
+    def _moments(self):
+        return getattr(self, self._first_moment), getattr(self, self._second_moment), getattr(self, self._debias)
+
+    def _stats_device(self):
+        return getattr(self, self._first_moment).device
+
+    def _as_tensor(self, x):
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(x)
+        return x.to(dtype=torch.float32, device=self._stats_device())
+
+    def zero_moments(self):
+        for buf in self._moments():
+            buf.zero_()
+
+    # -- statistics
+    def _mean_var(self):
+        m1, m2, d = self._moments()
+        d = d.clamp(min=self.epsilon)
+        mean = m1 / d
+        return mean, (m2 / d - mean ** 2).clamp(min=_VAR_FLOOR)
+
+    def _batch_moments(self, x):
+        axes = tuple(range(self.norm_axes))
+        return x.mean(dim=axes), (x ** 2).mean(dim=axes)
+
+    @torch.no_grad()
+    def _fold_in(self, input_vector, batch_moments, weight):
+        mean, mean_sq = batch_moments if batch_moments is not None \
+            else self._batch_moments(self._as_tensor(input_vector))
+        m1, m2, d = self._moments()
+        m1.mul_(weight).add_(mean * (1.0 - weight))
+        m2.mul_(weight).add_(mean_sq * (1.0 - weight))
+        d.mul_(weight).add_(1.0 * (1.0 - weight))
+
+    def denorm_scalars(self):
+        """float32 device tensor [sigma, mu] (scalar statistics, input_shape == 1)."""
+        mean, var = self._mean_var()
+        return torch.stack([torch.sqrt(var).reshape(()), mean.reshape(())])
+
+    # -- maps
+    def _broadcast(self):
+        mean, var = self._mean_var()
+        lead = (None,) * self.norm_axes
+        return mean[lead], torch.sqrt(var)[lead]
+
+    def normalize(self, input_vector):
+        mean, sigma = self._broadcast()
+        return (self._as_tensor(input_vector) - mean) / sigma
+
+    def denormalize(self, input_vector):
+        """x * sigma + mean.  ndarray -> ndarray (what the reference returns); tensor -> tensor on the device."""
+        mean, sigma = self._broadcast()
+        out = self._as_tensor(input_vector) * sigma + mean
+        return out.cpu().numpy() if isinstance(input_vector, np.ndarray) else out

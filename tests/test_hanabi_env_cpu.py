@@ -302,3 +302,54 @@ def test_policy_learns_to_score_on_the_real_engine(cpu_launch):
               if json.loads(l)["tag"] == "average_score"]
     assert len(scores) >= 30
     assert np.mean(scores[:3]) < 0.3 and np.mean(scores[-5:]) > 0.8, (scores[:3], scores[-5:])
+
+
+def test_engine_invariants_under_random_rules_and_play():
+    """Property test over random rule sets and uniformly random legal play: cards are conserved (deck + hands +
+    discards + fireworks = the full deck), scores and tokens stay in range, a running game always offers a legal
+    move, finished games report a consistent ending, and identical seeds replay identically."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=30, deadline=None)
+    @given(seed=st.integers(0, 2 ** 31 - 1), colors=st.integers(1, 5), ranks=st.integers(2, 5),
+           players=st.integers(2, 5), hand=st.integers(1, 5), info=st.integers(0, 8), lives=st.integers(1, 4),
+           obs_type=st.integers(0, 2))
+    def run(seed, colors, ranks, players, hand, info, lives, obs_type):
+        copies = sum(3 if r == 0 else (1 if r == ranks - 1 else 2) for r in range(ranks))
+        deck = copies * colors
+        rules = dict(colors=colors, ranks=ranks, players=players, hand_size=hand, max_information_tokens=info,
+                     max_life_tokens=lives, observation_type=obs_type, random_start_player=seed % 2)
+        if hand * players > deck:
+            with pytest.raises(ValueError, match="invalid Hanabi rules"):
+                hb.HanabiBatch(rules, [seed])
+            return
+        n = 3
+        a, b = hb.HanabiBatch(rules, [seed, seed + 1, seed + 2]), hb.HanabiBatch(rules, [seed, seed + 1, seed + 2])
+        rng = np.random.default_rng(seed)
+        for batch in (a, b):
+            batch.reset()
+            batch.encode()
+        for _ in range(60):
+            assert np.array_equal(a.obs, b.obs) and np.array_equal(a.available_actions, b.available_actions)
+            assert a.available_actions.any(axis=1).all()             # somebody can always move in a running game
+            moves = np.array([rng.choice(np.flatnonzero(row)) for row in a.available_actions], dtype=np.int32)
+            for batch in (a, b):
+                batch.step(moves)
+            assert np.array_equal(a.rewards, b.rewards) and np.array_equal(a.status, b.status)
+            for i in range(n):
+                s = a.table_state(i)
+                in_hands = sum(int(a.player_view(i, p)[1].sum()) for p in range(players))
+                assert s["deck_size"] + in_hands + s["discards"] + sum(s["fireworks"]) == deck
+                assert 0 <= s["information_tokens"] <= info and 0 <= s["life_tokens"] <= lives
+                assert 0 <= s["score"] <= colors * ranks and all(0 <= f <= ranks for f in s["fireworks"])
+                assert (s["end_of_game"] != 0) == bool(a.status[i])
+                if s["end_of_game"] == 1:
+                    assert s["life_tokens"] == 0 and s["score"] == 0
+                if s["end_of_game"] == 3:
+                    assert s["score"] == colors * ranks
+            done = a.status == 1
+            for batch in (a, b):
+                if done.any():
+                    batch.reset(done)
+                batch.encode()
+    run()

@@ -1,0 +1,47 @@
+"""Compile-time guard on the kernels' register / LDS budgets (no GPU needed: hipcc cross-compiles and reports each
+kernel's resource usage).  profiles/kernel_resources.json is the committed snapshot (tools/kernel_resources.py
+--write); here: no kernel may spill to scratch memory, the hot kernels keep the occupancy they were tuned for, and the
+quick-to-compile sources still produce exactly the snapshot (all five with MAPPO_CHECK_ALL_KERNEL_RESOURCES=1)."""
+import importlib.util
+import json
+import os
+import shutil
+
+import pytest
+
+from conftest import ROOT
+
+SNAPSHOT = os.path.join(ROOT, "profiles", "kernel_resources.json")
+
+
+def _tool():
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_snapshot_has_no_spills_and_expected_occupancy():
+    table = json.load(open(SNAPSHOT))
+    assert len(table) > 250 and {k.split(" :: ")[0] for k in table} == {"mappo_gae.hip", "mappo_copy.hip",
+                                                                        "mappo_norm.hip", "mappo_loss.hip", "mappo_rnn.hip"}
+    assert all(k["scratch_bytes"] == 0 for k in table.values())
+    pick = lambda frag: [v for k, v in table.items() if frag in k]      # noqa: E731
+    assert all(v["occupancy"] >= 7 for v in pick("ppo_loss_kernel"))
+    assert all(v["occupancy"] >= 6 for v in pick("gru_fwd_kernel")) and all(v["occupancy"] == 8 for v in pick("gru_bwd_kernel"))
+    (step,) = pick("gru_step_fwd_kernel")                                # one workgroup per CU by design: W_hh in LDS
+    assert step["lds_bytes"] == 49152 and step["occupancy"] == 1
+    # the H = 64 LayerNorm instances of the benchmarked MLP (D = 64: <1|4, 16, 1, ...>) run at full occupancy
+    assert all(v["occupancy"] == 8 for k, v in table.items() if "ln_fwd_kernel<4, 16, 1" in k or "ln_bwd_kernel<4, 16, 1" in k)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_sources_still_compile_to_the_snapshot():
+    tool = _tool()
+    table = json.load(open(SNAPSHOT))
+    sources = tool.SOURCES if os.environ.get("MAPPO_CHECK_ALL_KERNEL_RESOURCES") == "1" else \
+        ("mappo_copy.hip", "mappo_loss.hip", "mappo_rnn.hip")
+    for src in sources:
+        fresh = {"%s :: %s" % (src, k.pop("kernel")): k for k in tool.analyse(src)}
+        committed = {k: v for k, v in table.items() if k.startswith(src + " :: ")}
+        assert fresh == committed, "%s: resource usage changed -- rerun tools/kernel_resources.py --write and review" % src

@@ -45,3 +45,25 @@ def test_sources_still_compile_to_the_snapshot():
         fresh = {"%s :: %s" % (src, k.pop("kernel")): k for k in tool.analyse(src)}
         committed = {k: v for k, v in table.items() if k.startswith(src + " :: ")}
         assert fresh == committed, "%s: resource usage changed -- rerun tools/kernel_resources.py --write and review" % src
+
+
+def test_isa_snapshot_shows_the_cdna4_instructions_the_design_relies_on():
+    """profiles/isa_summary.json (tools/isa_summary.py --write): the GAE scan stages its tiles with gfx950's 128-bit
+    direct-to-LDS loads, the one-kernel GRU step runs its hidden projection on the f32 MFMA, streaming kernels use
+    128-bit and non-temporal accesses, and nothing touches scratch memory."""
+    isa = json.load(open(os.path.join(ROOT, "profiles", "isa_summary.json")))
+    assert isa["mappo_gae.hip"]["lds_dma_128bit"] > 1000 and isa["mappo_gae.hip"]["dpp_or_permute"] > 0
+    assert isa["mappo_rnn.hip"]["mfma_kinds"] == {"v_mfma_f32_32x32x2_f32": isa["mappo_rnn.hip"]["mfma_f32"]}
+    assert all(isa[s]["mfma_f32"] == 0 for s in isa if s != "mappo_rnn.hip")      # the buffer path is HBM-bound: no MFMA
+    for src in ("mappo_gae.hip", "mappo_copy.hip", "mappo_norm.hip"):
+        assert isa[src]["global_load_128bit"] > 0 and isa[src]["non_temporal"] > 0, src
+    assert all(row["scratch_access"] == 0 for row in isa.values())
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_gru_step_still_compiles_to_mfma():
+    spec = importlib.util.spec_from_file_location("isa_summary", os.path.join(ROOT, "tools", "isa_summary.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    fresh = mod.summarise("mappo_rnn.hip")
+    assert fresh == json.load(open(os.path.join(ROOT, "profiles", "isa_summary.json")))["mappo_rnn.hip"]

@@ -36,6 +36,9 @@ class MATTrainer(object):
         for attr, flag in _SWITCHES.items():
             setattr(self, attr, getattr(args, flag))
         self.value_normalizer = ValueNorm(1, device=self.device) if self._use_valuenorm else None
+        from onpolicy.utils import dist as mdist
+        if mdist.is_distributed():       # replicas would drift apart silently: no gradient exchange is wired in here
+            raise NotImplementedError("MATTrainer has no data-parallel form yet (one process / one GPU)")
 
     def cal_value_loss(self, values, value_preds_batch, return_batch, active_masks_batch):
         """Clipped value loss against the (normalised) returns; the normaliser is updated with this minibatch first."""

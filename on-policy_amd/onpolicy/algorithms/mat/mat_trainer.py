@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from onpolicy.algorithms.utils.util import check
+from onpolicy.utils import dist as mdist
 from onpolicy.utils.util import get_gard_norm, huber_loss, mse_loss
 from onpolicy.utils.valuenorm import ValueNorm
 
@@ -36,14 +37,16 @@ class MATTrainer(object):
         for attr, flag in _SWITCHES.items():
             setattr(self, attr, getattr(args, flag))
         self.value_normalizer = ValueNorm(1, device=self.device) if self._use_valuenorm else None
-        from onpolicy.utils import dist as mdist
-        if mdist.is_distributed():       # replicas would drift apart silently: no gradient exchange is wired in here
-            raise NotImplementedError("MATTrainer has no data-parallel form yet (one process / one GPU)")
+        # data parallel over rollout threads (no-op for one process): the transformer's gradients live in one flat
+        # bucket that is all-reduced once per minibatch, next to one small collective for the loss denominators and
+        # the ValueNorm moments -- the same scheme as R_MAPPO (onpolicy/utils/dist.py)
+        self.dp = mdist.DataParallel(policy.transformer, nn.Module(), device)
 
-    def cal_value_loss(self, values, value_preds_batch, return_batch, active_masks_batch):
-        """Clipped value loss against the (normalised) returns; the normaliser is updated with this minibatch first."""
+    def cal_value_loss(self, values, value_preds_batch, return_batch, active_masks_batch, batch_moments=None):
+        """Clipped value loss against the (normalised) returns; the normaliser is updated with this minibatch first
+        (``batch_moments``: the all-reduced moments of the GLOBAL minibatch in a data-parallel job)."""
         if self._use_valuenorm:
-            self.value_normalizer.update(return_batch)
+            self.value_normalizer.update(return_batch, batch_moments=batch_moments)
             target = self.value_normalizer.normalize(return_batch)
         else:
             target = return_batch
@@ -66,14 +69,22 @@ class MATTrainer(object):
         share_obs, obs, rnn_a, rnn_c, actions, value_preds, returns, masks, active, old_logp, adv, avail = sample[:12]
         old_logp, adv, value_preds, returns, active = (check(x).to(**self.tpdv)
                                                        for x in (old_logp, adv, value_preds, returns, active))
+        # each rank's loss terms are means over ITS rows; weighting them by local / global denominators makes the
+        # summed gradient the gradient of the global-batch means (weights are exactly 1 for one process)
+        w_actor, w_critic, moments = 1.0, 1.0, None
+        if self.dp.active:
+            w_actor, w_critic, moments = self.dp.minibatch_stats(active, returns, self._use_policy_active_masks,
+                                                                 self._use_value_active_masks)
         values, action_log_probs, dist_entropy = self.policy.evaluate_actions(
             share_obs, obs, rnn_a, rnn_c, actions, masks, avail, active)
         policy_loss, imp_weights = self._surrogate(action_log_probs, old_logp, adv, active)
-        value_loss = self.cal_value_loss(values, value_preds, returns, active)
-        loss = policy_loss - dist_entropy * self.entropy_coef + value_loss * self.value_loss_coef
+        value_loss = self.cal_value_loss(values, value_preds, returns, active, moments)
+        loss = (policy_loss - dist_entropy * self.entropy_coef) * w_actor + value_loss * self.value_loss_coef * w_critic
+        self._last_weights = (w_actor, w_critic)
 
-        self.policy.optimizer.zero_grad()
+        self.dp.zero_grad(self.policy.optimizer)
         loss.backward()
+        self.dp.all_reduce_grads()
         params = self.policy.transformer.parameters()
         grad_norm = nn.utils.clip_grad_norm_(params, self.max_grad_norm) if self._use_max_grad_norm \
             else get_gard_norm(params)
@@ -83,8 +94,17 @@ class MATTrainer(object):
     def _advantages(self, buffer):
         """(advantages - mean) / (std + 1e-5) over the active entries (mat_trainer.py:160-164)."""
         if hasattr(buffer, "normalized_advantages"):
-            return buffer.normalized_advantages(self.value_normalizer)
+            return buffer.normalized_advantages(self.value_normalizer,
+                                                all_reduce=self.dp.all_reduce if self.dp.active else None)
         adv = np.asarray(buffer.advantages)
+        if self.dp.active:         # host buffers in a multi-rank job: global moments from three all-reduced sums
+            on = np.asarray(buffer.active_masks[:-1]) != 0.0
+            sums = torch.tensor([adv[on].astype(np.float64).sum(), (adv[on].astype(np.float64) ** 2).sum(),
+                                 float(on.sum())], dtype=torch.float64, device=self.device)
+            self.dp.all_reduce(sums)
+            mean = float(sums[0] / sums[2])
+            std = float(torch.sqrt(torch.clamp(sums[1] / sums[2] - mean ** 2, min=0.0)))
+            return (adv - np.float32(mean)) / (np.float32(std) + 1e-5)
         masked = adv.copy()
         masked[np.asarray(buffer.active_masks[:-1]) == 0.0] = np.nan
         return (adv - np.nanmean(masked)) / (np.nanstd(masked) + 1e-5)
@@ -98,12 +118,18 @@ class MATTrainer(object):
                 value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights = \
                     self.ppo_update(sample)
                 with torch.no_grad():
+                    # rank means become global means when weighted by local / global denominators and SUMMED over
+                    # ranks; average_info below divides by the world size, hence the factor
+                    w_actor, w_critic = (torch.as_tensor(w, **self.tpdv).reshape(()) * self.dp.world_size
+                                         if self.dp.active else 1.0 for w in self._last_weights)
                     totals += torch.stack([
-                        value_loss.detach().reshape(()), policy_loss.detach().reshape(()),
-                        dist_entropy.detach().reshape(()), torch.as_tensor(actor_grad_norm, **self.tpdv).reshape(()),
+                        value_loss.detach().reshape(()) * w_critic, policy_loss.detach().reshape(()) * w_actor,
+                        dist_entropy.detach().reshape(()) * w_actor,
+                        torch.as_tensor(actor_grad_norm, **self.tpdv).reshape(()),
                         torch.as_tensor(critic_grad_norm, **self.tpdv).reshape(()),
                         imp_weights.detach().mean().reshape(())])
-        return dict(zip(keys, (totals / (self.ppo_epoch * self.num_mini_batch)).tolist()))
+        totals = self.dp.average_info(totals / (self.ppo_epoch * self.num_mini_batch))
+        return dict(zip(keys, totals.tolist()))
 
     def prep_training(self):
         self.policy.train()

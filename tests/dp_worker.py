@@ -33,6 +33,33 @@ def full_arrays(N, dims):
     return arrays
 
 
+def run_update_mat(N_global, lo, hi, args_over):
+    """The same for the Multi-Agent Transformer: host OracleBuffer (mat branches of compute_returns, transformer
+    sampler) + TransformerPolicy / MATTrainer on rollout threads [lo, hi)."""
+    from helpers import load_into
+    from oracle import oracle
+    from onpolicy.algorithms.mat.algorithm.transformer_policy import TransformerPolicy
+    from onpolicy.algorithms.mat.mat_trainer import MATTrainer
+    args, spaces, dims = build_case(hi - lo, dict(args_over, algorithm_name="mat", n_embd=16, n_head=2))
+    arrays = full_arrays(N_global, dims)
+    shard = {k: (v[:, lo:hi] if k != "next_value" else v[lo:hi]) for k, v in arrays.items()}
+    torch.manual_seed(1)
+    np.random.seed(1)
+    policy = TransformerPolicy(args, *spaces, dims[1])
+    trainer = MATTrainer(args, policy, dims[1])
+    buf = oracle.OracleBuffer(args, dims[1], *spaces)
+    load_into(buf, shard)
+    buf.compute_returns(shard["next_value"], trainer.value_normalizer)
+    trainer.prep_training()
+    torch.manual_seed(100)
+    info = trainer.train(buf)
+    sd = {"transformer." + k: v.detach().cpu().clone() for k, v in policy.transformer.state_dict().items()}
+    if trainer.value_normalizer is not None:
+        sd["vn.mean"] = trainer.value_normalizer.running_mean.cpu().clone()
+        sd["vn.sq"] = trainer.value_normalizer.running_mean_sq.cpu().clone()
+    return info, sd, trainer.dp.world_size
+
+
 def run_update(N_global, lo, hi, args_over, device=None):
     """compute_returns + train on rollout threads [lo, hi) of the global case.  ``device`` None: host
     OracleBuffer + CPU trainer; a HIP device: the HBM buffer and the trainer (fused loss) on it."""
@@ -68,7 +95,7 @@ def run_update(N_global, lo, hi, args_over, device=None):
     return info, sd, trainer.dp.world_size
 
 
-def worker(rank, world, port, N_global, args_over, out_dir, device=None):
+def worker(rank, world, port, N_global, args_over, out_dir, device=None, mat=False):
     """``device``: None = CPU ranks; "cuda:0" = every rank on GPU 0 with the gloo backend (RCCL refuses
     duplicate devices), which exercises the device buffer + fused loss under data parallelism."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -81,7 +108,7 @@ def worker(rank, world, port, N_global, args_over, out_dir, device=None):
     mdist.init_from_env(torch.device("cpu") if device is None else device)
     assert dist.get_backend() == "gloo"
     lo, hi = mdist.shard_threads(N_global, rank, world)
-    info, sd, ws = run_update(N_global, lo, hi, args_over, device)
+    info, sd, ws = run_update_mat(N_global, lo, hi, args_over) if mat else run_update(N_global, lo, hi, args_over, device)
     assert ws == world
     torch.save({"info": info, "sd": sd, "span": (lo, hi)}, os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()

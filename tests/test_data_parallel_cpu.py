@@ -67,3 +67,33 @@ def test_two_rank_update_equals_single_process(tmp_path, args_over):
         assert ranks[0]["info"][k] == pytest.approx(ranks[1]["info"][k], rel=1e-6)
         if not recurrent:
             assert ranks[0]["info"][k] == pytest.approx(info[k], rel=1e-3, abs=1e-6)
+
+
+@pytest.mark.parametrize("args_over", [
+    dict(),
+    dict(use_policy_active_masks=False, use_value_active_masks=False, use_valuenorm=False),
+], ids=["default", "unmasked_nonorm"])
+def test_two_rank_transformer_update_equals_single_process(tmp_path, args_over):
+    """MATTrainer under data parallelism: globally normalised advantages (three all-reduced sums), loss terms weighted
+    to global denominators, ValueNorm fed the global moments, one flat-bucket gradient all-reduce per minibatch."""
+    N, world = 6, 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=dp_worker.worker, args=(r, world, port, N, args_over, str(tmp_path), None, True))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    ranks = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=False) for r in range(world)]
+    for k in ranks[0]["sd"]:
+        assert torch.equal(ranks[0]["sd"][k], ranks[1]["sd"][k]), k              # replicas stay identical
+    info, sd, ws = dp_worker.run_update_mat(N, 0, N, args_over)
+    assert ws == 1
+    for k in sd:
+        np.testing.assert_allclose(ranks[0]["sd"][k].numpy(), sd[k].numpy(), rtol=5e-4, atol=5e-6, err_msg=k)
+    # logged losses are global-batch values too: rank means weighted by local / global denominators, summed
+    for k, rel in (("actor_grad_norm", 2e-3), ("value_loss", 2e-3), ("policy_loss", 2e-3), ("dist_entropy", 2e-3)):
+        assert ranks[0]["info"][k] == pytest.approx(ranks[1]["info"][k], rel=1e-6)
+        assert ranks[0]["info"][k] == pytest.approx(info[k], rel=rel, abs=2e-3), k

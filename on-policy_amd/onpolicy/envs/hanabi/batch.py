@@ -94,7 +94,9 @@ class HanabiBatch(object):
 
     def __init__(self, rules, seeds, share_mode=SHARE_OWN_HAND):
         self._lib = lib()
-        seeds = np.ascontiguousarray(seeds, dtype=np.int32).reshape(-1)
+        # the engine seeds std::mt19937, which takes the seed modulo 2^32: wider Python ints wrap the same way
+        seeds = (np.asarray(seeds, dtype=np.int64).reshape(-1) % (1 << 32)).astype(np.uint32).view(np.int32)
+        seeds = np.ascontiguousarray(seeds)
         self._rules = Rules(**rules)
         self._handle = self._lib.hanabi_batch_create(ctypes.byref(self._rules), len(seeds), _ptr(seeds))
         if not self._handle:

@@ -1,6 +1,4 @@
 """Shared test helpers: duck-typed spaces, reference-default args, buffer fillers."""
-import json
-import os
 
 import numpy as np
 import torch

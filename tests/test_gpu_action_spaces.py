@@ -1,6 +1,5 @@
 """-m gpu: continuous / MultiDiscrete heads through the HBM buffer and the trainer on the device against the
 reference fixtures of oracle/make_golden_spaces.py (same CPU seed => same permutations)."""
-import numpy as np
 import pytest
 import torch
 

@@ -2,7 +2,6 @@
 and differentiated by autograd (a float32 torch reference of the op: r_mappo.py:52-89, :119-153), for every
 flag combination, and the trainer with / without the fused path."""
 import itertools
-import os
 
 import numpy as np
 import pytest

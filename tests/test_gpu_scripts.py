@@ -6,7 +6,6 @@ import os
 import sys
 import textwrap
 
-import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu

@@ -45,7 +45,6 @@ def test_reference_train_script_imports_resolve(script):
 def test_reference_flags_are_accepted_by_our_scripts():
     """The per-script flags of the reference (parse_args of each train script) exist here with the same
     defaults."""
-    import sys
     from onpolicy.config import get_config
     from onpolicy.scripts.train import train_mpe, train_smac, train_hanabi_forward, train_football
     for ours, script in ((train_mpe, "train_mpe.py"), (train_smac, "train_smac.py"),

@@ -167,6 +167,22 @@ class HanabiBatch(object):
     __del__ = close
 
 
+class _ScoreInfos(object):
+    """``infos[i] == {"score": s_i}`` without building N dicts per step (the runner reads the finished tables only)."""
+
+    def __init__(self, scores):
+        self._scores = scores.copy()
+
+    def __len__(self):
+        return len(self._scores)
+
+    def __getitem__(self, i):
+        return {"score": int(self._scores[i])}
+
+    def __iter__(self):
+        return ({"score": int(s)} for s in self._scores)
+
+
 _DONE_OF_STATUS = np.array([False, True, None], dtype=object)      # status 2 = idle: the reference env's done = None
 
 
@@ -202,7 +218,7 @@ class HanabiBatchVecEnv(object):
         b.encode(a != -1)
         rewards = np.repeat(b.rewards[:, None, None], b.players, axis=1)
         dones = _DONE_OF_STATUS[b.status]
-        infos = [{"score": int(s)} for s in b.scores]
+        infos = _ScoreInfos(b.scores)
         return self._out(b.obs), self._out(b.share_obs), rewards, dones, infos, self._out(b.available_actions)
 
     def close(self):

@@ -1,0 +1,40 @@
+"""bench.py pieces that can run without a GPU: the workload table and the `cpu_baseline` leg (oracle buffer + the
+product's trainer on host cores) on a shrunken copy of every workload; the timed HIP path itself is covered by the
+-m gpu bench test."""
+import importlib.util
+import os
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def bench():
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_workload_table(bench):
+    assert set(bench.WORKLOADS) == {"ns", "ns_rnn", "cfg2", "smac", "hanabi"}
+    ns = bench.WORKLOADS["ns"]
+    assert (ns["T"], ns["N"], ns["A"], ns["Do"], ns["Ds"], ns["na"]) == (400, 4096, 8, 48, 384, 5)     # BASELINE north star
+    args = bench.make_args(ns, 512)
+    assert args.n_rollout_threads == 512 and args.ppo_epoch == 10 and args.use_ReLU is False             # --use_ReLU => Tanh
+    assert bench.make_args(bench.WORKLOADS["smac"], 8).use_recurrent_policy is True
+
+
+@pytest.mark.parametrize("name", ["ns", "ns_rnn", "smac"])
+def test_cpu_baseline_leg_runs(bench, name):
+    threads = torch.get_num_threads()
+    wl = dict(bench.WORKLOADS[name], T=20, cpu_sample_N=2)
+    wl["flags"] = [f if f != "10" or wl["flags"][i - 1] != "--ppo_epoch" else "2" for i, f in enumerate(wl["flags"])]
+    try:
+        out = bench.cpu_baseline(wl)
+    finally:
+        torch.set_num_threads(threads)
+    assert out["kind"] == "port" and out["unit"] == "env-steps/s" and out["value"] > 0 and out["cores"] >= 1
+    assert "n_rollout_threads=2" in out["sample"]

@@ -159,6 +159,20 @@ def cpu_baseline(wl):
                       "%.3f s compute_returns + %.2f s train" % (n, wl["T"], wl["A"], t1 - t0, t2 - t1)}
 
 
+def self_launch(n_gpus):
+    """Re-run this command line under ``torch.distributed.run`` with one rank per GPU (what the driver's own
+    multi-GPU launch line does) and return its exit code.  The ranks inherit stdout, so rank 0's JSON line is
+    this process's output."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,10 +186,15 @@ def main():
                     help="leave GEMM kernel selection to the library heuristic (onpolicy/utils/gemm_tuning.py)")
     opt = ap.parse_args()
 
+    if opt.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks (one per GPU, RCCL) and relay rank 0's line
+        sys.exit(self_launch(opt.gpus))
+
     wl = dict(WORKLOADS[opt.workload])
     if opt.threads:
         wl["N"] = opt.threads
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == opt.gpus, "--gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (opt.gpus, world)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("MAPPO_SINGLE_DEVICE", "0") == "1":
@@ -224,6 +243,7 @@ def main():
     for _ in range(opt.warmup):
         step()
     buf.profile_kernels(True)
+    trainer.dp.time_collectives(True)
     fence()
     t0 = time.perf_counter()
     for _ in range(opt.steps):
@@ -231,6 +251,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kt = buf.kernel_times()
+    n_coll, coll_ms, coll_bytes = trainer.dp.collective_times()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -273,6 +294,10 @@ def main():
                        "share_obs_dim": wl["Ds"], "actions": wl["na"], "ppo_epoch": args.ppo_epoch,
                        "num_mini_batch": args.num_mini_batch, "gemm_tuning": bool(tuned), "sampler_rng": opt.sampler_rng,
                        "parallelism": "dp%d over rollout threads" % world},
+            # RCCL: ranks in the job and the gradient all-reduce (one flat actor+critic bucket per update) on rank 0
+            "rccl_ranks": world if dist.is_initialized() and dist.get_backend() == "nccl" else 0,
+            "grad_allreduce": {"per_step": n_coll // max(1, opt.steps), "bucket_bytes": coll_bytes,
+                               "ms_per_step": round(coll_ms / max(1, opt.steps), 4)},
             "roofline": roof("mappo_gae_f32"),
             "roofline_gather": roof("mappo_gather_chunks" if wl["recurrent"] else "mappo_gather_rows"),
             "train_info": {k: round(float(v), 6) for k, v in info.items()},

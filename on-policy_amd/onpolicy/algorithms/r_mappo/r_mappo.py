@@ -198,20 +198,26 @@ class R_MAPPO():
         # (local denominator / global denominator) makes the all-reduced gradient the gradient of
         # the global-batch mean.  Weights are exactly 1 for world size 1.
         normalized = (self._use_popart or self._use_valuenorm) and self._updates_normalizer
-        norm_done = False
+        # The normaliser is fed once per minibatch, AFTER the first forward pass and before the loss -- the
+        # reference's order (r_mappo.py:120 evaluate_actions, then :65 update inside cal_value_loss).  It matters
+        # under PopArt, whose update rescales the value head the forward pass runs through.  ``pending`` is what
+        # the update will be fed: None = nothing to do, () = the local minibatch, (mean, mean_sq) = global moments.
+        pending = () if normalized else None
         if self.dp.active:      # one small collective for the loss denominators and the normaliser moments
             w_actor, w_critic, moments = self.dp.minibatch_stats(
                 active_masks_batch, return_batch, self._use_policy_active_masks, self._use_value_active_masks)
             if normalized:
-                self._normalizer_update(return_batch, moments)
-                norm_done = True
+                pending = moments
         else:
             w_actor = w_critic = 1.0
 
         self.dp.zero_grad(self.policy.actor_optimizer, self.policy.critic_optimizer)
-        if normalized and not norm_done and len(spans) > 1:
-            self._normalizer_update(return_batch)   # once per minibatch, before it is used (r_mappo.py:65-66)
-            norm_done = True
+
+        def feed_normalizer():
+            nonlocal pending
+            if pending is not None:
+                self._normalizer_update(return_batch, pending or None)
+                pending = None
 
         single = len(spans) == 1
 
@@ -234,7 +240,7 @@ class R_MAPPO():
                 spans, cut, (share_obs_batch, obs_batch, rnn_states_batch, rnn_states_critic_batch, actions_batch,
                              value_preds_batch, return_batch, masks_batch, active_masks_batch,
                              old_action_log_probs_batch, adv_targ, available_actions_batch, factor_batch),
-                w_actor, w_critic, normalized and not norm_done, update_actor)
+                w_actor, w_critic, feed_normalizer, update_actor)
         for lo, hi in ([] if fused else spans):
             am = cut(active_masks_batch, lo, hi)
             values, action_log_probs, entropy = self.policy.evaluate_actions(
@@ -255,8 +261,9 @@ class R_MAPPO():
                 p_loss = (per_sample * am).sum() / am.sum()
             else:
                 p_loss = per_sample.mean()
+            feed_normalizer()
             v_loss = self._value_loss(values, cut(value_preds_batch, lo, hi), cut(return_batch, lo, hi), am,
-                                      update_normalizer=not norm_done)
+                                      update_normalizer=False)
 
             # span weights: this span's share of the minibatch denominators (exactly 1 for one span)
             if len(spans) == 1:
@@ -299,7 +306,7 @@ class R_MAPPO():
 
         return value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights
 
-    def _fused_spans(self, spans, cut, tensors, w_actor, w_critic, update_normalizer, update_actor):
+    def _fused_spans(self, spans, cut, tensors, w_actor, w_critic, feed_normalizer, update_actor):
         """The span loop of ppo_update through the fused loss kernel (K7): per span one forward to the
         head's logits / the critic's values, one ``mappo_ppo_loss_f32`` launch that evaluates the loss and
         its gradient, one backward from those gradients.  -> (value_loss, policy_loss, dist_entropy,
@@ -322,9 +329,7 @@ class R_MAPPO():
             values, logits = self.policy.evaluate_logits(
                 cut(share_obs, lo, hi), cut(obs, lo, hi), cut(rnn_a, lo, hi), cut(rnn_c, lo, hi), cut(masks, lo, hi),
                 **self._eval_kwargs())
-            if update_normalizer:       # reference order: forward, normaliser update, loss (r_mappo.py:120-66)
-                self._normalizer_update(returns)
-                update_normalizer = False
+            feed_normalizer()           # reference order: forward, normaliser update, loss (r_mappo.py:120-66)
             norm = self.value_normalizer.denorm_scalars().to(**f32).contiguous() if normalized else None
             dlogits, dvalues = fused_loss.ppo_loss(
                 logits, cut(avail, lo, hi), cut(actions, lo, hi), cut(old_logp, lo, hi), cut(adv, lo, hi),
@@ -377,7 +382,10 @@ class R_MAPPO():
         (means over the updates; global-batch values in a data-parallel job)."""
         advantages = self._advantages(buffer)
         # let the sampler do the parameter-free half of the input LayerNorm while it copies the rows
+        # (only for observation widths the standardising gather has kernels for: wider rows are gathered as
+        # they are and go through the policy's own feature_norm)
         fold = bool(getattr(buffer, "supports_standardized_obs", False)) and \
+            getattr(buffer, "can_standardize_obs", lambda: True)() and \
             hasattr(self.policy, "can_fold_input_norm") and self.policy.can_fold_input_norm()
         gen_kwargs = {"standardize_obs": True} if fold else {}
 

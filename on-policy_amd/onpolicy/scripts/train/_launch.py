@@ -30,11 +30,33 @@ def apply_algorithm_flags(all_args, allowed=("rmappo", "mappo", "ippo")):
 
 
 def device_of(all_args):
-    if all_args.cuda and torch.cuda.is_available():
-        print("choose to use gpu...")
-        torch.set_num_threads(all_args.n_training_threads)
+    """The HIP device of this process.  Single process: cuda:0 like the reference (train_mpe.py:86-96).  Under a
+    one-process-per-GPU launcher (``torchrun --nproc-per-node W train_*.py ...``: WORLD_SIZE / RANK / LOCAL_RANK in
+    the environment) the job is data parallel over rollout threads: this rank takes cuda:<LOCAL_RANK>, joins the
+    RCCL process group and keeps its contiguous share of ``--n_rollout_threads`` -- ``all_args.n_rollout_threads``
+    becomes the LOCAL count, ``all_args.rollout_thread_offset`` the index of its first thread (env seeds are
+    offset by it so that the union of the ranks' envs is the single-process set) -- and R_MAPPO all-reduces the
+    gradients (onpolicy/utils/dist.py).  Step counters and logs of a rank count its own threads."""
+    if not (all_args.cuda and torch.cuda.is_available()):
+        raise RuntimeError("the rollout buffer of this implementation lives in HBM: a HIP device is required")
+    print("choose to use gpu...")
+    torch.set_num_threads(all_args.n_training_threads)
+    all_args.rollout_thread_offset = 0
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
         return torch.device("cuda:0")
-    raise RuntimeError("the rollout buffer of this implementation lives in HBM: a HIP device is required")
+    from onpolicy.utils import dist as mdist
+    single = os.environ.get("MAPPO_SINGLE_DEVICE", "0") == "1"     # test mode: every rank on GPU 0, gloo collectives
+    device = torch.device("cuda", 0 if single else int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(device)
+    mdist.init_from_env(device)
+    lo, hi = mdist.shard_threads(all_args.n_rollout_threads)
+    if hi == lo:
+        raise ValueError("--n_rollout_threads %d is smaller than the number of ranks %d"
+                         % (all_args.n_rollout_threads, world))
+    all_args.global_n_rollout_threads = all_args.n_rollout_threads
+    all_args.n_rollout_threads, all_args.rollout_thread_offset = hi - lo, lo
+    return device
 
 
 def new_run_dir(all_args, *levels):
@@ -44,6 +66,9 @@ def new_run_dir(all_args, *levels):
     run_dir.mkdir(parents=True, exist_ok=True)
     existing = [int(p.name[3:]) for p in run_dir.iterdir() if p.name.startswith("run") and p.name[3:].isdigit()]
     run_dir = run_dir / ("run%d" % (max(existing) + 1 if existing else 1))
+    rank = int(os.environ.get("RANK", "0"))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and rank > 0:    # ranks of one job never share a directory
+        run_dir = run_dir.parent / ("%s_rank%d_%d" % (run_dir.name, rank, os.getpid()))
     run_dir.mkdir(parents=True)
     return run_dir
 

@@ -19,6 +19,7 @@ from onpolicy.scripts.train import _launch
 
 def make_train_env(all_args, n_threads=None, seed_offset=0, device=None):
     n = all_args.n_rollout_threads if n_threads is None else n_threads
+    seed_offset += 1000 * getattr(all_args, "rollout_thread_offset", 0)      # data-parallel rank: its own worlds
     if all_args.scenario_name == "simple_spread" and device is not None:    # worlds held on the device (row f1)
         from onpolicy.envs.mpe.simple_spread import TorchSimpleSpread
         return TorchSimpleSpread(n, all_args.num_agents, all_args.num_landmarks, all_args.episode_length,

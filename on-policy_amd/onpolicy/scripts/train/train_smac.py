@@ -81,7 +81,7 @@ def main(args):
     device = _launch.device_of(all_args)
     run_dir = _launch.new_run_dir(all_args, all_args.map_name)
     _launch.seed_everything(all_args)
-    envs = make_env(all_args, all_args.n_rollout_threads, lambda rank: all_args.seed + rank * 1000)
+    envs = make_env(all_args, all_args.n_rollout_threads, lambda rank: all_args.seed + (getattr(all_args, "rollout_thread_offset", 0) + rank) * 1000)
     eval_envs = make_env(all_args, all_args.n_eval_rollout_threads,
                          lambda rank: all_args.seed * 50000 + rank * 10000) if all_args.use_eval else None
     if all_args.share_policy and all_args.algorithm_name not in ("happo", "hatrpo"):

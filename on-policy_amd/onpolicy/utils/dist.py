@@ -74,6 +74,7 @@ class DataParallel(object):
         self.rank = dist.get_rank(group) if self.active else 0
         self.device = device
         self._flat = None
+        self._timing = None                  # list of (start, end) events around the gradient all-reduce
         if self.active:
             params = [p for net in (actor, critic) for p in net.parameters() if p.requires_grad]
             total = sum(p.numel() for p in params)
@@ -111,8 +112,27 @@ class DataParallel(object):
             self._flat.zero_()  # grads are views of the bucket: one memset, nothing set to None
 
     def all_reduce_grads(self):
-        if self.active:
-            dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
+        if not self.active:
+            return
+        timed = self._timing is not None and self._flat.is_cuda
+        if timed:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
+        if timed:
+            ev[1].record()
+            self._timing.append(ev)
+
+    def time_collectives(self, on=True):
+        """Start (or stop) recording an event pair around every gradient all-reduce (bench.py)."""
+        self._timing = [] if on else None
+
+    def collective_times(self):
+        """-> (number of gradient all-reduces recorded, their total milliseconds on the device, bucket bytes).
+        The caller must have synchronised the device."""
+        ev = self._timing or []
+        ms = sum(a.elapsed_time(b) for a, b in ev)
+        return len(ev), ms, (0 if self._flat is None else self._flat.numel() * 4)
 
     def loss_weights(self, active_masks, policy_masked, value_masked):
         """(w_actor, w_critic): local / global denominators of the masked means

@@ -56,6 +56,9 @@ class SeparatedReplayBuffer(object):
 
     supports_standardized_obs = True
 
+    def can_standardize_obs(self):
+        return self._inner.can_standardize_obs()
+
     def update_factor(self, factor):
         """HAPPO's running product of the other agents' probability ratios, [T, N, k]."""
         f = self._inner._dev(factor).reshape(self.episode_length, self.n_rollout_threads, 1, -1).clone()

@@ -342,6 +342,7 @@ class SharedReplayBuffer(object):
             self._adv_denormalized = bool(self._use_popart or self._use_valuenorm)   # = what MATTrainer reads
             self._adv_is_gae = True
             self._stats_fresh = False
+            self._adv_inputs = self._adv_input_versions()
             return
         self._adv_is_gae = False
         # algorithmic bytes: r, v, m reads + returns write (16 B) + advantages write + active read
@@ -358,6 +359,13 @@ class SharedReplayBuffer(object):
         self._adv_fresh = True
         self._adv_denormalized = denorm is not None      # what the fused advantages subtracted
         self._stats_fresh = False
+        self._adv_inputs = self._adv_input_versions()
+
+    def _adv_input_versions(self):
+        """In-place torch writes to the fields the fused advantages / moments were formed from bump these
+        counters (runners do edit them between compute_returns and train, e.g. ``active_masks[-1] = ...``);
+        this class's own kernels write through raw pointers and leave them alone."""
+        return (self.returns._version, self.value_preds._version, self.active_masks._version)
 
     def normalized_advantages(self, value_normalizer=None, all_reduce=None, denormalize=None):
         """What the prologue of the reference's ``R_MAPPO.train`` computes (r_mappo.py:179-187), as an
@@ -374,6 +382,8 @@ class SharedReplayBuffer(object):
         want = flagged if denormalize is None else bool(denormalize)
         if want and not flagged:
             raise ValueError("denormalize=True needs a buffer built with use_popart / use_valuenorm")
+        if self._adv_fresh and getattr(self, "_adv_inputs", None) != self._adv_input_versions():
+            self._adv_fresh = False        # returns / value_preds / active_masks were edited in place since
         if self._adv_fresh and self._adv_is_gae and denormalize is None:
             pass       # MAT: buffer.advantages is what the trainer normalises (mat_trainer.py:160-164)
         elif not self._adv_fresh or self._adv_denormalized != want:
@@ -387,6 +397,7 @@ class SharedReplayBuffer(object):
             self._content_version += 1
             self._adv_fresh = True
             self._stats_fresh = False
+            self._adv_inputs = self._adv_input_versions()
         if not self._stats_fresh or all_reduce is not None:
             _native.check(self._lib.mappo_adv_reduce(p(self._adv_partials), self._partial_rows,
                                                      p(self._adv_sums), self._stream()), "mappo_adv_reduce")
@@ -445,11 +456,16 @@ class SharedReplayBuffer(object):
             ("action_log_probs", self.action_log_probs, False),
         ]
         stats = None
+        self._adv_external = False
         if advantages is None:
             adv = None
         elif isinstance(advantages, AdvantageHandle):
             adv, stats = advantages.raw, advantages.stats
         else:
+            # the reference's protocol: an array / tensor the caller owns.  It is gathered as a field of its
+            # own and never enters the packed records: the upload below is a temporary whose address and
+            # version counter can repeat across calls, so it cannot key the record cache
+            self._adv_external = True
             adv = self._dev(advantages)
             if adv.numel() != T * self.n_rollout_threads * self.num_agents:
                 raise ValueError("advantages has the wrong number of elements")
@@ -460,6 +476,23 @@ class SharedReplayBuffer(object):
         return table, stats
 
     supports_standardized_obs = True   # generators take standardize_obs=True (see feed_forward_generator)
+
+    @staticmethod
+    def _standardize_width_ok(width):
+        """Widths the standardising gather has kernels for (pick_shape, csrc/mappo_norm.hip): rows of whole
+        float4s up to 2048 floats, any other width up to 1536."""
+        return (width % 4 == 0 and width <= 2048) or width <= 1536
+
+    def can_standardize_obs(self):
+        """Whether ``standardize_obs=True`` is available for BOTH observation fields of this buffer (vector
+        observations of a supported width).  The trainer folds the input LayerNorm into the sampler only then;
+        otherwise (e.g. simple_spread with >= 19 agents: share_obs 2166 wide) it gathers plain rows and the policy
+        applies its own feature_norm."""
+        for field in (self.share_obs, self.obs):
+            tail = tuple(field.shape[3:])
+            if len(tail) != 1 or not self._standardize_width_ok(int(tail[0])):
+                return False
+        return True
 
     # fields at most this wide are packed into one record per sample before sampling
     _NARROW = 8
@@ -476,6 +509,8 @@ class SharedReplayBuffer(object):
         for name, src, is_state in table:
             if src is None or is_state or name in ("share_obs", "obs"):
                 continue   # observations / RNN states keep their own (wide or standardising) path
+            if name == "advantages" and self._adv_external:
+                continue
             tail = tuple(src.shape[3:])
             width = int(np.prod(tail)) if tail else 1
             if width > self._NARROW or off + width > self._MAX_RECORD:

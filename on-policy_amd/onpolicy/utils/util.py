@@ -22,7 +22,8 @@ def get_gard_norm(params):
     for p in params:
         if p.grad is not None:
             total = total + p.grad.norm() ** 2
-    return math.sqrt(total)
+    # tensor in, tensor out: no host sync per minibatch (the trainer reads its logged scalars once per train())
+    return torch.sqrt(total) if torch.is_tensor(total) else math.sqrt(total)
 
 
 def update_linear_schedule(optimizer, epoch, total_num_epochs, initial_lr):

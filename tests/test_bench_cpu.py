@@ -38,3 +38,25 @@ def test_cpu_baseline_leg_runs(bench, name):
         torch.set_num_threads(threads)
     assert out["kind"] == "port" and out["unit"] == "env-steps/s" and out["value"] > 0 and out["cores"] >= 1
     assert "n_rollout_threads=2" in out["sample"]
+
+
+def test_plain_gpus_flag_launches_one_rank_per_gpu(bench, monkeypatch):
+    """`python bench.py --gpus N` without a launcher around it starts N ranks itself through torch.distributed.run
+    (loop-back rendezvous) and hands the original flags on; under a launcher the world size must match --gpus."""
+    import subprocess
+    import sys
+    seen = {}
+    monkeypatch.setattr(subprocess, "call", lambda cmd: seen.setdefault("cmd", cmd) and 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--threads", "64"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "2", "--threads", "64"] and cmd[-7].endswith("bench.py")
+    # a launcher that started a different number of ranks than --gpus asks for is an error, not a silent N = 1 run
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(AssertionError, match="--gpus 4"):
+        bench.main()

@@ -64,6 +64,28 @@ def test_two_ranks_on_one_gpu_strong_scaling_path():
     assert all(abs(v) < 1e6 for v in d["train_info"].values())
 
 
+def test_plain_gpus_flag_runs_two_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it: bench.py starts the two ranks itself (both mapped onto
+    this box's one GPU, gloo carrying the collectives) and rank 0's line reports n_gpus = 2; `--gpus 1` is one plain
+    process as before."""
+    env = dict(os.environ)
+    env.update(MAPPO_DIST_BACKEND="gloo", MAPPO_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--threads", "64", "--steps", "1",
+                          "--warmup", "1", "--sampler-rng", "host", "--no-gemm-tuning"],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["threads_per_gpu"] == 32
+    assert d["rccl_ranks"] == 0                       # gloo in this test mode; RCCL ranks are reported when nccl carries them
+    assert d["grad_allreduce"]["per_step"] == 10 and d["grad_allreduce"]["bucket_bytes"] > 0
+    one = _run(args=("--gpus", "1"))
+    assert one["n_gpus"] == 1 and one["grad_allreduce"]["per_step"] == 0
+
+
 @pytest.mark.parametrize("args_over", [dict(), dict(use_policy_active_masks=False, use_valuenorm=False, use_huber_loss=False)],
                          ids=["default", "unmasked_nonorm_mse"])
 def test_two_rank_device_update_equals_single_process(tmp_path, args_over):

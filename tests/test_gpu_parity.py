@@ -410,6 +410,41 @@ def test_train_on_device_vs_reference(gold, cname):
         np.testing.assert_allclose(got, z[key + "final_norm"], rtol=1e-5, atol=1e-9)
 
 
+def test_train_with_observations_wider_than_the_standardising_gather():
+    """simple_spread with 19 agents under a centralised critic has share_obs 2166 wide: no standardising-gather
+    kernel covers it (and FusedLayerNorm falls back to PyTorch there).  train() must then gather plain rows and
+    let the policy apply its own feature_norm instead of dying in the first minibatch; the update must equal
+    the same update on the CPU port of the path (oracle buffer + the same trainer)."""
+    from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy
+    from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO
+    from onpolicy.utils.shared_buffer import SharedReplayBuffer
+    T, N, A, Do, Ds, na = 6, 3, 2, 114, 2166, 5
+    assert not SharedReplayBuffer._standardize_width_ok(Ds) and SharedReplayBuffer._standardize_width_ok(Do)
+    args = make_args(episode_length=T, n_rollout_threads=N, ppo_epoch=2, num_mini_batch=1, sampler_rng="host")
+    spaces = Box((Do,)), Box((Ds,)), Discrete(na)
+    arrays = fill_buffer_arrays(buffer_shapes(T, N, A, Do, Ds, na, 64), np.random.default_rng(5), na=na)
+    results = []
+    for dev in (_dev(), torch.device("cpu")):
+        torch.manual_seed(1)
+        policy = R_MAPPOPolicy(args, *spaces, device=dev)
+        trainer = R_MAPPO(args, policy, device=dev)
+        buf = SharedReplayBuffer(args, A, *spaces, device=dev) if dev.type == "cuda" \
+            else oracle.OracleBuffer(args, A, *spaces)
+        if dev.type == "cuda":
+            assert not buf.can_standardize_obs() and policy.can_fold_input_norm()
+        load_into(buf, arrays)
+        buf.compute_returns(arrays["next_value"], trainer.value_normalizer)
+        trainer.prep_training()
+        torch.manual_seed(33)
+        info = trainer.train(buf)
+        results.append((info, {k: v.detach().cpu().numpy() for k, v in policy.critic.state_dict().items()}))
+    (gi, gw), (ci, cw) = results
+    for k in ci:
+        assert gi[k] == pytest.approx(ci[k], rel=1e-3, abs=1e-5), k
+    for k in cw:
+        np.testing.assert_allclose(gw[k], cw[k], rtol=1e-3, atol=5e-5, err_msg=k)
+
+
 # ------------------------------------------------------------------ K6: LayerNorm kernels
 @pytest.mark.parametrize("D", [48, 64, 384, 18, 54, 370, 435, 512, 1285, 30, 150, 4, 3, 2048, 1536])
 def test_fused_layernorm_vs_torch(D):

@@ -81,6 +81,10 @@ class Runner(object):
             self.render_envs = config['render_envs']
 
         a = self.all_args
+        # --sampler_rng host = integer-parity mode: minibatch permutations AND the action
+        # noise are drawn on the CPU generator like the reference does, so a device run reproduces its action stream
+        from onpolicy.algorithms.utils import distributions
+        distributions.set_sampling_rng(getattr(a, "sampler_rng", "device"))
         self.env_name = a.env_name
         self.algorithm_name = a.algorithm_name
         self.experiment_name = a.experiment_name

@@ -5,6 +5,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 
@@ -48,3 +49,20 @@ def test_simple_spread_learns(tmp_path, monkeypatch):
     first, last = np.mean(r[:5]), np.mean(r[-5:])
     print("average episode rewards: first 5 = %.2f, last 5 = %.2f" % (first, last))
     assert last > first + 0.02 * abs(first), (first, last)
+
+
+@pytest.mark.parametrize("algo", ["mappo", "rmappo"])
+def test_train_mpe_with_device_resident_worlds(tmp_path, monkeypatch, algo):
+    """Row f1: the training worlds are tensors on the policy's device (TorchSimpleSpread, pinned to the reference's
+    trajectories on CPU tensors in tests/test_mpe_env_cpu.py); collect -> env step -> insert never leaves the GPU."""
+    from onpolicy.scripts.train import train_mpe
+    monkeypatch.setenv("MAPPO_RESULTS_DIR", str(tmp_path / "results"))
+    runner = train_mpe.main(["--env_name", "MPE", "--scenario_name", "simple_spread", "--num_agents", "3",
+                             "--num_landmarks", "3", "--algorithm_name", algo, "--n_rollout_threads", "16",
+                             "--episode_length", "10", "--num_env_steps", "480", "--ppo_epoch", "2", "--num_mini_batch", "1",
+                             "--data_chunk_length", "5", "--hidden_size", "16", "--use_wandb", "--log_interval", "1",
+                             "--n_training_threads", "1", "--use_device_env"])
+    assert type(runner.envs).__name__ == "TorchSimpleSpread" and runner.envs.pos.is_cuda
+    tags = {json.loads(l)["tag"] for l in open(os.path.join(runner.log_dir, "scalars.jsonl"))}
+    assert {"value_loss", "average_episode_rewards", "agent0/individual_rewards"} <= tags
+    assert torch.isfinite(runner.buffer.rewards).all() and float(runner.buffer.masks.min()) == 0.0

@@ -236,3 +236,27 @@ def test_other_action_spaces_on_the_device_buffer(kind):
     assert all(np.isfinite(v) for v in info.values()), info
     sample = next(iter(buf.feed_forward_generator(None, 2)))
     assert sample[11] is None and tuple(sample[4].shape) == (T * N * A // 2, width)
+
+
+# ------------------------------------------------------------------ a12: the reference's runners, replayed on the HBM buffer
+@pytest.mark.parametrize("cname", ["mpe_mlp", "mpe_rnn", "smac_rnn"])
+def test_rollout_and_update_vs_reference_runner(gold, tmp_path, cname):
+    """tests/test_runners_cpu.py's comparison with the REFERENCE's runners (runner_cases.npz: rollout buffer, update,
+    buffer after the update, parameters, eval log) with the real thing in place of the host stand-in: policy on the
+    GPU, rollout buffer in HBM, returns / samplers / loss through the HIP kernels.  ``--sampler_rng host`` draws the
+    action noise and the minibatch permutations on the CPU generator like the reference, so the sampled actions must
+    be identical; floats to the tolerances of the CPU test (2e-4)."""
+    import runner_replay
+    runner = runner_replay.replay_shared_case(gold, tmp_path, cname, device=torch.device("cuda", 0), init_exact=False,
+                                              sampler_rng="host")
+    assert runner.buffer.obs.is_cuda and type(runner.buffer).__name__ == "SharedReplayBuffer"
+    assert next(runner.policy.actor.parameters()).is_cuda
+
+
+def test_hanabi_turn_loop_vs_reference_runner(gold, tmp_path):
+    """The reference's whole turn-based Hanabi loop (chooseinsert / reward shift / chooseafter_update, four episodes with
+    lr decay) replayed on the HBM buffer."""
+    import runner_replay
+    runner = runner_replay.replay_hanabi_case(gold, tmp_path, device=torch.device("cuda", 0), init_exact=False,
+                                              sampler_rng="host")
+    assert runner.buffer.obs.is_cuda

@@ -159,6 +159,27 @@ def cpu_baseline(wl):
                       "%.3f s compute_returns + %.2f s train" % (n, wl["T"], wl["A"], t1 - t0, t2 - t1)}
 
 
+def reference_recorded(workload):
+    """The REFERENCE's own CPU path (its SharedReplayBuffer.compute_returns + R_MAPPO.train, imported in place)
+    timed by tools/time_reference_cpu.py where /root/reference is mounted -- the GPU box has no reference, so the
+    committed record (profiles/r02_cpu_reference.json) is quoted, never re-measured here."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_cpu_reference.json")) as f:
+            doc = json.load(f)
+    except Exception:
+        return None
+    runs = [r for r in doc["runs"] if r["workload"] == workload]
+    if not runs:
+        return None
+    return {"kind": "reference", "source": "profiles/r02_cpu_reference.json (tools/time_reference_cpu.py)",
+            "host": doc["host"]["cpu"] + ", %d logical cores, build container" % doc["host"]["logical_cores"],
+            "n_rollout_threads_timed": runs[0]["n_rollout_threads_timed"],
+            "note": "same T / agents / dims / ppo_epoch as the GPU run, fewer rollout threads (host memory); env-steps/s "
+                    "is a per-sample rate",
+            "runs": [{"torch_threads": r["torch_threads"], "env_steps_per_s": r["env_steps_per_s"],
+                      "compute_returns_s": r["compute_returns_s"], "train_s": r["train_s"]} for r in runs]}
+
+
 def self_launch(n_gpus):
     """Re-run this command line under ``torch.distributed.run`` with one rank per GPU (what the driver's own
     multi-GPU launch line does) and return its exit code.  The ranks inherit stdout, so rank 0's JSON line is
@@ -281,6 +302,7 @@ def main():
             achieved = nbytes / (ms * 1e-3) / 1e9
             return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(name, nbytes),
+                    "traffic_source": "committed rocprofv3 PMC passes (profiles/r01_pmc_summary.json), not this run",
                     "launch_ms": round(ms, 5), "launches": launches, "algorithmic_bytes": int(nbytes)}
 
         out = {
@@ -306,6 +328,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(wl)
             out["cpu_baseline"]["sample"] += "; GPU/CPU ratio on env-steps/s = %.0fx" % (
                 value / out["cpu_baseline"]["value"])
+            ref = reference_recorded(opt.workload)
+            if ref is not None:
+                out["cpu_baseline"]["reference_recorded"] = ref
     else:
         out = None
     if dist.is_initialized():

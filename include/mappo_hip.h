@@ -344,6 +344,64 @@ int mappo_gru_step_fwd(const float* gi, const float* hm, const float* w_hh, cons
                        const float* mask_next, float* h_out, float* hm_next, float* ws, int64_t B, int H,
                        mappo_stream_t stream);
 
+/* --------------------------------------------------------------- K9: fused hidden-64 trunk ----
+ * The actor / critic network of the update as three kernels instead of ~25 launches per minibatch span: what
+ * MLPBase + the output Linear compute (reference onpolicy/algorithms/utils/mlp.py:6-58: [LayerNorm(obs)] ->
+ * (Linear -> Tanh | ReLU -> LayerNorm) x (1 + layer_N); act.py / distributions.py:55-68 Categorical head and
+ * r_actor_critic.py:147-175 v_out are plain Linears on the trunk's features), evaluated straight from the rollout
+ * buffer: the rows are read through the sampler's index list (shared_buffer.py:379-396 rows mode, :554-604 chunk
+ * mode), so the gathered [mb, obs_dim] minibatch of feed_forward_generator / recurrent_generator is never written.
+ * hidden_size must be 64.  All products run on the float32 matrix cores (exact f32 fma chains).
+ *
+ * Input LayerNorm: pass row_stats = the per-row {mean, 1 / sqrt(var + eps)} of the source matrix
+ * (mappo_row_stats, computed once per train() -- the observations do not change during the ppo epochs) and fold
+ * the LayerNorm's affine half into the first Linear on the caller's side (w1 = W * gamma, bias[0] = b + W beta);
+ * row_stats = NULL feeds the rows as they are (use_feature_normalization = False).
+ *
+ *   src        [src_rows, din]   matrix the rows come from (e.g. buffer.share_obs[:-1] viewed [T*N*A, din])
+ *   idx        [mb] int64        sampler indices; NULL: launch row r reads source row r
+ *   chunk_len  0: rows mode (row r <- source row idx[r]);  L > 0: chunk mode, rows = L * mb, row l * mb + j <- element
+ *              idx[j] * L + l of the (n, a, t)-ordered sequence (needs T, N, A)
+ *   w1 [64, din], bias[l] / ln_g[l] / ln_b[l] [64] for l < n_layers (n_layers = 1 + layer_N <= 3), w2[l-1] [64, 64]
+ *   act        1 Tanh, 2 ReLU (0 identity)
+ *   wh [out, 64], bh [out]   output Linear (out <= 64); out = 0: y receives the trunk's features [rows, 64]
+ * mappo_mlp_forward writes y [rows, out] and, when z[l] != NULL, the pre-activations z[l] [rows, 64] of every layer
+ *   (saved for the backward; NULL in rollouts).
+ * mappo_mlp_backward reads dy [rows, out] (or [rows, 64] for out = 0) and z[l]; writes `grads`, the parameter gradients
+ *   as one flat array [w1 64*din | per layer: bias 64, ln weight 64, ln bias 64 | per hidden layer: w 64*64 | wh out*64 |
+ *   bh out] (mappo_mlp_grad_floats), using dz1 [rows, 64] and workspace [mappo_mlp_workspace_floats] as scratch.
+ *   Gradients are plain sums over the rows in a fixed order (deterministic run to run). */
+#define MAPPO_MLP_MAX_LAYERS 3
+typedef struct mappo_mlp {
+    const float* src;
+    const float* row_stats;
+    const int64_t* idx;
+    int64_t rows;
+    int64_t mb;
+    int32_t chunk_len, T, N, A;
+    int32_t din, n_layers, act, out;
+    float ln_eps;
+    const float* w1;
+    const float* bias[MAPPO_MLP_MAX_LAYERS];
+    const float* ln_g[MAPPO_MLP_MAX_LAYERS];
+    const float* ln_b[MAPPO_MLP_MAX_LAYERS];
+    const float* w2[MAPPO_MLP_MAX_LAYERS - 1];
+    const float* wh;
+    const float* bh;
+    float* y;
+    float* z[MAPPO_MLP_MAX_LAYERS];
+    const float* dy;
+    float* dz1;
+    float* workspace;
+    float* grads;
+} mappo_mlp_t;
+int     mappo_mlp_forward(const mappo_mlp_t* net, mappo_stream_t stream);
+int     mappo_mlp_backward(const mappo_mlp_t* net, mappo_stream_t stream);
+int64_t mappo_mlp_grad_floats(int din, int n_layers, int out);
+int64_t mappo_mlp_workspace_floats(int din, int n_layers, int out);
+/* stats[r] = {mean, 1 / sqrt(var + eps)} of src[r, 0:D] (population variance, as nn.LayerNorm: mlp.py:47-48) */
+int     mappo_row_stats(const float* src, int64_t rows, int D, float eps, float* stats, mappo_stream_t stream);
+
 /* --------------------------------------------------------------------- misc ---- */
 int         mappo_abi_version(void);
 const char* mappo_build_info(void);        /* "gfx950 ..." static string */

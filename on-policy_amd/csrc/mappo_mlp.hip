@@ -1,0 +1,68 @@
+// K9: fused hidden-64 trunk (forward, backward chain, first-layer weight gradient) -- gfx950 binding of
+// mappo_mlp_impl.h, which holds the kernels and their launchers.
+#include <hip/hip_runtime.h>
+
+#include "mappo_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4 __attribute__((ext_vector_type(4)));
+typedef float v4u __attribute__((ext_vector_type(4), aligned(4)));
+
+namespace prim {
+// v_mfma_f32_32x32x2_f32: A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31],
+// D[row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5)][col = lane & 31]
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
+__device__ __forceinline__ float sum16(float v) {
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+__device__ __forceinline__ float* lds() {
+    extern __shared__ __attribute__((aligned(16))) float mappo_dyn_lds[];
+    return mappo_dyn_lds;
+}
+}  // namespace prim
+
+namespace {
+int g_launch_error = 0;
+// dynamic LDS above 64 KB has to be granted per kernel function before the launch
+template <class K>
+void grant_lds(K kernel, size_t bytes) {
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) g_launch_error = (int)e;
+    }
+}
+}  // namespace
+
+#define MAPPO_LAUNCH(kernel, grid, block, lds_bytes, stream, ...)                                      \
+    do {                                                                                               \
+        grant_lds(kernel, (lds_bytes));                                                                \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (lds_bytes), stream, __VA_ARGS__);         \
+    } while (0)
+#define MAPPO_LAUNCH_ERROR() (g_launch_error ? g_launch_error : (int)hipGetLastError())
+
+#include "mappo_mlp_impl.h"
+
+extern "C" int mappo_mlp_forward(const mappo_mlp_t* net, mappo_stream_t stream) {
+    g_launch_error = 0;
+    return mlp::forward(net, static_cast<hipStream_t>(stream));
+}
+extern "C" int mappo_mlp_backward(const mappo_mlp_t* net, mappo_stream_t stream) {
+    g_launch_error = 0;
+    return mlp::backward(net, static_cast<hipStream_t>(stream));
+}
+extern "C" int64_t mappo_mlp_grad_floats(int din, int n_layers, int out) { return mlp::g_total(din, n_layers, out); }
+extern "C" int64_t mappo_mlp_workspace_floats(int din, int n_layers, int out) {
+    return mlp::workspace_floats(din, n_layers, out);
+}
+extern "C" int mappo_row_stats(const float* src, int64_t rows, int D, float eps, float* stats, mappo_stream_t stream) {
+    g_launch_error = 0;
+    return mlp::row_stats(src, rows, D, eps, stats, static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,253 @@
+"""Fused hidden-64 trunk (K9, ``mappo_mlp_forward`` / ``mappo_mlp_backward``): the whole MLPBase chain plus the output
+Linear of an actor / critic as one forward kernel and two backward kernels on the float32 matrix cores, reading the
+observation rows of a sampler minibatch straight from the rollout buffer through the sampler's index list.
+
+Reference modules it evaluates (same parameters, same function): onpolicy/algorithms/utils/mlp.py:6-58 (MLPLayer /
+MLPBase: [LayerNorm] -> (Linear -> Tanh | ReLU -> LayerNorm) x (1 + layer_N)), the Categorical head's Linear
+(distributions.py:55-68) and the critic's v_out (r_actor_critic.py:147-175).
+
+``RowSource`` is what the buffer's samplers hand out instead of a gathered ``[mb, obs_dim]`` tensor when asked for
+``lazy_obs=True``: the source matrix, the per-row standardisation constants and the minibatch's indices.  Networks that
+cannot take it call ``materialize()`` and get the tensor the eager gather would have produced.
+
+Autograd sees one node per network (``_FusedTrunkFn``); the input LayerNorm's affine half is folded into the first
+Linear with ordinary torch ops in front of it (``LN(x) W^T + b = xhat (W * gamma)^T + (b + W beta)``), so gamma / beta
+receive their gradients from autograd.  ``MAPPO_FUSED_MLP=0`` disables the path.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from onpolicy import _native
+
+HIDDEN = 64
+MAX_LAYERS = 3
+MAX_OUT = 64
+
+
+def enabled():
+    return os.environ.get("MAPPO_FUSED_MLP", "1") != "0"
+
+
+class RowSource(object):
+    """Rows of a 2-D source matrix selected by a sampler minibatch, not yet gathered.
+
+    ``src``   [src_rows, din] float32 device matrix (a time-major buffer field viewed as rows)
+    ``stats`` [src_rows, 2] {mean, 1 / sqrt(var + 1e-5)} per source row, or None
+    ``idx``   int64 device indices; ``chunk`` = (L, T, N, A) for recurrent_generator's chunk rows, None for row indices
+    """
+
+    def __init__(self, src, stats, idx, chunk=None):
+        self.src, self.stats, self.idx, self.chunk = src, stats, idx, chunk
+        self.mb = int(idx.shape[0])
+        self.rows = self.mb * (chunk[0] if chunk else 1)
+
+    @property
+    def shape(self):
+        return (self.rows, int(self.src.shape[1]))
+
+    @property
+    def device(self):
+        return self.src.device
+
+    is_cuda = True
+
+    def rows_slice(self, lo, hi):
+        """Row span [lo, hi) of a rows-mode minibatch / chunk span [lo, hi) of a chunk-mode one (every span keeps all
+        L steps of its chunks, row l * (hi - lo) + j)."""
+        return RowSource(self.src, self.stats, self.idx[lo:hi], self.chunk)
+
+    def __getitem__(self, key):
+        if not (isinstance(key, slice) and key.step in (None, 1)) or self.chunk:
+            raise TypeError("RowSource supports contiguous row slices of rows-mode minibatches only")
+        lo, hi, _ = key.indices(self.rows)
+        return self.rows_slice(lo, hi)
+
+    def source_rows(self):
+        """int64 [rows] source row of every minibatch row (shared_buffer.py:379-396 / :554-604)."""
+        if not self.chunk:
+            return self.idx
+        L, T, N, A = self.chunk
+        r = torch.arange(self.rows, device=self.idx.device)
+        l, j = r // self.mb, r % self.mb
+        f = self.idx[j] * L + l
+        n, rem = f // (A * T), f % (A * T)
+        a, t = rem // T, rem % T
+        return (t * N + n) * A + a
+
+    def materialize(self, standardized):
+        """The [rows, din] tensor the eager samplers produce (standardised rows when ``standardized``)."""
+        sr = self.source_rows()
+        x = self.src[sr]
+        if standardized:
+            if self.stats is None:
+                raise ValueError("this RowSource carries no row statistics")
+            st = self.stats[sr]
+            x = (x - st[:, :1]) * st[:, 1:]
+        return x
+
+
+def row_stats(src2d, eps=1e-5):
+    """[rows, 2] {mean, 1 / sqrt(var + eps)} of every row of a float32 device matrix (``mappo_row_stats``)."""
+    rows, D = src2d.shape
+    out = torch.empty((rows, 2), dtype=torch.float32, device=src2d.device)
+    _native.check(_native.lib().mappo_row_stats(src2d.data_ptr(), rows, D, float(eps), out.data_ptr(),
+                                                _native.stream_of(src2d.device)), "mappo_row_stats")
+    return out
+
+
+def _act_kind(module):
+    return 1 if isinstance(module, nn.Tanh) else 2 if isinstance(module, nn.ReLU) else None
+
+
+def trunk_supported(base):
+    """Whether an ``MLPBase`` can run through the fused kernels: hidden 64, <= 3 Linear blocks, Tanh / ReLU, float32
+    parameters on a HIP device, input LayerNorm (if any) with the sampler's eps."""
+    if not enabled() or not hasattr(base, "mlp"):
+        return False
+    mlp = base.mlp
+    blocks = [mlp.fc1] + list(mlp.fc2)
+    if len(blocks) > MAX_LAYERS or base.hidden_size != HIDDEN:
+        return False
+    for blk in blocks:
+        lin, act, norm = blk[0], blk[1], blk[2]
+        if _act_kind(act) is None or lin.out_features != HIDDEN or not isinstance(norm, nn.LayerNorm):
+            return False
+        if not norm.elementwise_affine or norm.bias is None or lin.bias is None:
+            return False
+    eps = {float(blk[2].eps) for blk in blocks}
+    if len(eps) != 1:
+        return False
+    if base._use_feature_normalization and abs(base.feature_norm.eps - 1e-5) > 1e-12:
+        return False
+    p = lin.weight
+    return p.is_cuda and p.dtype == torch.float32
+
+
+class _FusedTrunkFn(torch.autograd.Function):
+    """y = head(trunk(rows)).  Tensor inputs: w1, b1 (input LayerNorm already folded), then per layer ln weight / bias,
+    per hidden layer weight / bias, then head weight / bias (absent for out = 0)."""
+
+    @staticmethod
+    def forward(ctx, rs, act, eps, n_layers, out, *params):
+        lib = _native.lib()
+        dev = rs.src.device
+        params = [p.detach().contiguous() for p in params]
+        m = _native.MLP()
+        _fill_rows(m, rs)
+        m.n_layers, m.act, m.out, m.ln_eps = n_layers, act, out, float(eps)
+        _fill_params(m, params, n_layers, out)
+        rows = rs.rows
+        y = torch.empty((rows, out if out else HIDDEN), dtype=torch.float32, device=dev)
+        m.y = y.data_ptr()
+        need_grad = any(ctx.needs_input_grad[5:])
+        zs = []
+        if need_grad:
+            zbuf = torch.empty((n_layers, rows, HIDDEN), dtype=torch.float32, device=dev)
+            for l in range(n_layers):
+                m.z[l] = zbuf[l].data_ptr()
+            zs = [zbuf]
+        _native.check(lib.mappo_mlp_forward(m, _native.stream_of(dev)), "mappo_mlp_forward")
+        ctx.rs, ctx.cfg = rs, (act, eps, n_layers, out)
+        ctx.save_for_backward(*(zs + params))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _native.lib()
+        rs = ctx.rs
+        act, eps, n_layers, out = ctx.cfg
+        saved = ctx.saved_tensors
+        zbuf, params = saved[0], list(saved[1:])
+        dev = rs.src.device
+        din = int(rs.src.shape[1])
+        m = _native.MLP()
+        _fill_rows(m, rs)
+        m.n_layers, m.act, m.out, m.ln_eps = n_layers, act, out, float(eps)
+        _fill_params(m, params, n_layers, out)
+        for l in range(n_layers):
+            m.z[l] = zbuf[l].data_ptr()
+        dy = dy.contiguous()
+        grads = torch.empty(lib.mappo_mlp_grad_floats(din, n_layers, out), dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.mappo_mlp_workspace_floats(din, n_layers, out), dtype=torch.float32, device=dev)
+        dz1 = torch.empty((rs.rows, HIDDEN), dtype=torch.float32, device=dev)
+        m.dy, m.dz1, m.workspace, m.grads = dy.data_ptr(), dz1.data_ptr(), ws.data_ptr(), grads.data_ptr()
+        _native.check(lib.mappo_mlp_backward(m, _native.stream_of(dev)), "mappo_mlp_backward")
+        return (None, None, None, None, None) + tuple(_split_grads(grads, din, n_layers, out))
+
+
+def _fill_rows(m, rs):
+    m.src = rs.src.data_ptr()
+    m.row_stats = _native.ptr(rs.stats)
+    m.idx = rs.idx.data_ptr()
+    m.rows, m.mb, m.din = rs.rows, rs.mb, int(rs.src.shape[1])
+    if rs.chunk:
+        m.chunk_len, m.T, m.N, m.A = rs.chunk
+    else:
+        m.chunk_len = m.T = m.N = m.A = 0
+
+
+def _fill_params(m, params, n_layers, out):
+    """params: [w1, b1, (ln_g, ln_b) x n_layers, (w, b) x (n_layers - 1), (wh, bh) if out]."""
+    it = iter(params)
+    m.w1 = next(it).data_ptr()
+    m.bias[0] = next(it).data_ptr()
+    for l in range(n_layers):
+        m.ln_g[l] = next(it).data_ptr()
+        m.ln_b[l] = next(it).data_ptr()
+    for l in range(1, n_layers):
+        m.w2[l - 1] = next(it).data_ptr()
+        m.bias[l] = next(it).data_ptr()
+    if out:
+        m.wh = next(it).data_ptr()
+        m.bh = next(it).data_ptr()
+
+
+def _split_grads(g, din, n_layers, out):
+    """Flat library order [w1 | per layer: bias, ln weight, ln bias | hidden weights | wh | bh] -> the order of
+    ``_fill_params``."""
+    vec = lambda l, q: g[64 * din + 192 * l + 64 * q: 64 * din + 192 * l + 64 * (q + 1)]
+    res = [g[:64 * din].view(64, din), vec(0, 0)]
+    for l in range(n_layers):
+        res += [vec(l, 1), vec(l, 2)]
+    base = 64 * din + 192 * n_layers
+    for l in range(1, n_layers):
+        res += [g[base + 4096 * (l - 1): base + 4096 * l].view(64, 64), vec(l, 0)]
+    if out:
+        h0 = base + 4096 * (n_layers - 1)
+        res += [g[h0:h0 + 64 * out].view(out, 64), g[h0 + 64 * out:h0 + 65 * out]]
+    return res
+
+
+def trunk_forward(base, rs, head=None):
+    """``head(base(rows))`` for an ``MLPBase`` (see ``trunk_supported``) on the rows of a ``RowSource``; ``head``: an
+    ``nn.Linear``-like module with ``weight`` [out, 64] / ``bias`` [out] (out <= 64) or None for the trunk's features."""
+    mlp = base.mlp
+    blocks = [mlp.fc1] + list(mlp.fc2)
+    lin0 = blocks[0][0]
+    if base._use_feature_normalization:
+        if rs.stats is None:
+            raise ValueError("the trunk has an input LayerNorm: the RowSource must carry row statistics")
+        fn = base.feature_norm
+        w1 = lin0.weight * fn.weight
+        b1 = lin0.bias + lin0.weight @ fn.bias
+    else:
+        if rs.stats is not None:
+            rs = RowSource(rs.src, None, rs.idx, rs.chunk)
+        w1, b1 = lin0.weight, lin0.bias
+    params = [w1, b1]
+    for blk in blocks:
+        params += [blk[2].weight, blk[2].bias]
+    for blk in blocks[1:]:
+        params += [blk[0].weight, blk[0].bias]
+    out = 0
+    if head is not None:
+        out = int(head.weight.shape[0])
+        params += [head.weight, head.bias]
+    return _FusedTrunkFn.apply(rs, _act_kind(blocks[0][1]), blocks[0][2].eps, len(blocks), out, *params)
+
+
+def head_supported(head):
+    return head is not None and getattr(head, "bias", None) is not None and head.weight.dim() == 2 \
+        and head.weight.shape[1] == HIDDEN and head.weight.shape[0] <= MAX_OUT

@@ -1,0 +1,41 @@
+// TEST INFRASTRUCTURE: the kernels of csrc/mappo_mlp_impl.h compiled for the host against the SIMT emulator
+// (simt_emu.h), exported under the product's C ABI names with HOST pointers.  Built by tests/simt/build.py into
+// tests/simt/_build/libmlp_emu.so; used only by tests/test_mlp_kernels_emulated.py.
+#include "simt_emu.h"
+
+simt_dim3 simt::g_threadIdx, simt::g_blockIdx, simt::g_blockDim, simt::g_gridDim;
+
+namespace prim {
+// sum over the 16-lane group of the calling lane (a wave collective)
+inline float sum16(float v) {
+    simt::Wave& w = my_wave();
+    const unsigned lane = simt::st().cur->tid & 63;
+    w.x[lane] = v;
+    simt::wait(w.bar);
+    float s = 0.f;
+    // butterfly order of the device version: ((v + v^8) + (..^4)) ... evaluated pairwise
+    float t[16];
+    for (int i = 0; i < 16; ++i) t[i] = w.x[(lane & ~15u) + i];
+    for (int m = 8; m >= 1; m >>= 1) {
+        float u[16];
+        for (int i = 0; i < 16; ++i) u[i] = t[i] + t[i ^ m];
+        for (int i = 0; i < 16; ++i) t[i] = u[i];
+    }
+    s = t[lane & 15];
+    simt::wait(w.bar);
+    return s;
+}
+}  // namespace prim
+
+#include "../../on-policy_amd/csrc/mappo_mlp_impl.h"
+
+extern "C" int mappo_mlp_forward(const mappo_mlp_t* net, mappo_stream_t stream) { return mlp::forward(net, stream); }
+extern "C" int mappo_mlp_backward(const mappo_mlp_t* net, mappo_stream_t stream) { return mlp::backward(net, stream); }
+extern "C" int64_t mappo_mlp_grad_floats(int din, int n_layers, int out) { return mlp::g_total(din, n_layers, out); }
+extern "C" int64_t mappo_mlp_workspace_floats(int din, int n_layers, int out) {
+    return mlp::workspace_floats(din, n_layers, out);
+}
+extern "C" int mappo_row_stats(const float* src, int64_t rows, int D, float eps, float* stats, mappo_stream_t stream) {
+    return mlp::row_stats(src, rows, D, eps, stats, stream);
+}
+extern "C" unsigned long long simt_mfma_count() { return simt::st().n_mfma; }

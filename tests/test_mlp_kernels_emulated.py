@@ -1,0 +1,113 @@
+"""The fused hidden-64 trunk kernels (K9: csrc/mappo_mlp_impl.h -- gather + standardise + MFMA layer chain forward,
+backward chain, first-layer weight gradient) executed on the host SIMT emulator (tests/simt) and compared with the
+float64 torch restatement of the reference's modules (tests/mlp_reference.py).  This checks what cannot be seen without
+running the code: MFMA fragment layouts, the slot <-> feature permutation between layers, LDS staging between barriers,
+index mapping of both samplers, tile tails.  The same source is compiled for gfx950 into libmappo_hip.so; the -m gpu
+tests (tests/test_gpu_mlp.py) repeat these comparisons on the device."""
+import ctypes
+import os
+import shutil
+
+import numpy as np
+import pytest
+import torch
+
+import mlp_reference as R
+
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="ROCm clang++ (host build of the emulator) not found")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt"))
+    import build
+    return R.bind(ctypes.CDLL(build.build()))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def _run(emu, rng, din, n_layers, act, out, rows, src_rows, standardize=True, chunk=None, backward=True):
+    src = (rng.standard_normal((src_rows, din)) * 1.5 + 0.7).astype(np.float32)
+    p = R.random_net(rng, din, n_layers, out)
+    kw = dict(chunk_len=0, mb=0, T=0, N=0, A=0)
+    if chunk is None:
+        idx = rng.permutation(src_rows)[:rows].astype(np.int64)
+    else:
+        L, T, N, A = chunk
+        assert src_rows == T * N * A and rows % L == 0
+        mb = rows // L
+        idx = rng.permutation(src_rows // L)[:mb].astype(np.int64)
+        kw = dict(chunk_len=L, mb=mb, T=T, N=N, A=A)
+    stats = np.zeros((src_rows, 2), np.float32)
+    if standardize:
+        assert emu.mappo_row_stats(_ptr(src), src_rows, din, 1e-5, _ptr(stats), None) == 0
+        ref = R.row_stats_ref(src, 1e-5).numpy()
+        np.testing.assert_allclose(stats, ref, rtol=2e-5, atol=2e-6)
+    y = np.full((rows, out if out else 64), np.nan, np.float32)
+    z = [np.full((rows, 64), np.nan, np.float32) for _ in range(n_layers)]
+    m = R.MLP(src=_ptr(src), row_stats=_ptr(stats) if standardize else None, idx=_ptr(idx), rows=rows, din=din,
+              n_layers=n_layers, act=act, out=out, ln_eps=1e-5, w1=_ptr(p["w1"]), wh=_ptr(p["wh"]) if out else None,
+              bh=_ptr(p["bh"]) if out else None, y=_ptr(y), **kw)
+    for l in range(n_layers):
+        m.bias[l], m.ln_g[l], m.ln_b[l] = _ptr(p["bias%d" % l]), _ptr(p["ln_g%d" % l]), _ptr(p["ln_b%d" % l])
+        m.z[l] = _ptr(z[l])
+        if l > 0:
+            m.w2[l - 1] = _ptr(p["w2_%d" % (l - 1)])
+    assert emu.mappo_mlp_forward(ctypes.byref(m), None) == 0
+    tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    srows = R.source_rows(idx, rows, **kw)
+    y_ref, z_ref = R.forward_ref(tp, src, srows, standardize, n_layers, act, out)
+    np.testing.assert_allclose(y, y_ref.detach().numpy(), rtol=2e-4, atol=2e-5)
+    for l in range(n_layers):
+        np.testing.assert_allclose(z[l], z_ref[l].detach().numpy(), rtol=2e-4, atol=2e-5)
+    if not backward:
+        return
+    dy = rng.standard_normal(y.shape).astype(np.float32)
+    n_g = emu.mappo_mlp_grad_floats(din, n_layers, out)
+    grads = np.full(n_g, np.nan, np.float32)
+    ws = np.full(emu.mappo_mlp_workspace_floats(din, n_layers, out), np.nan, np.float32)
+    dz1 = np.full((rows, 64), np.nan, np.float32)
+    m.dy, m.dz1, m.workspace, m.grads = _ptr(dy), _ptr(dz1), _ptr(ws), _ptr(grads)
+    assert emu.mappo_mlp_backward(ctypes.byref(m), None) == 0
+    (y_ref * torch.tensor(dy, dtype=torch.float64)).sum().backward()
+    g_ref = R.flat_grads({k: v.grad for k, v in tp.items()}, din, n_layers, out).numpy()
+    assert g_ref.shape == grads.shape
+    scale = np.abs(g_ref).max()
+    np.testing.assert_allclose(grads, g_ref, rtol=2e-4, atol=2e-5 * scale)
+
+
+# (din, n_layers, act, out, rows, src_rows): tails in every dimension -- rows not a multiple of the 128-row tile / the
+# 32-row wave tile, din not a multiple of the 64-wide chunk / of 4, several workgroups per launch
+CASES = [
+    (48, 2, 1, 5, 70, 200),        # north-star actor shapes (tanh, Discrete(5))
+    (30, 2, 2, 1, 128, 128),       # cfg2 actor width, ReLU, value head, exactly one tile
+    (19, 1, 1, 3, 37, 64),         # single layer, odd width (unaligned rows)
+    (130, 3, 1, 0, 150, 300),      # layer_N = 2, trunk only (features for the GRU), three chunks with a tail
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
+def test_rows_mode_vs_float64_reference(emu, case):
+    din, L, act, out, rows, src_rows = case
+    _run(emu, np.random.default_rng(din * 7 + rows), din, L, act, out, rows, src_rows)
+
+
+def test_unstandardised_input_and_identity_rows(emu):
+    rng = np.random.default_rng(3)
+    _run(emu, rng, 40, 2, 1, 4, 45, 45, standardize=False)
+
+
+def test_chunk_mode_rows(emu):
+    """recurrent_generator's rows: row l * mb + j <- element idx[j] * L + l of the (n, a, t)-ordered sequence, with
+    T % L != 0 (chunks that straddle trajectories)."""
+    T, N, A, L = 7, 3, 2, 3
+    _run(emu, np.random.default_rng(5), 24, 2, 1, 0, L * 10, T * N * A, chunk=(L, T, N, A))
+
+
+def test_first_layer_slab_split(emu):
+    """Widths above 384 split the weight-gradient kernel over k slabs (blockIdx.y); critic width of the north star."""
+    _run(emu, np.random.default_rng(11), 435, 2, 1, 1, 40, 50)

@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""GPU-box microbenchmark of the fused hidden-64 trunk kernels (K9) at the north-star shapes: forward and backward
+launch times with HIP events on the launch stream, TFLOP/s against the dense f32 MFMA peak (157.3 TFLOP/s,
+MI355X_MICROARCH.md) and the HBM bytes each launch has to move.
+
+    python tools/bench_mlp.py [--rows 2621440] [--din 384 48] [--reps 5]
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "on-policy_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch
+
+PEAK_TF = 157.3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=2621440)
+    ap.add_argument("--din", type=int, nargs="+", default=[384, 48])
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--out", type=int, default=None)
+    opt = ap.parse_args()
+    from onpolicy.algorithms.utils import fused_mlp
+    from onpolicy.algorithms.utils.mlp import MLPBase
+    from helpers import make_args
+    dev = torch.device("cuda", 0)
+    res = []
+    for din in opt.din:
+        out = opt.out if opt.out is not None else (1 if din > 100 else 5)
+        args = make_args(hidden_size=64, layer_N=1, use_ReLU=False)
+        torch.manual_seed(0)
+        base = MLPBase(args, (din,)).to(dev)
+        head = torch.nn.Linear(64, out).to(dev)
+        src_rows = opt.rows + 4096
+        src = torch.randn(src_rows, din, device=dev)
+        stats = fused_mlp.row_stats(src)
+        idx = torch.randperm(src_rows, device=dev)[:opt.rows]
+        rs = fused_mlp.RowSource(src, stats, idx)
+        dy = torch.randn(opt.rows, out, device=dev)
+
+        def timed(fn):
+            fn()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(opt.reps):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                fn()
+                b.record()
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b))
+            return sorted(ts)[len(ts) // 2]
+
+        holder = {}
+
+        def fwd():
+            holder["y"] = fused_mlp.trunk_forward(base, rs, head)
+
+        def bwd():
+            for p in list(base.parameters()) + list(head.parameters()):
+                p.grad = None
+            holder["y"].backward(dy, retain_graph=True)
+
+        t_stats = timed(lambda: fused_mlp.row_stats(src))
+        t_f = timed(fwd)
+        t_b = timed(bwd)
+        R = opt.rows
+        f_fwd = 2.0 * R * (din * 64 + 64 * 64 + 64 * out)
+        f_bwd = 2.0 * R * (din * 64 + 2 * 64 * 64 + 2 * 64 * out)
+        b_fwd = R * (4 * din + 8 + 8 + 2 * 256 + 4 * out)
+        b_bwd = R * (4 * din + 8 + 8 + 2 * 256 + 4 * out + 2 * 256 * (1 + max(1, -(-din // 384))))
+        rec = {"din": din, "out": out, "rows": R, "row_stats_ms": round(t_stats, 3),
+               "fwd_ms": round(t_f, 3), "fwd_tflops": round(f_fwd / t_f / 1e9, 1),
+               "fwd_frac_mfma": round(f_fwd / t_f / 1e9 / PEAK_TF, 3), "fwd_gbs": round(b_fwd / t_f / 1e6, 1),
+               "bwd_ms": round(t_b, 3), "bwd_tflops": round(f_bwd / t_b / 1e9, 1),
+               "bwd_frac_mfma": round(f_bwd / t_b / 1e9 / PEAK_TF, 3), "bwd_gbs": round(b_bwd / t_b / 1e6, 1)}
+        print(json.dumps(rec), flush=True)
+        res.append(rec)
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -353,32 +353,33 @@ int mappo_gru_step_fwd(const float* gi, const float* hm, const float* w_hh, cons
  * mode), so the gathered [mb, obs_dim] minibatch of feed_forward_generator / recurrent_generator is never written.
  * hidden_size must be 64.  All products run on the float32 matrix cores (exact f32 fma chains).
  *
- * Input LayerNorm: pass row_stats = the per-row {mean, 1 / sqrt(var + eps)} of the source matrix
- * (mappo_row_stats, computed once per train() -- the observations do not change during the ppo epochs) and fold
- * the LayerNorm's affine half into the first Linear on the caller's side (w1 = W * gamma, bias[0] = b + W beta);
- * row_stats = NULL feeds the rows as they are (use_feature_normalization = False).
+ * Rows: the caller resolves the sampler's row map once per minibatch into a row table (mappo_mlp_row_table): the source
+ * row (int32) of every launch row, mappo_mlp_row_table_ints(rows) = rows rounded up to 128 entries (padding entries repeat
+ * the last row, so no kernel clamps a row index).  The kernels then issue coalesced table loads instead of a dependent
+ * idx chain and do no index arithmetic.  Input LayerNorm: pass src = a standardised copy of the observation matrix
+ * (mappo_standardize_rows, made once per train() -- the observations do not change during the ppo epochs) and fold the
+ * LayerNorm's affine half into the first Linear on the caller's side (w1 = W * gamma, bias[0] = b + W beta); the kernels
+ * themselves use the rows as they are (use_feature_normalization = False: src = the field itself).
  *
  *   src        [src_rows, din]   matrix the rows come from (e.g. buffer.share_obs[:-1] viewed [T*N*A, din])
- *   idx        [mb] int64        sampler indices; NULL: launch row r reads source row r
- *   chunk_len  0: rows mode (row r <- source row idx[r]);  L > 0: chunk mode, rows = L * mb, row l * mb + j <- element
- *              idx[j] * L + l of the (n, a, t)-ordered sequence (needs T, N, A)
+ *   row_tab    see above (int32, 16-byte aligned); din >= 4
  *   w1 [64, din], bias[l] / ln_g[l] / ln_b[l] [64] for l < n_layers (n_layers = 1 + layer_N <= 3), w2[l-1] [64, 64]
  *   act        1 Tanh, 2 ReLU (0 identity)
  *   wh [out, 64], bh [out]   output Linear (out <= 64); out = 0: y receives the trunk's features [rows, 64]
- * mappo_mlp_forward writes y [rows, out] and, when z[l] != NULL, the pre-activations z[l] [rows, 64] of every layer
- *   (saved for the backward; NULL in rollouts).
- * mappo_mlp_backward reads dy [rows, out] (or [rows, 64] for out = 0) and z[l]; writes `grads`, the parameter gradients
+ * mappo_mlp_forward writes y [rows, out] and, when z[l] != NULL, what the backward needs of every layer: z[l] [rows, 64]
+ *   = the LayerNorm's normalised input (act(.) - mean) * rstd and ln_stats[l] [rows, 2] = {mean, rstd} (NULL in rollouts).
+ * mappo_mlp_backward reads dy [rows, out] (or [rows, 64] for out = 0), z[l] and ln_stats[l]; writes `grads`, the parameter gradients
  *   as one flat array [w1 64*din | per layer: bias 64, ln weight 64, ln bias 64 | per hidden layer: w 64*64 | wh out*64 |
  *   bh out] (mappo_mlp_grad_floats), using dz1 [rows, 64] and workspace [mappo_mlp_workspace_floats] as scratch.
- *   Gradients are plain sums over the rows in a fixed order (deterministic run to run). */
+ *   Gradients are plain sums over the rows in a fixed order (deterministic run to run).
+ * mappo_mlp_row_table: idx [mb] int64 sampler indices (NULL: launch row r = source row r);
+ *   chunk_len 0: rows mode (rows = mb, row r <- idx[r]); L > 0: chunk mode, rows = L * mb, row l * mb + j <- element
+ *   idx[j] * L + l of the (n, a, t)-ordered sequence (needs T, N, A). */
 #define MAPPO_MLP_MAX_LAYERS 3
 typedef struct mappo_mlp {
     const float* src;
-    const float* row_stats;
-    const int64_t* idx;
+    const int32_t* row_tab;
     int64_t rows;
-    int64_t mb;
-    int32_t chunk_len, T, N, A;
     int32_t din, n_layers, act, out;
     float ln_eps;
     const float* w1;
@@ -390,17 +391,28 @@ typedef struct mappo_mlp {
     const float* bh;
     float* y;
     float* z[MAPPO_MLP_MAX_LAYERS];
+    float* ln_stats[MAPPO_MLP_MAX_LAYERS];
     const float* dy;
     float* dz1;
     float* workspace;
     float* grads;
 } mappo_mlp_t;
+int64_t mappo_mlp_row_table_ints(int64_t rows);
+int     mappo_mlp_row_table(const int64_t* idx, int64_t rows, int64_t mb, int chunk_len, int T, int N, int A,
+                            int32_t* row_tab, mappo_stream_t stream);
+/* tuning / test hook: at most `cap` workgroups per K9 kernel (0 = default sizing); small caps make every workgroup loop
+ * over many tiles */
+int     mappo_mlp_set_grid_cap(int cap);
+/* tuning hook: device buffer of >= 512 int64 that receives shader-clock stamps of workgroup 0's first pipeline
+ * iterations of mappo_mlp_forward (tools/bench_mlp.py --stamps), NULL = off */
+int     mappo_mlp_set_debug(long long* buf);
 int     mappo_mlp_forward(const mappo_mlp_t* net, mappo_stream_t stream);
 int     mappo_mlp_backward(const mappo_mlp_t* net, mappo_stream_t stream);
 int64_t mappo_mlp_grad_floats(int din, int n_layers, int out);
 int64_t mappo_mlp_workspace_floats(int din, int n_layers, int out);
-/* stats[r] = {mean, 1 / sqrt(var + eps)} of src[r, 0:D] (population variance, as nn.LayerNorm: mlp.py:47-48) */
-int     mappo_row_stats(const float* src, int64_t rows, int D, float eps, float* stats, mappo_stream_t stream);
+/* dst[r, :] = (src[r, :] - mean_r) / sqrt(var_r + eps) for every row of a [rows, D] matrix (population variance: the
+ * parameter-free half of nn.LayerNorm, reference onpolicy/algorithms/utils/mlp.py:47-48, 56-57) */
+int     mappo_standardize_rows(const float* src, int64_t rows, int D, float eps, float* dst, mappo_stream_t stream);
 
 /* --------------------------------------------------------------------- misc ---- */
 int         mappo_abi_version(void);

@@ -22,6 +22,14 @@ __device__ __forceinline__ float sum16(float v) {
     v += __shfl_xor(v, 1);
     return v;
 }
+__device__ __forceinline__ float exp2_fast(float v) { return __builtin_amdgcn_exp2f(v); }   // v_exp_f32
+__device__ __forceinline__ float rcp_fast(float v) { return __builtin_amdgcn_rcpf(v); }     // v_rcp_f32
+// scheduling barrier: the compiler may not move instructions across it (used to keep operand prefetches early)
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+__device__ __forceinline__ void set_priority_high() { __builtin_amdgcn_s_setprio(3); }
+__device__ __forceinline__ long long clock() { return (long long)__builtin_readcyclecounter(); }
+__device__ __forceinline__ int f2i(float v) { return __float_as_int(v); }
+__device__ __forceinline__ float i2f(int v) { return __int_as_float(v); }
 __device__ __forceinline__ float* lds() {
     extern __shared__ __attribute__((aligned(16))) float mappo_dyn_lds[];
     return mappo_dyn_lds;
@@ -58,11 +66,25 @@ extern "C" int mappo_mlp_backward(const mappo_mlp_t* net, mappo_stream_t stream)
     g_launch_error = 0;
     return mlp::backward(net, static_cast<hipStream_t>(stream));
 }
+extern "C" int mappo_mlp_set_debug(long long* buf) {
+    mlp::debug_buffer() = buf;
+    return 0;
+}
+extern "C" int mappo_mlp_set_grid_cap(int cap) {
+    mlp::grid_cap_override() = cap;
+    return 0;
+}
+extern "C" int64_t mappo_mlp_row_table_ints(int64_t rows) { return mlp::rows128(rows); }
+extern "C" int mappo_mlp_row_table(const int64_t* idx, int64_t rows, int64_t mb, int chunk_len, int T, int N, int A,
+                                   int32_t* row_tab, mappo_stream_t stream) {
+    g_launch_error = 0;
+    return mlp::row_table(reinterpret_cast<const long long*>(idx), rows, mb, chunk_len, T, N, A, row_tab, static_cast<hipStream_t>(stream));
+}
 extern "C" int64_t mappo_mlp_grad_floats(int din, int n_layers, int out) { return mlp::g_total(din, n_layers, out); }
 extern "C" int64_t mappo_mlp_workspace_floats(int din, int n_layers, int out) {
     return mlp::workspace_floats(din, n_layers, out);
 }
-extern "C" int mappo_row_stats(const float* src, int64_t rows, int D, float eps, float* stats, mappo_stream_t stream) {
+extern "C" int mappo_standardize_rows(const float* src, int64_t rows, int D, float eps, float* dst, mappo_stream_t stream) {
     g_launch_error = 0;
-    return mlp::row_stats(src, rows, D, eps, stats, static_cast<hipStream_t>(stream));
+    return mlp::standardize_rows(src, rows, D, eps, dst, static_cast<hipStream_t>(stream));
 }

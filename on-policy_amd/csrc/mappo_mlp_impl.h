@@ -38,11 +38,13 @@ constexpr int kTR = 128;        // rows per workgroup tile = 4 waves x 32
 constexpr int kWS = 68;         // LDS row stride of a permuted 64-wide weight row
 constexpr int kTS = 36;         // LDS row stride of the [feature][32 rows] transposes of the backward
 constexpr int kThreads = 256;
-constexpr int kFwdGridCap = 512;     // 2 workgroups per CU
+constexpr int kPipeThreads = 512;    // forward / weight-gradient kernels: 4 compute waves + 4 loader waves
+constexpr int kDepth = 3;            // chunk loads a loader thread keeps in flight (register buffers)
+constexpr int kFwdGridCap = 256;     // 1 workgroup per CU (2 LDS stages of 48 KB)
 constexpr int kBwdGridCap = 256;     // 1 workgroup per CU (108 KB of LDS)
 constexpr int kDw1Rows = 32;         // rows per iteration of the first-layer weight-gradient kernel
 constexpr int kDw1Slab = 384;        // k columns per workgroup of that kernel (6 accumulator tiles per wave)
-constexpr int kDw1GridCap = 512;
+constexpr int kDw1GridCap = 256;
 
 __host__ __device__ __forceinline__ int feat_of(int h, int s) {
     return 32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2) + 4 * h;
@@ -58,30 +60,64 @@ __host__ __device__ __forceinline__ long long g_total(int din, int L, int out) {
 // the chain kernel's per-wave partial row is the same layout without w1
 __host__ __device__ __forceinline__ long long p_main(int L, int out) { return 192LL * L + 4096LL * (L - 1) + 65LL * out; }
 
+// The rows of a launch: row r reads row srow[r] of `src`.  The table is the sampler's row map (shared_buffer.py:379-396
+// rows mode, :554-604 chunk mode) resolved once per minibatch by rowtab_kernel (int32, padded to the 128-row tile with
+// copies of the last row so that no kernel clamps an index): the hot kernels do one coalesced table load per tile instead
+// of a dependent idx chain with 64-bit divisions.  Rows are used as they are: a network with an input LayerNorm reads
+// from a standardised copy of the observation field (standardize_rows_kernel, once per train()).
 struct RowSrc {
     const float* src;
-    const float* stats;
-    const long long* idx;
+    const int* srow;        // [rows128]
     long long rows;
-    long long mb;
-    int chunk_len, T, N, A;
     int din;
 };
+__host__ __device__ __forceinline__ long long rows128(long long rows) { return (rows + 127) & ~127LL; }
 
-// source row (time-major [T, N, A] row space) of launch row r  (shared_buffer.py:379-396 / :554-604)
-__device__ __forceinline__ long long source_row(const RowSrc& m, long long r) {
-    if (m.idx == nullptr) return r;
-    if (m.chunk_len <= 0) return m.idx[r];
-    const long long l = r / m.mb, j = r - l * m.mb;
-    const long long f = m.idx[j] * m.chunk_len + l;
-    const long long at = (long long)m.A * m.T;
-    const long long n = f / at, rem = f - n * at;
-    const long long ag = rem / m.T, t = rem - ag * m.T;
-    return (t * m.N + n) * m.A + ag;
+struct RowMapArgs {
+    const long long* idx;
+    long long rows, mb;
+    int chunk_len, T, N, A;
+    int* srow;
+};
+
+__global__ void __launch_bounds__(kThreads) rowtab_kernel(RowMapArgs m) {
+    const long long padded = rows128(m.rows);
+    for (long long rr = (long long)blockIdx.x * kThreads + threadIdx.x; rr < padded; rr += (long long)gridDim.x * kThreads) {
+        const long long r = rr < m.rows ? rr : m.rows - 1;
+        long long sr = r;
+        if (m.idx != nullptr) {
+            if (m.chunk_len <= 0) {
+                sr = m.idx[r];
+            } else {
+                const long long l = r / m.mb, j = r - l * m.mb;
+                const long long f = m.idx[j] * m.chunk_len + l;
+                const long long at = (long long)m.A * m.T;
+                const long long n = f / at, rem = f - n * at;
+                const long long ag = rem / m.T, t = rem - ag * m.T;
+                sr = (t * m.N + n) * m.A + ag;
+            }
+        }
+        m.srow[rr] = (int)sr;
+    }
 }
 
-// 4 consecutive floats of a row starting at column k (rows are only 4-byte aligned for odd widths: the unaligned
-// 16-byte load is legal on gfx950), zero beyond the row's end
+// 4 consecutive floats of a row of `din` floats starting at column k, zero beyond the row's end, in two halves so that
+// the software pipelines below can separate issue from use.  Rows are only 4-byte aligned for odd widths (the unaligned
+// 16-byte load is legal on gfx950).  piece_at(): where to load from -- a piece that sticks out of the row is fetched
+// from the row's last four floats (din >= 4) -- always exactly ONE load instruction and no branch, because the compiler's
+// wait counts are only exact if every path issues the same loads.  shift4(): applied when the data is consumed; `sft` =
+// k - piece_at(k) is 0 for an interior piece, 1..3 on the row's tail, >= 4 past the end.
+__device__ __forceinline__ int piece_at(int k, int din) { return k > din - 4 ? din - 4 : k; }
+__device__ __forceinline__ v4 shift4(v4 v, int sft) {
+    if (sft == 0) return v;
+    v4 r;
+    r[0] = sft == 1 ? v[1] : sft == 2 ? v[2] : sft == 3 ? v[3] : 0.f;
+    r[1] = sft == 1 ? v[2] : sft == 2 ? v[3] : 0.f;
+    r[2] = sft == 1 ? v[3] : 0.f;
+    r[3] = 0.f;
+    return r;
+}
+// (guarded variant for code outside the pipelines)
 __device__ __forceinline__ v4 load4_guard(const float* p, int remaining) {
     v4 r = {0.f, 0.f, 0.f, 0.f};
     if (remaining >= 4) {
@@ -94,10 +130,27 @@ __device__ __forceinline__ v4 load4_guard(const float* p, int remaining) {
     return r;
 }
 
-__device__ __forceinline__ float act_fn(float z, int act) { return act == 1 ? tanhf(z) : (act == 2 ? fmaxf(z, 0.f) : z); }
+// tanh in ~12 instructions (the library tanhf was 60 % of the forward kernel's time: 64 calls per row).  |x| >= 0.25:
+// 1 - 2 / (exp(2|x|) + 1) on the hardware exp2 / rcp (1 ulp each; absolute error ~1e-7, saturates to 1 for large |x|);
+// |x| < 0.25, where that form cancels: the odd Taylor polynomial up to x^7 (truncation < 1e-7 relative).  The backward
+// differentiates through the activation OUTPUT (1 - a^2) of this same function.
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float ax = fabsf(x), x2 = x * x;
+    const float e = prim::exp2_fast(ax * 2.8853900817779268f);
+    const float big = 1.f - 2.f * prim::rcp_fast(e + 1.f);
+    const float small = ax * (1.f + x2 * (-0.33333333333f + x2 * (0.13333333333f + x2 * -0.05396825397f)));
+    return copysignf(ax < 0.25f ? small : big, x);
+}
+// The activation is a template parameter of the kernels: a run-time switch inside the unrolled per-feature loops costs
+// several scalar branches per element (measured: 13 k of a tile's 20 k epilogue cycles).
+template <int ACT>
+__device__ __forceinline__ float act_fn(float z) {
+    return ACT == 1 ? fast_tanh(z) : (ACT == 2 ? fmaxf(z, 0.f) : z);
+}
 // derivative from the activation output a (tanh) / the pre-activation z (ReLU)
-__device__ __forceinline__ float act_grad(float z, float a, int act) {
-    return act == 1 ? 1.f - a * a : (act == 2 ? (z > 0.f ? 1.f : 0.f) : 1.f);
+template <int ACT>
+__device__ __forceinline__ float act_grad(float z, float a) {
+    return ACT == 1 ? 1.f - a * a : (ACT == 2 ? (z > 0.f ? 1.f : 0.f) : 1.f);
 }
 
 struct Net {
@@ -114,47 +167,52 @@ struct Net {
 
 // ---------------------------------------------------------------- LDS layouts (float offsets) ----
 struct FwdLds {
-    int vec, w2p, whp, bh, xt, wt, total;
+    int vec, w2p, whp, bh, stage, total;
 };
+constexpr int kStageX = kTR * kKC;              // floats: [128 rows][64 k], 16-byte pieces XOR-swizzled by row & 15
+constexpr int kStageW = 64 * kKC;               // first-layer weight chunk [64 features][64 k], same swizzle
+constexpr int kStage = kStageX + kStageW;
 __host__ __device__ __forceinline__ FwdLds fwd_lds(int L, int out) {
     FwdLds o;
     o.vec = 0;                                // [L][bias | g | beta][64]
     o.w2p = o.vec + 192 * L;                  // [L - 1][2][32][kWS]
     o.whp = o.w2p + (L - 1) * 2 * 32 * kWS;   // [out][64] permuted
     o.bh = o.whp + out * 64;                  // [out]
-    o.xt = (o.bh + out + 3) & ~3;             // [kTR][kXS]
-    o.wt = o.xt + kTR * kXS;                  // [64][kXS]
-    o.total = o.wt + 64 * kXS;
+    o.stage = (o.bh + out + 3) & ~3;          // [2][kStage]
+    o.total = o.stage + 2 * kStage;
     return o;
 }
 
 // Parameters that every tile needs, staged once per workgroup.  w2p[l-1][t][i][h * 32 + s] = W2_l[32 t + i][f(h, s)]:
 // the A operand (output feature 32 t + i on lane i) of the step that consumes slot s of the previous layer's registers.
 __device__ __forceinline__ void stage_fwd_params(const Net& n, float* lds, const FwdLds& o) {
-    const int tid = threadIdx.x;
-    for (int e = tid; e < 192 * n.L; e += kThreads) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    for (int e = tid; e < 192 * n.L; e += nthr) {
         const int l = e / 192, q = (e - 192 * l) >> 6, c = e & 63;
         const float* p = q == 0 ? n.bias[l] : (q == 1 ? n.ln_g[l] : n.ln_b[l]);
         lds[o.vec + e] = p[c];
     }
     for (int l = 1; l < n.L; ++l)
-        for (int e = tid; e < 64 * 64; e += kThreads) {
+        for (int e = tid; e < 64 * 64; e += nthr) {
             const int fo = e >> 6, hs = e & 63;          // output feature, (h, s)
             const int k = feat_of(hs >> 5, hs & 31);
             lds[o.w2p + (l - 1) * 2 * 32 * kWS + fo * kWS + hs] = n.w2[l - 1][fo * 64 + k];
         }
-    for (int e = tid; e < n.out * 64; e += kThreads) {
+    for (int e = tid; e < n.out * 64; e += nthr) {
         const int oo = e >> 6, hs = e & 63;
         lds[o.whp + e] = n.wh[oo * 64 + feat_of(hs >> 5, hs & 31)];
     }
-    for (int e = tid; e < n.out; e += kThreads) lds[o.bh + e] = n.bh[e];
+    for (int e = tid; e < n.out; e += nthr) lds[o.bh + e] = n.bh[e];
 }
 
 // One layer's tail on the accumulators: z = acc + bias (optionally kept for saving), a = act(z), LayerNorm over the
 // row's 64 features (mlp.py:17-22).  In: acc[2] (this lane's 32 slots).  Out: hreg[32] = LayerNorm output.
-template <bool KEEPZ>
+// KEEP: what the backward needs of this layer is the NORMALISED activation nhat (-> nreg) and the row's (mean, rstd):
+// the activation output is a = nhat / rstd + mean, its derivative follows from a (tanh: 1 - a^2, ReLU: a > 0), so the
+// backward never re-evaluates tanh or the LayerNorm statistics (a third of its instructions when it saved z instead).
+template <bool KEEP, int ACT>
 __device__ __forceinline__ void layer_tail(const f32x16* acc, const float* vec /* bias | g | beta in LDS */, int h,
-                                           int act, float eps, float* hreg, float* zreg) {
+                                           float eps, float* hreg, float* nreg, float& mean_out, float& rstd_out) {
     float a[32];
     float sum = 0.f;
 #pragma unroll
@@ -166,8 +224,7 @@ __device__ __forceinline__ void layer_tail(const f32x16* acc, const float* vec /
             for (int e = 0; e < 4; ++e) {
                 const int s = 16 * t + 4 * q + e;
                 const float z = acc[t][4 * q + e] + b[e];
-                if (KEEPZ) zreg[s] = z;
-                a[s] = act_fn(z, act);
+                a[s] = act_fn<ACT>(z);
                 sum += a[s];
             }
         }
@@ -181,6 +238,8 @@ __device__ __forceinline__ void layer_tail(const f32x16* acc, const float* vec /
     }
     var += prim::xhalf(var);
     const float rstd = 1.f / sqrtf(var * (1.f / 64.f) + eps);
+    mean_out = mean;
+    rstd_out = rstd;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -190,7 +249,9 @@ __device__ __forceinline__ void layer_tail(const f32x16* acc, const float* vec /
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int s = 16 * t + 4 * q + e;
-                hreg[s] = a[s] * rstd * g[e] + be[e];
+                const float nh = a[s] * rstd;
+                if (KEEP) nreg[s] = nh;
+                hreg[s] = nh * g[e] + be[e];
             }
         }
 }
@@ -226,10 +287,15 @@ __device__ __forceinline__ void dense64(const float* wp, int c, int h, const flo
         for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
     const float* w0 = wp + c * kWS + 32 * h;
     const float* w1 = wp + (32 + c) * kWS + 32 * h;
+    v4 a0n = *reinterpret_cast<const v4*>(w0), a1n = *reinterpret_cast<const v4*>(w1);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const v4 a0 = *reinterpret_cast<const v4*>(w0 + 4 * q);
-        const v4 a1 = *reinterpret_cast<const v4*>(w1 + 4 * q);
+        const v4 a0 = a0n, a1 = a1n;
+        if (q < 7) {        // next group's operands in flight behind this group's MFMAs
+            a0n = *reinterpret_cast<const v4*>(w0 + 4 * q + 4);
+            a1n = *reinterpret_cast<const v4*>(w1 + 4 * q + 4);
+        }
+        prim::sched_fence();
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             acc[0] = prim::mfma32(a0[e], reg[4 * q + e], acc[0]);
@@ -243,98 +309,211 @@ struct FwdArgs {
     RowSrc rs;
     Net net;
     float* y;
-    float* z[3];
+    float* z[3];        // saved normalised activations [rows, 64] per layer (NULL: inference)
+    float* st[3];       // saved {mean, rstd} [rows, 2] per layer
+    long long* dbg;     // tuning hook (mappo_mlp_set_debug): cycle stamps of workgroup 0's first iterations, or NULL
 };
 
-__global__ void __launch_bounds__(kThreads) mlp_fwd_kernel(FwdArgs a) {
+// Workgroup = 4 compute waves (one per SIMD: MFMA + the layer tails of 32 rows each) + 4 loader waves that do nothing
+// but move data: global -> registers (kDepth chunk loads in flight per thread, across tile boundaries) -> one of two LDS
+// stages.  One barrier per chunk hands a stage over in both directions.  The loaders store raw rows; the compute lanes
+// standardise their own row's operands on the fly ((x - mean) * rstd, two VALU ops per 128 MFMA cycles), so padding
+// columns (zero in both operands) stay exact zeros.
+typedef int i4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+// One chunk in flight in a loader thread's registers + what the buffer's NEXT load needs: the source rows are fetched
+// right after this chunk's loads were issued, i.e. three issues ahead of their use, so that waiting for them never
+// waits for younger data loads (the wait counter is in order).
+struct ChunkBuf {
+    v4 xv[8], wv[4];
+    int sft;
+    i4 rlo, rhi;        // source rows of the 8 rows this thread serves in the tile of the buffer's next chunk
+};
+
+// ALIGNED: din % 4 == 0 -- a 16-byte piece is either inside the row or past its end, so the loaders need no tail shifting
+// (their VALU work shares the SIMD's issue slots and the chip's power budget with the MFMA stream).
+template <int ACT, bool ALIGNED>
+__global__ void __launch_bounds__(kPipeThreads) mlp_fwd_kernel(FwdArgs a) {
     float* lds = prim::lds();
     const Net& n = a.net;
     const FwdLds o = fwd_lds(n.L, n.out);
     stage_fwd_params(n, lds, o);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5;
-    const int xr = tid >> 4, xq = tid & 15;          // staging role: row within a group of 16, 16-byte piece of the chunk
     const int din = n.din;
     const int nch = (din + kKC - 1) / kKC;
     const long long rows = a.rs.rows;
     const long long ntiles = (rows + kTR - 1) / kTR;
-    float* xt = lds + o.xt;
-    float* wt = lds + o.wt;
+    const long long my_tiles = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const long long n_it = my_tiles * nch;
+    float* stage0 = lds + o.stage;
 
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long long row0 = tile * kTR;
-        // the 8 rows this thread stages: source offsets and standardisation constants
-        const float* xsrc[8];
-        float mu[8], rsd[8];
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            long long r = row0 + xr + 16 * p;
-            if (r >= rows) r = rows - 1;
-            const long long sr = source_row(a.rs, r);
-            xsrc[p] = a.rs.src + sr * din;
-            mu[p] = 0.f;
-            rsd[p] = 1.f;
-            if (a.rs.stats != nullptr) {
-                mu[p] = a.rs.stats[2 * sr];
-                rsd[p] = a.rs.stats[2 * sr + 1];
-            }
-        }
-        f32x16 acc[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
-
-        v4 xv[8], wv[4];
-        auto load_chunk = [&](int kc) {
-            const int k = kc * kKC + 4 * xq;
-#pragma unroll
-            for (int p = 0; p < 8; ++p) xv[p] = load4_guard(xsrc[p] + k, din - k);
-#pragma unroll
-            for (int p = 0; p < 4; ++p) wv[p] = load4_guard(n.w1 + (long long)(xr + 16 * p) * din + k, din - k);
+    if (wave >= 4) {
+        // ------------------------------------------------------------ loader
+        // thread = (group xg of 8 consecutive rows, 16-byte piece xq of the chunk); pass p serves row 8 xg + p, so one
+        // wave instruction reads 4 rows x 256 contiguous bytes and the thread's 8 source rows are two 16-byte table loads
+        const int lt = tid - 256, xg = lt >> 4, xq = lt & 15;
+        // row offset of the tile of a pipeline position, clamped to the last tile (chunks issued past the end are never
+        // stored; rows are padded to the 128-row tile, so every table index is valid).  Positions are tracked as (tile,
+        // chunk) counters: no division in the loop.
+        auto tile_row0 = [&](long long ti) {
+            if (ti >= my_tiles) ti = my_tiles - 1;
+            return (blockIdx.x + ti * gridDim.x) * kTR;
         };
-        load_chunk(0);
-        for (int kc = 0; kc < nch; ++kc) {
-            __syncthreads();        // the previous chunk's operands (and the previous tile's) have been consumed
-            {
-                const int k = kc * kKC + 4 * xq;
-#pragma unroll
-                for (int p = 0; p < 8; ++p) {
-                    v4 x = xv[p];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) x[e] = (k + e < din) ? (x[e] - mu[p]) * rsd[p] : 0.f;
-                    *reinterpret_cast<v4*>(xt + (xr + 16 * p) * kXS + 4 * xq) = x;
-                }
-#pragma unroll
-                for (int p = 0; p < 4; ++p) *reinterpret_cast<v4*>(wt + (xr + 16 * p) * kXS + 4 * xq) = wv[p];
+        auto fetch_rows = [&](long long ti, ChunkBuf& B) {
+            const long long r0 = tile_row0(ti) + 8 * xg;
+            B.rlo = *reinterpret_cast<const i4*>(a.rs.srow + r0);
+            B.rhi = *reinterpret_cast<const i4*>(a.rs.srow + r0 + 4);
+        };
+        long long it_tile = 0, ft_tile = 0;     // tile of the next issue / of the issue kDepth later
+        int it_kc = 0, ft_kc = 0;               // its chunk within the tile
+        auto advance = [&](long long& t, int& kc) {
+            if (++kc == nch) {
+                kc = 0;
+                ++t;
             }
+        };
+        // every issue is exactly 8 + 4 + 2 loads, whatever the chunk
+        auto issue = [&](ChunkBuf& B) {
+            const int k = it_kc * kKC + 4 * xq, kk = piece_at(k, din);
+            B.sft = k - kk;
+            const i4 lo = B.rlo, hi = B.rhi;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                B.xv[p] = *reinterpret_cast<const v4u*>(a.rs.src + (long long)lo[p] * din + kk);
+                B.xv[4 + p] = *reinterpret_cast<const v4u*>(a.rs.src + (long long)hi[p] * din + kk);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) B.wv[p] = *reinterpret_cast<const v4u*>(n.w1 + (long long)(xg + 16 * p) * din + kk);
+            fetch_rows(ft_tile, B);
+            advance(it_tile, it_kc);
+            advance(ft_tile, ft_kc);
+        };
+        auto store = [&](long long m, const ChunkBuf& B) {
+            float* st = stage0 + (m & 1) * kStage;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int r = 8 * xg + p;
+                *reinterpret_cast<v4*>(st + r * kKC + ((xq ^ (r & 15)) << 2)) =
+                    ALIGNED ? (B.sft ? v4{0.f, 0.f, 0.f, 0.f} : B.xv[p]) : shift4(B.xv[p], B.sft);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int r = xg + 16 * p;
+                *reinterpret_cast<v4*>(st + kStageX + r * kKC + ((xq ^ (r & 15)) << 2)) =
+                    ALIGNED ? (B.sft ? v4{0.f, 0.f, 0.f, 0.f} : B.wv[p]) : shift4(B.wv[p], B.sft);
+            }
+        };
+        ChunkBuf B0, B1, B2;
+        if (n_it > 0) {
+            fetch_rows(ft_tile, B0);
+            advance(ft_tile, ft_kc);
+            fetch_rows(ft_tile, B1);
+            advance(ft_tile, ft_kc);
+            fetch_rows(ft_tile, B2);
+            advance(ft_tile, ft_kc);
+            issue(B0);
+            issue(B1);
+            issue(B2);
+            store(0, B0);
+            issue(B0);
+        }
+        // iteration j (after its barrier): chunk j + 1 leaves its buffer for the stage the compute waves released at the
+        // barrier, chunk j + 4 takes the buffer over
+        const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && lt == 0;
+        long long j = 0;
+        for (; j + 3 <= n_it; j += 3) {
             __syncthreads();
-            if (kc + 1 < nch) load_chunk(kc + 1);     // in flight during this chunk's MFMAs
-            const float* xa = xt + (32 * wave + c) * kXS + 32 * h;
-            const float* w0 = wt + c * kXS + 32 * h;
-            const float* w1 = wt + (32 + c) * kXS + 32 * h;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const v4 b = *reinterpret_cast<const v4*>(xa + 4 * q);
-                const v4 a0 = *reinterpret_cast<const v4*>(w0 + 4 * q);
-                const v4 a1 = *reinterpret_cast<const v4*>(w1 + 4 * q);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[0] = prim::mfma32(a0[e], b[e], acc[0]);
-                    acc[1] = prim::mfma32(a1[e], b[e], acc[1]);
-                }
+            if (stamp && j < 60) a.dbg[256 + 4 * j] = prim::clock();
+            store(j + 1, B1);
+            if (stamp && j < 60) a.dbg[256 + 4 * j + 1] = prim::clock();
+            issue(B1);
+            if (stamp && j < 60) a.dbg[256 + 4 * j + 2] = prim::clock();
+            __syncthreads();
+            if (stamp && j < 60) a.dbg[256 + 4 * j + 4] = prim::clock();
+            store(j + 2, B2);
+            issue(B2);
+            if (stamp && j < 60) a.dbg[256 + 4 * j + 6] = prim::clock();
+            __syncthreads();
+            if (stamp && j < 60) a.dbg[256 + 4 * j + 8] = prim::clock();
+            store(j + 3, B0);
+            issue(B0);
+            if (stamp && j < 60) a.dbg[256 + 4 * j + 10] = prim::clock();
+        }
+        if (j < n_it) {
+            __syncthreads();
+            store(j + 1, B1);
+            if (j + 1 < n_it) {
+                __syncthreads();
+                store(j + 2, B2);
             }
         }
+        return;
+    }
+    // ---------------------------------------------------------------- compute
+    // the loader wave on this SIMD issues a few hundred VALU / LDS-store instructions per chunk; without a priority
+    // they take issue slots from the MFMA stream (measured 85 instead of 64 cycles per MFMA)
+    prim::set_priority_high();
+    const bool cstamp = a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+    const int rsw = c & 15;
+    f32x16 acc[2];
+    long long ti = 0;
+    int kc = 0;
+    int off[8];         // swizzled float offsets of this lane's 8 operand pieces within a stage row
+#pragma unroll
+    for (int q = 0; q < 8; ++q) off[q] = ((8 * h + q) ^ rsw) << 2;
+    for (long long j = 0; j < n_it; ++j) {
+        if (cstamp && j < 60) a.dbg[4 * j] = prim::clock();
+        __syncthreads();
+        if (cstamp && j < 60) a.dbg[4 * j + 1] = prim::clock();
+        if (kc == 0) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+        }
+        const float* st = stage0 + (j & 1) * kStage;
+        const float* xa = st + (32 * wave + c) * kKC;
+        const float* w0 = st + kStageX + c * kKC;
+        const float* w1 = st + kStageX + (32 + c) * kKC;
+        // The MFMA stream of a chunk: 64 MFMAs and 24 operand reads, nothing else -- a wave issues its instructions one
+        // after the other, and every VALU instruction in this loop would cost ~8 of the 64 cycles an MFMA occupies
+        // (tools/probes/probe_mfma.hip).  The operand reads of group q + 1 are issued before the MFMAs of group q.
+        v4 bn = *reinterpret_cast<const v4*>(xa + off[0]);
+        v4 a0n = *reinterpret_cast<const v4*>(w0 + off[0]);
+        v4 a1n = *reinterpret_cast<const v4*>(w1 + off[0]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const v4 b = bn, a0 = a0n, a1 = a1n;
+            if (q < 7) {
+                bn = *reinterpret_cast<const v4*>(xa + off[q + 1]);
+                a0n = *reinterpret_cast<const v4*>(w0 + off[q + 1]);
+                a1n = *reinterpret_cast<const v4*>(w1 + off[q + 1]);
+            }
+            prim::sched_fence();        // keep the compiler from sinking these reads down to their first use
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0] = prim::mfma32(a0[e], b[e], acc[0]);
+                acc[1] = prim::mfma32(a1[e], b[e], acc[1]);
+            }
+        }
+        if (cstamp && j < 60) a.dbg[4 * j + 2] = prim::clock();
+        if (++kc < nch) continue;
+        kc = 0;
         // ---- the rest of the network on this lane's row
-        const long long row = row0 + 32 * wave + c;
+        const long long row = (blockIdx.x + ti * gridDim.x) * kTR + 32 * wave + c;
+        ++ti;
         const bool ok = row < rows;
-        float hreg[32], zreg[32];
+        float hreg[32], nreg[32], mean, rstd;
         for (int l = 0; l < n.L; ++l) {
             if (l > 0) dense64(lds + o.w2p + (l - 1) * 2 * 32 * kWS, c, h, hreg, acc);
             if (a.z[l] != nullptr) {
-                layer_tail<true>(acc, lds + o.vec + 192 * l, h, n.act, n.eps, hreg, zreg);
-                if (ok) store_row64(a.z[l] + row * 64, zreg, h);
+                layer_tail<true, ACT>(acc, lds + o.vec + 192 * l, h, n.eps, hreg, nreg, mean, rstd);
+                if (ok) {
+                    store_row64(a.z[l] + row * 64, nreg, h);
+                    if (h == 0) *reinterpret_cast<f2*>(a.st[l] + 2 * row) = f2{mean, rstd};
+                }
             } else {
-                layer_tail<false>(acc, lds + o.vec + 192 * l, h, n.act, n.eps, hreg, zreg);
+                layer_tail<false, ACT>(acc, lds + o.vec + 192 * l, h, n.eps, hreg, nreg, mean, rstd);
             }
         }
         if (n.out == 0) {
@@ -380,7 +559,8 @@ __host__ __device__ __forceinline__ BwdLds bwd_lds(int L, int out) {
 struct BwdArgs {
     RowSrc rs;          // only rows is used here
     Net net;
-    const float* z[3];
+    const float* z[3];  // saved normalised activations / {mean, rstd} of every layer (forward kernel)
+    const float* st[3];
     const float* dy;    // [rows, out] (head) or [rows, 64] (out == 0)
     float* dz1;         // [rows, 64]
     float* partials;    // [gridDim.x * 4][p_main]
@@ -403,7 +583,9 @@ __device__ __forceinline__ void put_transposed(float* T, const float* reg, int c
     for (int s = 0; s < 32; ++s) T[feat_of(h, s) * kTS + c] = reg[s];
 }
 
-template <int L>
+constexpr int kDyRegs = 8;      // prefetch registers for the next tile's dy block: covers out <= 16 (32 * out / 64 floats per lane)
+
+template <int L, int ACT>
 __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a) {
     float* lds = prim::lds();
     const Net& n = a.net;
@@ -445,33 +627,68 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a) {
 
     const long long rows = a.rs.rows;
     const long long ntiles = (rows + kTR - 1) / kTR;
+    const bool dy_regs = out > 0 && 32 * out <= 64 * kDyRegs;
+    // ---- global inputs of a tile, fetched one tile ahead: the saved normalised activations / statistics of this lane's
+    // row and (head case) this wave's [32, out] block of dy, which is contiguous in memory
+    float zn[L][32], dyn[kDyRegs], dhn[32];
+    f2 stn[L];
+    auto fetch = [&](long long tile) {
+        const long long row = tile * kTR + 32 * wave + c;
+        const long long rrow = row < rows ? row : rows - 1;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            load_row64(a.z[l] + rrow * 64, zn[l], h);
+            stn[l] = *reinterpret_cast<const f2*>(a.st[l] + 2 * rrow);
+        }
+        if (out == 0) {
+            load_row64(a.dy + rrow * 64, dhn, h);
+            if (row >= rows) {
+#pragma unroll
+                for (int s = 0; s < 32; ++s) dhn[s] = 0.f;
+            }
+        } else if (dy_regs) {
+            const long long base = (tile * kTR + 32 * wave) * out;
+#pragma unroll
+            for (int i = 0; i < kDyRegs; ++i) {
+                const long long e = base + lane + 64 * i;
+                dyn[i] = (lane + 64 * i < 32 * out && e < rows * out) ? a.dy[e] : 0.f;
+            }
+        }
+    };
+    if (blockIdx.x < ntiles) fetch(blockIdx.x);
+
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long row = tile * kTR + 32 * wave + c;
         const bool ok = row < rows;
-        const long long rrow = ok ? row : rows - 1;
-        float dh[32];       // gradient w.r.t. the output of the layer being processed (slot order)
-        float zr[32], nh[32], hr[32];
-        float rstd;
-        // ---- top layer forward quantities
-        auto recompute = [&](int l) {
-            load_row64(a.z[l] + rrow * 64, zr, h);
-            float av[32];       // the saved z already contains the bias: act + LayerNorm restated on it
-            float sum = 0.f;
+        float nc[L][32];        // this tile's normalised activations
+        float mean[L], rstd[L], sd[L];
+        float dh[32];           // gradient w.r.t. the output of the layer being processed (slot order)
 #pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                av[s] = act_fn(zr[s], n.act);
-                sum += av[s];
-            }
-            sum += prim::xhalf(sum);
-            const float mean = sum * (1.f / 64.f);
-            float var = 0.f;
+        for (int l = 0; l < L; ++l) {
 #pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                av[s] -= mean;
-                var += av[s] * av[s];
+            for (int s = 0; s < 32; ++s) nc[l][s] = zn[l][s];
+            mean[l] = stn[l][0];
+            rstd[l] = stn[l][1];
+            sd[l] = 1.f / rstd[l];
+        }
+        if (out == 0) {
+#pragma unroll
+            for (int s = 0; s < 32; ++s) dh[s] = dhn[s];
+        } else if (dy_regs) {
+            // dy block -> DY[o][row] (wave-private LDS)
+#pragma unroll
+            for (int i = 0; i < kDyRegs; ++i) {
+                const int e = lane + 64 * i;
+                if (e < 32 * out) DY[(e % out) * 32 + e / out] = dyn[i];
             }
-            var += prim::xhalf(var);
-            rstd = 1.f / sqrtf(var * (1.f / 64.f) + n.eps);
+        } else {
+            for (int oo = 0; oo < out; ++oo)
+                if (h == 0) DY[oo * 32 + c] = ok ? a.dy[row * out + oo] : 0.f;
+        }
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);     // in flight during this tile's arithmetic
+
+        // T[feature][c] = output of layer l = nhat * gamma + beta  (transposed into wave-private LDS)
+        auto put_output = [&](float* T, int l) {
             const float* vec = lds + o.vec + 192 * l;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -482,26 +699,18 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int s = 16 * t + 4 * q + e;
-                        nh[s] = av[s] * rstd;
-                        hr[s] = nh[s] * g[e] + be[e];
+                        T[feat_of(h, s) * kTS + c] = nc[l][s] * g[e] + be[e];
                     }
                 }
         };
-        recompute(L - 1);
         // ---- head
-        if (out == 0) {
-            load_row64(a.dy + rrow * 64, dh, h);
-            if (!ok) {
-#pragma unroll
-                for (int s = 0; s < 32; ++s) dh[s] = 0.f;
-            }
-        } else {
+        if (out > 0) {
+            put_output(TA, L - 1);
+            __syncthreads();        // DY and TA of this wave are complete
 #pragma unroll
             for (int s = 0; s < 32; ++s) dh[s] = 0.f;
-            put_transposed(TA, hr, c, h);
             for (int oo = 0; oo < out; ++oo) {
-                const float d = ok ? a.dy[row * out + oo] : 0.f;
-                if (h == 0) DY[oo * 32 + c] = d;
+                const float d = DY[oo * 32 + c];
                 const float* wp = lds + o.whp + oo * 64 + 32 * h;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -510,7 +719,6 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a) {
                     for (int e = 0; e < 4; ++e) dh[4 * q + e] += w[e] * d;
                 }
             }
-            __syncthreads();
             // lane = feature: d loss / d Wh[o][lane] += sum over the tile's rows of dy[row][o] * h[lane][row]
             {
                 float hrow[32];
@@ -540,14 +748,11 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a) {
             const float* vec = lds + o.vec + 192 * l;
             float* va = vacc + 192 * l;
             // LayerNorm backward: d beta = sum dh, d gamma = sum dh * nhat; then d a, d z
-            float dn[32];
             float m1 = 0.f, m2 = 0.f;
-            {
-                float prod[32];
 #pragma unroll
-                for (int s = 0; s < 32; ++s) prod[s] = dh[s] * nh[s];
-                put_transposed(TA, dh, c, h);
-                put_transposed(TB, prod, c, h);
+            for (int s = 0; s < 32; ++s) {
+                TA[feat_of(h, s) * kTS + c] = dh[s];
+                TB[feat_of(h, s) * kTS + c] = dh[s] * nc[l][s];
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -557,9 +762,9 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int s = 16 * t + 4 * q + e;
-                        dn[s] = dh[s] * g[e];
-                        m1 += dn[s];
-                        m2 += dn[s] * nh[s];
+                        dh[s] *= g[e];                      // dh now holds d nhat
+                        m1 += dh[s];
+                        m2 += dh[s] * nc[l][s];
                     }
                 }
             m1 += prim::xhalf(m1);
@@ -569,10 +774,17 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a) {
             float dz[32];
 #pragma unroll
             for (int s = 0; s < 32; ++s) {
-                const float da = rstd * (dn[s] - m1 - nh[s] * m2);
-                // act output: a = nhat / rstd + mean is not kept; tanh' = 1 - tanh(z)^2 is re-evaluated from z
-                const float av = act_fn(zr[s], n.act);
-                dz[s] = da * act_grad(zr[s], av, n.act);
+                const float da = rstd[l] * (dh[s] - m1 - nc[l][s] * m2);
+                float dact = 1.f;
+                if (ACT == 1) {
+                    const float av = nc[l][s] * sd[l] + mean[l];     // the activation output of the forward pass
+                    dact = 1.f - av * av;
+                } else if (ACT == 2) {
+                    // every zero of a ReLU row maps to the same nhat, (0 - mean) * rstd, evaluated here with the forward's
+                    // own operations (no contraction): the active entries are exactly those above it
+                    dact = nc[l][s] > (0.f - mean[l]) * rstd[l] ? 1.f : 0.f;
+                }
+                dz[s] = da * dact;
             }
             __syncthreads();
             va[128 + lane] += rowsum32(TA + lane * kTS);      // d beta
@@ -584,36 +796,35 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a) {
                 __syncthreads();
                 va[lane] += rowsum32(TA + lane * kTS);        // d bias
                 __syncthreads();
-                break;
-            }
-            // hidden layer l >= 1: its input is the output of layer l - 1
-            recompute(l - 1);     // overwrites zr / nh / hr / rstd with layer l - 1's
-            put_transposed(TB, hr, c, h);
-            __syncthreads();
-            va[lane] += rowsum32(TA + lane * kTS);            // d bias
-            // dW[f][k] += sum over rows dz[f][row] * hin[k][row]: A = TA (lane = f), B = TB (lane = k), rows 16 h + s
+            } else {
+                // hidden layer l >= 1: its input is the output of layer l - 1
+                put_output(TB, l > 0 ? l - 1 : 0);
+                __syncthreads();
+                va[lane] += rowsum32(TA + lane * kTS);            // d bias
+                // dW[f][k] += sum over rows dz[f][row] * hin[k][row]: A = TA (lane = f), B = TB (lane = k), rows 16 h + s
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const v4 a0 = *reinterpret_cast<const v4*>(TA + c * kTS + 16 * h + 4 * q);
-                const v4 a1 = *reinterpret_cast<const v4*>(TA + (32 + c) * kTS + 16 * h + 4 * q);
-                const v4 b0 = *reinterpret_cast<const v4*>(TB + c * kTS + 16 * h + 4 * q);
-                const v4 b1 = *reinterpret_cast<const v4*>(TB + (32 + c) * kTS + 16 * h + 4 * q);
+                for (int q = 0; q < 4; ++q) {
+                    const v4 a0 = *reinterpret_cast<const v4*>(TA + c * kTS + 16 * h + 4 * q);
+                    const v4 a1 = *reinterpret_cast<const v4*>(TA + (32 + c) * kTS + 16 * h + 4 * q);
+                    const v4 b0 = *reinterpret_cast<const v4*>(TB + c * kTS + 16 * h + 4 * q);
+                    const v4 b1 = *reinterpret_cast<const v4*>(TB + (32 + c) * kTS + 16 * h + 4 * q);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    dw2[l - 1][0] = prim::mfma32(a0[e], b0[e], dw2[l - 1][0]);
-                    dw2[l - 1][1] = prim::mfma32(a0[e], b1[e], dw2[l - 1][1]);
-                    dw2[l - 1][2] = prim::mfma32(a1[e], b0[e], dw2[l - 1][2]);
-                    dw2[l - 1][3] = prim::mfma32(a1[e], b1[e], dw2[l - 1][3]);
+                    for (int e = 0; e < 4; ++e) {
+                        dw2[l > 0 ? l - 1 : 0][0] = prim::mfma32(a0[e], b0[e], dw2[l > 0 ? l - 1 : 0][0]);
+                        dw2[l > 0 ? l - 1 : 0][1] = prim::mfma32(a0[e], b1[e], dw2[l > 0 ? l - 1 : 0][1]);
+                        dw2[l > 0 ? l - 1 : 0][2] = prim::mfma32(a1[e], b0[e], dw2[l > 0 ? l - 1 : 0][2]);
+                        dw2[l > 0 ? l - 1 : 0][3] = prim::mfma32(a1[e], b1[e], dw2[l > 0 ? l - 1 : 0][3]);
+                    }
                 }
+                // d hin = W^T dz
+                f32x16 dx[2];
+                dense64(lds + o.w2t + (l - 1) * 2 * 32 * kWS, c, h, dz, dx);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) dh[16 * t + v] = dx[t][v];
+                __syncthreads();
             }
-            // d hin = W^T dz
-            f32x16 dx[2];
-            dense64(lds + o.w2t + (l - 1) * 2 * 32 * kWS, c, h, dz, dx);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) dh[16 * t + v] = dx[t][v];
-            __syncthreads();
         }
     }
     // ---- flush this wave's partial sums
@@ -636,31 +847,110 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a) {
 
 // ================================================================== backward: first-layer weight gradient ====
 // dW1[f][k] = sum over rows dz1[row][f] * xhat[row][k] with xhat gathered and standardised on the fly: a split-K GEMM
-// (K = rows) whose B operand is read through the sampler's index list.  A workgroup owns a slab of <= 384 k columns
-// (blockIdx.y) and a strided set of 32-row tiles; wave w owns k tiles w, w + 4, w + 8 of the slab x both feature tiles.
+// (K = rows) whose B operand is read through the sampler's row table.  A workgroup owns a slab of <= 384 k columns
+// (blockIdx.y) and a strided set of 32-row tiles.  Same role split as the forward: 4 loader waves keep kDepth tiles in
+// flight in registers (a thread always serves the same row of a tile, so standardisation needs 2 registers) and fill
+// one of two LDS stages; compute wave w owns k tiles w, w + 4, w + 8 of the slab x both feature tiles (96 accumulator
+// registers) and reads operands lane-consecutively (ds_read_b32, no padding needed).
 struct Dw1Args {
     RowSrc rs;
     const float* dz1;
     float* partials;    // [gridDim.x][64 * din]
 };
+constexpr int kDw1StageX = kDw1Rows * kDw1Slab;                        // floats
+constexpr int kDw1Stage = kDw1StageX + kDw1Rows * 64;                  // + dz1 tile [32][64]
 
-__global__ void __launch_bounds__(kThreads) mlp_dw1_kernel(Dw1Args a) {
+// (same discipline as ChunkBuf: loaded values are either stored to LDS kDepth iterations later or used as an address)
+struct TileBuf {
+    v4 xv[12], dv[2];
+    int live;               // 0: the row in flight lies past the last row (its dz1 is dropped at the store)
+    int sr_n;               // source row of the row this buffer loads next (fetched three issues ahead)
+};
+
+__global__ void __launch_bounds__(kPipeThreads) mlp_dw1_kernel(Dw1Args a) {
     float* lds = prim::lds();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5;
     const int din = a.rs.din;
     const int k0 = blockIdx.y * kDw1Slab;
     const int kw = (din - k0 < kDw1Slab ? ((din - k0 + 31) / 32) * 32 : kDw1Slab);    // slab width, multiple of 32
-    const int xs = kw + 4;
-    const int pieces = kw / 4;                    // 16-byte pieces per row of the slab
-    const int per_thread = (kDw1Rows * pieces + kThreads - 1) / kThreads;   // <= 12
-    float* xt = lds;                              // [32][xs]
-    float* dzt = lds + kDw1Rows * (kDw1Slab + 4); // [32][kWS]
-    long long* srow = reinterpret_cast<long long*>(dzt + kDw1Rows * kWS);   // [2][32] source rows of a tile
-    float* sst = reinterpret_cast<float*>(srow + 2 * kDw1Rows);             // [2][32][2] their (mean, rstd)
     const long long rows = a.rs.rows;
     const long long ntiles = (rows + kDw1Rows - 1) / kDw1Rows;
-    const int ntk = kw / 32;
+    const long long n_it = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
 
+    if (wave >= 4) {
+        // ------------------------------------------------------------ loader: thread = (row of the tile, 1 of 8 lanes)
+        const int lt = tid - 256, lr = lt >> 3, sub = lt & 7;
+        const int np = kw >> 5;                  // 16-byte pieces per thread: piece sub + 8 p, p < np (<= 12)
+        long long issued = 0;
+        auto row_of = [&](long long m) {         // launch row this thread serves in its m-th tile (clamped past the end)
+            if (m >= n_it) m = n_it - 1;
+            return (blockIdx.x + m * gridDim.x) * kDw1Rows + lr;     // < rows128
+        };
+        auto fetch_row = [&](long long m, TileBuf& B) { B.sr_n = a.rs.srow[row_of(m)]; };
+        // every issue is exactly 12 + 2 + 1 loads
+        auto issue = [&](TileBuf& B) {
+            const float* xrow = a.rs.src + (long long)B.sr_n * din;
+            long long gr = row_of(issued);
+            B.live = gr < rows;
+            if (gr >= rows) gr = rows - 1;
+#pragma unroll
+            for (int p = 0; p < 12; ++p) {
+                const int pp = p < np ? p : np - 1;          // unused pieces re-read the last one (dropped at the store)
+                B.xv[p] = *reinterpret_cast<const v4u*>(xrow + piece_at(k0 + 4 * (sub + 8 * pp), din));
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) B.dv[p] = *reinterpret_cast<const v4*>(a.dz1 + gr * 64 + 4 * (sub + 8 * p));
+            fetch_row(issued + kDepth, B);
+            ++issued;
+        };
+        auto store = [&](long long m, const TileBuf& B) {
+            float* st = lds + (m & 1) * kDw1Stage;
+#pragma unroll
+            for (int p = 0; p < 12; ++p)
+                if (p < np) {
+                    const int kl = 4 * (sub + 8 * p);
+                    *reinterpret_cast<v4*>(st + lr * kw + kl) = shift4(B.xv[p], k0 + kl - piece_at(k0 + kl, din));
+                }
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                *reinterpret_cast<v4*>(st + kDw1StageX + lr * 64 + 4 * (sub + 8 * p)) = B.live ? B.dv[p] : v4{0.f, 0.f, 0.f, 0.f};
+        };
+        TileBuf B0, B1, B2;
+        if (n_it > 0) {
+            fetch_row(0, B0);
+            fetch_row(1, B1);
+            fetch_row(2, B2);
+            issue(B0);
+            issue(B1);
+            issue(B2);
+            store(0, B0);
+            issue(B0);
+        }
+        long long j = 0;
+        for (; j + 3 <= n_it; j += 3) {
+            __syncthreads();
+            store(j + 1, B1);
+            issue(B1);
+            __syncthreads();
+            store(j + 2, B2);
+            issue(B2);
+            __syncthreads();
+            store(j + 3, B0);
+            issue(B0);
+        }
+        if (j < n_it) {
+            __syncthreads();
+            store(j + 1, B1);
+            if (j + 1 < n_it) {
+                __syncthreads();
+                store(j + 2, B2);
+            }
+        }
+        return;
+    }
+    // ---------------------------------------------------------------- compute
+    prim::set_priority_high();
+    const int ntk = kw / 32;
     f32x16 acc[3][2];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -668,89 +958,37 @@ __global__ void __launch_bounds__(kThreads) mlp_dw1_kernel(Dw1Args a) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][t][v] = 0.f;
-
-    auto rowinfo = [&](long long tile, int slot) {
-        if (tid < kDw1Rows) {
-            long long r = tile * kDw1Rows + tid;
-            if (r >= rows) r = rows - 1;
-            const long long sr = source_row(a.rs, r);
-            srow[slot * kDw1Rows + tid] = sr;
-            float m = 0.f, s = 1.f;
-            if (a.rs.stats != nullptr) {
-                m = a.rs.stats[2 * sr];
-                s = a.rs.stats[2 * sr + 1];
-            }
-            sst[(slot * kDw1Rows + tid) * 2] = m;
-            sst[(slot * kDw1Rows + tid) * 2 + 1] = s;
-        }
-    };
-    v4 xv[12], dv[2];
-    float mu[12], rsd[12];
-    auto load_tile = [&](long long tile, int slot) {
-#pragma unroll
-        for (int p = 0; p < 12; ++p) {
-            const int e = tid + kThreads * p;
-            xv[p] = v4{0.f, 0.f, 0.f, 0.f};
-            mu[p] = 0.f;
-            rsd[p] = 1.f;
-            if (p < per_thread && e < kDw1Rows * pieces) {
-                const int r = e / pieces, q = e - r * pieces;
-                const int k = k0 + 4 * q;
-                xv[p] = load4_guard(a.rs.src + srow[slot * kDw1Rows + r] * din + k, din - k);
-                mu[p] = sst[(slot * kDw1Rows + r) * 2];
-                rsd[p] = sst[(slot * kDw1Rows + r) * 2 + 1];
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int e = tid + kThreads * p;       // 32 rows x 16 pieces
-            const int r = e >> 4, q = e & 15;
-            const long long gr = tile * kDw1Rows + r;
-            dv[p] = gr < rows ? *reinterpret_cast<const v4*>(a.dz1 + gr * 64 + 4 * q) : v4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-
-    long long tile = blockIdx.x;
-    int slot = 0;
-    if (tile < ntiles) rowinfo(tile, slot);
-    __syncthreads();
-    if (tile < ntiles) load_tile(tile, slot);
-    for (; tile < ntiles; tile += gridDim.x) {
-        const long long next = tile + gridDim.x;
-        if (next < ntiles) rowinfo(next, slot ^ 1);
-        __syncthreads();            // previous tile's operands consumed; next tile's row info visible
-#pragma unroll
-        for (int p = 0; p < 12; ++p) {
-            const int e = tid + kThreads * p;
-            if (p < per_thread && e < kDw1Rows * pieces) {
-                const int r = e / pieces, q = e - r * pieces;
-                const int k = k0 + 4 * q;
-                v4 x = xv[p];
-#pragma unroll
-                for (int ee = 0; ee < 4; ++ee) x[ee] = (k + ee < din) ? (x[ee] - mu[p]) * rsd[p] : 0.f;
-                *reinterpret_cast<v4*>(xt + r * xs + 4 * q) = x;
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int e = tid + kThreads * p;
-            *reinterpret_cast<v4*>(dzt + (e >> 4) * kWS + 4 * (e & 15)) = dv[p];
-        }
+    for (long long j = 0; j < n_it; ++j) {
         __syncthreads();
-        if (next < ntiles) load_tile(next, slot ^ 1);
-        slot ^= 1;
+        const float* xt = lds + (j & 1) * kDw1Stage;
+        const float* dzt = xt + kDw1StageX;
+        // MFMA-only stream (see the forward kernel): operand reads of step s + 1 are issued before the MFMAs of step s
+        // (= rows 16 h + s of the tile)
+        float a0n, a1n, bn[3];
+        auto rd_step = [&](int st, float& ra0, float& ra1, float* rb) {
+            const int r = 16 * h + st;
+            ra0 = dzt[r * 64 + c];
+            ra1 = dzt[r * 64 + 32 + c];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) rb[i] = (wave + 4 * i < ntk) ? xt[r * kw + 32 * (wave + 4 * i) + c] : 0.f;
+        };
+        rd_step(0, a0n, a1n, bn);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const int r = 16 * h + s;
-            const float a0 = dzt[r * kWS + c], a1 = dzt[r * kWS + 32 + c];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int nt = wave + 4 * i;
-                if (nt < ntk) {
-                    const float b = xt[r * xs + 32 * nt + c];
-                    acc[i][0] = prim::mfma32(a0, b, acc[i][0]);
-                    acc[i][1] = prim::mfma32(a1, b, acc[i][1]);
-                }
+            const float a0 = a0n, a1 = a1n, b0 = bn[0], b1 = bn[1], b2 = bn[2];
+            if (s < 15) rd_step(s + 1, a0n, a1n, bn);
+            prim::sched_fence();
+            if (wave < ntk) {
+                acc[0][0] = prim::mfma32(a0, b0, acc[0][0]);
+                acc[0][1] = prim::mfma32(a1, b0, acc[0][1]);
+            }
+            if (wave + 4 < ntk) {
+                acc[1][0] = prim::mfma32(a0, b1, acc[1][0]);
+                acc[1][1] = prim::mfma32(a1, b1, acc[1][1]);
+            }
+            if (wave + 8 < ntk) {
+                acc[2][0] = prim::mfma32(a0, b2, acc[2][0]);
+                acc[2][1] = prim::mfma32(a1, b2, acc[2][1]);
             }
         }
     }
@@ -771,22 +1009,34 @@ __global__ void __launch_bounds__(kThreads) mlp_dw1_kernel(Dw1Args a) {
     }
 }
 
-// out[e] = sum over n partial rows (row stride `stride`); deterministic order
+// out[e] = sum over n partial rows (row stride `stride`); fixed order.  A block handles 32 consecutive elements with 8
+// row groups (group g sums rows g, g + 8, ...), combined through LDS.
 __global__ void __launch_bounds__(kThreads) mlp_reduce_kernel(const float* partials, long long n, long long stride,
                                                               long long count, float* out) {
-    for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < count; e += (long long)gridDim.x * kThreads) {
-        float s = 0.f;
-        for (long long r = 0; r < n; ++r) s += partials[r * stride + e];
-        out[e] = s;
+    float* sh = prim::lds();        // [8][32]
+    const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const long long e = (long long)blockIdx.x * 32 + el;
+    float s = 0.f;
+    if (e < count)
+        for (long long r = g; r < n; r += 8) s += partials[r * stride + e];
+    sh[g * 32 + el] = s;
+    __syncthreads();
+    if (g == 0 && e < count) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += sh[q * 32 + el];
+        out[e] = t;
     }
 }
 
-// ================================================================== per-row input statistics ====
-// stats[r] = {mean, 1 / sqrt(var + eps)} of src[r, :] (population variance, like nn.LayerNorm: mlp.py:47-48).  The
+// ================================================================== input LayerNorm, parameter-free half ====
+// dst[r, :] = (src[r, :] - mean_r) / sqrt(var_r + eps) (population variance, as nn.LayerNorm: mlp.py:47-48).  The
 // observation fields of the rollout buffer do not change during the ppo epochs, so this runs once per train() and the
-// trunk kernels standardise rows on the fly from 8 bytes per row.  16 lanes per row.
-__global__ void __launch_bounds__(kThreads) row_stats_kernel(const float* src, long long rows, int D, float eps,
-                                                             float* stats) {
+// trunk kernels read standardised rows with no per-row constants in their inner loops (the LayerNorm's affine half is
+// folded into the first Linear by the caller).  16 lanes per row; the row is re-read from cache for the second moment
+// and for the output.
+__global__ void __launch_bounds__(kThreads) standardize_rows_kernel(const float* src, long long rows, int D, float eps,
+                                                                    float* dst) {
     const int sub = threadIdx.x & 15;
     const long long groups = ((long long)gridDim.x * kThreads) >> 4;
     const long long first = ((long long)blockIdx.x * kThreads + threadIdx.x) >> 4;
@@ -813,35 +1063,33 @@ __global__ void __launch_bounds__(kThreads) row_stats_kernel(const float* src, l
                 }
         }
         q = prim::sum16(q);
-        if (ok && sub == 0) {
-            stats[2 * r] = mean;
-            stats[2 * r + 1] = 1.f / sqrtf(q / (float)D + eps);
+        const float rstd = 1.f / sqrtf(q / (float)D + eps);
+        if (ok) {
+            float* o = dst + r * D;
+            for (int k = 4 * sub; k < D; k += 64) {
+                const v4 x = load4_guard(p + k, D - k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (k + e < D) o[k + e] = (x[e] - mean) * rstd;
+            }
         }
     }
 }
 
 // ================================================================== host side ====
 inline bool net_ok(const mappo_mlp_t* m) {
-    if (m->n_layers < 1 || m->n_layers > MAPPO_MLP_MAX_LAYERS || m->din <= 0 || m->out < 0 || m->out > 64) return false;
+    if (m->n_layers < 1 || m->n_layers > MAPPO_MLP_MAX_LAYERS || m->din < 4 || m->out < 0 || m->out > 64) return false;
     if (m->act < 0 || m->act > 2) return false;
     return true;
 }
 
 inline int fill(const mappo_mlp_t* m, RowSrc& rs, Net& n) {
-    if (!m || !m->src || !m->w1) return MAPPO_E_NULL;
+    if (!m || !m->src || !m->w1 || !m->row_tab) return MAPPO_E_NULL;
     if (!net_ok(m) || m->rows <= 0) return MAPPO_E_SHAPE;
-    if (m->chunk_len > 0 && (!m->idx || m->mb <= 0 || m->T <= 0 || m->N <= 0 || m->A <= 0 ||
-                             m->rows != m->mb * (int64_t)m->chunk_len))
-        return MAPPO_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(m->row_tab) & 15) != 0) return MAPPO_E_ALIGN;
     rs.src = m->src;
-    rs.stats = m->row_stats;
-    rs.idx = reinterpret_cast<const long long*>(m->idx);
+    rs.srow = m->row_tab;
     rs.rows = m->rows;
-    rs.mb = m->mb;
-    rs.chunk_len = m->chunk_len;
-    rs.T = m->T;
-    rs.N = m->N;
-    rs.A = m->A;
     rs.din = m->din;
     n.din = m->din;
     n.L = m->n_layers;
@@ -867,17 +1115,43 @@ inline int fill(const mappo_mlp_t* m, RowSrc& rs, Net& n) {
 
 inline long long ceil_div(long long a, long long b) { return (a + b - 1) / b; }
 
+// tuning / test hook (mappo_mlp_set_grid_cap): upper bound on the workgroups of the persistent kernels; 0 = one or
+// two per CU as the kernels were sized.  Small caps make every workgroup loop over many tiles (tests).
+inline int& grid_cap_override() {
+    static int cap = 0;
+    return cap;
+}
+inline long long*& debug_buffer() {
+    static long long* p = nullptr;
+    return p;
+}
+inline long long capped(long long grid, int default_cap) {
+    const int cap = grid_cap_override() > 0 && grid_cap_override() < default_cap ? grid_cap_override() : default_cap;
+    return grid > cap ? cap : grid;
+}
+
 inline int forward(const mappo_mlp_t* m, hipStream_t stream) {
     FwdArgs a;
     int code = fill(m, a.rs, a.net);
     if (code) return code;
     if (!m->y) return MAPPO_E_NULL;
     a.y = m->y;
-    for (int l = 0; l < 3; ++l) a.z[l] = l < m->n_layers ? m->z[l] : nullptr;
+    a.dbg = debug_buffer();
+    for (int l = 0; l < 3; ++l) {
+        a.z[l] = l < m->n_layers ? m->z[l] : nullptr;
+        a.st[l] = l < m->n_layers ? m->ln_stats[l] : nullptr;
+        if (a.z[l] != nullptr && a.st[l] == nullptr) return MAPPO_E_NULL;
+    }
     const FwdLds o = fwd_lds(m->n_layers, m->out);
-    long long grid = ceil_div(m->rows, kTR);
-    if (grid > kFwdGridCap) grid = kFwdGridCap;
-    MAPPO_LAUNCH(mlp_fwd_kernel, (unsigned)grid, kThreads, (size_t)o.total * 4, stream, a);
+    const long long grid = capped(ceil_div(m->rows, kTR), kFwdGridCap);
+    const bool al = m->din % 4 == 0;
+#define MAPPO_FWD_CASE(AA, AL)                                                                                 \
+    if (m->act == AA && al == AL) {                                                                            \
+        MAPPO_LAUNCH((mlp_fwd_kernel<AA, AL>), (unsigned)grid, kPipeThreads, (size_t)o.total * 4, stream, a);  \
+    }
+    MAPPO_FWD_CASE(0, false) MAPPO_FWD_CASE(1, false) MAPPO_FWD_CASE(2, false)
+    MAPPO_FWD_CASE(0, true) MAPPO_FWD_CASE(1, true) MAPPO_FWD_CASE(2, true)
+#undef MAPPO_FWD_CASE
     return MAPPO_LAUNCH_ERROR();
 }
 
@@ -892,22 +1166,23 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
     if (!m->dy || !m->dz1 || !m->workspace || !m->grads) return MAPPO_E_NULL;
     for (int l = 0; l < 3; ++l) {
         b.z[l] = l < m->n_layers ? m->z[l] : nullptr;
-        if (l < m->n_layers && !m->z[l]) return MAPPO_E_NULL;
+        b.st[l] = l < m->n_layers ? m->ln_stats[l] : nullptr;
+        if (l < m->n_layers && (!m->z[l] || !m->ln_stats[l])) return MAPPO_E_NULL;
     }
     const int L = m->n_layers, out = m->out, din = m->din;
     b.dy = m->dy;
     b.dz1 = m->dz1;
     b.partials = m->workspace;
     const BwdLds o = bwd_lds(L, out);
-    long long grid = ceil_div(m->rows, kTR);
-    if (grid > kBwdGridCap) grid = kBwdGridCap;
-    if (L == 1) {
-        MAPPO_LAUNCH(mlp_bwd_kernel<1>, (unsigned)grid, kThreads, (size_t)o.total * 4, stream, b);
-    } else if (L == 2) {
-        MAPPO_LAUNCH(mlp_bwd_kernel<2>, (unsigned)grid, kThreads, (size_t)o.total * 4, stream, b);
-    } else {
-        MAPPO_LAUNCH(mlp_bwd_kernel<3>, (unsigned)grid, kThreads, (size_t)o.total * 4, stream, b);
+    const long long grid = capped(ceil_div(m->rows, kTR), kBwdGridCap);
+#define MAPPO_BWD_CASE(LL, AA)                                                                             \
+    if (L == LL && m->act == AA) {                                                                         \
+        MAPPO_LAUNCH((mlp_bwd_kernel<LL, AA>), (unsigned)grid, kThreads, (size_t)o.total * 4, stream, b);  \
     }
+    MAPPO_BWD_CASE(1, 0) MAPPO_BWD_CASE(1, 1) MAPPO_BWD_CASE(1, 2)
+    MAPPO_BWD_CASE(2, 0) MAPPO_BWD_CASE(2, 1) MAPPO_BWD_CASE(2, 2)
+    MAPPO_BWD_CASE(3, 0) MAPPO_BWD_CASE(3, 1) MAPPO_BWD_CASE(3, 2)
+#undef MAPPO_BWD_CASE
     code = MAPPO_LAUNCH_ERROR();
     if (code) return code;
 
@@ -915,30 +1190,50 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
     d.rs = b.rs;
     d.dz1 = m->dz1;
     d.partials = m->workspace + (long long)kBwdGridCap * 4 * p_main(L, out);
-    long long gx = ceil_div(m->rows, kDw1Rows);
-    if (gx > kDw1GridCap) gx = kDw1GridCap;
     const int gy = (int)ceil_div(din, kDw1Slab);
-    if (gx * gy > kDw1GridCap) gx = kDw1GridCap / gy > 0 ? kDw1GridCap / gy : 1;
-    const size_t dw1_lds = ((size_t)kDw1Rows * (kDw1Slab + 4) + kDw1Rows * kWS) * 4 + 2 * kDw1Rows * 8 + 2 * kDw1Rows * 8;
-    MAPPO_LAUNCH(mlp_dw1_kernel, dim3((unsigned)gx, (unsigned)gy), kThreads, dw1_lds, stream, d);
+    const long long gx = capped(ceil_div(m->rows, kDw1Rows), kDw1GridCap / gy > 0 ? kDw1GridCap / gy : 1);
+    const size_t dw1_lds = (size_t)2 * kDw1Stage * 4;
+    MAPPO_LAUNCH(mlp_dw1_kernel, dim3((unsigned)gx, (unsigned)gy), kPipeThreads, dw1_lds, stream, d);
     code = MAPPO_LAUNCH_ERROR();
     if (code) return code;
 
     // every slab's workgroups write disjoint k columns of their partial row; rows of unused workgroups do not exist
     const long long pm = p_main(L, out);
-    MAPPO_LAUNCH(mlp_reduce_kernel, (unsigned)ceil_div(64LL * din, kThreads), kThreads, 0, stream, d.partials, gx,
+    MAPPO_LAUNCH(mlp_reduce_kernel, (unsigned)ceil_div(64LL * din, 32), kThreads, 1024, stream, d.partials, gx,
                  64LL * din, 64LL * din, m->grads);
-    MAPPO_LAUNCH(mlp_reduce_kernel, (unsigned)ceil_div(pm, kThreads), kThreads, 0, stream, b.partials, grid * 4, pm, pm,
+    MAPPO_LAUNCH(mlp_reduce_kernel, (unsigned)ceil_div(pm, 32), kThreads, 1024, stream, b.partials, grid * 4, pm, pm,
                  m->grads + 64LL * din);
     return MAPPO_LAUNCH_ERROR();
 }
 
-inline int row_stats(const float* src, long long rows, int D, float eps, float* stats, hipStream_t stream) {
-    if (!src || !stats) return MAPPO_E_NULL;
+inline int row_table(const long long* idx, long long rows, long long mb, int chunk_len, int T, int N, int A, int* tab,
+                     hipStream_t stream) {
+    if (!tab) return MAPPO_E_NULL;
+    if (rows <= 0) return MAPPO_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(tab) & 15) != 0) return MAPPO_E_ALIGN;
+    if (chunk_len > 0 && (!idx || mb <= 0 || T <= 0 || N <= 0 || A <= 0 || rows != mb * (long long)chunk_len))
+        return MAPPO_E_SHAPE;
+    RowMapArgs m;
+    m.idx = idx;
+    m.rows = rows;
+    m.mb = mb;
+    m.chunk_len = chunk_len;
+    m.T = T;
+    m.N = N;
+    m.A = A;
+    m.srow = tab;
+    long long grid = ceil_div(rows128(rows), kThreads);
+    if (grid > 256 * 8) grid = 256 * 8;
+    MAPPO_LAUNCH(rowtab_kernel, (unsigned)grid, kThreads, 0, stream, m);
+    return MAPPO_LAUNCH_ERROR();
+}
+
+inline int standardize_rows(const float* src, long long rows, int D, float eps, float* dst, hipStream_t stream) {
+    if (!src || !dst) return MAPPO_E_NULL;
     if (rows <= 0 || D <= 0) return MAPPO_E_SHAPE;
     long long grid = ceil_div(rows * 16, kThreads);
     if (grid > 256 * 8) grid = 256 * 8;
-    MAPPO_LAUNCH(row_stats_kernel, (unsigned)grid, kThreads, 0, stream, src, rows, D, eps, stats);
+    MAPPO_LAUNCH(standardize_rows_kernel, (unsigned)grid, kThreads, 0, stream, src, rows, D, eps, dst);
     return MAPPO_LAUNCH_ERROR();
 }
 

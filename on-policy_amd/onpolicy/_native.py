@@ -48,11 +48,10 @@ class PPOLoss(ctypes.Structure):
 
 class MLP(ctypes.Structure):
     """struct mappo_mlp (include/mappo_hip.h): the fused hidden-64 trunk."""
-    _fields_ = [("src", _vp), ("row_stats", _vp), ("idx", _vp), ("rows", _i64), ("mb", _i64),
-                ("chunk_len", ctypes.c_int32), ("T", ctypes.c_int32), ("N", ctypes.c_int32), ("A", ctypes.c_int32),
+    _fields_ = [("src", _vp), ("row_tab", _vp), ("rows", _i64),
                 ("din", ctypes.c_int32), ("n_layers", ctypes.c_int32), ("act", ctypes.c_int32), ("out", ctypes.c_int32),
                 ("ln_eps", ctypes.c_float), ("w1", _vp), ("bias", _vp * 3), ("ln_g", _vp * 3), ("ln_b", _vp * 3),
-                ("w2", _vp * 2), ("wh", _vp), ("bh", _vp), ("y", _vp), ("z", _vp * 3), ("dy", _vp), ("dz1", _vp),
+                ("w2", _vp * 2), ("wh", _vp), ("bh", _vp), ("y", _vp), ("z", _vp * 3), ("ln_stats", _vp * 3), ("dy", _vp), ("dz1", _vp),
                 ("workspace", _vp), ("grads", _vp)]
 
 
@@ -93,7 +92,11 @@ SIGNATURES = {
     "mappo_mlp_backward": (_int, [ctypes.POINTER(MLP), _vp]),
     "mappo_mlp_grad_floats": (_i64, [_int, _int, _int]),
     "mappo_mlp_workspace_floats": (_i64, [_int, _int, _int]),
-    "mappo_row_stats": (_int, [_vp, _i64, _int, ctypes.c_float, _vp, _vp]),
+    "mappo_mlp_row_table_ints": (_i64, [_i64]),
+    "mappo_mlp_set_grid_cap": (_int, [_int]),
+    "mappo_mlp_set_debug": (_int, [_vp]),
+    "mappo_mlp_row_table": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _vp, _vp]),
+    "mappo_standardize_rows": (_int, [_vp, _i64, _int, ctypes.c_float, _vp, _vp]),
     "mappo_abi_version": (_int, []),
     "mappo_build_info": (ctypes.c_char_p, []),
     "mappo_error_string": (ctypes.c_char_p, [_int]),

@@ -7,8 +7,9 @@ MLPBase: [LayerNorm] -> (Linear -> Tanh | ReLU -> LayerNorm) x (1 + layer_N)), t
 (distributions.py:55-68) and the critic's v_out (r_actor_critic.py:147-175).
 
 ``RowSource`` is what the buffer's samplers hand out instead of a gathered ``[mb, obs_dim]`` tensor when asked for
-``lazy_obs=True``: the source matrix, the per-row standardisation constants and the minibatch's indices.  Networks that
-cannot take it call ``materialize()`` and get the tensor the eager gather would have produced.
+``lazy_obs=True``: the source matrix (for networks with an input LayerNorm: a copy of the observation field standardised
+once per train()) and the minibatch's indices.  Networks that cannot take it call ``materialize()`` and get the tensor the
+eager (standardising) gather would have produced.
 
 Autograd sees one node per network (``_FusedTrunkFn``); the input LayerNorm's affine half is folded into the first
 Linear with ordinary torch ops in front of it (``LN(x) W^T + b = xhat (W * gamma)^T + (b + W beta)``), so gamma / beta
@@ -33,15 +34,28 @@ def enabled():
 class RowSource(object):
     """Rows of a 2-D source matrix selected by a sampler minibatch, not yet gathered.
 
-    ``src``   [src_rows, din] float32 device matrix (a time-major buffer field viewed as rows)
-    ``stats`` [src_rows, 2] {mean, 1 / sqrt(var + 1e-5)} per source row, or None
+    ``src``   [src_rows, din] float32 device matrix the fused kernels read: a time-major buffer field viewed as rows or,
+              for networks with an input LayerNorm, its standardised copy (``standardized`` = True)
     ``idx``   int64 device indices; ``chunk`` = (L, T, N, A) for recurrent_generator's chunk rows, None for row indices
     """
 
-    def __init__(self, src, stats, idx, chunk=None):
-        self.src, self.stats, self.idx, self.chunk = src, stats, idx, chunk
+    def __init__(self, src, idx, chunk=None, standardized=False):
+        self.src, self.idx, self.chunk, self.standardized = src, idx, chunk, bool(standardized)
         self.mb = int(idx.shape[0])
         self.rows = self.mb * (chunk[0] if chunk else 1)
+        self._tab = None
+
+    def table(self):
+        """int32 row table for the kernels (``mappo_mlp_row_table``): the source row of every launch row; built on first
+        use and kept for the other launches on this minibatch (forward, backward)."""
+        if self._tab is None:
+            lib = _native.lib()
+            tab = torch.empty(lib.mappo_mlp_row_table_ints(self.rows), dtype=torch.int32, device=self.src.device)
+            L, T, N, A = self.chunk if self.chunk else (0, 0, 0, 0)
+            _native.check(lib.mappo_mlp_row_table(self.idx.data_ptr(), self.rows, self.mb, L, T, N, A, tab.data_ptr(),
+                                                  _native.stream_of(self.src.device)), "mappo_mlp_row_table")
+            self._tab = tab
+        return self._tab
 
     @property
     def shape(self):
@@ -56,7 +70,7 @@ class RowSource(object):
     def rows_slice(self, lo, hi):
         """Row span [lo, hi) of a rows-mode minibatch / chunk span [lo, hi) of a chunk-mode one (every span keeps all
         L steps of its chunks, row l * (hi - lo) + j)."""
-        return RowSource(self.src, self.stats, self.idx[lo:hi], self.chunk)
+        return RowSource(self.src, self.idx[lo:hi], self.chunk, self.standardized)
 
     def __getitem__(self, key):
         if not (isinstance(key, slice) and key.step in (None, 1)) or self.chunk:
@@ -76,24 +90,18 @@ class RowSource(object):
         a, t = rem // T, rem % T
         return (t * N + n) * A + a
 
-    def materialize(self, standardized):
-        """The [rows, din] tensor the eager samplers produce (standardised rows when ``standardized``)."""
-        sr = self.source_rows()
-        x = self.src[sr]
-        if standardized:
-            if self.stats is None:
-                raise ValueError("this RowSource carries no row statistics")
-            st = self.stats[sr]
-            x = (x - st[:, :1]) * st[:, 1:]
-        return x
+    def materialize(self):
+        """The [rows, din] tensor an eager sampler would have produced from ``src``."""
+        return self.src[self.source_rows()]
 
 
-def row_stats(src2d, eps=1e-5):
-    """[rows, 2] {mean, 1 / sqrt(var + eps)} of every row of a float32 device matrix (``mappo_row_stats``)."""
+def standardize_rows(src2d, eps=1e-5):
+    """(x - mean) / sqrt(var + eps) of every row of a float32 device matrix (``mappo_standardize_rows``): the
+    parameter-free half of the networks' input LayerNorm, applied to a whole observation field once per train()."""
     rows, D = src2d.shape
-    out = torch.empty((rows, 2), dtype=torch.float32, device=src2d.device)
-    _native.check(_native.lib().mappo_row_stats(src2d.data_ptr(), rows, D, float(eps), out.data_ptr(),
-                                                _native.stream_of(src2d.device)), "mappo_row_stats")
+    out = torch.empty_like(src2d)
+    _native.check(_native.lib().mappo_standardize_rows(src2d.data_ptr(), rows, D, float(eps), out.data_ptr(),
+                                                       _native.stream_of(src2d.device)), "mappo_standardize_rows")
     return out
 
 
@@ -135,7 +143,8 @@ class _FusedTrunkFn(torch.autograd.Function):
         dev = rs.src.device
         params = [p.detach().contiguous() for p in params]
         m = _native.MLP()
-        _fill_rows(m, rs)
+        tab = rs.table()
+        _fill_rows(m, rs, tab)
         m.n_layers, m.act, m.out, m.ln_eps = n_layers, act, out, float(eps)
         _fill_params(m, params, n_layers, out)
         rows = rs.rows
@@ -143,14 +152,16 @@ class _FusedTrunkFn(torch.autograd.Function):
         m.y = y.data_ptr()
         need_grad = any(ctx.needs_input_grad[5:])
         zs = []
-        if need_grad:
+        if need_grad:       # what the backward needs of every layer: normalised activations + {mean, rstd} per row
             zbuf = torch.empty((n_layers, rows, HIDDEN), dtype=torch.float32, device=dev)
+            sbuf = torch.empty((n_layers, rows, 2), dtype=torch.float32, device=dev)
             for l in range(n_layers):
                 m.z[l] = zbuf[l].data_ptr()
-            zs = [zbuf]
+                m.ln_stats[l] = sbuf[l].data_ptr()
+            zs = [zbuf, sbuf]
         _native.check(lib.mappo_mlp_forward(m, _native.stream_of(dev)), "mappo_mlp_forward")
         ctx.rs, ctx.cfg = rs, (act, eps, n_layers, out)
-        ctx.save_for_backward(*(zs + params))
+        ctx.save_for_backward(*(zs + [tab] + params))
         return y
 
     @staticmethod
@@ -159,15 +170,16 @@ class _FusedTrunkFn(torch.autograd.Function):
         rs = ctx.rs
         act, eps, n_layers, out = ctx.cfg
         saved = ctx.saved_tensors
-        zbuf, params = saved[0], list(saved[1:])
+        zbuf, sbuf, tab, params = saved[0], saved[1], saved[2], list(saved[3:])
         dev = rs.src.device
         din = int(rs.src.shape[1])
         m = _native.MLP()
-        _fill_rows(m, rs)
+        _fill_rows(m, rs, tab)
         m.n_layers, m.act, m.out, m.ln_eps = n_layers, act, out, float(eps)
         _fill_params(m, params, n_layers, out)
         for l in range(n_layers):
             m.z[l] = zbuf[l].data_ptr()
+            m.ln_stats[l] = sbuf[l].data_ptr()
         dy = dy.contiguous()
         grads = torch.empty(lib.mappo_mlp_grad_floats(din, n_layers, out), dtype=torch.float32, device=dev)
         ws = torch.empty(lib.mappo_mlp_workspace_floats(din, n_layers, out), dtype=torch.float32, device=dev)
@@ -177,15 +189,10 @@ class _FusedTrunkFn(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(_split_grads(grads, din, n_layers, out))
 
 
-def _fill_rows(m, rs):
+def _fill_rows(m, rs, tab):
     m.src = rs.src.data_ptr()
-    m.row_stats = _native.ptr(rs.stats)
-    m.idx = rs.idx.data_ptr()
-    m.rows, m.mb, m.din = rs.rows, rs.mb, int(rs.src.shape[1])
-    if rs.chunk:
-        m.chunk_len, m.T, m.N, m.A = rs.chunk
-    else:
-        m.chunk_len = m.T = m.N = m.A = 0
+    m.row_tab = tab.data_ptr()
+    m.rows, m.din = rs.rows, int(rs.src.shape[1])
 
 
 def _fill_params(m, params, n_layers, out):
@@ -227,14 +234,14 @@ def trunk_forward(base, rs, head=None):
     blocks = [mlp.fc1] + list(mlp.fc2)
     lin0 = blocks[0][0]
     if base._use_feature_normalization:
-        if rs.stats is None:
-            raise ValueError("the trunk has an input LayerNorm: the RowSource must carry row statistics")
+        if not rs.standardized:
+            raise ValueError("the trunk has an input LayerNorm: the RowSource must read standardised rows")
         fn = base.feature_norm
         w1 = lin0.weight * fn.weight
         b1 = lin0.bias + lin0.weight @ fn.bias
     else:
-        if rs.stats is not None:
-            rs = RowSource(rs.src, None, rs.idx, rs.chunk)
+        if rs.standardized:
+            raise ValueError("the trunk has no input LayerNorm: the RowSource must read the rows as they are")
         w1, b1 = lin0.weight, lin0.bias
     params = [w1, b1]
     for blk in blocks:

@@ -11,11 +11,10 @@ _vp, _i64, _i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
 
 
 class MLP(ctypes.Structure):
-    _fields_ = [("src", _vp), ("row_stats", _vp), ("idx", _vp), ("rows", _i64), ("mb", _i64),
-                ("chunk_len", _i32), ("T", _i32), ("N", _i32), ("A", _i32),
+    _fields_ = [("src", _vp), ("row_tab", _vp), ("rows", _i64),
                 ("din", _i32), ("n_layers", _i32), ("act", _i32), ("out", _i32), ("ln_eps", ctypes.c_float),
                 ("w1", _vp), ("bias", _vp * 3), ("ln_g", _vp * 3), ("ln_b", _vp * 3), ("w2", _vp * 2),
-                ("wh", _vp), ("bh", _vp), ("y", _vp), ("z", _vp * 3), ("dy", _vp), ("dz1", _vp),
+                ("wh", _vp), ("bh", _vp), ("y", _vp), ("z", _vp * 3), ("ln_stats", _vp * 3), ("dy", _vp), ("dz1", _vp),
                 ("workspace", _vp), ("grads", _vp)]
 
 
@@ -28,8 +27,14 @@ def bind(lib):
     lib.mappo_mlp_grad_floats.argtypes = [ctypes.c_int] * 3
     lib.mappo_mlp_workspace_floats.restype = _i64
     lib.mappo_mlp_workspace_floats.argtypes = [ctypes.c_int] * 3
-    lib.mappo_row_stats.restype = ctypes.c_int
-    lib.mappo_row_stats.argtypes = [_vp, _i64, ctypes.c_int, ctypes.c_float, _vp, _vp]
+    lib.mappo_mlp_row_table_ints.restype = _i64
+    lib.mappo_mlp_row_table_ints.argtypes = [_i64]
+    lib.mappo_mlp_row_table.restype = ctypes.c_int
+    lib.mappo_mlp_row_table.argtypes = [_vp, _i64, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp]
+    lib.mappo_standardize_rows.restype = ctypes.c_int
+    lib.mappo_standardize_rows.argtypes = [_vp, _i64, ctypes.c_int, ctypes.c_float, _vp, _vp]
+    lib.mappo_mlp_set_grid_cap.restype = ctypes.c_int
+    lib.mappo_mlp_set_grid_cap.argtypes = [ctypes.c_int]
     return lib
 
 
@@ -59,11 +64,9 @@ def source_rows(idx, rows, chunk_len=0, mb=0, T=0, N=0, A=0):
     return (t * N + n) * A + a
 
 
-def row_stats_ref(src, eps):
+def standardize_ref(src, eps):
     x = torch.as_tensor(src, dtype=torch.float64)
-    mean = x.mean(1)
-    var = x.var(1, unbiased=False)
-    return torch.stack([mean, 1.0 / torch.sqrt(var + eps)], 1)
+    return (x - x.mean(1, keepdim=True)) / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + eps)
 
 
 def forward_ref(params, src, srows, standardize, n_layers, act, out, eps=1e-5, in_eps=1e-5):

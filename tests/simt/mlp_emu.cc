@@ -6,6 +6,21 @@
 simt_dim3 simt::g_threadIdx, simt::g_blockIdx, simt::g_blockDim, simt::g_gridDim;
 
 namespace prim {
+inline float exp2_fast(float v) { return exp2f(v); }
+inline float rcp_fast(float v) { return 1.f / v; }
+inline void sched_fence() {}
+inline void set_priority_high() {}
+inline long long clock() { return 0; }
+inline int f2i(float v) {
+    int r;
+    memcpy(&r, &v, 4);
+    return r;
+}
+inline float i2f(int v) {
+    float r;
+    memcpy(&r, &v, 4);
+    return r;
+}
 // sum over the 16-lane group of the calling lane (a wave collective)
 inline float sum16(float v) {
     simt::Wave& w = my_wave();
@@ -31,11 +46,24 @@ inline float sum16(float v) {
 
 extern "C" int mappo_mlp_forward(const mappo_mlp_t* net, mappo_stream_t stream) { return mlp::forward(net, stream); }
 extern "C" int mappo_mlp_backward(const mappo_mlp_t* net, mappo_stream_t stream) { return mlp::backward(net, stream); }
+extern "C" int mappo_mlp_set_debug(long long* buf) {
+    mlp::debug_buffer() = buf;
+    return 0;
+}
+extern "C" int mappo_mlp_set_grid_cap(int cap) {
+    mlp::grid_cap_override() = cap;
+    return 0;
+}
+extern "C" int64_t mappo_mlp_row_table_ints(int64_t rows) { return mlp::rows128(rows); }
+extern "C" int mappo_mlp_row_table(const int64_t* idx, int64_t rows, int64_t mb, int chunk_len, int T, int N, int A,
+                                   int32_t* row_tab, mappo_stream_t stream) {
+    return mlp::row_table(reinterpret_cast<const long long*>(idx), rows, mb, chunk_len, T, N, A, row_tab, stream);
+}
 extern "C" int64_t mappo_mlp_grad_floats(int din, int n_layers, int out) { return mlp::g_total(din, n_layers, out); }
 extern "C" int64_t mappo_mlp_workspace_floats(int din, int n_layers, int out) {
     return mlp::workspace_floats(din, n_layers, out);
 }
-extern "C" int mappo_row_stats(const float* src, int64_t rows, int D, float eps, float* stats, mappo_stream_t stream) {
-    return mlp::row_stats(src, rows, D, eps, stats, stream);
+extern "C" int mappo_standardize_rows(const float* src, int64_t rows, int D, float eps, float* dst, mappo_stream_t stream) {
+    return mlp::standardize_rows(src, rows, D, eps, dst, stream);
 }
 extern "C" unsigned long long simt_mfma_count() { return simt::st().n_mfma; }

@@ -42,8 +42,8 @@ def _compare(din, layer_N, relu, out, rows, src_rows, chunk=None, feature_norm=T
         L = chunk[0]
         idx = torch.randperm(src_rows // L, generator=g)[:rows // L]
     src_d = src.to(DEV)
-    stats = fused_mlp.row_stats(src_d) if feature_norm else None
-    rs = fused_mlp.RowSource(src_d, stats, idx.to(DEV), chunk)
+    xin = fused_mlp.standardize_rows(src_d) if feature_norm else src_d      # once per train() in the trainer
+    rs = fused_mlp.RowSource(xin, idx.to(DEV), chunk, standardized=feature_norm)
     y = fused_mlp.trunk_forward(base, rs, head)
     dy = torch.randn(y.shape, generator=g)
     y.backward(dy.to(DEV))
@@ -96,7 +96,8 @@ def test_trunk_at_scale_is_deterministic_and_finite():
     base, head = base.to(DEV), head.to(DEV)
     rows = 1 << 21
     src = torch.randn(rows + 1000, 384, device=DEV)
-    rs = fused_mlp.RowSource(src, fused_mlp.row_stats(src), torch.randperm(rows + 1000, device=DEV)[:rows])
+    rs = fused_mlp.RowSource(fused_mlp.standardize_rows(src), torch.randperm(rows + 1000, device=DEV)[:rows],
+                             standardized=True)
     dy = torch.randn(rows, 1, device=DEV)
     outs = []
     for _ in range(2):
@@ -115,11 +116,10 @@ def test_trunk_at_scale_is_deterministic_and_finite():
 def test_row_source_materialize_equals_eager_gather():
     from onpolicy.algorithms.utils import fused_mlp
     src = torch.randn(500, 54, device=DEV) * 3 + 1
-    stats = fused_mlp.row_stats(src)
-    ref = torch.stack([src.mean(1), 1 / torch.sqrt(src.var(1, unbiased=False) + 1e-5)], 1)
-    torch.testing.assert_close(stats, ref, rtol=2e-5, atol=1e-6)
+    xhat = fused_mlp.standardize_rows(src)
+    torch.testing.assert_close(xhat, torch.nn.functional.layer_norm(src, (54,)), rtol=1e-4, atol=1e-5)
     idx = torch.randperm(500, device=DEV)[:123]
-    rs = fused_mlp.RowSource(src, stats, idx)
-    x = rs.materialize(True)
-    torch.testing.assert_close(x, torch.nn.functional.layer_norm(src[idx], (54,)), rtol=1e-4, atol=1e-5)
+    rs = fused_mlp.RowSource(xhat, idx, standardized=True)
+    assert torch.equal(rs.materialize(), xhat[idx])
     assert rs[10:20].rows == 10 and torch.equal(rs[10:20].idx, idx[10:20])
+    assert rs.table().dtype == torch.int32 and torch.equal(rs.table()[:123].long(), idx)

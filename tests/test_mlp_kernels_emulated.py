@@ -42,28 +42,41 @@ def _run(emu, rng, din, n_layers, act, out, rows, src_rows, standardize=True, ch
         mb = rows // L
         idx = rng.permutation(src_rows // L)[:mb].astype(np.int64)
         kw = dict(chunk_len=L, mb=mb, T=T, N=N, A=A)
-    stats = np.zeros((src_rows, 2), np.float32)
-    if standardize:
-        assert emu.mappo_row_stats(_ptr(src), src_rows, din, 1e-5, _ptr(stats), None) == 0
-        ref = R.row_stats_ref(src, 1e-5).numpy()
-        np.testing.assert_allclose(stats, ref, rtol=2e-5, atol=2e-6)
+    xin = src
+    if standardize:      # the kernels read a standardised copy of the source matrix (made once per train())
+        xin = np.full_like(src, np.nan)
+        assert emu.mappo_standardize_rows(_ptr(src), src_rows, din, 1e-5, _ptr(xin), None) == 0
+        np.testing.assert_allclose(xin, R.standardize_ref(src, 1e-5).numpy(), rtol=2e-5, atol=2e-6)
     y = np.full((rows, out if out else 64), np.nan, np.float32)
     z = [np.full((rows, 64), np.nan, np.float32) for _ in range(n_layers)]
-    m = R.MLP(src=_ptr(src), row_stats=_ptr(stats) if standardize else None, idx=_ptr(idx), rows=rows, din=din,
+    tab = np.full(emu.mappo_mlp_row_table_ints(rows), -1, np.int32)
+    R128 = (rows + 127) // 128 * 128
+    assert tab.size == R128
+    assert emu.mappo_mlp_row_table(_ptr(idx), rows, kw["mb"], kw["chunk_len"], kw["T"], kw["N"], kw["A"], _ptr(tab),
+                                   None) == 0
+    srows = R.source_rows(idx, rows, **kw)
+    np.testing.assert_array_equal(tab[:rows], srows)
+    np.testing.assert_array_equal(tab[rows:], np.full(R128 - rows, srows[-1]))     # padding = last row
+    m = R.MLP(src=_ptr(xin), row_tab=_ptr(tab), rows=rows, din=din,
               n_layers=n_layers, act=act, out=out, ln_eps=1e-5, w1=_ptr(p["w1"]), wh=_ptr(p["wh"]) if out else None,
-              bh=_ptr(p["bh"]) if out else None, y=_ptr(y), **kw)
+              bh=_ptr(p["bh"]) if out else None, y=_ptr(y))
+    st = [np.full((rows, 2), np.nan, np.float32) for _ in range(n_layers)]
     for l in range(n_layers):
         m.bias[l], m.ln_g[l], m.ln_b[l] = _ptr(p["bias%d" % l]), _ptr(p["ln_g%d" % l]), _ptr(p["ln_b%d" % l])
-        m.z[l] = _ptr(z[l])
+        m.z[l], m.ln_stats[l] = _ptr(z[l]), _ptr(st[l])
         if l > 0:
             m.w2[l - 1] = _ptr(p["w2_%d" % (l - 1)])
     assert emu.mappo_mlp_forward(ctypes.byref(m), None) == 0
     tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
-    srows = R.source_rows(idx, rows, **kw)
     y_ref, z_ref = R.forward_ref(tp, src, srows, standardize, n_layers, act, out)
     np.testing.assert_allclose(y, y_ref.detach().numpy(), rtol=2e-4, atol=2e-5)
-    for l in range(n_layers):
-        np.testing.assert_allclose(z[l], z_ref[l].detach().numpy(), rtol=2e-4, atol=2e-5)
+    fn = {0: lambda v: v, 1: torch.tanh, 2: torch.relu}[act]
+    for l in range(n_layers):       # saved for the backward: normalised activation and its row statistics
+        a_ref = fn(z_ref[l].detach())
+        mean, var = a_ref.mean(1, keepdim=True), a_ref.var(1, unbiased=False, keepdim=True)
+        rstd = 1.0 / torch.sqrt(var + 1e-5)
+        np.testing.assert_allclose(z[l], ((a_ref - mean) * rstd).numpy(), rtol=2e-4, atol=5e-5)
+        np.testing.assert_allclose(st[l], torch.cat([mean, rstd], 1).numpy(), rtol=2e-4, atol=2e-5)
     if not backward:
         return
     dy = rng.standard_normal(y.shape).astype(np.float32)
@@ -87,6 +100,7 @@ CASES = [
     (30, 2, 2, 1, 128, 128),       # cfg2 actor width, ReLU, value head, exactly one tile
     (19, 1, 1, 3, 37, 64),         # single layer, odd width (unaligned rows)
     (130, 3, 1, 0, 150, 300),      # layer_N = 2, trunk only (features for the GRU), three chunks with a tail
+    (70, 2, 1, 2, 128 * 5 + 9, 900),   # several tiles and two chunks: the loaders' in-flight chunks cross tile boundaries
 ]
 
 
@@ -94,6 +108,20 @@ CASES = [
 def test_rows_mode_vs_float64_reference(emu, case):
     din, L, act, out, rows, src_rows = case
     _run(emu, np.random.default_rng(din * 7 + rows), din, L, act, out, rows, src_rows)
+
+
+@pytest.mark.parametrize("cap", [1, 2])
+@pytest.mark.parametrize("din,tiles", [(48, 7), (48, 6), (48, 5), (100, 2), (100, 3), (130, 3), (200, 4)])
+def test_workgroups_looping_over_many_tiles(emu, cap, din, tiles):
+    """Persistent loops: with the grid capped at 1 or 2 workgroups a workgroup processes several tiles, so the loaders'
+    in-flight chunk loads cross tile boundaries and the pipelines run through their steady state and every tail length
+    (number of pipeline iterations modulo the prefetch depth of 3)."""
+    emu.mappo_mlp_set_grid_cap(cap)
+    try:
+        rows = 128 * tiles - 37
+        _run(emu, np.random.default_rng(din + tiles), din, 2, 1, 3, rows, rows + 50)
+    finally:
+        emu.mappo_mlp_set_grid_cap(0)
 
 
 def test_unstandardised_input_and_identity_rows(emu):

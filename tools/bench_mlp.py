@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--din", type=int, nargs="+", default=[384, 48])
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--out", type=int, default=None)
+    ap.add_argument("--stamps", action="store_true", help="print shader-clock stamps of workgroup 0 (forward kernel)")
     opt = ap.parse_args()
     from onpolicy.algorithms.utils import fused_mlp
     from onpolicy.algorithms.utils.mlp import MLPBase
@@ -39,9 +40,9 @@ def main():
         head = torch.nn.Linear(64, out).to(dev)
         src_rows = opt.rows + 4096
         src = torch.randn(src_rows, din, device=dev)
-        stats = fused_mlp.row_stats(src)
+        xhat = fused_mlp.standardize_rows(src)
         idx = torch.randperm(src_rows, device=dev)[:opt.rows]
-        rs = fused_mlp.RowSource(src, stats, idx)
+        rs = fused_mlp.RowSource(xhat, idx, standardized=True)
         dy = torch.randn(opt.rows, out, device=dev)
 
         def timed(fn):
@@ -67,7 +68,27 @@ def main():
                 p.grad = None
             holder["y"].backward(dy, retain_graph=True)
 
-        t_stats = timed(lambda: fused_mlp.row_stats(src))
+        if opt.stamps:
+            from onpolicy import _native
+            dbg = torch.zeros(1024, dtype=torch.int64, device=dev)
+            with torch.no_grad():
+                fused_mlp.trunk_forward(base, rs, head)
+                _native.lib().mappo_mlp_set_debug(dbg.data_ptr())
+                fused_mlp.trunk_forward(base, rs, head)
+                torch.cuda.synchronize()
+                _native.lib().mappo_mlp_set_debug(None)
+            d = dbg.cpu().numpy()
+            comp = d[:240].reshape(60, 4)
+            load = d[256:256 + 240 + 16]
+            print("compute: j, wait_at_barrier, mfma, tail(to next iteration start)")
+            for j in range(24):
+                nxt = comp[j + 1][0] if j + 1 < 60 else 0
+                print(j, comp[j][1] - comp[j][0], comp[j][2] - comp[j][1], nxt - comp[j][2])
+            print("loader (every 3 iterations): after barrier -> store done, -> issue done, -> next barrier passed")
+            for j in range(0, 24, 3):
+                b = load[4 * j:4 * j + 12]
+                print(j, b[1] - b[0], b[2] - b[1], b[4] - b[2], "|", b[6] - b[4], b[8] - b[6], "|", b[10] - b[8])
+        t_stats = timed(lambda: fused_mlp.standardize_rows(src))
         t_f = timed(fwd)
         t_b = timed(bwd)
         R = opt.rows
@@ -75,7 +96,7 @@ def main():
         f_bwd = 2.0 * R * (din * 64 + 2 * 64 * 64 + 2 * 64 * out)
         b_fwd = R * (4 * din + 8 + 8 + 2 * 256 + 4 * out)
         b_bwd = R * (4 * din + 8 + 8 + 2 * 256 + 4 * out + 2 * 256 * (1 + max(1, -(-din // 384))))
-        rec = {"din": din, "out": out, "rows": R, "row_stats_ms": round(t_stats, 3),
+        rec = {"din": din, "out": out, "rows": R, "standardize_ms": round(t_stats, 3),
                "fwd_ms": round(t_f, 3), "fwd_tflops": round(f_fwd / t_f / 1e9, 1),
                "fwd_frac_mfma": round(f_fwd / t_f / 1e9 / PEAK_TF, 3), "fwd_gbs": round(b_fwd / t_f / 1e6, 1),
                "bwd_ms": round(t_b, 3), "bwd_tflops": round(f_bwd / t_b / 1e9, 1),

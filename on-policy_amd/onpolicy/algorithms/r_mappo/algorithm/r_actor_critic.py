@@ -17,6 +17,8 @@ from onpolicy.algorithms.utils.rnn import RNNLayer
 from onpolicy.algorithms.utils.act import ACTLayer
 from onpolicy.algorithms.utils.popart import PopArt
 from onpolicy.algorithms.utils.tall_linear import TallLinear
+from onpolicy.algorithms.utils import fused_mlp
+from onpolicy.algorithms.utils.fused_mlp import RowSource
 from onpolicy.utils.util import get_shape_from_obs_space
 
 
@@ -28,8 +30,13 @@ class _DeviceMixin(object):
     def _to_device(self, *xs):
         out = []
         for x in xs:
-            out.append(None if x is None else check(x).to(**self.tpdv))
+            # a RowSource (rows of the HBM buffer named by a sampler minibatch) is already on the device
+            out.append(x if (x is None or isinstance(x, RowSource)) else check(x).to(**self.tpdv))
         return out
+
+    def _fuses_head(self, x, head):
+        """The trunk AND this output Linear run as one fused kernel launch for input ``x`` (feed-forward nets)."""
+        return not self._recurrent and hasattr(self.base, "fuses") and self.base.fuses(x) and fused_mlp.head_supported(head)
 
 
 class R_Actor(nn.Module, _DeviceMixin):
@@ -82,8 +89,11 @@ class R_Actor(nn.Module, _DeviceMixin):
     def evaluate_logits(self, obs, rnn_states, masks, obs_standardized=False):
         """Raw outputs of the Discrete action head for the fused PPO loss (K7), [B, n_actions]."""
         obs, rnn_states, masks = self._to_device(obs, rnn_states, masks)
+        head = self.act.action_out.linear
+        if self._fuses_head(obs, head):
+            return self.base(obs, head=head)          # gather + trunk + head: one launch
         feats, _ = self._features(obs, rnn_states, masks, obs_standardized)
-        return self.act.action_out.linear(feats)
+        return head(feats)
 
 
 class R_Critic(nn.Module, _DeviceMixin):
@@ -112,6 +122,8 @@ class R_Critic(nn.Module, _DeviceMixin):
 
     def forward(self, cent_obs, rnn_states, masks, obs_standardized=False):
         cent_obs, rnn_states, masks = self._to_device(cent_obs, rnn_states, masks)
+        if self._fuses_head(cent_obs, self.v_out):
+            return self.base(cent_obs, head=self.v_out), rnn_states
         feats = self.base(cent_obs, standardized=True) if obs_standardized else self.base(cent_obs)
         if self._recurrent:
             feats, rnn_states = self.rnn(feats, rnn_states, masks)

@@ -29,6 +29,7 @@ from onpolicy.utils.valuenorm import ValueNorm
 from onpolicy.algorithms.utils.util import check
 from onpolicy.utils import dist as mdist
 from onpolicy.algorithms.utils import fused_loss
+from onpolicy.algorithms.utils.fused_mlp import RowSource
 
 
 class R_MAPPO():
@@ -163,7 +164,9 @@ class R_MAPPO():
         [lo, hi); recurrent ones ([L * mb, ...] sequence fields with row l * mb + j and [mb, ...] RNN states)
         into spans of whole chunks j in [lo, hi), every span keeping all L steps of its chunks."""
         rows = sample[10].shape[0] if sample[10] is not None else sample[5].shape[0]
-        widest = max(int(np.prod(t.shape[1:])) for t in (sample[0], sample[1]) if t is not None)
+        # a RowSource is never materialised by the fused trunk: what the networks write per row are 64-wide activations
+        widest = max((64 if isinstance(t, RowSource) else int(np.prod(t.shape[1:])))
+                     for t in (sample[0], sample[1]) if t is not None)
         cap = max(1, self.MAX_TENSOR_ELEMENTS // max(1, widest))
         recurrent = sample[2] is not None and sample[2].shape[0] != rows
         if rows <= cap:
@@ -227,6 +230,8 @@ class R_MAPPO():
             """The part of a minibatch tensor that belongs to span [lo, hi)."""
             if x is None or single:
                 return x
+            if isinstance(x, RowSource):
+                return x.rows_slice(lo, hi)
             if chunk_len is None or x.shape[0] == n_chunks:        # row spans / per-chunk RNN states
                 return x[lo:hi]
             tail = x.shape[1:]                                      # [L * mb, ...] with row l * mb + j
@@ -346,6 +351,19 @@ class R_MAPPO():
         means = sums.float()
         return means[2] * inv_local[1], means[0] * inv_local[0], means[1] * inv_local[0], means[3] / n_rows
 
+    def _fused_trunks(self, fold):
+        """Both networks' trunks qualify for the fused kernels (K9) and expect the kind of rows the sampler would hand
+        them (standardised iff the input LayerNorm is folded)."""
+        from onpolicy.algorithms.utils import fused_mlp
+        nets = (getattr(self.policy, "actor", None), getattr(self.policy, "critic", None))
+        if not fused_mlp.enabled() or torch.device(self.device).type != "cuda" or any(n is None for n in nets):
+            return False
+        for net in nets:
+            base = getattr(net, "base", None)
+            if base is None or not fused_mlp.trunk_supported(base) or bool(base._use_feature_normalization) != bool(fold):
+                return False
+        return True
+
     def _eval_kwargs(self):
         return {"obs_standardized": True} if self._obs_standardized else {}
 
@@ -388,6 +406,9 @@ class R_MAPPO():
             getattr(buffer, "can_standardize_obs", lambda: True)() and \
             hasattr(self.policy, "can_fold_input_norm") and self.policy.can_fold_input_norm()
         gen_kwargs = {"standardize_obs": True} if fold else {}
+        # ... and, where both trunks run through the fused hidden-64 kernels, not copy the rows at all
+        if getattr(buffer, "supports_lazy_obs", False) and self._fused_trunks(fold):
+            gen_kwargs["lazy_obs"] = True
 
         if hasattr(buffer, "plan_epochs"):
             buffer.plan_epochs(self.ppo_epoch)      # lets the sampler draw the next permutation ahead

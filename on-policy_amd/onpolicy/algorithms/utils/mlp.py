@@ -6,6 +6,7 @@ MLPBase :33), so reference checkpoints load and a given seed yields the same wei
 """
 import torch.nn as nn
 
+from . import fused_mlp
 from .fused_norm import FusedLayerNorm, DenseBlock
 from .tall_linear import TallLinear, tall_linear
 from .util import init
@@ -55,17 +56,32 @@ class MLPBase(nn.Module):
             self.feature_norm = FusedLayerNorm(obs_dim)
         self.mlp = MLPLayer(obs_dim, self.hidden_size, self._layer_N, self._use_orthogonal, self._use_ReLU)
 
+    def fuses(self, x):
+        """Whether ``forward(x)`` takes the fused-kernel route for this input."""
+        return isinstance(x, fused_mlp.RowSource) and fused_mlp.trunk_supported(self) \
+            and x.standardized == bool(self._use_feature_normalization) and x.shape[1] >= 4
+
     def can_fold_input_norm(self):
         """True if ``forward(x, standardized=True)`` is available: the input LayerNorm exists and its
         eps is the one the standardising gather uses."""
         return bool(self._use_feature_normalization) and abs(self.feature_norm.eps - 1e-5) < 1e-12
 
-    def forward(self, x, standardized=False):
-        """``standardized=True``: ``x`` already holds (x - mean) / sqrt(var + eps) per row (the sampler
+    def forward(self, x, standardized=False, head=None):
+        """``x`` may be a ``fused_mlp.RowSource`` (rows of the rollout buffer named by a sampler minibatch, not yet
+        gathered): the whole trunk -- and ``head``, an output Linear, when given -- then runs through the fused hidden-64
+        kernels (K9) if this trunk qualifies; otherwise the rows are gathered and evaluated as below.  ``head`` is only
+        applied on the fused route (callers check ``fuses(x)``).
+
+        ``standardized=True``: ``x`` already holds (x - mean) / sqrt(var + eps) per row (the sampler
         computed it while gathering).  The LayerNorm's affine half is then folded into the first
         Linear, LN(x) W^T + b = xhat (W * gamma)^T + (b + W beta): the same function of the same
         parameters (autograd reaches gamma / beta through the two tiny products), without ever
         materialising the normalised [rows, D] input or its gradient."""
+        if isinstance(x, fused_mlp.RowSource):
+            if self.fuses(x):
+                return fused_mlp.trunk_forward(self, x, head)
+            standardized = x.standardized
+            x = x.materialize()
         if not self._use_feature_normalization:
             return self.mlp(x)
         if not standardized:

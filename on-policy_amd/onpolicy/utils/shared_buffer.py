@@ -132,6 +132,7 @@ class SharedReplayBuffer(object):
         self._adv_sums = torch.zeros(3, dtype=torch.float64, device=dev)
         self._adv_stats = torch.zeros(2, **f32)
         self._content_version = 0  # bumped by every method that writes buffer fields
+        self._std_rows = {}        # field name -> (key, row-standardised copy) for the fused trunk kernels
         self._adv_fresh = False   # advantages/moments match the current returns & value_preds
         self._adv_denormalized = False   # ... and were formed as returns - D(value_preds)
         self._adv_is_gae = False         # ... or are the GAE accumulator of the MAT branches
@@ -539,9 +540,30 @@ class SharedReplayBuffer(object):
         self._records_key = key
         return self._records, rw, layout
 
-    def _gather(self, table, stats, idx, mb, chunk_len=None, standardize_obs=False, packed=None):
+    supports_lazy_obs = True           # generators take lazy_obs=True (see feed_forward_generator)
+
+    def _obs_rows(self, name, standardized):
+        """The [T*N*A, D] matrix the fused trunk kernels read the rows of field ``name`` from: the field itself (a view)
+        or, for networks with an input LayerNorm, its row-standardised copy -- made once per buffer content (the
+        observations do not change during the ppo epochs) by ``mappo_standardize_rows``."""
+        field = getattr(self, name)
+        T = self.episode_length
+        rows = field[:T].reshape(T * self.n_rollout_threads * self.num_agents, -1)
+        if not standardized:
+            return rows
+        key = (name, self._content_version, field._version)
+        hit = self._std_rows.get(name)
+        if hit is None or hit[0] != key:
+            from onpolicy.algorithms.utils import fused_mlp
+            hit = (key, fused_mlp.standardize_rows(rows))
+            self._std_rows[name] = hit
+        return hit[1]
+
+    def _gather(self, table, stats, idx, mb, chunk_len=None, standardize_obs=False, packed=None, lazy_obs=False):
         """One minibatch -> the 12-tuple of fresh device tensors: wide fields through the fused tile
-        gather / standardising gather (K3 / K4), narrow fields through one record gather."""
+        gather / standardising gather (K3 / K4), narrow fields through one record gather.  ``lazy_obs``: the two
+        observation fields are not gathered; their places hold ``RowSource`` objects (source matrix + this minibatch's
+        indices) for the fused trunk kernels, which read the rows straight from the buffer."""
         T, N, A = self.episode_length, self.n_rollout_threads, self.num_agents
         rows_out = mb if chunk_len is None else mb * chunk_len
         records, rw, layout = packed if packed is not None else (None, 0, {})
@@ -552,6 +574,11 @@ class SharedReplayBuffer(object):
                 continue
             tail = tuple(src.shape[3:])
             width = int(np.prod(tail)) if tail else 1
+            if lazy_obs and name in ("share_obs", "obs") and len(tail) == 1:
+                from onpolicy.algorithms.utils.fused_mlp import RowSource
+                chunk = None if chunk_len is None else (int(chunk_len), T, N, A)
+                outs.append(RowSource(self._obs_rows(name, standardize_obs), idx, chunk, standardized=standardize_obs))
+                continue
             if is_state and not self._recurrent:
                 outs.append(src[0, 0, 0].expand((mb,) + tail))  # zeros, no traffic
                 continue
@@ -591,7 +618,7 @@ class SharedReplayBuffer(object):
         return tuple(outs)
 
     def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None,
-                               standardize_obs=False):
+                               standardize_obs=False, lazy_obs=False):
         """Minibatches of independent (t, n, a) samples for MLP policies
         (reference shared_buffer.py:340-400).  Yields
         (share_obs, obs, rnn_states, rnn_states_critic, actions, value_preds, returns, masks,
@@ -600,7 +627,11 @@ class SharedReplayBuffer(object):
         ``standardize_obs=True`` (all three generators): share_obs / obs rows come out standardised,
         ``(x - mean(x)) / sqrt(var(x) + 1e-5)`` per row -- the parameter-free half of the networks'
         input LayerNorm, computed while the row is being copied.  The trainer asks for it when the
-        policy can fold the LayerNorm's affine half into its first Linear (MLPBase)."""
+        policy can fold the LayerNorm's affine half into its first Linear (MLPBase).
+
+        ``lazy_obs=True`` (all three generators; the trainer's private route): share_obs / obs come out as
+        ``fused_mlp.RowSource`` objects instead of gathered tensors -- the fused trunk kernels (K9) read the rows from the
+        buffer through the minibatch's indices, so the [mb, obs_dim] copies are never written."""
         T, N, A = self.episode_length, self.n_rollout_threads, self.num_agents
         batch_size = N * T * A
         if mini_batch_size is None:
@@ -615,9 +646,10 @@ class SharedReplayBuffer(object):
         packed = self._pack_records(table)
         for i in range(num_mini_batch):
             idx = rand[i * mini_batch_size:(i + 1) * mini_batch_size]
-            yield self._gather(table, stats, idx, mini_batch_size, standardize_obs=standardize_obs, packed=packed)
+            yield self._gather(table, stats, idx, mini_batch_size, standardize_obs=standardize_obs, packed=packed,
+                               lazy_obs=lazy_obs)
 
-    def recurrent_generator(self, advantages, num_mini_batch, data_chunk_length, standardize_obs=False):
+    def recurrent_generator(self, advantages, num_mini_batch, data_chunk_length, standardize_obs=False, lazy_obs=False):
         """Minibatches of length-L chunks for truncated BPTT (reference shared_buffer.py:499-608):
         sequence fields come out as [L*mb, dim] (row l*mb + j), RNN states as [mb, R, H] (chunk
         start only)."""
@@ -631,9 +663,9 @@ class SharedReplayBuffer(object):
         for i in range(num_mini_batch):
             idx = rand[i * mini_batch_size:(i + 1) * mini_batch_size]
             yield self._gather(table, stats, idx, mini_batch_size, chunk_len=data_chunk_length,
-                               standardize_obs=standardize_obs, packed=packed)
+                               standardize_obs=standardize_obs, packed=packed, lazy_obs=lazy_obs)
 
-    def naive_recurrent_generator(self, advantages, num_mini_batch, standardize_obs=False):
+    def naive_recurrent_generator(self, advantages, num_mini_batch, standardize_obs=False, lazy_obs=False):
         """Whole-trajectory minibatches (reference shared_buffer.py:402-497): a chunk gather with
         L = T over a permutation of the N*A trajectories."""
         T, N, A = self.episode_length, self.n_rollout_threads, self.num_agents
@@ -649,7 +681,7 @@ class SharedReplayBuffer(object):
         for start in range(0, batch_size, num_envs_per_batch):
             idx = perm[start:start + num_envs_per_batch]
             yield self._gather(table, stats, idx, idx.numel(), chunk_len=T, standardize_obs=standardize_obs,
-                               packed=packed)
+                               packed=packed, lazy_obs=lazy_obs)
 
     def feed_forward_generator_transformer(self, advantages, num_mini_batch=None, mini_batch_size=None):
         """Minibatches of whole (t, n) agent groups for the transformer policies (reference

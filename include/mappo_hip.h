@@ -344,6 +344,21 @@ int mappo_gru_step_fwd(const float* gi, const float* hm, const float* w_hh, cons
                        const float* mask_next, float* h_out, float* hm_next, float* ws, int64_t B, int H,
                        mappo_stream_t stream);
 
+/* --------------------------------------------------------------- K10: sort-free minibatch index lists ----
+ * Device-side replacement of `rand = torch.randperm(B); slices = [rand[i*mb:(i+1)*mb] for i in range(n_mb)]`
+ * (reference onpolicy/utils/shared_buffer.py:360-361 feed-forward, :415-416 whole trajectories, :511-512 chunks).
+ * Sample r belongs to slice perm(r) / mb, perm = a keyed bijection of [0, n) (6-round balanced Feistel network with
+ * cycle walking, keys[0..5] = 32-bit round keys drawn by the caller); samples with perm(r) >= n_mb * mb are dropped,
+ * as the reference drops the permutation's tail.  idx [n_mb * mb] int64 receives the slices back to back, every
+ * slice in ASCENDING sample order (a minibatch is a set: its loss does not depend on row order, and ascending order turns
+ * the gathers into monotonic walks over the buffer).  No sort, no n-sized temporary: workspace
+ * [mappo_minibatch_workspace_ints(n, n_mb)] int32.  n_mb <= MAPPO_PERM_MAX_MINIBATCHES.  The integer-parity mode of the
+ * samplers (--sampler_rng host) does not use this: it uploads the reference's CPU permutation unchanged. */
+#define MAPPO_PERM_MAX_MINIBATCHES 64
+int64_t mappo_minibatch_workspace_ints(int64_t n, int n_mb);
+int     mappo_minibatch_indices(int64_t n, int64_t mb, int n_mb, const uint32_t* keys, int64_t* idx, int32_t* workspace,
+                                mappo_stream_t stream);
+
 /* --------------------------------------------------------------- K9: fused hidden-64 trunk ----
  * The actor / critic network of the update as three kernels instead of ~25 launches per minibatch span: what
  * MLPBase + the output Linear compute (reference onpolicy/algorithms/utils/mlp.py:6-58: [LayerNorm(obs)] ->

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MAPPO_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libmappo_hip.so"))
 
 MAX_FIELDS = 16
+MAX_MINIBATCHES = 64        # MAPPO_PERM_MAX_MINIBATCHES
 GAE_USE_GAE, GAE_PROPER_TIME_LIMITS, GAE_DENORM = 1, 2, 4
 
 _vp = ctypes.c_void_p
@@ -88,6 +89,8 @@ SIGNATURES = {
     "mappo_gru_cell_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]),
     "mappo_gru_step_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]),
     "mappo_ppo_loss_f32": (_int, [ctypes.POINTER(PPOLoss), _vp]),
+    "mappo_minibatch_workspace_ints": (_i64, [_i64, _int]),
+    "mappo_minibatch_indices": (_int, [_i64, _i64, _int, _vp, _vp, _vp, _vp]),
     "mappo_mlp_forward": (_int, [ctypes.POINTER(MLP), _vp]),
     "mappo_mlp_backward": (_int, [ctypes.POINTER(MLP), _vp]),
     "mappo_mlp_grad_floats": (_i64, [_int, _int, _int]),

@@ -117,7 +117,7 @@ class SeparatedReplayBuffer(object):
             "to be greater than or equal to the number of "
             "data chunk length ({}).".format(N, T, L))
         assert data_chunks >= 2, ("need larger batch size")
-        rand = inner._randperm(data_chunks)
+        rand = inner._sampler_indices(data_chunks, mb, num_mini_batch)
         table, stats = inner._field_table(self._adv(advantages))
         packed = inner._pack_records(table)
         seq_table = [(name, None if is_state else src, is_state) for name, src, is_state in table]

@@ -19,6 +19,7 @@ constructor, attributes, methods and 12-tuple minibatch protocol, but
 There is no CPU implementation here: the constructor raises unless it gets a HIP device and
 ``libmappo_hip.so`` (see onpolicy/_native.py).
 """
+import ctypes
 import os
 
 import numpy as np
@@ -119,8 +120,6 @@ class SharedReplayBuffer(object):
         self.active_masks = torch.ones_like(self.masks)
 
         self.step = 0
-        self._prefetch_perms = self.device.type == "cuda" and os.environ.get("MAPPO_PREFETCH_PERM", "1") != "0"
-        self._perm_stream, self._perm_ready, self._perm_plan = None, {}, 0
         # optional extra per-sample fields ([T, N, A, k] tensors) that the samplers gather after the
         # 12 standard ones (the separated buffer's HAPPO ``factor`` is one)
         self.extra_fields = {}
@@ -410,36 +409,29 @@ class SharedReplayBuffer(object):
         return AdvantageHandle(self.advantages, self._adv_stats, self)
 
     # ------------------------------------------------------------------ samplers
-    def _randperm(self, n):
-        if self._sampler_rng == "host":
-            # the reference's draw (shared_buffer.py:360,415,511): CPU generator, then upload
-            return torch.randperm(n).to(self.device, non_blocking=True)
-        cur = torch.cuda.current_stream(self.device)
-        ready = self._perm_ready.pop(n, None)
-        if ready is None:
-            perm = torch.randperm(n, device=self.device)
-        else:
-            perm, done = ready
-            cur.wait_event(done)
-            perm.record_stream(cur)
-        # device draw: while more epochs are planned (plan_epochs), the radix-sort passes of the NEXT
-        # permutation run on a side stream during the current epoch instead of in front of the next one
-        self._perm_plan -= 1
-        if self._prefetch_perms and self._perm_plan > 0:
-            if self._perm_stream is None:
-                self._perm_stream = torch.cuda.Stream(device=self.device)
-            with torch.cuda.stream(self._perm_stream):
-                nxt = torch.randperm(n, device=self.device)
-                done = torch.cuda.Event()
-                done.record(self._perm_stream)
-            self._perm_ready = {n: (nxt, done)}       # at most one spare permutation is kept
-        return perm
+    def _sampler_indices(self, n, mb, n_mb):
+        """Index lists of ``n_mb`` minibatches of ``mb`` samples out of ``n``, back to back in one int64 device tensor
+        (minibatch i = ``[i * mb, (i + 1) * mb)``): what ``rand = torch.randperm(n)`` and its slices are to the reference
+        (shared_buffer.py:360-361, :511-512).
+
+        ``--sampler_rng host`` (integer parity): exactly that -- the CPU generator's permutation, uploaded.
+        ``device`` (default): K10, ``mappo_minibatch_indices`` -- a keyed bijection of [0, n) assigns every sample its
+        slice and each slice comes out in ascending memory order: no sort (the radix sort behind ``torch.randperm`` was
+        5 % of the north-star step), no random-order gathers.  The six round keys come from the CPU generator (no device
+        sync), so ``torch.manual_seed`` fixes the minibatches."""
+        if self._sampler_rng == "host" or n_mb > _native.MAX_MINIBATCHES or n_mb * mb > n or n_mb < 1 or mb < 1:
+            return torch.randperm(n).to(self.device, non_blocking=True) if self._sampler_rng == "host" \
+                else torch.randperm(n, device=self.device)
+        keys = torch.randint(0, 1 << 32, (6,), dtype=torch.int64).tolist()
+        idx = torch.empty(n_mb * mb, dtype=torch.int64, device=self.device)
+        ws = torch.empty(self._lib.mappo_minibatch_workspace_ints(n, n_mb), dtype=torch.int32, device=self.device)
+        _native.check(self._lib.mappo_minibatch_indices(n, mb, n_mb, (ctypes.c_uint32 * 6)(*keys), idx.data_ptr(),
+                                                        ws.data_ptr(), self._stream()), "mappo_minibatch_indices")
+        return idx
 
     def plan_epochs(self, n_epochs):
-        """The trainer announces how many sampler passes follow (``ppo_epoch``): all but the last draw
-        the next permutation ahead.  Nothing is drawn ahead without a plan, so no sort ever overlaps
-        work of the next rollout / ``compute_returns``."""
-        self._perm_plan = int(n_epochs)
+        """Kept for callers of the previous sampler (which drew the next permutation ahead on a side stream): the
+        device sampler no longer sorts, there is nothing to overlap."""
 
     def _field_table(self, advantages):
         """(name, source tensor whose rows are gathered, trailing shape, first_only, adv mode)."""
@@ -641,7 +633,7 @@ class SharedReplayBuffer(object):
                 "to be greater than or equal to the number of PPO mini batches ({})."
                 "".format(N, T, A, batch_size, num_mini_batch))
             mini_batch_size = batch_size // num_mini_batch
-        rand = self._randperm(batch_size)
+        rand = self._sampler_indices(batch_size, mini_batch_size, num_mini_batch)
         table, stats = self._field_table(advantages)
         packed = self._pack_records(table)
         for i in range(num_mini_batch):
@@ -657,7 +649,7 @@ class SharedReplayBuffer(object):
         batch_size = N * T * A
         data_chunks = batch_size // data_chunk_length
         mini_batch_size = data_chunks // num_mini_batch
-        rand = self._randperm(data_chunks)
+        rand = self._sampler_indices(data_chunks, mini_batch_size, num_mini_batch)
         table, stats = self._field_table(advantages)
         packed = self._pack_records(table)
         for i in range(num_mini_batch):
@@ -675,7 +667,11 @@ class SharedReplayBuffer(object):
             "to be greater than or equal to the number of "
             "PPO mini batches ({}).".format(N, A, num_mini_batch))
         num_envs_per_batch = batch_size // num_mini_batch
-        perm = self._randperm(batch_size)
+        if batch_size % num_envs_per_batch == 0:
+            perm = self._sampler_indices(batch_size, num_envs_per_batch, batch_size // num_envs_per_batch)
+        else:       # the reference's last, shorter slice (shared_buffer.py:417): a full permutation
+            perm = torch.randperm(batch_size).to(self.device) if self._sampler_rng == "host" \
+                else torch.randperm(batch_size, device=self.device)
         table, stats = self._field_table(advantages)
         packed = self._pack_records(table)
         for start in range(0, batch_size, num_envs_per_batch):
@@ -697,7 +693,7 @@ class SharedReplayBuffer(object):
                 "to be greater than or equal to the number of PPO mini batches ({})."
                 "".format(N, T, batch_size, num_mini_batch))
             mini_batch_size = batch_size // num_mini_batch
-        rand = self._randperm(batch_size)
+        rand = self._sampler_indices(batch_size, mini_batch_size, num_mini_batch)
         table, stats = self._field_table(advantages)
         packed = self._pack_records(table)
         agents = torch.arange(A, device=self.device)

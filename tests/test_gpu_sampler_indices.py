@@ -1,0 +1,117 @@
+"""-m gpu: K10, the sort-free device sampler (mappo_minibatch_indices): minibatch index lists from a keyed bijection of
+[0, n) instead of torch.randperm + slicing (reference onpolicy/utils/shared_buffer.py:360-361, :511-512).  Integer work:
+checked bit for bit against a numpy restatement of the same Feistel network, plus the properties a sampler needs
+(disjoint slices of exactly mb samples in ascending order, the right samples dropped, assignment that looks uniform
+and changes with the keys)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+M32 = 0xFFFFFFFF
+
+
+def _mix(r, k):
+    h = (r * 0x9E3779B1 + k) & M32
+    h ^= h >> 15
+    h = (h * 0x85EBCA6B) & M32
+    h ^= h >> 13
+    return h
+
+
+def _permute_ref(n, keys):
+    """perm(r) for r in [0, n): 6-round balanced Feistel on the next even power-of-two domain, cycle walking."""
+    bits = 2
+    while (1 << bits) < n:
+        bits += 2
+    half = bits // 2
+    mask = (1 << half) - 1
+    x = np.arange(n, dtype=np.uint64)
+    out = np.empty(n, dtype=np.uint64)
+    todo = np.arange(n)
+    while todo.size:
+        l = (x[todo] >> np.uint64(half)).astype(np.uint64)
+        r = (x[todo] & np.uint64(mask)).astype(np.uint64)
+        for k in keys:
+            t = l ^ (_mix(r, k) & np.uint64(mask))
+            l, r = r, t
+        y = (l << np.uint64(half)) | r
+        x[todo] = y
+        done = y < n
+        out[todo[done]] = y[done]
+        todo = todo[~done]
+    return out.astype(np.int64)
+
+
+def _indices(n, mb, n_mb, keys):
+    from onpolicy import _native
+    lib = _native.lib()
+    idx = torch.full((n_mb * mb,), -1, dtype=torch.int64, device=DEV)
+    ws = torch.empty(lib.mappo_minibatch_workspace_ints(n, n_mb), dtype=torch.int32, device=DEV)
+    _native.check(lib.mappo_minibatch_indices(n, mb, n_mb, (ctypes.c_uint32 * 6)(*keys), idx.data_ptr(), ws.data_ptr(),
+                                              None), "mappo_minibatch_indices")
+    torch.cuda.synchronize()
+    return idx.cpu().numpy()
+
+
+@pytest.mark.parametrize("n,mb,n_mb", [(1000, 1000, 1), (1000, 333, 3), (4097, 1024, 4), (75000, 7500, 10),
+                                       (300001, 9375, 32), (2048 * 3 + 5, 6149, 1), (17, 4, 4), (5, 1, 5)])
+def test_slices_equal_numpy_restatement(n, mb, n_mb):
+    keys = [int(k) for k in np.random.default_rng(n).integers(0, 1 << 32, 6)]
+    got = _indices(n, mb, n_mb, keys)
+    perm = _permute_ref(n, keys)
+    assert np.array_equal(np.sort(perm), np.arange(n))                      # the restatement is a bijection
+    for m in range(n_mb):
+        members = np.flatnonzero((perm >= m * mb) & (perm < (m + 1) * mb))    # ascending by construction
+        np.testing.assert_array_equal(got[m * mb:(m + 1) * mb], members)
+
+
+def test_large_batch_properties_and_key_dependence():
+    n, n_mb = 13_107_200, 4            # the north-star batch in four minibatches
+    mb = n // n_mb
+    a = _indices(n, mb, n_mb, [1, 2, 3, 4, 5, 6])
+    b = _indices(n, mb, n_mb, [7, 2, 3, 4, 5, 6])
+    for idx in (a, b):
+        assert np.array_equal(np.sort(idx), np.arange(n))                    # a partition of all samples
+        for m in range(n_mb):
+            s = idx[m * mb:(m + 1) * mb]
+            assert np.all(np.diff(s) > 0)                                     # ascending memory order
+    # assignment looks uniform: every minibatch takes about a quarter of any contiguous region of the buffer
+    region = a[:mb] < n // 8
+    assert abs(region.mean() - 1 / 8) < 2e-3
+    # and it changes with the keys: two draws share about 1/4 of a slice, like independent random partitions
+    overlap = np.intersect1d(a[:mb], b[:mb]).size / mb
+    assert 0.24 < overlap < 0.26
+
+
+def test_buffer_generators_use_the_device_sampler():
+    """feed_forward_generator / recurrent_generator in device mode: every minibatch ascending, the epoch a partition, a
+    different partition every epoch, reproducible under torch.manual_seed."""
+    from helpers import Box, Discrete, make_args
+    from onpolicy.utils.shared_buffer import SharedReplayBuffer
+    T, N, A = 12, 10, 3
+    args = make_args(episode_length=T, n_rollout_threads=N, data_chunk_length=4)
+    buf = SharedReplayBuffer(args, A, Box((6,)), Box((18,)), Discrete(5), device=DEV)
+    buf.obs.copy_(torch.arange((T + 1) * N * A * 6, device=DEV).float().reshape(buf.obs.shape))
+    adv = torch.zeros(T, N, A, 1, device=DEV)
+
+    def epoch():
+        rows = []
+        for sample in buf.feed_forward_generator(adv, num_mini_batch=3):
+            r = (sample[1][:, 0] / 6).long().cpu().numpy()      # obs row -> flat sample index
+            assert np.all(np.diff(r) > 0)
+            rows.append(r)
+        return rows
+    torch.manual_seed(3)
+    e1 = epoch()
+    e2 = epoch()
+    assert np.array_equal(np.sort(np.concatenate(e1)), np.arange(T * N * A))
+    assert not np.array_equal(e1[0], e2[0])
+    torch.manual_seed(3)
+    e3 = epoch()
+    assert all(np.array_equal(x, y) for x, y in zip(e1, e3))
+    chunks = [s[1].shape[0] for s in buf.recurrent_generator(adv, 2, 4)]
+    assert chunks == [T * N * A // 4 // 2 * 4] * 2

@@ -55,7 +55,14 @@ typedef void* mappo_stream_t; /* hipStream_t; NULL = the null stream */
  * rounds to float32 (shared_buffer.py:239), and so does this call.
  * Arithmetic is float32 in exactly the reference's operation order, with no FMA
  * contraction, so results are bit-identical to the numpy path given the same
- * (sigma, mu).
+ * (sigma, mu) -- with one exception: narrow buffers in the GAE modes (2048 <= C < 16384
+ * columns, 64 <= T <= 416) run a TIME-PARALLEL scan (the recurrence is affine in the
+ * accumulator, T is cut into 16 segments that are folded independently and stitched by
+ * composing their affine maps; the serial walk otherwise leaves such buffers at < 10 % of
+ * HBM bandwidth).  Inside a segment the operations are the reference's, the 15 segment
+ * boundaries carry a few ulp of re-association error: results agree to ~1e-6 relative, the
+ * "fp32 tolerance" of BASELINE.json's north star.  MAPPO_GAE_EXACT forces the bit-exact
+ * kernels for every shape.
  *
  *   rewards      [T,   C]  read
  *   value_preds  [T+1, C]  read; row T is first overwritten with next_value in the
@@ -78,6 +85,7 @@ typedef void* mappo_stream_t; /* hipStream_t; NULL = the null stream */
  */
 #define MAPPO_GAE_USE_GAE            1u
 #define MAPPO_GAE_PROPER_TIME_LIMITS 2u
+#define MAPPO_GAE_EXACT              8u   /* never take the time-parallel scan (see below): bit-identical results */
 #define MAPPO_GAE_DENORM             4u
 
 int mappo_gae_f32(const float* rewards, float* value_preds, const float* next_value,

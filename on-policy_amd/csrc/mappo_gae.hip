@@ -819,6 +819,153 @@ __global__ void __launch_bounds__(64) gae_column_kernel(GaeArgs a) {
 }
 
 // ------------------------------------------------------- K5: moments and stats ----
+// ------------------------------------------------------------------ time-parallel scan ----
+// Narrow buffers (C = N * A of a few thousand columns: cfg2, SMAC, one rank's shard of a data-parallel job) do not
+// have enough columns to hide a 200 .. 400-step serial walk: the strip kernels above sit on a ~40-60 us latency floor
+// whatever the byte count.  The recurrence g_t = delta_t + c_t * g_{t+1} is an affine map in g, and affine maps
+// compose: a segment [t0, t1) acts as g_{t0} = Q + P * g_{t1} with (P, Q) computable without knowing g_{t1}.
+// A workgroup takes 32 columns x all T steps; T is cut into 16 segments, one per half-wave (8 waves x 2).  Every lane
+//   1. loads ITS segment of ITS column into registers -- all loads of the tile are in flight at once, the memory
+//      system sees the whole problem instead of one time step after the other;
+//   2. folds the segment into (P, Q) walking backwards;
+//   3. after one barrier composes the (P, Q) of the later segments (<= 15 fused multiply-adds) into its incoming g;
+//   4. walks its segment again -- now with the true incoming g and the REFERENCE's operation order (gae_step) --
+//      writing returns / advantages / moments.
+// Only the 15 segment-boundary values carry the re-association error of step 3 (a few ulp); everything inside a segment
+// is the bit-exact recurrence started from them.  Hence "tolerance mode": results agree with the reference to ~1e-6
+// relative instead of bit for bit, which is what BASELINE.json's north star asks of returns / advantages.  Selected for
+// 2048 <= C < 16384 (wide buffers keep the bit-exact strip kernels; MAPPO_GAE_EXACT forces them everywhere).
+constexpr int kScanSegs = 16;
+constexpr int kScanLmax = 26;      // steps per segment held in registers: T <= 416
+
+// W columns per workgroup, 64 / W segments per wave: W = 16 -> 4 waves, 64-byte row pieces, C / 16 workgroups;
+// W = 32 -> 8 waves, 128-byte pieces; W = 64 -> 16 waves, 256-byte pieces
+template <int W, bool PTL, bool DENORM, bool ACT>
+__global__ void __launch_bounds__(W * kScanSegs) gae_scan_kernel(GaeArgs a) {
+    constexpr int kScanCols = W;
+    constexpr int NWAVES = W * kScanSegs / 64;
+    __shared__ float PQ[kScanSegs][kScanCols][2];
+    __shared__ double red[NWAVES][3];
+    const long long C = a.C;
+    const int T = a.T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & (W - 1), seg = (64 / W) * wave + lane / W;
+    long long col = (long long)blockIdx.x * kScanCols + c;
+    const bool live = col < C;
+    if (!live) col = C - 1;
+    const int Ls = (T + kScanSegs - 1) / kScanSegs;
+    const int t0 = seg * Ls;
+    int n = T - t0;
+    if (n > Ls) n = Ls;
+    if (n < 0) n = 0;
+    const bool has_adv = a.adv != nullptr;
+    float sigma = 1.f, mu = 0.f;
+    if (DENORM) {
+        sigma = a.denorm[0];
+        mu = a.denorm[1];
+    }
+    const float gamma = a.gamma, gl = a.gl;
+
+    // ---- 1. the whole segment into registers
+    float r[kScanLmax], v0[kScanLmax], m1[kScanLmax], bad1[kScanLmax], am[kScanLmax];
+    const float nv = a.next_value[col];
+#pragma unroll
+    for (int i = 0; i < kScanLmax; ++i) {
+        const int t = t0 + (i < n ? i : 0);
+        const long long o = (long long)(t < T ? t : 0) * C + col;
+        r[i] = a.rewards[o];
+        v0[i] = a.value_preds[o];
+        m1[i] = a.masks[o + C];
+        bad1[i] = PTL ? a.bad[o + C] : 1.f;
+        am[i] = ACT ? a.active[o] : 1.f;
+    }
+    // D(v) of the step after the segment (the bootstrap value for the last one)
+    float vend = nv;
+    if (t0 + n < T) vend = a.value_preds[(long long)(t0 + n) * C + col];
+    float dvend = vend;
+    if (DENORM) {
+        const float s = vend * sigma;
+        dvend = s + mu;
+    }
+    if (seg == 0 && live) a.value_preds[(long long)T * C + col] = nv;      // shared_buffer.py:187,218
+
+    // ---- 2. (P, Q) of the segment
+    float P = 1.f, Q = 0.f;
+    {
+        float dv1 = dvend;
+#pragma unroll
+        for (int i = kScanLmax - 1; i >= 0; --i) {
+            if (i < n) {
+                float dv0 = v0[i];
+                if (DENORM) {
+                    const float s = v0[i] * sigma;
+                    dv0 = s + mu;
+                }
+                const float delta = (r[i] + (gamma * dv1) * m1[i]) - dv0;
+                float cc = gl * m1[i];
+                float dd = delta;
+                if (PTL) {
+                    cc *= bad1[i];
+                    dd *= bad1[i];
+                }
+                Q = dd + cc * Q;
+                P = cc * P;
+                dv1 = dv0;
+            }
+        }
+    }
+    PQ[seg][c][0] = P;
+    PQ[seg][c][1] = Q;
+    __syncthreads();
+    // ---- 3. incoming g: the later segments composed from the end (g_T = 0)
+    float g = 0.f;
+    for (int s2 = kScanSegs - 1; s2 > seg; --s2) g = PQ[s2][c][1] + PQ[s2][c][0] * g;
+
+    // ---- 4. the segment again, reference operation order
+    double s1 = 0.0, sq = 0.0, cnt = 0.0;
+    {
+        float dv1 = dvend;
+#pragma unroll
+        for (int i = kScanLmax - 1; i >= 0; --i) {
+            if (i < n) {
+                float dv0;
+                const float ret = gae_step<PTL, DENORM>(r[i], v0[i], m1[i], bad1[i], sigma, mu, gamma, gl, dv1, g, dv0);
+                if (live) {
+                    const long long o = (long long)(t0 + i) * C + col;
+                    a.returns[o] = ret;
+                    if (has_adv) {
+                        const float adv = ret - dv0;
+                        a.adv[o] = adv;
+                        if (am[i] != 0.f) {
+                            const double d = (double)adv;
+                            s1 += d;
+                            sq += d * d;
+                            cnt += 1.0;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    zero_unowned_partials(a.partials, a.partial_rows);
+    if (a.partials != nullptr) {
+        s1 = wave_sum(s1);
+        sq = wave_sum(sq);
+        cnt = wave_sum(cnt);
+        if (lane == 0) {
+            red[wave][0] = s1;
+            red[wave][1] = sq;
+            red[wave][2] = cnt;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            double t = 0.0;
+            for (int w = 0; w < NWAVES; ++w) t += red[w][threadIdx.x];
+            a.partials[(long long)blockIdx.x * 3 + threadIdx.x] = t;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) adv_reduce_kernel(const double* partials, long long rows,
                                                           double* sums) {
     __shared__ double sh[3][256];
@@ -907,6 +1054,22 @@ __global__ void __launch_bounds__(256) advantages_kernel(const float* ret, const
 }
 
 int g_variant = 0;
+
+template <int W>
+hipError_t launch_scan(const GaeArgs& a, unsigned flags, hipStream_t stream) {
+    const bool ptl = flags & MAPPO_GAE_PROPER_TIME_LIMITS, dn = flags & MAPPO_GAE_DENORM, act = a.active != nullptr;
+    const dim3 grid((unsigned)((a.C + W - 1) / W)), block(W * kScanSegs);
+#define MAPPO_SCAN_CASE(P_, D_, A_)                                                               \
+    if (ptl == P_ && dn == D_ && act == A_) {                                                     \
+        hipLaunchKernelGGL((gae_scan_kernel<W, P_, D_, A_>), grid, block, 0, stream, a);          \
+        return hipGetLastError();                                                                 \
+    }
+    MAPPO_SCAN_CASE(false, false, false) MAPPO_SCAN_CASE(false, false, true) MAPPO_SCAN_CASE(false, true, false)
+    MAPPO_SCAN_CASE(false, true, true) MAPPO_SCAN_CASE(true, false, false) MAPPO_SCAN_CASE(true, false, true)
+    MAPPO_SCAN_CASE(true, true, false) MAPPO_SCAN_CASE(true, true, true)
+#undef MAPPO_SCAN_CASE
+    return hipErrorInvalidValue;
+}
 
 #define MAPPO_DISPATCH_FLAGS(KERNEL, ...)                                                        \
     do {                                                                                         \
@@ -1158,7 +1321,7 @@ extern "C" int mappo_gae_f32(const float* rewards, float* value_preds, const flo
     if (!rewards || !value_preds || !next_value || !masks || !returns) return MAPPO_E_NULL;
     if ((flags & MAPPO_GAE_PROPER_TIME_LIMITS) && !bad_masks) return MAPPO_E_NULL;
     if ((flags & MAPPO_GAE_DENORM) && !denorm) return MAPPO_E_NULL;
-    if (flags & ~7u) return MAPPO_E_FLAGS;
+    if (flags & ~15u) return MAPPO_E_FLAGS;
     if (T <= 0 || C <= 0) return MAPPO_E_SHAPE;
     if (adv_partials && !advantages) return MAPPO_E_NULL;
     if (active_masks && !advantages) return MAPPO_E_NULL;
@@ -1190,6 +1353,10 @@ extern "C" int mappo_gae_f32(const float* rewards, float* value_preds, const flo
     int variant = g_variant % 1000;
     a.opts = g_variant / 1000;
     if (!strip_ok) variant = 99;
+    // narrow buffers: the time-parallel scan (tolerance mode) unless the caller insists on bit-exact results
+    const bool scan_ok = strip_ok && T <= kScanSegs * kScanLmax && (!a.partials || a.partial_rows >= (C + 31) / 32);
+    if (variant >= 70 && variant <= 72 && !scan_ok) variant = 0;
+    if (variant == 0 && scan_ok && !(flags & MAPPO_GAE_EXACT) && C >= 2048 && C < 16384 && T >= 64) variant = 70;
     if (variant == 0) {
         // LDS-DMA ring kernel; strip width by column count so that >= 256 workgroups exist;
         // XCD-contiguous strip order + non-temporal DMA (measured best on cold data)
@@ -1214,6 +1381,9 @@ extern "C" int mappo_gae_f32(const float* rewards, float* value_preds, const flo
         case 54: e = launch_dma_epi<64, 2, 16, 4>(a, flags, stream); break;
         case 56: e = launch_dma_epi<32, 2, 16, 4>(a, flags, stream); break;
         case 57: e = launch_dma_epi<128, 6, 12, 4>(a, flags, stream); break;
+        case 70: e = launch_scan<32>(a, flags, stream); break;
+        case 71: e = launch_scan<64>(a, flags, stream); break;
+        case 72: e = launch_scan<16>(a, flags, stream); break;
         default: e = launch_column(a, flags, stream); break;
     }
     return (int)e;

@@ -27,6 +27,8 @@
 #ifndef MAPPO_MLP_IMPL_H
 #define MAPPO_MLP_IMPL_H
 
+#include <stdlib.h>
+
 #include "../../include/mappo_hip.h"
 
 namespace mlp {
@@ -312,6 +314,7 @@ struct FwdArgs {
     float* z[3];        // saved normalised activations [rows, 64] per layer (NULL: inference)
     float* st[3];       // saved {mean, rstd} [rows, 2] per layer
     long long* dbg;     // tuning hook (mappo_mlp_set_debug): cycle stamps of workgroup 0's first iterations, or NULL
+    int probe;          // tuning hook (MAPPO_MLP_PROBE): 1 = loaders skip the row loads, 2 = skip the weight loads (timing only)
 };
 
 // Workgroup = 4 compute waves (one per SIMD: MFMA + the layer tails of 32 rows each) + 4 loader waves that do nothing
@@ -377,13 +380,18 @@ __global__ void __launch_bounds__(kPipeThreads) mlp_fwd_kernel(FwdArgs a) {
             const int k = it_kc * kKC + 4 * xq, kk = piece_at(k, din);
             B.sft = k - kk;
             const i4 lo = B.rlo, hi = B.rhi;
+            if (!(a.probe & 1)) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                B.xv[p] = *reinterpret_cast<const v4u*>(a.rs.src + (long long)lo[p] * din + kk);
-                B.xv[4 + p] = *reinterpret_cast<const v4u*>(a.rs.src + (long long)hi[p] * din + kk);
+                for (int p = 0; p < 4; ++p) {
+                    B.xv[p] = *reinterpret_cast<const v4u*>(a.rs.src + (long long)lo[p] * din + kk);
+                    B.xv[4 + p] = *reinterpret_cast<const v4u*>(a.rs.src + (long long)hi[p] * din + kk);
+                }
             }
+            if (!(a.probe & 2)) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) B.wv[p] = *reinterpret_cast<const v4u*>(n.w1 + (long long)(xg + 16 * p) * din + kk);
+                for (int p = 0; p < 4; ++p)
+                    B.wv[p] = *reinterpret_cast<const v4u*>(n.w1 + (long long)(xg + 16 * p) * din + kk);
+            }
             fetch_rows(ft_tile, B);
             advance(it_tile, it_kc);
             advance(ft_tile, ft_kc);
@@ -1121,6 +1129,14 @@ inline int& grid_cap_override() {
     static int cap = 0;
     return cap;
 }
+inline int probe_flags() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MAPPO_MLP_PROBE");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
 inline long long*& debug_buffer() {
     static long long* p = nullptr;
     return p;
@@ -1137,6 +1153,7 @@ inline int forward(const mappo_mlp_t* m, hipStream_t stream) {
     if (!m->y) return MAPPO_E_NULL;
     a.y = m->y;
     a.dbg = debug_buffer();
+    a.probe = probe_flags();
     for (int l = 0; l < 3; ++l) {
         a.z[l] = l < m->n_layers ? m->z[l] : nullptr;
         a.st[l] = l < m->n_layers ? m->ln_stats[l] : nullptr;

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MAPPO_HIP_LIB", os.path.join(os.path.dirname(_HERE), 
 
 MAX_FIELDS = 16
 MAX_MINIBATCHES = 64        # MAPPO_PERM_MAX_MINIBATCHES
-GAE_USE_GAE, GAE_PROPER_TIME_LIMITS, GAE_DENORM = 1, 2, 4
+GAE_USE_GAE, GAE_PROPER_TIME_LIMITS, GAE_DENORM, GAE_EXACT = 1, 2, 4, 8
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64

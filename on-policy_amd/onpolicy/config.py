@@ -108,6 +108,9 @@ _NEW_FLAGS = [
     # 'device': minibatch permutations from the GPU generator (fast);
     # 'host': torch.randperm on the CPU generator, bit-identical index streams to the reference
     ("sampler_rng", str, "device", ["device", "host"]),
+    # bit-identical GAE returns for every buffer shape (default: narrow buffers, 2048 <= N * A < 16384, take the
+    # time-parallel scan, which agrees with the reference to ~1e-6 relative; see include/mappo_hip.h K1)
+    ("gae_exact", ON, False),
 ]
 
 

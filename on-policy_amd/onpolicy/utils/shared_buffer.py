@@ -73,6 +73,9 @@ class SharedReplayBuffer(object):
         self._recurrent = bool(getattr(args, "use_recurrent_policy", False) or
                                getattr(args, "use_naive_recurrent_policy", False))
         self._sampler_rng = getattr(args, "sampler_rng", "device")
+        # --gae_exact (or MAPPO_GAE_EXACT=1): bit-identical returns for every buffer shape; by default narrow buffers
+        # (2048 <= N * A < 16384) take the time-parallel GAE scan, which agrees with the reference to ~1e-6 relative
+        self._gae_exact = bool(getattr(args, "gae_exact", False)) or os.environ.get("MAPPO_GAE_EXACT", "0") == "1"
 
         self.device = dev = self._resolve_device(args, device)
         self._lib = _native.lib()  # raises if the HIP library is not built
@@ -312,6 +315,8 @@ class SharedReplayBuffer(object):
             flags |= _native.GAE_PROPER_TIME_LIMITS
         if denorm is not None:
             flags |= _native.GAE_DENORM
+        if self._gae_exact:
+            flags |= _native.GAE_EXACT
         return flags
 
     def compute_returns(self, next_value, value_normalizer=None, _scan_denorm=True):

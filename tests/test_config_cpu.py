@@ -7,7 +7,7 @@ import os
 from conftest import GOLD
 from onpolicy.config import get_config
 
-OURS_ONLY = {"buffer_device", "sampler_rng"}
+OURS_ONLY = {"buffer_device", "sampler_rng", "gae_exact"}
 
 
 def _describe(parser):

@@ -785,3 +785,41 @@ def test_storage_vs_reference_fixtures(gold, kind, mode):
     assert buf.step == int(z["%s_%s_step" % (kind, mode)])
     for name in STORED:
         np.testing.assert_array_equal(getattr(buf, name).cpu().numpy(), z["%s_%s_%s" % (kind, mode, name)], err_msg=name)
+
+
+# ------------------------------------------------------------------ K1: time-parallel scan for narrow buffers
+@pytest.mark.parametrize("T,N,A,ptl,norm", [(200, 1024, 5, False, True), (400, 512, 10, True, True),
+                                            (400, 512, 8, False, False), (100, 2048, 2, True, False),
+                                            (64, 1024, 3, False, True), (397, 700, 4, False, True)])
+def test_gae_time_parallel_scan_vs_oracle(T, N, A, ptl, norm):
+    """Narrow buffers (2048 <= N * A < 16384 columns) take the time-parallel scan (csrc/mappo_gae.hip gae_scan_kernel):
+    16 segments folded independently and stitched through their affine maps.  Tolerance mode -- rtol 1e-5 against the
+    oracle (the north star's "fp32 tolerance for returns / advantages"; measured ~1e-6), moments 2e-6; ``gae_exact``
+    switches back to the bit-identical kernels for the same shape."""
+    C = N * A
+    assert 2048 <= C < 16384
+    rng = np.random.default_rng(T + C)
+    arrays = fill_buffer_arrays(buffer_shapes(T, N, A, 3, 4, 5, 8), rng, na=5)
+    triplet = [0.7e-4, 3.1e-4, 2.5e-5] if norm else None
+    kw = dict(episode_length=T, n_rollout_threads=N, use_proper_time_limits=ptl, use_valuenorm=norm, hidden_size=8)
+    ob = oracle.OracleBuffer(make_args(**kw), A, Box((3,)), Box((4,)), Discrete(5))
+    load_into(ob, arrays)
+    ob.compute_returns(arrays["next_value"], _vn(triplet) if norm else None)
+    ref = ob.returns
+    stats_exact = None
+    for exact in (True, False):
+        buf = _buffer(make_args(gae_exact=exact, **kw), A)
+        load_into(buf, arrays)
+        vn = _vn(triplet) if norm else None
+        buf.compute_returns(arrays["next_value"], vn)
+        got = buf.returns.cpu().numpy()
+        np.testing.assert_array_equal(buf.value_preds[-1].cpu().numpy(), arrays["next_value"])
+        stats = buf.normalized_advantages(vn).stats.cpu().numpy()
+        if exact:
+            np.testing.assert_array_equal(got, ref)
+            stats_exact = stats
+        else:
+            scale = np.abs(ref).max()
+            np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5 * scale)
+            assert not np.array_equal(got, ref)                  # it really is the other kernel
+            np.testing.assert_allclose(stats, stats_exact, rtol=5e-5)     # advantage mean / std from the fused moments

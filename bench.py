@@ -36,6 +36,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32 MFMA peak (v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md); no xf32 / tf32 on gfx950
 
 WORKLOADS = {
     # north star: simple_spread generalised to 8 agents, flags of train_mpe_spread.sh
@@ -264,6 +265,8 @@ def main():
     for _ in range(opt.warmup):
         step()
     buf.profile_kernels(True)
+    from onpolicy.algorithms.utils import fused_mlp
+    fused_mlp.profile(True)
     trainer.dp.time_collectives(True)
     fence()
     t0 = time.perf_counter()
@@ -272,6 +275,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kt = buf.kernel_times()
+    mt = fused_mlp.profile_times()
     n_coll, coll_ms, coll_bytes = trainer.dp.collective_times()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -287,8 +291,12 @@ def main():
             2 x FETCH_SIZE + WRITE_SIZE, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950) --
             only quoted when the profiled launch had the same algorithmic byte count."""
             try:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
-                    rec = json.load(f).get(name)
+                rec = None
+                for fn in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+                    path = os.path.join(ROOT, "profiles", fn)
+                    if rec is None and os.path.exists(path):
+                        with open(path) as f:
+                            rec = json.load(f).get(name)
                 if rec and abs(rec["algorithmic_bytes"] - nbytes) <= 0.01 * nbytes:
                     return rec["hbm_bytes"]
             except Exception:
@@ -305,6 +313,23 @@ def main():
                     "traffic_source": "committed rocprofv3 PMC passes (profiles/r01_pmc_summary.json), not this run",
                     "launch_ms": round(ms, 5), "launches": launches, "algorithmic_bytes": int(nbytes)}
 
+        def roof_mfma(name, what):
+            """K9 launches (the fused trunk): achieved = algorithmic FLOPs of the launches / their time on the launch
+            stream, against the dense f32 MFMA peak -- these kernels are matrix-core bound, not HBM bound (their
+            algorithmic HBM bytes per launch are quoted as `hbm_gbs` for comparison)."""
+            if name not in mt:
+                return None
+            launches, ms, flops, nbytes = mt[name]
+            tf = flops / launches / (ms * 1e-3) / 1e12
+            return {"kernel": what, "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                    "traffic": pmc_traffic(name, nbytes / launches), "traffic_source":
+                    "committed rocprofv3 PMC passes (profiles/r02_pmc_summary.json), not this run",
+                    "launch_ms": round(ms, 4), "launches": launches, "flop_per_launch": int(flops / launches),
+                    "algorithmic_bytes": int(nbytes / launches),
+                    "hbm_gbs": round(nbytes / launches / (ms * 1e-3) / 1e9, 1),
+                    "share_of_step": round(launches * ms / opt.steps / ms_per_step, 3)}
+
         out = {
             # BASELINE.json's metric (quoted on the north star); other workloads name their own shape
             "metric": "env-steps/sec through GAE+ppo_update, %d threads×%d agents×%d steps" % (wl["N"], wl["A"], wl["T"]),
@@ -320,7 +345,13 @@ def main():
             "rccl_ranks": world if dist.is_initialized() and dist.get_backend() == "nccl" else 0,
             "grad_allreduce": {"per_step": n_coll // max(1, opt.steps), "bucket_bytes": coll_bytes,
                                "ms_per_step": round(coll_ms / max(1, opt.steps), 4)},
-            "roofline": roof("mappo_gae_f32"),
+            # the dominant kernel of the step: the fused trunk's forward launch (mlp_fwd_kernel; actor and critic
+            # launches averaged, as rocprofv3 --stats averages them), f32 matrix-core bound
+            "roofline": roof_mfma("mappo_mlp_forward", "mlp_fwd_kernel (mappo_mlp_forward)") or roof("mappo_gae_f32"),
+            "roofline_mlp_backward": roof_mfma("mappo_mlp_backward",
+                                               "mlp_bwd_kernel + mlp_dw1_kernel + reduce (mappo_mlp_backward)"),
+            # the kernel BASELINE.json's north star names (>= 70 % of HBM in the GAE scan), HBM bound
+            "roofline_gae": roof("mappo_gae_f32"),
             "roofline_gather": roof("mappo_gather_chunks" if wl["recurrent"] else "mappo_gather_rows"),
             "train_info": {k: round(float(v), 6) for k, v in info.items()},
         }

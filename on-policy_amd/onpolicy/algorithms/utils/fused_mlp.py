@@ -31,6 +31,53 @@ def enabled():
     return os.environ.get("MAPPO_FUSED_MLP", "1") != "0"
 
 
+# ---- launch timing (bench.py): HIP events on the launch stream around every K9 call while profiling is on
+_PROFILE = None
+
+
+def profile(on=True):
+    """Start (or stop) recording an event pair + the algorithmic FLOPs / bytes of every fused-trunk launch."""
+    global _PROFILE
+    _PROFILE = {} if on else None
+
+
+def profile_times():
+    """-> {name: (launches, mean milliseconds, total FLOPs, total algorithmic HBM bytes)}; the caller has synchronised."""
+    out = {}
+    for name, recs in (_PROFILE or {}).items():
+        ms = sum(a.elapsed_time(b) for a, b, _, _ in recs)
+        out[name] = (len(recs), ms / max(1, len(recs)), sum(f for _, _, f, _ in recs), sum(b for _, _, _, b in recs))
+    return out
+
+
+class _Timed(object):
+    def __init__(self, name, flops, nbytes):
+        self.rec = None
+        if _PROFILE is not None:
+            self.rec = (name, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), flops, nbytes)
+
+    def __enter__(self):
+        if self.rec:
+            self.rec[1].record()
+
+    def __exit__(self, *exc):
+        if self.rec:
+            self.rec[2].record()
+            _PROFILE.setdefault(self.rec[0], []).append(self.rec[1:])
+
+
+def _work(rows, din, n_layers, out, backward):
+    """Algorithmic FLOPs and HBM bytes of one launch: forward = every Linear once; backward = first-layer weight
+    gradient, weight + input gradient of the hidden layers and of the head.  Bytes: the observation row (once forward,
+    once more for the weight gradient), the saved activations / statistics, the head's output / its gradient, the
+    first-layer gradient round trip through HBM."""
+    lin = din * 64 + (n_layers - 1) * 64 * 64 + 64 * out
+    if not backward:
+        return 2.0 * rows * lin, rows * (4 * din + 4 + n_layers * (256 + 8) + 4 * max(out, 64 if out == 0 else out))
+    flops = 2.0 * rows * (din * 64 + 2 * (n_layers - 1) * 64 * 64 + 2 * 64 * out)
+    return flops, rows * (4 * din + 4 + n_layers * (256 + 8) + 4 * max(out, 64 if out == 0 else out) + 2 * 256)
+
+
 class RowSource(object):
     """Rows of a 2-D source matrix selected by a sampler minibatch, not yet gathered.
 
@@ -159,7 +206,8 @@ class _FusedTrunkFn(torch.autograd.Function):
                 m.z[l] = zbuf[l].data_ptr()
                 m.ln_stats[l] = sbuf[l].data_ptr()
             zs = [zbuf, sbuf]
-        _native.check(lib.mappo_mlp_forward(m, _native.stream_of(dev)), "mappo_mlp_forward")
+        with _Timed("mappo_mlp_forward", *_work(rows, int(rs.src.shape[1]), n_layers, out, False)):
+            _native.check(lib.mappo_mlp_forward(m, _native.stream_of(dev)), "mappo_mlp_forward")
         ctx.rs, ctx.cfg = rs, (act, eps, n_layers, out)
         ctx.save_for_backward(*(zs + [tab] + params))
         return y
@@ -185,7 +233,8 @@ class _FusedTrunkFn(torch.autograd.Function):
         ws = torch.empty(lib.mappo_mlp_workspace_floats(din, n_layers, out), dtype=torch.float32, device=dev)
         dz1 = torch.empty((rs.rows, HIDDEN), dtype=torch.float32, device=dev)
         m.dy, m.dz1, m.workspace, m.grads = dy.data_ptr(), dz1.data_ptr(), ws.data_ptr(), grads.data_ptr()
-        _native.check(lib.mappo_mlp_backward(m, _native.stream_of(dev)), "mappo_mlp_backward")
+        with _Timed("mappo_mlp_backward", *_work(rs.rows, din, n_layers, out, True)):
+            _native.check(lib.mappo_mlp_backward(m, _native.stream_of(dev)), "mappo_mlp_backward")
         return (None, None, None, None, None) + tuple(_split_grads(grads, din, n_layers, out))
 
 

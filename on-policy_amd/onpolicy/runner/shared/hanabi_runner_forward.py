@@ -4,15 +4,21 @@ train :222, eval :229).
 
 Hanabi is turn based: within one buffer "step" the agents act one after the other, only the envs
 whose current player has a legal move take part (``choose``), and a reward arrives only after the
-*other* players have moved.  That bookkeeping is per-environment host logic and stays in numpy (the
-``turn_*`` arrays, one row per rollout thread); what goes through the HBM path is
+*other* players have moved.  The reference keeps that bookkeeping in a dozen numpy arrays shaped like
+a buffer row and re-uploads all of them with every ``chooseinsert``.  Here the turn state lives on the
+policy's device (``_TurnState``: one tensor per buffer field, [N, A, ...]):
 
-  * ``buffer.chooseinsert`` / ``chooseafter_update`` (fused slab writes),
-  * the in-buffer reward shift before each update (reference :59-63) as device copies,
-  * ``compute`` (GAE kernel) and ``train`` (fused samplers + PPO update).
+  * per player move the only host -> device traffic is what the env just produced -- the movers'
+    observation / centralised observation / legal-move rows, the rewards and the done flags -- packed
+    into one page-locked staging buffer and sent as ONE asynchronous copy (``_HostStage``);
+  * the policy's outputs never leave the device except the action indices the env needs;
+  * the reference's masked numpy assignments become ``index_put`` / ``where`` updates of the turn
+    tensors (no boolean-mask indexing on the device: that would synchronise);
+  * ``chooseinsert`` then is a device-to-device slab write (K2), the reward shift before each update
+    (reference :59-63) device copies, ``compute`` / ``train`` the GAE kernel and the fused update.
 
-The turn state is kept in one small container instead of twelve attributes; the control flow and
-the order of the env calls are the reference's.
+The host keeps what decides control flow: the legal-move table (who moves), the done flags (which
+games reset) and the scores.  Control flow and the order of the env calls are the reference's.
 """
 import time
 
@@ -23,11 +29,11 @@ from onpolicy.runner.shared.base_runner import Runner, _t2n
 
 
 class _TurnState(object):
-    """Per-thread data of the turn in progress, shaped like one buffer row [N, A, ...]."""
+    """Per-thread data of the turn in progress, shaped like one buffer row [N, A, ...], on ``device``."""
 
-    def __init__(self, n, buffer):
-        z = lambda t: np.zeros((n,) + tuple(t.shape[2:]), dtype=np.float32)
-        o = lambda t: np.ones((n,) + tuple(t.shape[2:]), dtype=np.float32)
+    def __init__(self, n, buffer, device):
+        z = lambda t: torch.zeros((n,) + tuple(t.shape[2:]), dtype=torch.float32, device=device)
+        o = lambda t: torch.ones((n,) + tuple(t.shape[2:]), dtype=torch.float32, device=device)
         self.obs, self.share_obs = z(buffer.obs), z(buffer.share_obs)
         self.available_actions = z(buffer.available_actions)
         self.values, self.actions = z(buffer.value_preds), z(buffer.actions)
@@ -38,13 +44,46 @@ class _TurnState(object):
         self.rewards_since_last_action = z(buffer.rewards)
 
 
+class _HostStage(object):
+    """Host arrays of one env call -> device tensors through one pinned staging buffer and one async copy (two
+    buffers alternate; an event per buffer guards reuse).  On a CPU device: plain tensor views of copies."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.bufs, self.turn = None, 0
+
+    def upload(self, arrays):
+        """arrays: list of numpy arrays -> list of float32 device tensors of the same shapes."""
+        arrays = [np.asarray(a) for a in arrays]
+        if self.device.type != "cuda":
+            return [torch.from_numpy(np.array(a, dtype=np.float32)) for a in arrays]
+        total = sum(a.size for a in arrays)
+        if self.bufs is None or self.bufs[0][0].numel() < total:
+            self.bufs = [(torch.empty(total, dtype=torch.float32, pin_memory=True),
+                          torch.empty(total, dtype=torch.float32, device=self.device), [None]) for _ in range(2)]
+        pin, dev, done = self.bufs[self.turn]
+        self.turn = 1 - self.turn
+        if done[0] is not None:
+            done[0].synchronize()
+        pin_np, out, off = pin.numpy(), [], 0
+        for a in arrays:
+            np.copyto(pin_np[off:off + a.size].reshape(a.shape), a, casting="unsafe")
+            out.append(dev[off:off + a.size].view(a.shape))
+            off += a.size
+        dev[:off].copy_(pin[:off], non_blocking=True)
+        done[0] = torch.cuda.Event()
+        done[0].record(torch.cuda.current_stream(self.device))
+        return out
+
+
 class HanabiRunner(Runner):
     def __init__(self, config):
         super(HanabiRunner, self).__init__(config)
         self.true_total_num_steps = 0
 
     def run(self):
-        self.turn = _TurnState(self.n_rollout_threads, self.buffer)
+        self.turn = _TurnState(self.n_rollout_threads, self.buffer, self.buffer.device)
+        self._stage = _HostStage(self.buffer.device)
         self.warmup()
         start = time.time()
         episodes = int(self.num_env_steps) // self.episode_length // self.n_rollout_threads
@@ -61,14 +100,13 @@ class HanabiRunner(Runner):
 
                 if step == 0 and episode > 0:
                     # the last buffer row gets the turn that has just been played ...
-                    f32 = torch.float32
-                    b.share_obs[-1] = torch.as_tensor(turn.share_obs, dtype=f32)
-                    b.obs[-1] = torch.as_tensor(turn.obs, dtype=f32)
-                    b.available_actions[-1] = torch.as_tensor(turn.available_actions, dtype=f32)
-                    b.active_masks[-1] = torch.as_tensor(turn.active_masks, dtype=f32)
+                    b.share_obs[-1] = turn.share_obs
+                    b.obs[-1] = turn.obs
+                    b.available_actions[-1] = turn.available_actions
+                    b.active_masks[-1] = turn.active_masks
                     # ... and every reward moves one step earlier (it is only known a turn later)
                     b.rewards[0:T - 1] = b.rewards[1:].clone()
-                    b.rewards[-1] = torch.as_tensor(turn.rewards, dtype=f32)
+                    b.rewards[-1] = turn.rewards
                     self.compute()
                     train_infos = self.train()
 
@@ -78,9 +116,13 @@ class HanabiRunner(Runner):
                 obs, share_obs, available_actions = self.envs.reset(self.reset_choose)
                 share_obs = share_obs if self.use_centralized_V else obs
                 rc = self.reset_choose
-                self.use_obs[rc] = obs[rc]
-                self.use_share_obs[rc] = share_obs[rc]
-                self.use_available_actions[rc] = available_actions[rc]
+                if rc.any():        # only the restarted games' rows cross to the device
+                    rows = torch.as_tensor(np.flatnonzero(rc), device=self.buffer.device)
+                    o_d, s_d, a_d = self._stage.upload([obs[rc], share_obs[rc], available_actions[rc]])
+                    self.use_obs[rows] = o_d
+                    self.use_share_obs[rows] = s_d
+                    self.use_available_actions[rows] = a_d
+                    self.avail_host[rc] = available_actions[rc]
 
             total_num_steps = (episode + 1) * T * self.n_rollout_threads
             if episode % self.save_interval == 0 or episode == episodes - 1:
@@ -104,71 +146,96 @@ class HanabiRunner(Runner):
         self.reset_choose = np.ones(self.n_rollout_threads, dtype=bool)
         obs, share_obs, available_actions = self.envs.reset(self.reset_choose)
         share_obs = share_obs if self.use_centralized_V else obs
-        self.use_obs = obs.copy()
-        self.use_share_obs = share_obs.copy()
-        self.use_available_actions = available_actions.copy()
+        self._take_env_rows(obs, share_obs, available_actions)
+
+    def _take_env_rows(self, obs, share_obs, available_actions, extra=()):
+        """The env's current rows -> device (``use_*``); the legal-move table also stays on the host, where it
+        decides who moves.  -> the device tensors of ``extra``."""
+        up = self._stage.upload([obs, share_obs, available_actions] + list(extra))
+        # clones: the staging area is reused two uploads later, these rows live until the next move
+        self.use_obs, self.use_share_obs, self.use_available_actions = (t.clone() for t in up[:3])
+        self.avail_host = np.array(available_actions, dtype=np.float32)
+        return up[3:]
 
     @torch.no_grad()
     def collect(self, step):
         turn, n, A = self.turn, self.n_rollout_threads, self.num_agents
+        dev = self.buffer.device
         for agent_id in range(A):
             env_actions = -np.ones((n,) + tuple(self.buffer.actions.shape[3:]), dtype=np.float32)
-            choose = np.any(self.use_available_actions == 1, axis=1)    # envs whose player can move
+            choose = np.any(self.avail_host == 1, axis=1)    # envs whose player can move
             if not np.any(choose):
                 self.reset_choose = np.ones(n, dtype=bool)
                 break
 
             # rows of the envs that move: a plain slice (views, no gather) when every env does, else their indices
-            sel = slice(None) if choose.all() else np.flatnonzero(choose)
+            every = bool(choose.all())
+            sel_host = slice(None) if every else np.flatnonzero(choose)
+            sel = slice(None) if every else torch.as_tensor(sel_host, device=dev)
             obs_c, share_c, avail_c = self.use_obs[sel], self.use_share_obs[sel], self.use_available_actions[sel]
             self.trainer.prep_rollout()
             value, action, action_log_prob, rnn_state, rnn_state_critic = self.trainer.policy.get_actions(
                 share_c, obs_c, turn.rnn_states[sel, agent_id], turn.rnn_states_critic[sel, agent_id],
                 turn.masks[sel, agent_id], avail_c)
-            action_np = _t2n(action)
+            action_np = _t2n(action)             # the one device -> host transfer of a move: the env needs the actions
+            to = dict(device=dev, dtype=torch.float32)
             turn.obs[sel, agent_id] = obs_c
             turn.share_obs[sel, agent_id] = share_c
             turn.available_actions[sel, agent_id] = avail_c
-            turn.values[sel, agent_id] = _t2n(value)
-            turn.actions[sel, agent_id] = action_np
-            env_actions[sel] = action_np
-            turn.action_log_probs[sel, agent_id] = _t2n(action_log_prob)
-            turn.rnn_states[sel, agent_id] = _t2n(rnn_state)
-            turn.rnn_states_critic[sel, agent_id] = _t2n(rnn_state_critic)
+            turn.values[sel, agent_id] = value.to(**to)
+            turn.actions[sel, agent_id] = action.to(**to)
+            env_actions[sel_host] = action_np
+            turn.action_log_probs[sel, agent_id] = action_log_prob.to(**to)
+            turn.rnn_states[sel, agent_id] = rnn_state.to(**to)
+            turn.rnn_states_critic[sel, agent_id] = rnn_state_critic.to(**to)
 
             obs, share_obs, rewards, dones, infos, available_actions = self.envs.step(env_actions)
             self.true_total_num_steps += int(choose.sum())
             share_obs = share_obs if self.use_centralized_V else obs
-            self.use_obs = obs.copy()
-            self.use_share_obs = share_obs.copy()
-            self.use_available_actions = available_actions.copy()
+            done = np.asarray(dones) == True   # noqa: E712  (dones may hold None for idle envs)
+            alive = np.asarray(dones) == False  # noqa: E712
+            rewards_d, done_d, alive_d = self._take_env_rows(
+                obs, share_obs, available_actions,
+                extra=[np.asarray(rewards, dtype=np.float32).reshape(turn.rewards.shape), done, alive])
+            done_d, alive_d = done_d > 0, alive_d > 0
 
             # the acting player collects what accumulated since its previous move; everybody accrues
             # the new reward (the reward of buffer step 0 is discarded by the shift in run())
             turn.rewards[sel, agent_id] = turn.rewards_since_last_action[sel, agent_id]
             turn.rewards_since_last_action[sel, agent_id] = 0.0
-            turn.rewards_since_last_action[sel] += rewards[sel]
+            if every:
+                turn.rewards_since_last_action += rewards_d
+            else:
+                turn.rewards_since_last_action[sel] += rewards_d[sel]
 
-            done = np.asarray(dones) == True   # noqa: E712  (dones may hold None for idle envs)
-            alive = np.asarray(dones) == False  # noqa: E712
             self.reset_choose[done] = True
-            turn.masks[alive, agent_id] = 1.0                 # running games: the current player stays live
-            turn.active_masks[alive, agent_id] = 1.0
+            # running games: the current player stays live
+            live_col = alive_d.view(n, 1)
+            turn.masks[:, agent_id] = torch.where(live_col, torch.ones_like(turn.masks[:, agent_id]), turn.masks[:, agent_id])
+            turn.active_masks[:, agent_id] = torch.where(live_col, torch.ones_like(turn.active_masks[:, agent_id]),
+                                                         turn.active_masks[:, agent_id])
             if not done.any():
                 continue
             # finished games: nobody may act, states restart, players after the current one are inactive
-            self.use_available_actions[done] = 0.0
-            turn.masks[done] = 0.0
-            turn.rnn_states[done] = 0.0
-            turn.rnn_states_critic[done] = 0.0
-            turn.active_masks[done, agent_id] = 1.0
+            self.avail_host[done] = 0.0
+            row = lambda t: done_d.view((n,) + (1,) * (t.dim() - 1))
+            self.use_available_actions.masked_fill_(row(self.use_available_actions), 0.0)
+            turn.masks.masked_fill_(row(turn.masks), 0.0)
+            turn.rnn_states.masked_fill_(row(turn.rnn_states), 0.0)
+            turn.rnn_states_critic.masked_fill_(row(turn.rnn_states_critic), 0.0)
+            turn.active_masks[:, agent_id] = torch.where(done_d.view(n, 1), torch.ones_like(turn.active_masks[:, agent_id]),
+                                                         turn.active_masks[:, agent_id])
             rest = slice(agent_id + 1, A)
-            turn.active_masks[done, rest] = 0.0
-            turn.rewards[done, rest] = turn.rewards_since_last_action[done, rest]
-            turn.rewards_since_last_action[done, rest] = 0.0
-            turn.values[done, rest] = 0.0
-            turn.obs[done, rest] = 0.0
-            turn.share_obs[done, rest] = 0.0
+            if agent_id + 1 < A:
+                d3 = done_d.view(n, 1, 1)
+                turn.active_masks[:, rest] = torch.where(d3, torch.zeros_like(turn.active_masks[:, rest]),
+                                                         turn.active_masks[:, rest])
+                turn.rewards[:, rest] = torch.where(d3, turn.rewards_since_last_action[:, rest], turn.rewards[:, rest])
+                turn.rewards_since_last_action[:, rest] = torch.where(
+                    d3, torch.zeros_like(turn.rewards_since_last_action[:, rest]), turn.rewards_since_last_action[:, rest])
+                turn.values[:, rest] = torch.where(d3, torch.zeros_like(turn.values[:, rest]), turn.values[:, rest])
+                turn.obs[:, rest] = torch.where(d3, torch.zeros_like(turn.obs[:, rest]), turn.obs[:, rest])
+                turn.share_obs[:, rest] = torch.where(d3, torch.zeros_like(turn.share_obs[:, rest]), turn.share_obs[:, rest])
             for i in np.flatnonzero(done):
                 if 'score' in infos[i].keys():
                     self.scores.append(infos[i]['score'])

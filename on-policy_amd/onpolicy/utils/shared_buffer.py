@@ -135,6 +135,10 @@ class SharedReplayBuffer(object):
         self._adv_stats = torch.zeros(2, **f32)
         self._content_version = 0  # bumped by every method that writes buffer fields
         self._std_rows = {}        # field name -> (key, row-standardised copy) for the fused trunk kernels
+        # host inputs of insert() go through one pinned staging buffer + one async H2D copy (MAPPO_PINNED_INSERT=0:
+        # one pageable .to(device) per field, as before)
+        self._pinned_insert = os.environ.get("MAPPO_PINNED_INSERT", "1") != "0"
+        self._host_stage = None
         self._adv_fresh = False   # advantages/moments match the current returns & value_preds
         self._adv_denormalized = False   # ... and were formed as returns - D(value_preds)
         self._adv_is_gae = False         # ... or are the GAE accumulator of the MAT branches
@@ -206,8 +210,48 @@ class SharedReplayBuffer(object):
             x = x.to(device=self.device, dtype=torch.float32, non_blocking=True)
         return x.contiguous()
 
+    # ---- host -> HBM staging of a rollout step (the caller side of the boundary: envs that live on the host)
+    def _stage_host_values(self, pairs):
+        """Values that arrive as host arrays (numpy / CPU tensors / lists) are packed into ONE page-locked staging
+        buffer and cross PCIe as ONE asynchronous copy on the buffer's stream, instead of one synchronous pageable
+        ``.to(device)`` per field; the fused slab write (K2) that follows reads them from a device staging area.
+        ``insert()`` then returns as soon as the host memcpy into the staging buffer is done: the DMA (57 MB per step at
+        the north star) overlaps the next env step.  Two staging buffers alternate; an event per buffer keeps a step
+        from overwriting data whose copy is still in flight.  -> pairs with host values replaced by device views."""
+        host = [(i, v) for i, (_, v) in enumerate(pairs) if not (torch.is_tensor(v) and v.device == self.device)]
+        if not host or not self._pinned_insert:
+            return pairs
+        arrays = []
+        for i, v in host:
+            a = v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)
+            arrays.append((i, a))
+        total = sum(a.size for _, a in arrays)
+        st = self._host_stage
+        if st is None or st["pin"][0].numel() < total:
+            st = {"pin": [torch.empty(total, dtype=torch.float32, pin_memory=True) for _ in range(2)],
+                  "dev": [torch.empty(total, dtype=torch.float32, device=self.device) for _ in range(2)],
+                  "done": [None, None], "turn": 0}
+            self._host_stage = st
+        k = st["turn"]
+        st["turn"] = 1 - k
+        if st["done"][k] is not None:
+            st["done"][k].synchronize()                 # the copy issued two inserts ago (long finished in practice)
+        pin_np = st["pin"][k].numpy()
+        out, off = list(pairs), 0
+        for i, a in arrays:
+            np.copyto(pin_np[off:off + a.size].reshape(a.shape), a, casting="unsafe")      # cast to float32 on the way
+            out[i] = (pairs[i][0], st["dev"][k][off:off + a.size].view(a.shape))
+            off += a.size
+        st["dev"][k][:off].copy_(st["pin"][k][:off], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        st["done"][k] = ev
+        return out
+
     def _write_slabs(self, pairs):
         """One mappo_slab_copy launch for [(dst_view, value), ...] (K2)."""
+        if self.device.type == "cuda":
+            pairs = self._stage_host_values(pairs)
         keep, slabs = [], []
         for dst, value in pairs:
             src = self._dev(value)

@@ -34,8 +34,11 @@ def test_bench_contract_and_rccl_single_rank():
         assert key in plain, key
     assert plain["unit"] == "env-steps/s" and plain["n_gpus"] == 1 and plain["data"] == "synthetic"
     assert plain["config"]["workload"] and "model" not in plain["config"]
-    r = plain["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    r = plain["roofline"]       # dominant kernel: the fused trunk's forward launch, f32 matrix-core bound
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["launches"] == 20 and r["flop_per_launch"] > 0 and plain["roofline_mlp_backward"]["launches"] == 20
+    g = plain["roofline_gae"]   # the kernel the north star names, HBM bound
+    assert g["bound"] == "hbm" and g["unit"] == "GB/s" and abs(g["frac"] - g["achieved"] / g["peak"]) < 1e-3
     forced = _run({"MAPPO_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29577", "RANK": "0",
                    "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     # same seeds, same host permutations: the RCCL path must reproduce the plain update

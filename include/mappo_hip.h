@@ -437,6 +437,21 @@ int64_t mappo_mlp_workspace_floats(int din, int n_layers, int out);
  * parameter-free half of nn.LayerNorm, reference onpolicy/algorithms/utils/mlp.py:47-48, 56-57) */
 int     mappo_standardize_rows(const float* src, int64_t rows, int D, float eps, float* dst, mappo_stream_t stream);
 
+/* --------------------------------------------------------------- K11: simple_spread worlds on the device ----
+ * One env step of `n_worlds` cooperative-navigation worlds (the env of BASELINE.json configs[0] / configs[2]; reference
+ * onpolicy/envs/mpe/core.py:120-190, environment.py:100-180, scenarios/simple_spread.py:60-103) as one launch, so that
+ * a rollout step with the policy, the env and the buffer on the GPU moves nothing over PCIe (scope row f1).  State is
+ * float64 and updated in place: pos / vel [n, A, 2], landmarks [n, L, 2], t [n] int64.  actions [n, A] int64 in 0..4.
+ * Worlds whose t reaches world_length report done and (auto_reset) restart from fresh_pos [n, A, 2] / fresh_landmarks
+ * [n, L, 2] (uniform(-1, 1) draws for every world, used where needed).  Outputs: obs [n, A, 4 + 2 L + 4 (A - 1)]
+ * float32 (of the restarted world where one restarted), rewards [n, A, 1] float32 (shared reward), dones [n, A] bytes,
+ * per_agent [n, A] float64 (the individual_reward info).  A, L <= MAPPO_ENV_MAX_ENTITIES. */
+#define MAPPO_ENV_MAX_ENTITIES 16
+int mappo_simple_spread_step(double* pos, double* vel, double* landmarks, int64_t* t, const int64_t* actions,
+                             const double* fresh_pos, const double* fresh_landmarks, float* obs, float* rewards,
+                             uint8_t* dones, double* per_agent, int64_t n_worlds, int num_agents, int num_landmarks,
+                             int world_length, int auto_reset, mappo_stream_t stream);
+
 /* --------------------------------------------------------------------- misc ---- */
 int         mappo_abi_version(void);
 const char* mappo_build_info(void);        /* "gfx950 ..." static string */

@@ -398,6 +398,11 @@ class R_MAPPO():
         """ppo_epoch passes over the buffer in num_mini_batch minibatches (reference r_mappo.py:171-224).
         -> dict with value_loss, policy_loss, dist_entropy, actor_grad_norm, critic_grad_norm, ratio
         (means over the updates; global-batch values in a data-parallel job)."""
+        from onpolicy.utils import gemm_tuning
+        with gemm_tuning.tuning():      # the update's GEMM shapes repeat every iteration: worth benchmarking once
+            return self._train(buffer, update_actor)
+
+    def _train(self, buffer, update_actor):
         advantages = self._advantages(buffer)
         # let the sampler do the parameter-free half of the input LayerNorm while it copies the rows
         # (only for observation widths the standardising gather has kernels for: wider rows are gathered as

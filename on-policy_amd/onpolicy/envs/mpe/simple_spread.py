@@ -211,6 +211,38 @@ class TorchSimpleSpread(object):
     def step(self, actions):
         torch = self._torch
         actions = torch.as_tensor(actions, device=self.device)
+        if self.device.type == "cuda" and self.a <= 16 and self.l <= 16:
+            return self._step_kernel(actions)
+        return self._step_ops(actions)
+
+    def _step_kernel(self, actions):
+        """The whole step as one launch (K11, ``mappo_simple_spread_step``): same arithmetic and the same generator
+        draws as ``_step_ops`` (~60 small launches; 140 ms per step at 4096 worlds, against 30 us)."""
+        torch = self._torch
+        from onpolicy import _native
+        if actions.shape == (self.n, self.a, 5):                         # one-hot (the host protocol)
+            idx = actions.argmax(-1)
+        else:
+            idx = actions.reshape(self.n, self.a)
+        idx = idx.to(torch.int64).contiguous()
+        fresh_pos = self._uniform(self.n, self.a, 2) if self.auto_reset else None
+        fresh_land = self._uniform(self.n, self.l, 2) if self.auto_reset else None
+        obs_dim = 4 + 2 * self.l + 4 * (self.a - 1)
+        obs = torch.empty(self.n, self.a, obs_dim, dtype=torch.float32, device=self.device)
+        rewards = torch.empty(self.n, self.a, 1, dtype=torch.float32, device=self.device)
+        dones = torch.empty(self.n, self.a, dtype=torch.bool, device=self.device)
+        per_agent = torch.empty(self.n, self.a, dtype=torch.float64, device=self.device)
+        for name in ("pos", "vel", "landmarks", "t"):
+            setattr(self, name, getattr(self, name).contiguous())
+        p = _native.ptr
+        _native.check(_native.lib().mappo_simple_spread_step(
+            p(self.pos), p(self.vel), p(self.landmarks), p(self.t), p(idx), p(fresh_pos), p(fresh_land), p(obs),
+            p(rewards), p(dones), p(per_agent), self.n, self.a, self.l, self.world_length, int(self.auto_reset),
+            _native.stream_of(self.device)), "mappo_simple_spread_step")
+        return obs, rewards, dones, _LazyInfos(per_agent)
+
+    def _step_ops(self, actions):
+        torch = self._torch
         if actions.shape == (self.n, self.a, 5):                         # one-hot (the host protocol)
             a = actions.to(torch.float64)
             u = torch.stack([a[..., 1] - a[..., 2], a[..., 3] - a[..., 4]], -1) * _SENSITIVITY

@@ -80,7 +80,9 @@ def seed_everything(all_args):
     except Exception:
         pass
     from onpolicy.utils import gemm_tuning
-    gemm_tuning.enable()          # best GEMM kernel per shape (PyTorch TunableOp), winners cached per user
+    # best GEMM kernel per shape (PyTorch TunableOp), winners cached per user; new shapes are only benchmarked inside
+    # R_MAPPO.train() (fixed shapes), never during rollouts (row counts vary from step to step)
+    gemm_tuning.enable(tune_new=False)
     torch.manual_seed(all_args.seed)
     torch.cuda.manual_seed_all(all_args.seed)
     np.random.seed(all_args.seed)

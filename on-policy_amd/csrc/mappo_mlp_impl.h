@@ -1043,6 +1043,9 @@ __global__ void __launch_bounds__(kThreads) mlp_reduce_kernel(const float* parti
 // trunk kernels read standardised rows with no per-row constants in their inner loops (the LayerNorm's affine half is
 // folded into the first Linear by the caller).  16 lanes per row; the row is re-read from cache for the second moment
 // and for the output.
+// NV = 16-byte pieces per lane kept in registers (rows up to 64 * NV floats are read from HBM exactly once); NV = 0:
+// any width, the row is re-read from cache for the second moment and for the output.
+template <int NV>
 __global__ void __launch_bounds__(kThreads) standardize_rows_kernel(const float* src, long long rows, int D, float eps,
                                                                     float* dst) {
     const int sub = threadIdx.x & 15;
@@ -1053,32 +1056,70 @@ __global__ void __launch_bounds__(kThreads) standardize_rows_kernel(const float*
         const long long r = first + it * groups;
         const bool ok = r < rows;
         const float* p = src + (ok ? r : rows - 1) * D;
+        v4 keep[NV > 0 ? NV : 1];
         float s = 0.f;
-        for (int k = 4 * sub; k < D; k += 64) {
-            const v4 x = load4_guard(p + k, D - k);
-            s += (x[0] + x[1]) + (x[2] + x[3]);
+        if (NV > 0) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int k = 4 * sub + 64 * i;
+                keep[i] = load4_guard(p + k, D - k);
+                s += (keep[i][0] + keep[i][1]) + (keep[i][2] + keep[i][3]);
+            }
+        } else {
+            for (int k = 4 * sub; k < D; k += 64) {
+                const v4 x = load4_guard(p + k, D - k);
+                s += (x[0] + x[1]) + (x[2] + x[3]);
+            }
         }
         s = prim::sum16(s);
         const float mean = s / (float)D;
         float q = 0.f;
-        for (int k = 4 * sub; k < D; k += 64) {
-            const v4 x = load4_guard(p + k, D - k);
+        if (NV > 0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (k + e < D) {
-                    const float d = x[e] - mean;
-                    q += d * d;
-                }
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * sub + 64 * i + e < D) {
+                        const float d = keep[i][e] - mean;
+                        q += d * d;
+                    }
+        } else {
+            for (int k = 4 * sub; k < D; k += 64) {
+                const v4 x = load4_guard(p + k, D - k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (k + e < D) {
+                        const float d = x[e] - mean;
+                        q += d * d;
+                    }
+            }
         }
         q = prim::sum16(q);
         const float rstd = 1.f / sqrtf(q / (float)D + eps);
         if (ok) {
             float* o = dst + r * D;
-            for (int k = 4 * sub; k < D; k += 64) {
-                const v4 x = load4_guard(p + k, D - k);
+            if (NV > 0) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (k + e < D) o[k + e] = (x[e] - mean) * rstd;
+                for (int i = 0; i < NV; ++i) {
+                    const int k = 4 * sub + 64 * i;
+                    v4 y;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = (keep[i][e] - mean) * rstd;
+                    if (k + 3 < D) {
+                        *reinterpret_cast<v4u*>(o + k) = y;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (k + e < D) o[k + e] = y[e];
+                    }
+                }
+            } else {
+                for (int k = 4 * sub; k < D; k += 64) {
+                    const v4 x = load4_guard(p + k, D - k);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k + e < D) o[k + e] = (x[e] - mean) * rstd;
+                }
             }
         }
     }
@@ -1250,7 +1291,15 @@ inline int standardize_rows(const float* src, long long rows, int D, float eps, 
     if (rows <= 0 || D <= 0) return MAPPO_E_SHAPE;
     long long grid = ceil_div(rows * 16, kThreads);
     if (grid > 256 * 8) grid = 256 * 8;
-    MAPPO_LAUNCH(standardize_rows_kernel, (unsigned)grid, kThreads, 0, stream, src, rows, D, eps, dst);
+    if (D <= 64) {
+        MAPPO_LAUNCH(standardize_rows_kernel<1>, (unsigned)grid, kThreads, 0, stream, src, rows, D, eps, dst);
+    } else if (D <= 256) {
+        MAPPO_LAUNCH(standardize_rows_kernel<4>, (unsigned)grid, kThreads, 0, stream, src, rows, D, eps, dst);
+    } else if (D <= 512) {
+        MAPPO_LAUNCH(standardize_rows_kernel<8>, (unsigned)grid, kThreads, 0, stream, src, rows, D, eps, dst);
+    } else {
+        MAPPO_LAUNCH(standardize_rows_kernel<0>, (unsigned)grid, kThreads, 0, stream, src, rows, D, eps, dst);
+    }
     return MAPPO_LAUNCH_ERROR();
 }
 

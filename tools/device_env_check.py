@@ -26,9 +26,22 @@ if __name__ == "__main__":
             "--algorithm_name", "mappo", "--n_rollout_threads", str(opt.threads), "--episode_length",
             str(opt.episode_length), "--num_env_steps", str(steps), "--ppo_epoch", "10", "--use_ReLU", "--use_wandb",
             "--log_interval", "1000", "--save_interval", "1000"]
+    import torch
     for extra in (["--use_device_env"], []):
         t0 = time.time()
         runner = train_mpe.main(argv + extra)
         dt = time.time() - t0
-        print("%-18s %s: %.2f s, %.0f env-steps/s, mean reward %.3f" % (
-            " ".join(extra) or "host env", type(runner.envs).__name__, dt, steps / dt, float(runner.buffer.rewards.mean())))
+        # the rollout loop alone (collect -> env step -> insert), after everything is warm: what row f1 is about
+        n_steps = 4 * opt.episode_length
+        torch.cuda.synchronize()
+        r0 = time.time()
+        for i in range(n_steps):
+            values, actions, action_log_probs, rnn_states, rnn_states_critic, actions_env = runner.collect(i % opt.episode_length)
+            obs, rewards, dones, infos = runner.envs.step(actions_env)
+            runner.insert((obs, rewards, dones, infos, values, actions, action_log_probs, rnn_states, rnn_states_critic))
+        torch.cuda.synchronize()
+        rdt = time.time() - r0
+        print("%-18s %s: whole run %.2f s (%.0f env-steps/s incl. start-up and updates), mean reward %.3f; rollout loop "
+              "alone %.3f ms per step = %.0f env-steps/s" % (
+                  " ".join(extra) or "host env", type(runner.envs).__name__, dt, steps / dt,
+                  float(runner.buffer.rewards.mean()), 1e3 * rdt / n_steps, opt.threads * n_steps / rdt))

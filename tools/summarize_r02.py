@@ -1,0 +1,79 @@
+#!/usr/bin/env python
+"""Turns gpurun_out/r02/ (tools/profile_r02.sh on the MI355X box) into the committed evidence under profiles/:
+kernel-statistics CSVs, the bench lines of every workload and profiles/r02_pmc_summary.json -- HBM bytes per launch of
+the dominant kernels from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as
+MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE reports half the bytes of wide coalesced reads: doubled)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "r02")
+DST = os.path.join(ROOT, "profiles")
+sys.path.insert(0, os.path.join(ROOT, "on-policy_amd"))
+
+
+def counters(name):
+    f = glob.glob(os.path.join(SRC, "pmc_" + name, "*counter_collection.csv"))[0]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"]].append(1024.0 * float(r["Counter_Value"]))      # the counters are in KB
+    return acc
+
+
+def mean_of(acc, key):
+    vals = [v for k, vs in acc.items() if key in k for v in vs]
+    return sum(vals) / len(vals), len(vals)
+
+
+def main():
+    from onpolicy.algorithms.utils.fused_mlp import _work
+    fetch, write = counters("FETCH_SIZE"), counters("WRITE_SIZE")
+    rows = 400 * 4096 * 8
+    out = {}
+    # forward launch: actor (48 -> 64 -> 64 -> 5) and critic (384 -> 64 -> 64 -> 1) launches averaged, like bench.py and
+    # rocprofv3 --stats average them
+    alg_f = (_work(rows, 48, 2, 5, False)[1] + _work(rows, 384, 2, 1, False)[1]) / 2
+    f, n = mean_of(fetch, "mlp_fwd_kernel")
+    w, _ = mean_of(write, "mlp_fwd_kernel")
+    out["mappo_mlp_forward"] = {
+        "algorithmic_bytes": alg_f, "fetch_size_bytes_raw": f, "write_size_bytes": w, "hbm_bytes": 2 * f + w,
+        "dispatches_averaged": n, "kernel": "mlp::mlp_fwd_kernel<1, true>",
+        "note": "north-star bench.py step (separate --pmc passes with --kernel-trace only, tools/profile_r02.sh); actor "
+                "and critic launches averaged; FETCH_SIZE doubled (gfx950 counts 64 B per 128 B request of a wide "
+                "coalesced read, MI355X_MICROARCH.md)"}
+    alg_b = (_work(rows, 48, 2, 5, True)[1] + _work(rows, 384, 2, 1, True)[1]) / 2
+    fb = sum(mean_of(fetch, k)[0] for k in ("mlp_bwd_kernel", "mlp_dw1_kernel")) + 2 * mean_of(fetch, "mlp_reduce_kernel")[0]
+    wb = sum(mean_of(write, k)[0] for k in ("mlp_bwd_kernel", "mlp_dw1_kernel")) + 2 * mean_of(write, "mlp_reduce_kernel")[0]
+    out["mappo_mlp_backward"] = {
+        "algorithmic_bytes": alg_b, "fetch_size_bytes_raw": fb, "write_size_bytes": wb, "hbm_bytes": 2 * fb + wb,
+        "kernel": "mlp::mlp_bwd_kernel<2, 1> + mlp::mlp_dw1_kernel + 2 x mlp::mlp_reduce_kernel",
+        "note": "one mappo_mlp_backward call = chain kernel + first-layer weight-gradient kernel + two reductions"}
+    f, n = mean_of(fetch, "gae_")
+    w, _ = mean_of(write, "gae_")
+    out["mappo_gae_f32"] = {"algorithmic_bytes": 24 * rows, "fetch_size_bytes_raw": f, "write_size_bytes": w,
+                            "hbm_bytes": 2 * f + w, "dispatches_averaged": n,
+                            "note": "north-star size, fused advantages epilogue (24 B / element)"}
+    with open(os.path.join(DST, "r02_pmc_summary.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    for k, v in out.items():
+        print(k, "algorithmic %.3f GB, HBM %.3f GB (%.2fx)" % (v["algorithmic_bytes"] / 1e9, v["hbm_bytes"] / 1e9,
+                                                              v["hbm_bytes"] / v["algorithmic_bytes"]))
+    for w in ("ns", "cfg2", "smac"):
+        for f in glob.glob(os.path.join(SRC, "prof_" + w, "*kernel_stats.csv")):
+            shutil.copy(f, os.path.join(DST, "r02_bench_%s_kernel_stats.csv" % w))
+    lines = {}
+    for f in sorted(glob.glob(os.path.join(SRC, "bench_*.json"))):
+        name = os.path.basename(f)[6:-5]
+        lines[name] = json.loads(open(f).read())
+    with open(os.path.join(DST, "r02_bench_lines.json"), "w") as fh:
+        json.dump(lines, fh, indent=1)
+    print("bench lines:", {k: (round(v["value"]), v["ms_per_step"]) for k, v in lines.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -27,6 +27,44 @@ __device__ __forceinline__ float rcp_fast(float v) { return __builtin_amdgcn_rcp
 // scheduling barrier: the compiler may not move instructions across it (used to keep operand prefetches early)
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 __device__ __forceinline__ void set_priority_high() { __builtin_amdgcn_s_setprio(3); }
+// wave-uniform value -> scalar register
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// global_load_lds_dwordx4: lane l's 16 bytes at g go to LDS address (wave-uniform) base + 16 l, not through VGPRs.  Issued
+// from inline asm, so the compiler neither counts nor drains these loads: wait_lds_loads() before the data is read.
+__device__ __forceinline__ void load_lds16(const float* g, float* lds_wave_base) {
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)lds_wave_base);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g), "s"(dst)
+        : "memory");
+}
+// ... until at most N of this wave's vector memory loads are outstanding (they complete in order)
+template <int N>
+__device__ __forceinline__ void wait_lds_loads() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// the 4-byte form (global_load_lds_dword): lane l's int at g goes to base + 4 l
+__device__ __forceinline__ void load_lds4(const int* g, int* lds_wave_base) {
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)lds_wave_base);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g), "s"(dst)
+        : "memory");
+}
+__device__ __forceinline__ void wait_loads_14() { asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }   // (stamps only)
 __device__ __forceinline__ long long clock() { return (long long)__builtin_readcyclecounter(); }
 __device__ __forceinline__ int f2i(float v) { return __float_as_int(v); }
 __device__ __forceinline__ float i2f(int v) { return __int_as_float(v); }

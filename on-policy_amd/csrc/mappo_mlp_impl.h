@@ -34,15 +34,20 @@
 namespace mlp {
 
 constexpr int kH = 64;          // hidden width
-constexpr int kKC = 64;         // first-layer k chunk (256-byte pieces of an observation row)
-constexpr int kXS = kKC + 4;    // LDS row stride of the chunk tiles (floats): 16-lane ds_read_b128 groups hit 64 banks
+constexpr int kKC = 32;         // first-layer k chunk of the forward (128-byte pieces of an observation row)
+constexpr int kXS = kKC + 4;    // LDS row stride of its chunk tiles (floats): 16-byte slot (9 row + piece) mod 16, so 16
+                                // consecutive rows at one piece, or rows r and r + 8 at all 8 pieces, cover all 64 banks
 constexpr int kTR = 128;        // rows per workgroup tile = 4 waves x 32
 constexpr int kWS = 68;         // LDS row stride of a permuted 64-wide weight row
 constexpr int kTS = 36;         // LDS row stride of the [feature][32 rows] transposes of the backward
 constexpr int kThreads = 256;
-constexpr int kPipeThreads = 512;    // forward / weight-gradient kernels: 4 compute waves + 4 loader waves
-constexpr int kDepth = 3;            // chunk loads a loader thread keeps in flight (register buffers)
-constexpr int kFwdGridCap = 256;     // 1 workgroup per CU (2 LDS stages of 48 KB)
+constexpr int kPipeThreads = 512;    // weight-gradient kernel: 4 compute waves + 4 loader waves
+constexpr int kDepth = 3;            // tile loads a loader thread of that kernel keeps in flight (register buffers)
+constexpr int kFwdThreads = 512;     // forward kernel: 4 compute waves + 4 loader waves (waves go to the SIMDs round robin:
+                                     // every SIMD gets one compute and one loader wave of each workgroup)
+constexpr int kFwdDepth = 3;         // chunk loads a loader thread of the forward keeps in flight
+constexpr int kFwdGridCap = 512;     // 2 workgroups per CU (each 2 LDS stages of 27 KB + 19 KB of parameters; <= 128 VGPRs):
+                                     // while one workgroup's wave on a SIMD runs a layer tail (VALU), the other's feeds the MFMA
 constexpr int kBwdGridCap = 256;     // 1 workgroup per CU (108 KB of LDS)
 constexpr int kDw1Rows = 32;         // rows per iteration of the first-layer weight-gradient kernel
 constexpr int kDw1Slab = 384;        // k columns per workgroup of that kernel (6 accumulator tiles per wave)
@@ -171,8 +176,8 @@ struct Net {
 struct FwdLds {
     int vec, w2p, whp, bh, stage, total;
 };
-constexpr int kStageX = kTR * kKC;              // floats: [128 rows][64 k], 16-byte pieces XOR-swizzled by row & 15
-constexpr int kStageW = 64 * kKC;               // first-layer weight chunk [64 features][64 k], same swizzle
+constexpr int kStageX = kTR * kXS;              // floats: [128 rows][32 k], row stride kXS
+constexpr int kStageW = 64 * kXS;               // first-layer weight chunk [64 features][32 k], same stride
 constexpr int kStage = kStageX + kStageW;
 __host__ __device__ __forceinline__ FwdLds fwd_lds(int L, int out) {
     FwdLds o;
@@ -214,7 +219,8 @@ __device__ __forceinline__ void stage_fwd_params(const Net& n, float* lds, const
 // backward never re-evaluates tanh or the LayerNorm statistics (a third of its instructions when it saved z instead).
 template <bool KEEP, int ACT>
 __device__ __forceinline__ void layer_tail(const f32x16* acc, const float* vec /* bias | g | beta in LDS */, int h,
-                                           float eps, float* hreg, float* nreg, float& mean_out, float& rstd_out) {
+                                           float eps, float* hreg, float* keep_row /* KEEP: [64] in HBM */,
+                                           float& mean_out, float& rstd_out) {
     float a[32];
     float sum = 0.f;
 #pragma unroll
@@ -248,13 +254,15 @@ __device__ __forceinline__ void layer_tail(const f32x16* acc, const float* vec /
         for (int q = 0; q < 4; ++q) {
             const v4 g = *reinterpret_cast<const v4*>(vec + 64 + 32 * t + 8 * q + 4 * h);
             const v4 be = *reinterpret_cast<const v4*>(vec + 128 + 32 * t + 8 * q + 4 * h);
+            v4 nh;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int s = 16 * t + 4 * q + e;
-                const float nh = a[s] * rstd;
-                if (KEEP) nreg[s] = nh;
-                hreg[s] = nh * g[e] + be[e];
+                nh[e] = a[s] * rstd;
+                hreg[s] = nh[e] * g[e] + be[e];
             }
+            // slots 4q .. 4q+3 of tile t are 4 consecutive features (store_row64's layout), stored as they are produced
+            if (KEEP) *reinterpret_cast<v4*>(keep_row + 32 * t + 8 * q + 4 * h) = nh;
         }
 }
 
@@ -314,29 +322,29 @@ struct FwdArgs {
     float* z[3];        // saved normalised activations [rows, 64] per layer (NULL: inference)
     float* st[3];       // saved {mean, rstd} [rows, 2] per layer
     long long* dbg;     // tuning hook (mappo_mlp_set_debug): cycle stamps of workgroup 0's first iterations, or NULL
-    int probe;          // tuning hook (MAPPO_MLP_PROBE): 1 = loaders skip the row loads, 2 = skip the weight loads (timing only)
+    int flags;          // tuning hook (MAPPO_MLP_FLAGS): 1 = compute waves keep the default priority
 };
 
 // Workgroup = 4 compute waves (one per SIMD: MFMA + the layer tails of 32 rows each) + 4 loader waves that do nothing
-// but move data: global -> registers (kDepth chunk loads in flight per thread, across tile boundaries) -> one of two LDS
-// stages.  One barrier per chunk hands a stage over in both directions.  The loaders store raw rows; the compute lanes
-// standardise their own row's operands on the fly ((x - mean) * rstd, two VALU ops per 128 MFMA cycles), so padding
-// columns (zero in both operands) stay exact zeros.
+// but move data: global -> registers (kFwdDepth chunk loads in flight per thread, across tile boundaries) -> one of two
+// LDS stages.  One barrier per chunk hands a stage over in both directions.  Two such workgroups share a CU: their
+// barriers are independent, so the MFMA stream of one runs under the layer tails (VALU, transcendental, store work) of
+// the other.
 typedef int i4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 // One chunk in flight in a loader thread's registers + what the buffer's NEXT load needs: the source rows are fetched
 // right after this chunk's loads were issued, i.e. three issues ahead of their use, so that waiting for them never
 // waits for younger data loads (the wait counter is in order).
 struct ChunkBuf {
-    v4 xv[8], wv[4];
+    v4 xv[4], wv[2];
     int sft;
-    i4 rlo, rhi;        // source rows of the 8 rows this thread serves in the tile of the buffer's next chunk
+    i4 rws;             // source rows of the 4 rows this thread serves in the tile of the buffer's next chunk
 };
 
 // ALIGNED: din % 4 == 0 -- a 16-byte piece is either inside the row or past its end, so the loaders need no tail shifting
 // (their VALU work shares the SIMD's issue slots and the chip's power budget with the MFMA stream).
 template <int ACT, bool ALIGNED>
-__global__ void __launch_bounds__(kPipeThreads) mlp_fwd_kernel(FwdArgs a) {
+__global__ void __launch_bounds__(kFwdThreads, 4) mlp_fwd_kernel(FwdArgs a) {
     float* lds = prim::lds();
     const Net& n = a.net;
     const FwdLds o = fwd_lds(n.L, n.out);
@@ -352,9 +360,12 @@ __global__ void __launch_bounds__(kPipeThreads) mlp_fwd_kernel(FwdArgs a) {
 
     if (wave >= 4) {
         // ------------------------------------------------------------ loader
-        // thread = (group xg of 8 consecutive rows, 16-byte piece xq of the chunk); pass p serves row 8 xg + p, so one
-        // wave instruction reads 4 rows x 256 contiguous bytes and the thread's 8 source rows are two 16-byte table loads
-        const int lt = tid - 256, xg = lt >> 4, xq = lt & 15;
+        // thread = (group xg of 4 consecutive rows, 16-byte piece xq of the chunk): one wave instruction reads 8 rows x
+        // 128 contiguous bytes and the thread's 4 source rows are one 16-byte table load.  Row groups are numbered so
+        // that the two groups of a 16-lane store differ by 8 rows (LDS banks, see kXS); same for the 2 weight rows.
+        const int lt = tid - 256, xg = lt >> 3, xq = lt & 7;
+        const int xr0 = 16 * (xg >> 2) + 8 * (xg & 1) + 4 * ((xg >> 1) & 1);
+        const int wr0 = ((xg >> 1) & 7) + 8 * (xg & 1) + 16 * (xg >> 4);      // + 32 p
         // row offset of the tile of a pipeline position, clamped to the last tile (chunks issued past the end are never
         // stored; rows are padded to the 128-row tile, so every table index is valid).  Positions are tracked as (tile,
         // chunk) counters: no division in the loop.
@@ -363,11 +374,9 @@ __global__ void __launch_bounds__(kPipeThreads) mlp_fwd_kernel(FwdArgs a) {
             return (blockIdx.x + ti * gridDim.x) * kTR;
         };
         auto fetch_rows = [&](long long ti, ChunkBuf& B) {
-            const long long r0 = tile_row0(ti) + 8 * xg;
-            B.rlo = *reinterpret_cast<const i4*>(a.rs.srow + r0);
-            B.rhi = *reinterpret_cast<const i4*>(a.rs.srow + r0 + 4);
+            B.rws = *reinterpret_cast<const i4*>(a.rs.srow + tile_row0(ti) + xr0);
         };
-        long long it_tile = 0, ft_tile = 0;     // tile of the next issue / of the issue kDepth later
+        long long it_tile = 0, ft_tile = 0;     // tile of the next issue / of the issue kFwdDepth later
         int it_kc = 0, ft_kc = 0;               // its chunk within the tile
         auto advance = [&](long long& t, int& kc) {
             if (++kc == nch) {
@@ -375,23 +384,18 @@ __global__ void __launch_bounds__(kPipeThreads) mlp_fwd_kernel(FwdArgs a) {
                 ++t;
             }
         };
-        // every issue is exactly 8 + 4 + 2 loads, whatever the chunk
+        // every issue is exactly 4 + 2 + 1 loads, whatever the chunk
         auto issue = [&](ChunkBuf& B) {
             const int k = it_kc * kKC + 4 * xq, kk = piece_at(k, din);
             B.sft = k - kk;
-            const i4 lo = B.rlo, hi = B.rhi;
-            if (!(a.probe & 1)) {
+            const i4 rw = B.rws;
+            // (no conditional loads here: the compiler's wait counts are exact only if every path issues the same number)
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    B.xv[p] = *reinterpret_cast<const v4u*>(a.rs.src + (long long)lo[p] * din + kk);
-                    B.xv[4 + p] = *reinterpret_cast<const v4u*>(a.rs.src + (long long)hi[p] * din + kk);
-                }
-            }
-            if (!(a.probe & 2)) {
+            for (int p = 0; p < 4; ++p)
+                B.xv[p] = *reinterpret_cast<const v4u*>(a.rs.src + (long long)rw[p] * din + kk);
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
-                    B.wv[p] = *reinterpret_cast<const v4u*>(n.w1 + (long long)(xg + 16 * p) * din + kk);
-            }
+            for (int p = 0; p < 2; ++p)
+                B.wv[p] = *reinterpret_cast<const v4u*>(n.w1 + (long long)(wr0 + 32 * p) * din + kk);
             fetch_rows(ft_tile, B);
             advance(it_tile, it_kc);
             advance(ft_tile, ft_kc);
@@ -399,17 +403,13 @@ __global__ void __launch_bounds__(kPipeThreads) mlp_fwd_kernel(FwdArgs a) {
         auto store = [&](long long m, const ChunkBuf& B) {
             float* st = stage0 + (m & 1) * kStage;
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const int r = 8 * xg + p;
-                *reinterpret_cast<v4*>(st + r * kKC + ((xq ^ (r & 15)) << 2)) =
+            for (int p = 0; p < 4; ++p)
+                *reinterpret_cast<v4*>(st + (xr0 + p) * kXS + 4 * xq) =
                     ALIGNED ? (B.sft ? v4{0.f, 0.f, 0.f, 0.f} : B.xv[p]) : shift4(B.xv[p], B.sft);
-            }
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int r = xg + 16 * p;
-                *reinterpret_cast<v4*>(st + kStageX + r * kKC + ((xq ^ (r & 15)) << 2)) =
+            for (int p = 0; p < 2; ++p)
+                *reinterpret_cast<v4*>(st + kStageX + (wr0 + 32 * p) * kXS + 4 * xq) =
                     ALIGNED ? (B.sft ? v4{0.f, 0.f, 0.f, 0.f} : B.wv[p]) : shift4(B.wv[p], B.sft);
-            }
         };
         ChunkBuf B0, B1, B2;
         if (n_it > 0) {
@@ -431,7 +431,11 @@ __global__ void __launch_bounds__(kPipeThreads) mlp_fwd_kernel(FwdArgs a) {
         long long j = 0;
         for (; j + 3 <= n_it; j += 3) {
             __syncthreads();
-            if (stamp && j < 60) a.dbg[256 + 4 * j] = prim::clock();
+            if (stamp && j < 60) {
+                a.dbg[256 + 4 * j] = prim::clock();
+                prim::wait_loads_14();
+                a.dbg[256 + 4 * j + 3] = prim::clock();
+            }
             store(j + 1, B1);
             if (stamp && j < 60) a.dbg[256 + 4 * j + 1] = prim::clock();
             issue(B1);
@@ -458,17 +462,13 @@ __global__ void __launch_bounds__(kPipeThreads) mlp_fwd_kernel(FwdArgs a) {
         return;
     }
     // ---------------------------------------------------------------- compute
-    // the loader wave on this SIMD issues a few hundred VALU / LDS-store instructions per chunk; without a priority
-    // they take issue slots from the MFMA stream (measured 85 instead of 64 cycles per MFMA)
-    prim::set_priority_high();
+    // the loader waves issue a few hundred VALU / LDS-store instructions per chunk; without a priority they take issue
+    // slots from the MFMA stream (measured 85 instead of 64 cycles per MFMA)
+    if (!(a.flags & 1)) prim::set_priority_high();
     const bool cstamp = a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
-    const int rsw = c & 15;
     f32x16 acc[2];
     long long ti = 0;
     int kc = 0;
-    int off[8];         // swizzled float offsets of this lane's 8 operand pieces within a stage row
-#pragma unroll
-    for (int q = 0; q < 8; ++q) off[q] = ((8 * h + q) ^ rsw) << 2;
     for (long long j = 0; j < n_it; ++j) {
         if (cstamp && j < 60) a.dbg[4 * j] = prim::clock();
         __syncthreads();
@@ -480,22 +480,22 @@ __global__ void __launch_bounds__(kPipeThreads) mlp_fwd_kernel(FwdArgs a) {
                 for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
         }
         const float* st = stage0 + (j & 1) * kStage;
-        const float* xa = st + (32 * wave + c) * kKC;
-        const float* w0 = st + kStageX + c * kKC;
-        const float* w1 = st + kStageX + (32 + c) * kKC;
-        // The MFMA stream of a chunk: 64 MFMAs and 24 operand reads, nothing else -- a wave issues its instructions one
+        const float* xa = st + (32 * wave + c) * kXS + 16 * h;
+        const float* w0 = st + kStageX + c * kXS + 16 * h;
+        const float* w1 = st + kStageX + (32 + c) * kXS + 16 * h;
+        // The MFMA stream of a chunk: 32 MFMAs and 12 operand reads, nothing else -- a wave issues its instructions one
         // after the other, and every VALU instruction in this loop would cost ~8 of the 64 cycles an MFMA occupies
         // (tools/probes/probe_mfma.hip).  The operand reads of group q + 1 are issued before the MFMAs of group q.
-        v4 bn = *reinterpret_cast<const v4*>(xa + off[0]);
-        v4 a0n = *reinterpret_cast<const v4*>(w0 + off[0]);
-        v4 a1n = *reinterpret_cast<const v4*>(w1 + off[0]);
+        v4 bn = *reinterpret_cast<const v4*>(xa);
+        v4 a0n = *reinterpret_cast<const v4*>(w0);
+        v4 a1n = *reinterpret_cast<const v4*>(w1);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < 4; ++q) {
             const v4 b = bn, a0 = a0n, a1 = a1n;
-            if (q < 7) {
-                bn = *reinterpret_cast<const v4*>(xa + off[q + 1]);
-                a0n = *reinterpret_cast<const v4*>(w0 + off[q + 1]);
-                a1n = *reinterpret_cast<const v4*>(w1 + off[q + 1]);
+            if (q < 3) {
+                bn = *reinterpret_cast<const v4*>(xa + 4 * q + 4);
+                a0n = *reinterpret_cast<const v4*>(w0 + 4 * q + 4);
+                a1n = *reinterpret_cast<const v4*>(w1 + 4 * q + 4);
             }
             prim::sched_fence();        // keep the compiler from sinking these reads down to their first use
 #pragma unroll
@@ -507,25 +507,24 @@ __global__ void __launch_bounds__(kPipeThreads) mlp_fwd_kernel(FwdArgs a) {
         if (cstamp && j < 60) a.dbg[4 * j + 2] = prim::clock();
         if (++kc < nch) continue;
         kc = 0;
-        // ---- the rest of the network on this lane's row
-        const long long row = (blockIdx.x + ti * gridDim.x) * kTR + 32 * wave + c;
+        // ---- the rest of the network on this lane's row.  Rows past the end of the launch are copies of the last row
+        // (row table padding): those lanes compute the last row's values bit for bit and store them to the last row too,
+        // so no store below is conditional.
+        long long row = (blockIdx.x + ti * gridDim.x) * kTR + 32 * wave + c;
         ++ti;
-        const bool ok = row < rows;
-        float hreg[32], nreg[32], mean, rstd;
+        if (row >= rows) row = rows - 1;
+        float hreg[32], mean, rstd;
         for (int l = 0; l < n.L; ++l) {
             if (l > 0) dense64(lds + o.w2p + (l - 1) * 2 * 32 * kWS, c, h, hreg, acc);
             if (a.z[l] != nullptr) {
-                layer_tail<true, ACT>(acc, lds + o.vec + 192 * l, h, n.eps, hreg, nreg, mean, rstd);
-                if (ok) {
-                    store_row64(a.z[l] + row * 64, nreg, h);
-                    if (h == 0) *reinterpret_cast<f2*>(a.st[l] + 2 * row) = f2{mean, rstd};
-                }
+                layer_tail<true, ACT>(acc, lds + o.vec + 192 * l, h, n.eps, hreg, a.z[l] + row * 64, mean, rstd);
+                *reinterpret_cast<f2*>(a.st[l] + 2 * row) = f2{mean, rstd};     // both half-waves hold the same pair
             } else {
-                layer_tail<false, ACT>(acc, lds + o.vec + 192 * l, h, n.eps, hreg, nreg, mean, rstd);
+                layer_tail<false, ACT>(acc, lds + o.vec + 192 * l, h, n.eps, hreg, nullptr, mean, rstd);
             }
         }
         if (n.out == 0) {
-            if (ok) store_row64(a.y + row * 64, hreg, h);
+            store_row64(a.y + row * 64, hreg, h);
         } else {
             for (int oo = 0; oo < n.out; ++oo) {
                 const float* wp = lds + o.whp + oo * 64 + 32 * h;
@@ -537,7 +536,7 @@ __global__ void __launch_bounds__(kPipeThreads) mlp_fwd_kernel(FwdArgs a) {
                     for (int e = 0; e < 4; ++e) p += w[e] * hreg[4 * q + e];
                 }
                 p += prim::xhalf(p);
-                if (ok && h == (oo & 1)) a.y[row * n.out + oo] = p + lds[o.bh + oo];
+                a.y[row * n.out + oo] = p + lds[o.bh + oo];
             }
         }
     }
@@ -864,6 +863,7 @@ struct Dw1Args {
     RowSrc rs;
     const float* dz1;
     float* partials;    // [gridDim.x][64 * din]
+    long long* dbg;     // tuning hook (mappo_mlp_set_debug): cycle stamps of workgroup 0's first tiles at [512 ...], or NULL
 };
 constexpr int kDw1StageX = kDw1Rows * kDw1Slab;                        // floats
 constexpr int kDw1Stage = kDw1StageX + kDw1Rows * 64;                  // + dz1 tile [32][64]
@@ -1015,6 +1015,158 @@ __global__ void __launch_bounds__(kPipeThreads) mlp_dw1_kernel(Dw1Args a) {
                 }
         }
     }
+}
+
+// ---- the same product for din % 4 == 0, without loader waves and without registers in the load path
+// Measured on gfx950 (tools/probes/probe_lds_store.hip): while a wave streams v_mfma_f32_32x32x2_f32 back to back, an
+// LDS store or a global load issued by ANOTHER wave of that SIMD gets through only about once per 400 cycles (every
+// instruction that sends VGPRs out of the SIMD waits for a gap in the MFMA operand traffic), and one issued by the MFMA
+// wave itself costs about one MFMA slot.  The loader-wave version above needs 14 loads + 14 LDS stores per 96 MFMAs on
+// every SIMD and runs at half the MFMA rate.  Here each wave fetches its OWN operands with direct-to-LDS loads
+// (global_load_lds_dwordx4: 64 lanes x 16 B land in 1 KB of consecutive LDS; no VGPR data, no ds_write), issued in one
+// group between two tiles' MFMA streams: 6 for its three 32-column k tiles of a 16-row tile + 1 for its quarter of the
+// shared dz1 tile + 1 for the sampler's row table, per 48 MFMAs.  kD2Slots LDS slots per wave: the loads of tile m + 3
+// are issued before the MFMAs of tile m; the wait at the top of an iteration is counted (everything but the two youngest
+// groups), one barrier per tile publishes the dz1 quarters.  One workgroup of 4 waves per CU (120 KB of LDS).
+constexpr int kD2Rows = 16;
+constexpr int kD2Slots = 4;
+constexpr int kD2GridCap = 256;
+constexpr int kD2MinWidth = 192;                 // narrower inputs leave half of the waves without a k tile: loader version
+constexpr int kD2XSlot = 3 * kD2Rows * 32;       // floats: [k tile i < 3][16 rows][32]
+constexpr int kD2DzSlot = kD2Rows * 64;          // floats: [16 rows][64 features], shared by the 4 waves
+constexpr int kD2Lds = 4 * kD2Slots * kD2XSlot + kD2Slots * kD2DzSlot;       // floats, + the row-table rings:
+constexpr int kD2TabRing = 2 * kD2Slots;         // 256-byte slots per wave
+
+// the 8 MFMA steps of one 16-row tile (step s contracts rows s and 8 + s) for a wave that owns NT k tiles
+template <int NT>
+__device__ __forceinline__ void dw1_tile_steps(const float* xt, const float* dzt, int c, int h, f32x16 (*acc)[2]) {
+    constexpr int NB = NT > 0 ? NT : 1;
+    float a0n, a1n, bn[NB];
+    auto rd_step = [&](int st, float& ra0, float& ra1, float* rb) {
+        const int r = 8 * h + st;
+        ra0 = dzt[r * 64 + c];
+        ra1 = dzt[r * 64 + 32 + c];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) rb[i] = xt[i * (kD2Rows * 32) + r * 32 + c];
+    };
+    if (NT == 0) return;
+    rd_step(0, a0n, a1n, bn);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const float a0 = a0n, a1 = a1n;
+        float b[NB];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) b[i] = bn[i];
+        if (s < 7) rd_step(s + 1, a0n, a1n, bn);
+        prim::sched_fence();
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            acc[i][0] = prim::mfma32(a0, b[i], acc[i][0]);
+            acc[i][1] = prim::mfma32(a1, b[i], acc[i][1]);
+        }
+    }
+}
+
+// the whole kernel for a wave that owns NT (0 .. 3) k tiles: tiles wave, wave + 4, wave + 8 of the slab
+template <int NT>
+__device__ __forceinline__ void dw1_direct_body(const Dw1Args& a, float* lds, int wave, int k0) {
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, h = lane >> 5;
+    const int din = a.rs.din;
+    const long long rows = a.rs.rows;
+    const long long ntiles = (rows + kD2Rows - 1) / kD2Rows;
+    const long long n_it = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    float* xs = lds + wave * kD2Slots * kD2XSlot;           // this wave's slots
+    float* dzs = lds + 4 * kD2Slots * kD2XSlot;             // the workgroup's dz1 slots
+    constexpr int G = 2 * NT + 2;                           // loads per group
+
+    auto row0_of = [&](long long m) {       // first launch row of this workgroup's m-th tile; past the end: the last tile
+        if (m >= n_it) m = n_it - 1;        // again (loaded into a slot nobody reads, keeps every group the same size)
+        return (blockIdx.x + m * gridDim.x) * kD2Rows;
+    };
+    // lane roles in a load: x -- row 8 g + (lane >> 3) of the tile, 16-byte piece lane & 7 of a k tile;
+    // dz1 -- row 4 wave + (lane >> 4), piece lane & 15
+    // The sampler's row table takes the same road, kD2Slots - 1 tiles further ahead: 16 entries per tile into a ring of
+    // 256-byte LDS slots (lanes >= 16 repeat entry 15), read back with two ds_read_b32 per lane when the tile is issued.
+    const int q8 = lane >> 3;
+    int* tabs = reinterpret_cast<int*>(lds + kD2Lds) + wave * kD2TabRing * 64;
+    auto issue_table = [&](long long t) {
+        prim::load_lds4(a.rs.srow + row0_of(t) + (lane < 15 ? lane : 15), tabs + (int)(t % kD2TabRing) * 64);
+    };
+    auto issue = [&](long long m) {         // loads of tile m into slot m % kD2Slots + the table of tile m + kD2Slots - 1
+        const int slot = (int)(m % kD2Slots);
+        float* xslot = xs + slot * kD2XSlot;
+        const int* tb = tabs + (int)(m % kD2TabRing) * 64;
+        const int sr0 = tb[q8], sr1 = tb[8 + q8];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            int k = k0 + 32 * (wave + 4 * i) + 4 * (lane & 7);
+            if (k > din - 4) k = din - 4;           // a piece past the row's end: its columns are never written out
+            prim::load_lds16(a.rs.src + (long long)sr0 * din + k, xslot + i * (kD2Rows * 32));
+            prim::load_lds16(a.rs.src + (long long)sr1 * din + k, xslot + i * (kD2Rows * 32) + 256);
+        }
+        long long r = row0_of(m) + 4 * wave + (lane >> 4);
+        if (r >= rows) r = rows - 1;                // (zeroed in LDS before the product)
+        prim::load_lds16(a.dz1 + r * 64 + 4 * (lane & 15), dzs + slot * kD2DzSlot + wave * 256);
+        issue_table(m + kD2Slots - 1);
+    };
+    constexpr int NA = NT > 0 ? NT : 1;
+    f32x16 acc[NA][2];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][t][v] = 0.f;
+    if (n_it == 0) return;
+    for (int t = 0; t < kD2Slots - 1; ++t) issue_table(t);
+    prim::wait_lds_loads<0>();
+    for (int m = 0; m < kD2Slots - 1; ++m) issue(m);
+    const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+    for (long long m = 0; m < n_it; ++m) {
+        if (stamp && m < 40) a.dbg[512 + 4 * m] = prim::clock();
+        // this wave's loads of tile m (and the table of tile m + kD2Slots - 1) have landed: all but the youngest groups
+        prim::wait_lds_loads<(kD2Slots - 2) * G>();
+        if (stamp && m < 40) a.dbg[512 + 4 * m + 1] = prim::clock();
+        const long long live = rows - (blockIdx.x + m * gridDim.x) * kD2Rows;
+        if (live < kD2Rows && 4 * wave + (lane >> 4) >= live)      // last tile: rows past the end of the launch count as zero
+            *reinterpret_cast<v4*>(dzs + (int)(m % kD2Slots) * kD2DzSlot + wave * 256 + 4 * lane) = v4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();            // ... and everybody else's; all waves are done with tile m - 1's slot
+        if (stamp && m < 40) a.dbg[512 + 4 * m + 2] = prim::clock();
+        issue(m + kD2Slots - 1);
+        if (stamp && m < 40) a.dbg[512 + 4 * m + 3] = prim::clock();
+        const float* xt = xs + (int)(m % kD2Slots) * kD2XSlot;
+        const float* dzt = dzs + (int)(m % kD2Slots) * kD2DzSlot;
+        dw1_tile_steps<NT>(xt, dzt, c, h, acc);
+    }
+    prim::wait_lds_loads<0>();      // (the groups issued past the end)
+    float* prow = a.partials + (long long)blockIdx.x * 64 * din;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int k = k0 + 32 * (wave + 4 * i) + c;
+        if (k < din) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int f = 32 * t + (v & 3) + 8 * (v >> 2) + 4 * h;
+                    prow[(long long)f * din + k] = acc[i][t][v];
+                }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kThreads) mlp_dw1_direct_kernel(Dw1Args a) {
+    float* lds = prim::lds();
+    const int wave = prim::uniform(threadIdx.x >> 6);
+    const int din = a.rs.din;
+    const int k0 = blockIdx.y * kDw1Slab;
+    const int kw = (din - k0 < kDw1Slab ? ((din - k0 + 31) / 32) * 32 : kDw1Slab);
+    const int ntk = kw / 32;
+    const int n_own = (wave < ntk) + (wave + 4 < ntk) + (wave + 8 < ntk);
+    if (n_own == 3) dw1_direct_body<3>(a, lds, wave, k0);
+    else if (n_own == 2) dw1_direct_body<2>(a, lds, wave, k0);
+    else if (n_own == 1) dw1_direct_body<1>(a, lds, wave, k0);
+    else dw1_direct_body<0>(a, lds, wave, k0);
 }
 
 // out[e] = sum over n partial rows (row stride `stride`); fixed order.  A block handles 32 consecutive elements with 8
@@ -1170,10 +1322,10 @@ inline int& grid_cap_override() {
     static int cap = 0;
     return cap;
 }
-inline int probe_flags() {
+inline int tuning_flags() {
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("MAPPO_MLP_PROBE");
+        const char* e = getenv("MAPPO_MLP_FLAGS");
         v = e ? atoi(e) : 0;
     }
     return v;
@@ -1194,7 +1346,7 @@ inline int forward(const mappo_mlp_t* m, hipStream_t stream) {
     if (!m->y) return MAPPO_E_NULL;
     a.y = m->y;
     a.dbg = debug_buffer();
-    a.probe = probe_flags();
+    a.flags = tuning_flags();
     for (int l = 0; l < 3; ++l) {
         a.z[l] = l < m->n_layers ? m->z[l] : nullptr;
         a.st[l] = l < m->n_layers ? m->ln_stats[l] : nullptr;
@@ -1205,7 +1357,7 @@ inline int forward(const mappo_mlp_t* m, hipStream_t stream) {
     const bool al = m->din % 4 == 0;
 #define MAPPO_FWD_CASE(AA, AL)                                                                                 \
     if (m->act == AA && al == AL) {                                                                            \
-        MAPPO_LAUNCH((mlp_fwd_kernel<AA, AL>), (unsigned)grid, kPipeThreads, (size_t)o.total * 4, stream, a);  \
+        MAPPO_LAUNCH((mlp_fwd_kernel<AA, AL>), (unsigned)grid, kFwdThreads, (size_t)o.total * 4, stream, a);   \
     }
     MAPPO_FWD_CASE(0, false) MAPPO_FWD_CASE(1, false) MAPPO_FWD_CASE(2, false)
     MAPPO_FWD_CASE(0, true) MAPPO_FWD_CASE(1, true) MAPPO_FWD_CASE(2, true)
@@ -1214,7 +1366,7 @@ inline int forward(const mappo_mlp_t* m, hipStream_t stream) {
 }
 
 inline long long workspace_floats(int din, int n_layers, int out) {
-    return (long long)kBwdGridCap * 4 * p_main(n_layers, out) + (long long)kDw1GridCap * 64 * din;
+    return (long long)kBwdGridCap * 4 * p_main(n_layers, out) + (long long)kD2GridCap * 64 * din;
 }
 
 inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
@@ -1245,13 +1397,21 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
     if (code) return code;
 
     Dw1Args d;
+    d.dbg = debug_buffer();
     d.rs = b.rs;
     d.dz1 = m->dz1;
     d.partials = m->workspace + (long long)kBwdGridCap * 4 * p_main(L, out);
     const int gy = (int)ceil_div(din, kDw1Slab);
-    const long long gx = capped(ceil_div(m->rows, kDw1Rows), kDw1GridCap / gy > 0 ? kDw1GridCap / gy : 1);
-    const size_t dw1_lds = (size_t)2 * kDw1Stage * 4;
-    MAPPO_LAUNCH(mlp_dw1_kernel, dim3((unsigned)gx, (unsigned)gy), kPipeThreads, dw1_lds, stream, d);
+    long long gx;
+    if (din % 4 == 0 && din >= kD2MinWidth) {
+        gx = capped(ceil_div(m->rows, kD2Rows), kD2GridCap / gy > 0 ? kD2GridCap / gy : 1);
+        MAPPO_LAUNCH(mlp_dw1_direct_kernel, dim3((unsigned)gx, (unsigned)gy), kThreads,
+                     (size_t)(kD2Lds + 4 * kD2TabRing * 64) * 4, stream, d);
+    } else {
+        gx = capped(ceil_div(m->rows, kDw1Rows), kDw1GridCap / gy > 0 ? kDw1GridCap / gy : 1);
+        const size_t dw1_lds = (size_t)2 * kDw1Stage * 4;
+        MAPPO_LAUNCH(mlp_dw1_kernel, dim3((unsigned)gx, (unsigned)gy), kPipeThreads, dw1_lds, stream, d);
+    }
     code = MAPPO_LAUNCH_ERROR();
     if (code) return code;
 

@@ -11,16 +11,16 @@ inline float rcp_fast(float v) { return 1.f / v; }
 inline void sched_fence() {}
 inline void set_priority_high() {}
 inline long long clock() { return 0; }
-inline int f2i(float v) {
-    int r;
-    memcpy(&r, &v, 4);
-    return r;
+inline void wait_loads_14() {}
+inline int uniform(int v) { return v; }
+// direct-to-LDS load: lane l's 16 bytes land at base + 16 l.  The copy happens at once; wait_lds_loads() is a wave
+// barrier, so that no lane reads a slot before every lane of its wave has issued its part.
+inline void load_lds16(const float* g, float* lds_wave_base) {
+    memcpy(lds_wave_base + 4 * (simt::st().cur->tid & 63), g, 16);
 }
-inline float i2f(int v) {
-    float r;
-    memcpy(&r, &v, 4);
-    return r;
-}
+template <int N>
+inline void wait_lds_loads() { simt::wait(my_wave().bar); }
+inline void load_lds4(const int* g, int* lds_wave_base) { lds_wave_base[simt::st().cur->tid & 63] = *g; }
 // sum over the 16-lane group of the calling lane (a wave collective)
 inline float sum16(float v) {
     simt::Wave& w = my_wave();

@@ -101,6 +101,7 @@ CASES = [
     (19, 1, 1, 3, 37, 64),         # single layer, odd width (unaligned rows)
     (130, 3, 1, 0, 150, 300),      # layer_N = 2, trunk only (features for the GRU), three chunks with a tail
     (70, 2, 1, 2, 128 * 5 + 9, 900),   # several tiles and two chunks: the loaders' in-flight chunks cross tile boundaries
+    (388, 1, 2, 1, 45, 64),        # two k slabs in the first-layer weight gradient (din > 384), 16-byte aligned rows
 ]
 
 

@@ -25,12 +25,17 @@ def main():
     ap.add_argument("--din", type=int, nargs="+", default=[384, 48])
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--out", type=int, default=None)
+    ap.add_argument("--grid-cap", type=int, default=0, help="upper bound on the persistent kernels' workgroups (tuning hook)")
+    ap.add_argument("--sequential", action="store_true", help="rows in memory order instead of a random permutation")
     ap.add_argument("--stamps", action="store_true", help="print shader-clock stamps of workgroup 0 (forward kernel)")
     opt = ap.parse_args()
     from onpolicy.algorithms.utils import fused_mlp
     from onpolicy.algorithms.utils.mlp import MLPBase
     from helpers import make_args
     dev = torch.device("cuda", 0)
+    if opt.grid_cap:
+        from onpolicy import _native
+        _native.lib().mappo_mlp_set_grid_cap(opt.grid_cap)
     res = []
     for din in opt.din:
         out = opt.out if opt.out is not None else (1 if din > 100 else 5)
@@ -42,6 +47,8 @@ def main():
         src = torch.randn(src_rows, din, device=dev)
         xhat = fused_mlp.standardize_rows(src)
         idx = torch.randperm(src_rows, device=dev)[:opt.rows]
+        if opt.sequential:
+            idx = torch.arange(opt.rows, device=dev)
         rs = fused_mlp.RowSource(xhat, idx, standardized=True)
         dy = torch.randn(opt.rows, out, device=dev)
 
@@ -87,7 +94,19 @@ def main():
             print("loader (every 3 iterations): after barrier -> store done, -> issue done, -> next barrier passed")
             for j in range(0, 24, 3):
                 b = load[4 * j:4 * j + 12]
-                print(j, b[1] - b[0], b[2] - b[1], b[4] - b[2], "|", b[6] - b[4], b[8] - b[6], "|", b[10] - b[8])
+                print(j, "data wait", b[3] - b[0], "lds", b[1] - b[3], "issue", b[2] - b[1], "barrier", b[4] - b[2], "|",
+                      b[6] - b[4], b[8] - b[6], "|", b[10] - b[8])
+            if din % 4 == 0 and din >= 192:
+                fwd()
+                dbg.zero_()
+                _native.lib().mappo_mlp_set_debug(dbg.data_ptr())
+                bwd()
+                torch.cuda.synchronize()
+                _native.lib().mappo_mlp_set_debug(None)
+                d = dbg.cpu().numpy()[512:512 + 160].reshape(40, 4)
+                print("dw1 (wave 0 of workgroup 0): tile, wait for loads, barrier, issue, mfma steps")
+                for m in range(4, 24):
+                    print(m, d[m][1] - d[m][0], d[m][2] - d[m][1], d[m][3] - d[m][2], d[m + 1][0] - d[m][3])
         t_stats = timed(lambda: fused_mlp.standardize_rows(src))
         t_f = timed(fwd)
         t_b = timed(bwd)
@@ -96,7 +115,7 @@ def main():
         f_bwd = 2.0 * R * (din * 64 + 2 * 64 * 64 + 2 * 64 * out)
         b_fwd = R * (4 * din + 8 + 8 + 2 * 256 + 4 * out)
         b_bwd = R * (4 * din + 8 + 8 + 2 * 256 + 4 * out + 2 * 256 * (1 + max(1, -(-din // 384))))
-        rec = {"din": din, "out": out, "rows": R, "standardize_ms": round(t_stats, 3),
+        rec = {"din": din, "out": out, "rows": R, "grid_cap": opt.grid_cap, "sequential": opt.sequential, "standardize_ms": round(t_stats, 3),
                "fwd_ms": round(t_f, 3), "fwd_tflops": round(f_fwd / t_f / 1e9, 1),
                "fwd_frac_mfma": round(f_fwd / t_f / 1e9 / PEAK_TF, 3), "fwd_gbs": round(b_fwd / t_f / 1e6, 1),
                "bwd_ms": round(t_b, 3), "bwd_tflops": round(f_bwd / t_b / 1e9, 1),

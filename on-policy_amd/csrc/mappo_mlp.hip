@@ -64,6 +64,7 @@ __device__ __forceinline__ void load_lds4(const int* g, int* lds_wave_base) {
         : "v"(g), "s"(dst)
         : "memory");
 }
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ void wait_loads_14() { asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }   // (stamps only)
 __device__ __forceinline__ long long clock() { return (long long)__builtin_readcyclecounter(); }
 __device__ __forceinline__ int f2i(float v) { return __float_as_int(v); }

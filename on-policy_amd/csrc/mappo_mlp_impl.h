@@ -1169,6 +1169,98 @@ __global__ void __launch_bounds__(kThreads) mlp_dw1_direct_kernel(Dw1Args a) {
     else dw1_direct_body<0>(a, lds, wave, k0);
 }
 
+// ---- narrow inputs (din <= 64, din % 4 == 0): one or two k tiles are not enough to split among four waves, so every wave
+// owns ALL k tiles and its own 16-row tiles (strided over the launch wave by wave): the dz1 tile is private too, and the
+// loop has no barrier at all.  Same load path and slot ring as above; the four waves' accumulators are added through LDS
+// once, at the end.
+template <int NT>
+__global__ void __launch_bounds__(kThreads) mlp_dw1_rows_kernel(Dw1Args a) {
+    float* lds = prim::lds();
+    const int tid = threadIdx.x, lane = tid & 63, wave = prim::uniform(tid >> 6), c = lane & 31, h = lane >> 5;
+    const int din = a.rs.din;
+    const long long rows = a.rs.rows;
+    const long long ntiles = (rows + kD2Rows - 1) / kD2Rows;
+    const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
+    const long long n_it = gw < ntiles ? (ntiles - gw + nw - 1) / nw : 0;
+    constexpr int SL = NT * (kD2Rows * 32) + kD2DzSlot;     // floats per slot: [NT][16][32] x | [16][64] dz1
+    constexpr int G = 2 * NT + 4 + 1;                       // loads per group
+    float* ws = lds + wave * kD2Slots * SL;
+    int* tabs = reinterpret_cast<int*>(lds + 4 * kD2Slots * SL) + wave * kD2TabRing * 64;
+    auto row0_of = [&](long long m) {
+        if (m >= n_it) m = n_it - 1;
+        return (gw + m * nw) * kD2Rows;
+    };
+    const int q8 = lane >> 3;
+    auto issue_table = [&](long long t) {
+        prim::load_lds4(a.rs.srow + row0_of(t) + (lane < 15 ? lane : 15), tabs + (int)(t % kD2TabRing) * 64);
+    };
+    auto issue = [&](long long m) {
+        float* slot = ws + (int)(m % kD2Slots) * SL;
+        const int* tb = tabs + (int)(m % kD2TabRing) * 64;
+        const int sr0 = tb[q8], sr1 = tb[8 + q8];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            int k = 32 * i + 4 * (lane & 7);
+            if (k > din - 4) k = din - 4;
+            prim::load_lds16(a.rs.src + (long long)sr0 * din + k, slot + i * (kD2Rows * 32));
+            prim::load_lds16(a.rs.src + (long long)sr1 * din + k, slot + i * (kD2Rows * 32) + 256);
+        }
+        const long long r0 = row0_of(m);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            long long r = r0 + 4 * g + (lane >> 4);
+            if (r >= rows) r = rows - 1;
+            prim::load_lds16(a.dz1 + r * 64 + 4 * (lane & 15), slot + NT * (kD2Rows * 32) + g * 256);
+        }
+        issue_table(m + kD2Slots - 1);
+    };
+    f32x16 acc[NT][2];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][t][v] = 0.f;
+    if (n_it > 0) {
+        for (int t = 0; t < kD2Slots - 1; ++t) issue_table(t);
+        prim::wait_lds_loads<0>();
+        for (int m = 0; m < kD2Slots - 1; ++m) issue(m);
+        for (long long m = 0; m < n_it; ++m) {
+            prim::wait_lds_loads<(kD2Slots - 2) * G>();
+            float* slot = ws + (int)(m % kD2Slots) * SL;
+            const long long live = rows - (gw + m * nw) * kD2Rows;
+            if (live < kD2Rows) {       // last tile: rows past the end of the launch count as zero
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (4 * g + (lane >> 4) >= live)
+                        *reinterpret_cast<v4*>(slot + NT * (kD2Rows * 32) + g * 256 + 4 * lane) = v4{0.f, 0.f, 0.f, 0.f};
+                prim::wave_sync();      // (a wave's LDS operations execute in order: only the compiler / the emulator care)
+            }
+            issue(m + kD2Slots - 1);
+            dw1_tile_steps<NT>(slot, slot + NT * (kD2Rows * 32), c, h, acc);
+        }
+        prim::wait_lds_loads<0>();
+    }
+    // ---- add the four waves' tiles: [wave][i][t][v][lane]
+    __syncthreads();
+    float* red = lds;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) red[wave * (NT * 2048) + ((i * 2 + t) * 16 + v) * 64 + lane] = acc[i][t][v];
+    __syncthreads();
+    float* prow = a.partials + (long long)blockIdx.x * 64 * din;
+    for (int e = tid; e < NT * 2048; e += kThreads) {
+        const float sum = (red[e] + red[NT * 2048 + e]) + (red[2 * NT * 2048 + e] + red[3 * NT * 2048 + e]);
+        const int ln = e & 63, v = (e >> 6) & 15, t = (e >> 10) & 1, i = e >> 11;
+        const int f = 32 * t + (v & 3) + 8 * (v >> 2) + 4 * (ln >> 5);
+        const int k = 32 * i + (ln & 31);
+        if (k < din) prow[(long long)f * din + k] = sum;
+    }
+}
+
 // out[e] = sum over n partial rows (row stride `stride`); fixed order.  A block handles 32 consecutive elements with 8
 // row groups (group g sums rows g, g + 8, ...), combined through LDS.
 __global__ void __launch_bounds__(kThreads) mlp_reduce_kernel(const float* partials, long long n, long long stride,
@@ -1403,7 +1495,18 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
     d.partials = m->workspace + (long long)kBwdGridCap * 4 * p_main(L, out);
     const int gy = (int)ceil_div(din, kDw1Slab);
     long long gx;
-    if (din % 4 == 0 && din >= kD2MinWidth) {
+    if (din % 4 == 0 && din <= 64) {
+        gx = capped(ceil_div(m->rows, 4 * kD2Rows), kD2GridCap);
+        if (din <= 32) {
+            constexpr int SL = 1 * (kD2Rows * 32) + kD2DzSlot;
+            MAPPO_LAUNCH(mlp_dw1_rows_kernel<1>, (unsigned)gx, kThreads, (size_t)(4 * kD2Slots * SL + 4 * kD2TabRing * 64) * 4,
+                         stream, d);
+        } else {
+            constexpr int SL = 2 * (kD2Rows * 32) + kD2DzSlot;
+            MAPPO_LAUNCH(mlp_dw1_rows_kernel<2>, (unsigned)gx, kThreads, (size_t)(4 * kD2Slots * SL + 4 * kD2TabRing * 64) * 4,
+                         stream, d);
+        }
+    } else if (din % 4 == 0 && din >= kD2MinWidth) {
         gx = capped(ceil_div(m->rows, kD2Rows), kD2GridCap / gy > 0 ? kD2GridCap / gy : 1);
         MAPPO_LAUNCH(mlp_dw1_direct_kernel, dim3((unsigned)gx, (unsigned)gy), kThreads,
                      (size_t)(kD2Lds + 4 * kD2TabRing * 64) * 4, stream, d);

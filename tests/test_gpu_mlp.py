@@ -71,6 +71,8 @@ CASES = [
     (19, 0, False, 3, 37, 64),             # single Linear block, odd (unaligned) rows
     (435, 2, False, 18, 300, 700),         # SMAC widths: odd din > 384 (two k slabs), layer_N = 2, 18 actions
     (150, 1, False, 0, 1000, 4000),        # trunk only (features for the GRU)
+    (200, 1, False, 2, 16 * 700 + 3, 20000),   # direct-to-LDS weight gradient with waves of two and of one k tile, ragged end
+    (28, 1, True, 2, 64 * 300 + 17, 30000),    # one k tile: row-split weight gradient, several tiles per wave
 ]
 
 

@@ -102,6 +102,8 @@ CASES = [
     (130, 3, 1, 0, 150, 300),      # layer_N = 2, trunk only (features for the GRU), three chunks with a tail
     (70, 2, 1, 2, 128 * 5 + 9, 900),   # several tiles and two chunks: the loaders' in-flight chunks cross tile boundaries
     (388, 1, 2, 1, 45, 64),        # two k slabs in the first-layer weight gradient (din > 384), 16-byte aligned rows
+    (28, 1, 2, 2, 16 * 9 + 1, 300),   # one k tile (row-split weight-gradient kernel), a tile with a single live row
+    (200, 2, 1, 1, 16 * 7 + 5, 200),  # direct-to-LDS weight-gradient kernel: waves with two and with one k tile
 ]
 
 

@@ -389,8 +389,11 @@ int     mappo_minibatch_indices(int64_t n, int64_t mb, int n_mb, const uint32_t*
  *   w1 [64, din], bias[l] / ln_g[l] / ln_b[l] [64] for l < n_layers (n_layers = 1 + layer_N <= 3), w2[l-1] [64, 64]
  *   act        1 Tanh, 2 ReLU (0 identity)
  *   wh [out, 64], bh [out]   output Linear (out <= 64); out = 0: y receives the trunk's features [rows, 64]
- * mappo_mlp_forward writes y [rows, out] and, when z[l] != NULL, what the backward needs of every layer: z[l] [rows, 64]
- *   = the LayerNorm's normalised input (act(.) - mean) * rstd and ln_stats[l] [rows, 2] = {mean, rstd} (NULL in rollouts).
+ * mappo_mlp_forward writes y [rows, out] and, when z[l] != NULL, what the backward needs of every layer: z[l] = the
+ *   LayerNorm's normalised input (act(.) - mean) * rstd, 64 floats for each of mappo_mlp_row_table_ints(rows) rows (rows
+ *   rounded up to 128) in the kernels' own order -- opaque scratch between the two calls: element (row r, feature
+ *   32 t + 8 q + 4 h + e) sits at float (r / 32) * 2048 + (4 t + q) * 256 + (32 h + r % 32) * 4 + e -- and ln_stats[l]
+ *   = {mean, rstd} per row, room for the same padded row count (both NULL in rollouts).
  * mappo_mlp_backward reads dy [rows, out] (or [rows, 64] for out = 0), z[l] and ln_stats[l]; writes `grads`, the parameter gradients
  *   as one flat array [w1 64*din | per layer: bias 64, ln weight 64, ln bias 64 | per hidden layer: w 64*64 | wh out*64 |
  *   bh out] (mappo_mlp_grad_floats), using dz1 [rows, 64] and workspace [mappo_mlp_workspace_floats] as scratch.

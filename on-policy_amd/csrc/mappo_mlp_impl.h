@@ -219,8 +219,8 @@ __device__ __forceinline__ void stage_fwd_params(const Net& n, float* lds, const
 // backward never re-evaluates tanh or the LayerNorm statistics (a third of its instructions when it saved z instead).
 template <bool KEEP, int ACT>
 __device__ __forceinline__ void layer_tail(const f32x16* acc, const float* vec /* bias | g | beta in LDS */, int h,
-                                           float eps, float* hreg, float* keep_row /* KEEP: [64] in HBM */,
-                                           float& mean_out, float& rstd_out) {
+                                           float eps, float* hreg, float* ztile /* KEEP: wave-uniform, see load_frag64 */,
+                                           int lane, float& mean_out, float& rstd_out) {
     float a[32];
     float sum = 0.f;
 #pragma unroll
@@ -261,9 +261,25 @@ __device__ __forceinline__ void layer_tail(const f32x16* acc, const float* vec /
                 nh[e] = a[s] * rstd;
                 hreg[s] = nh[e] * g[e] + be[e];
             }
-            // slots 4q .. 4q+3 of tile t are 4 consecutive features (store_row64's layout), stored as they are produced
-            if (KEEP) *reinterpret_cast<v4*>(keep_row + 32 * t + 8 * q + 4 * h) = nh;
+            // (fragment order, see zfrag(): block 4 t + q) stored as they are produced
+            if (KEEP) *reinterpret_cast<v4*>(ztile + 4 * lane + 256 * (4 * t + q)) = nh;
         }
+}
+
+// The saved activations z[l] travel between the forward and the backward kernel only, so they are kept in the order the
+// registers hold them ("fragment order"): per group of 32 consecutive launch rows (one wave tile) 8 blocks of 1 KB,
+// block 4 t + q = slots 16 t + 4 q .. + 3 of all 64 lanes, lane (h, c) at 16 (32 h + c) bytes.  Every store / load
+// instruction of a wave then moves 1 KB of consecutive memory (row-major [rows, 64] made each of them touch 32 separate
+// 32-byte segments: a quarter of the backward kernel's time).  The buffers hold rows128(rows) rows.
+// A wave addresses its tile as (wave-uniform) z + 2048 * (first row / 32) plus 4 * lane: lane = 32 h + (row & 31).
+__device__ __forceinline__ void load_frag64(const float* ztile /* z + 2048 * (tile row / 32), wave-uniform */, int lane,
+                                            float* reg) {
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const v4 o = *reinterpret_cast<const v4*>(ztile + 4 * lane + 256 * b);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) reg[4 * b + e] = o[e];
+    }
 }
 
 // registers (slot order) -> a [rows, 64] row in HBM: slots 4q .. 4q+3 of tile t are 4 consecutive features
@@ -319,8 +335,8 @@ struct FwdArgs {
     RowSrc rs;
     Net net;
     float* y;
-    float* z[3];        // saved normalised activations [rows, 64] per layer (NULL: inference)
-    float* st[3];       // saved {mean, rstd} [rows, 2] per layer
+    float* z[3];        // saved normalised activations per layer, rows128(rows) rows in fragment order (NULL: inference)
+    float* st[3];       // saved {mean, rstd} per layer, [rows128(rows), 2]
     long long* dbg;     // tuning hook (mappo_mlp_set_debug): cycle stamps of workgroup 0's first iterations, or NULL
     int flags;          // tuning hook (MAPPO_MLP_FLAGS): 1 = compute waves keep the default priority
 };
@@ -465,6 +481,7 @@ __global__ void __launch_bounds__(kFwdThreads, 4) mlp_fwd_kernel(FwdArgs a) {
     // the loader waves issue a few hundred VALU / LDS-store instructions per chunk; without a priority they take issue
     // slots from the MFMA stream (measured 85 instead of 64 cycles per MFMA)
     if (!(a.flags & 1)) prim::set_priority_high();
+    const int wave_u = prim::uniform(wave);
     const bool cstamp = a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
     f32x16 acc[2];
     long long ti = 0;
@@ -508,23 +525,24 @@ __global__ void __launch_bounds__(kFwdThreads, 4) mlp_fwd_kernel(FwdArgs a) {
         if (++kc < nch) continue;
         kc = 0;
         // ---- the rest of the network on this lane's row.  Rows past the end of the launch are copies of the last row
-        // (row table padding): those lanes compute the last row's values bit for bit and store them to the last row too,
-        // so no store below is conditional.
-        long long row = (blockIdx.x + ti * gridDim.x) * kTR + 32 * wave + c;
+        // (row table padding); z and the statistics are padded to the tile, so only the output store is conditional.
+        const long long wrow0 = (blockIdx.x + ti * gridDim.x) * kTR + 32 * wave_u;      // first row of this wave's 32
+        const long long row = wrow0 + c;
         ++ti;
-        if (row >= rows) row = rows - 1;
         float hreg[32], mean, rstd;
         for (int l = 0; l < n.L; ++l) {
             if (l > 0) dense64(lds + o.w2p + (l - 1) * 2 * 32 * kWS, c, h, hreg, acc);
             if (a.z[l] != nullptr) {
-                layer_tail<true, ACT>(acc, lds + o.vec + 192 * l, h, n.eps, hreg, a.z[l] + row * 64, mean, rstd);
-                *reinterpret_cast<f2*>(a.st[l] + 2 * row) = f2{mean, rstd};     // both half-waves hold the same pair
+                layer_tail<true, ACT>(acc, lds + o.vec + 192 * l, h, n.eps, hreg, a.z[l] + wrow0 * 64, lane, mean, rstd);
+                *reinterpret_cast<f2*>(a.st[l] + 2 * wrow0 + 2 * c) = f2{mean, rstd};      // both half-waves hold the same pair
             } else {
-                layer_tail<false, ACT>(acc, lds + o.vec + 192 * l, h, n.eps, hreg, nullptr, mean, rstd);
+                layer_tail<false, ACT>(acc, lds + o.vec + 192 * l, h, n.eps, hreg, nullptr, lane, mean, rstd);
             }
         }
+        // (dead lanes hold the last row's values bit for bit -- its padding copies -- and store them to the last row)
+        const long long yrow = row < rows ? row : rows - 1;
         if (n.out == 0) {
-            store_row64(a.y + row * 64, hreg, h);
+            store_row64(a.y + yrow * 64, hreg, h);
         } else {
             for (int oo = 0; oo < n.out; ++oo) {
                 const float* wp = lds + o.whp + oo * 64 + 32 * h;
@@ -536,13 +554,15 @@ __global__ void __launch_bounds__(kFwdThreads, 4) mlp_fwd_kernel(FwdArgs a) {
                     for (int e = 0; e < 4; ++e) p += w[e] * hreg[4 * q + e];
                 }
                 p += prim::xhalf(p);
-                a.y[row * n.out + oo] = p + lds[o.bh + oo];
+                a.y[yrow * n.out + oo] = p + lds[o.bh + oo];
             }
         }
     }
 }
 
 // ================================================================== backward: row-parallel chain ====
+// (TA / TB / DY / the vector accumulators are private to a wave: the synchronisation points inside the tile loop are
+// wave-level -- a wave's LDS operations execute in order -- and the four waves of a workgroup drift freely.)
 // Per 32-row wave tile: recompute act / LayerNorm of every layer from the saved pre-activations, walk the chain
 // backwards in registers, write d loss / d z of the first layer to HBM (consumed by the weight-gradient kernel below)
 // and accumulate every other parameter gradient: hidden-layer weights in accumulator registers (MFMA over the rows of
@@ -571,6 +591,7 @@ struct BwdArgs {
     const float* dy;    // [rows, out] (head) or [rows, 64] (out == 0)
     float* dz1;         // [rows, 64]
     float* partials;    // [gridDim.x * 4][p_main]
+    long long* dbg;     // tuning hook (mappo_mlp_set_debug): cycle stamps of workgroup 0's first tiles at [1024 ...], or NULL
 };
 
 // row sums of a [64][32] transpose: lane = feature
@@ -615,6 +636,7 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a) {
         const int oo = e >> 6, hs = e & 63;
         lds[o.whp + e] = n.wh[oo * 64 + feat_of(hs >> 5, hs & 31)];
     }
+    const int wave_u = prim::uniform(wave);
     float* TA = lds + o.scratch + wave * o.scratch_per_wave;
     float* TB = TA + 64 * kTS;
     float* DY = TB + 64 * kTS;
@@ -644,7 +666,8 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a) {
         const long long rrow = row < rows ? row : rows - 1;
 #pragma unroll
         for (int l = 0; l < L; ++l) {
-            load_row64(a.z[l] + rrow * 64, zn[l], h);
+            // (padded to the tile: rows past the end repeat the last row)
+            load_frag64(a.z[l] + (tile * kTR + 32 * wave_u) * 64, lane, zn[l]);
             stn[l] = *reinterpret_cast<const f2*>(a.st[l] + 2 * rrow);
         }
         if (out == 0) {
@@ -664,9 +687,13 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a) {
     };
     if (blockIdx.x < ntiles) fetch(blockIdx.x);
 
+    const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+    int n_stamp = 0;
+#define MAPPO_BWD_STAMP(k) if (stamp && n_stamp < 12) a.dbg[1024 + 16 * n_stamp + (k)] = prim::clock()
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long row = tile * kTR + 32 * wave + c;
         const bool ok = row < rows;
+        MAPPO_BWD_STAMP(0);
         float nc[L][32];        // this tile's normalised activations
         float mean[L], rstd[L], sd[L];
         float dh[32];           // gradient w.r.t. the output of the layer being processed (slot order)
@@ -693,6 +720,7 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a) {
                 if (h == 0) DY[oo * 32 + c] = ok ? a.dy[row * out + oo] : 0.f;
         }
         if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);     // in flight during this tile's arithmetic
+        MAPPO_BWD_STAMP(1);
 
         // T[feature][c] = output of layer l = nhat * gamma + beta  (transposed into wave-private LDS)
         auto put_output = [&](float* T, int l) {
@@ -713,7 +741,7 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a) {
         // ---- head
         if (out > 0) {
             put_output(TA, L - 1);
-            __syncthreads();        // DY and TA of this wave are complete
+            prim::wave_sync();        // DY and TA of this wave are complete
 #pragma unroll
             for (int s = 0; s < 32; ++s) dh[s] = 0.f;
             for (int oo = 0; oo < out; ++oo) {
@@ -747,8 +775,9 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a) {
                 }
                 if (lane < out) vacc[192 * L + 64 * out + lane] += rowsum32(DY + lane * 32);
             }
-            __syncthreads();
+            prim::wave_sync();
         }
+        MAPPO_BWD_STAMP(2);
         // ---- layers, top down
 #pragma unroll
         for (int l = L - 1; l >= 0; --l) {
@@ -793,21 +822,24 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a) {
                 }
                 dz[s] = da * dact;
             }
-            __syncthreads();
+            MAPPO_BWD_STAMP(3 + 4 * (L - 1 - l));
+            prim::wave_sync();
             va[128 + lane] += rowsum32(TA + lane * kTS);      // d beta
             va[64 + lane] += rowsum32(TB + lane * kTS);       // d gamma
-            __syncthreads();
+            prim::wave_sync();
+            MAPPO_BWD_STAMP(4 + 4 * (L - 1 - l));
             put_transposed(TA, dz, c, h);
             if (l == 0) {
                 if (ok) store_row64(a.dz1 + row * 64, dz, h);
-                __syncthreads();
+                prim::wave_sync();
                 va[lane] += rowsum32(TA + lane * kTS);        // d bias
-                __syncthreads();
+                prim::wave_sync();
             } else {
                 // hidden layer l >= 1: its input is the output of layer l - 1
                 put_output(TB, l > 0 ? l - 1 : 0);
-                __syncthreads();
+                prim::wave_sync();
                 va[lane] += rowsum32(TA + lane * kTS);            // d bias
+                MAPPO_BWD_STAMP(5 + 4 * (L - 1 - l));
                 // dW[f][k] += sum over rows dz[f][row] * hin[k][row]: A = TA (lane = f), B = TB (lane = k), rows 16 h + s
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -830,10 +862,14 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a) {
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int v = 0; v < 16; ++v) dh[16 * t + v] = dx[t][v];
-                __syncthreads();
+                prim::wave_sync();
+                MAPPO_BWD_STAMP(6 + 4 * (L - 1 - l));
             }
         }
+        MAPPO_BWD_STAMP(15);
+        ++n_stamp;
     }
+#undef MAPPO_BWD_STAMP
     // ---- flush this wave's partial sums
     float* prow = a.partials + ((long long)blockIdx.x * 4 + wave) * p_main(L, out);
     for (int e = lane; e < 192 * L; e += 64) prow[e] = vacc[e];
@@ -1472,6 +1508,7 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
         if (l < m->n_layers && (!m->z[l] || !m->ln_stats[l])) return MAPPO_E_NULL;
     }
     const int L = m->n_layers, out = m->out, din = m->din;
+    b.dbg = debug_buffer();
     b.dy = m->dy;
     b.dz1 = m->dz1;
     b.partials = m->workspace;

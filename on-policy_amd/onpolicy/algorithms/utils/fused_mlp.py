@@ -200,8 +200,10 @@ class _FusedTrunkFn(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[5:])
         zs = []
         if need_grad:       # what the backward needs of every layer: normalised activations + {mean, rstd} per row
-            zbuf = torch.empty((n_layers, rows, HIDDEN), dtype=torch.float32, device=dev)
-            sbuf = torch.empty((n_layers, rows, 2), dtype=torch.float32, device=dev)
+            # (opaque scratch in the kernels' own order, padded to the 128-row tile: include/mappo_hip.h)
+            padded = lib.mappo_mlp_row_table_ints(rows)
+            zbuf = torch.empty((n_layers, padded, HIDDEN), dtype=torch.float32, device=dev)
+            sbuf = torch.empty((n_layers, padded, 2), dtype=torch.float32, device=dev)
             for l in range(n_layers):
                 m.z[l] = zbuf[l].data_ptr()
                 m.ln_stats[l] = sbuf[l].data_ptr()

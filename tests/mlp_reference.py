@@ -50,6 +50,16 @@ def random_net(rng, din, n_layers, out, scale=0.3):
     return p
 
 
+def rows_of_fragments(z, rows):
+    """The saved activations come back in the kernels' own order (include/mappo_hip.h: element (row r, feature
+    32 t + 8 q + 4 h + e) at float (r // 32) * 2048 + (4 t + q) * 256 + (32 h + r % 32) * 4 + e) -> [rows, 64]."""
+    flat = np.asarray(z).reshape(-1)
+    r = np.arange(rows)[:, None]
+    f = np.arange(64)[None, :]
+    t, q, h, e = f // 32, (f % 32) // 8, (f % 8) // 4, f % 4
+    return flat[(r // 32) * 2048 + (4 * t + q) * 256 + (32 * h + r % 32) * 4 + e]
+
+
 def source_rows(idx, rows, chunk_len=0, mb=0, T=0, N=0, A=0):
     """Source row of every launch row (shared_buffer.py:379-396 rows mode, :554-604 chunk mode)."""
     if idx is None:

@@ -48,7 +48,7 @@ def _run(emu, rng, din, n_layers, act, out, rows, src_rows, standardize=True, ch
         assert emu.mappo_standardize_rows(_ptr(src), src_rows, din, 1e-5, _ptr(xin), None) == 0
         np.testing.assert_allclose(xin, R.standardize_ref(src, 1e-5).numpy(), rtol=2e-5, atol=2e-6)
     y = np.full((rows, out if out else 64), np.nan, np.float32)
-    z = [np.full((rows, 64), np.nan, np.float32) for _ in range(n_layers)]
+    z = [np.full((emu.mappo_mlp_row_table_ints(rows), 64), np.nan, np.float32) for _ in range(n_layers)]
     tab = np.full(emu.mappo_mlp_row_table_ints(rows), -1, np.int32)
     R128 = (rows + 127) // 128 * 128
     assert tab.size == R128
@@ -60,7 +60,7 @@ def _run(emu, rng, din, n_layers, act, out, rows, src_rows, standardize=True, ch
     m = R.MLP(src=_ptr(xin), row_tab=_ptr(tab), rows=rows, din=din,
               n_layers=n_layers, act=act, out=out, ln_eps=1e-5, w1=_ptr(p["w1"]), wh=_ptr(p["wh"]) if out else None,
               bh=_ptr(p["bh"]) if out else None, y=_ptr(y))
-    st = [np.full((rows, 2), np.nan, np.float32) for _ in range(n_layers)]
+    st = [np.full((emu.mappo_mlp_row_table_ints(rows), 2), np.nan, np.float32) for _ in range(n_layers)]
     for l in range(n_layers):
         m.bias[l], m.ln_g[l], m.ln_b[l] = _ptr(p["bias%d" % l]), _ptr(p["ln_g%d" % l]), _ptr(p["ln_b%d" % l])
         m.z[l], m.ln_stats[l] = _ptr(z[l]), _ptr(st[l])
@@ -75,8 +75,8 @@ def _run(emu, rng, din, n_layers, act, out, rows, src_rows, standardize=True, ch
         a_ref = fn(z_ref[l].detach())
         mean, var = a_ref.mean(1, keepdim=True), a_ref.var(1, unbiased=False, keepdim=True)
         rstd = 1.0 / torch.sqrt(var + 1e-5)
-        np.testing.assert_allclose(z[l], ((a_ref - mean) * rstd).numpy(), rtol=2e-4, atol=5e-5)
-        np.testing.assert_allclose(st[l], torch.cat([mean, rstd], 1).numpy(), rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(R.rows_of_fragments(z[l], rows), ((a_ref - mean) * rstd).numpy(), rtol=2e-4, atol=5e-5)
+        np.testing.assert_allclose(st[l][:rows], torch.cat([mean, rstd], 1).numpy(), rtol=2e-4, atol=2e-5)
     if not backward:
         return
     dy = rng.standard_normal(y.shape).astype(np.float32)

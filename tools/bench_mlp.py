@@ -77,7 +77,7 @@ def main():
 
         if opt.stamps:
             from onpolicy import _native
-            dbg = torch.zeros(1024, dtype=torch.int64, device=dev)
+            dbg = torch.zeros(2048, dtype=torch.int64, device=dev)
             with torch.no_grad():
                 fused_mlp.trunk_forward(base, rs, head)
                 _native.lib().mappo_mlp_set_debug(dbg.data_ptr())
@@ -96,17 +96,26 @@ def main():
                 b = load[4 * j:4 * j + 12]
                 print(j, "data wait", b[3] - b[0], "lds", b[1] - b[3], "issue", b[2] - b[1], "barrier", b[4] - b[2], "|",
                       b[6] - b[4], b[8] - b[6], "|", b[10] - b[8])
-            if din % 4 == 0 and din >= 192:
+            if True:
                 fwd()
                 dbg.zero_()
                 _native.lib().mappo_mlp_set_debug(dbg.data_ptr())
                 bwd()
                 torch.cuda.synchronize()
                 _native.lib().mappo_mlp_set_debug(None)
-                d = dbg.cpu().numpy()[512:512 + 160].reshape(40, 4)
-                print("dw1 (wave 0 of workgroup 0): tile, wait for loads, barrier, issue, mfma steps")
-                for m in range(4, 24):
-                    print(m, d[m][1] - d[m][0], d[m][2] - d[m][1], d[m][3] - d[m][2], d[m + 1][0] - d[m][3])
+                dall = dbg.cpu().numpy()
+                d = dall[512:512 + 160].reshape(40, 4)
+                if din % 4 == 0 and din >= 192:
+                    print("dw1 (wave 0 of workgroup 0): tile, wait for loads, barrier, issue, mfma steps")
+                    for m in range(4, 12):
+                        print(m, d[m][1] - d[m][0], d[m][2] - d[m][1], d[m][3] - d[m][2], d[m + 1][0] - d[m][3])
+                b = dall[1024:1024 + 192].reshape(12, 16)
+                print("chain kernel (thread 0): tile | inputs+fetch | head | L1: ln+dz, sums, transposes+bias, dW+dX | "
+                      "L0: ln+dz, sums | rest | total")
+                for t in range(2, 10):
+                    r = b[t]
+                    print(t, r[1] - r[0], r[2] - r[1], "|", r[3] - r[2], r[4] - r[3], r[5] - r[4], r[6] - r[5], "|",
+                          r[7] - r[6], r[8] - r[7], "|", r[15] - r[8], "|", r[15] - r[0])
         t_stats = timed(lambda: fused_mlp.standardize_rows(src))
         t_f = timed(fwd)
         t_b = timed(bwd)

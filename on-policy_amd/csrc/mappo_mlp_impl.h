@@ -31,6 +31,12 @@
 
 #include "../../include/mappo_hip.h"
 
+// (the rest of the library is built with -ffp-contract=off because the GAE scan must round like numpy; nothing here is
+// compared bit for bit with a CPU evaluation, and fused multiply-adds are a quarter of these kernels' VALU instructions)
+#ifndef MAPPO_MLP_NO_CONTRACT
+#pragma clang fp contract(fast)
+#endif
+
 namespace mlp {
 
 constexpr int kH = 64;          // hidden width

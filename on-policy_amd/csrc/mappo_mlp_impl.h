@@ -691,7 +691,10 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a) {
             }
         }
     };
-    if (blockIdx.x < ntiles) fetch(blockIdx.x);
+    // (three layers: 96 prefetch registers on top of three layers of live state do not fit; the tile's inputs are then
+    // fetched when it starts)
+    constexpr bool kPrefetch = L <= 2;
+    if (kPrefetch && blockIdx.x < ntiles) fetch(blockIdx.x);
 
     const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
     int n_stamp = 0;
@@ -700,6 +703,7 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a) {
         const long long row = tile * kTR + 32 * wave + c;
         const bool ok = row < rows;
         MAPPO_BWD_STAMP(0);
+        if (!kPrefetch) fetch(tile);
         float nc[L][32];        // this tile's normalised activations
         float mean[L], rstd[L], sd[L];
         float dh[32];           // gradient w.r.t. the output of the layer being processed (slot order)
@@ -725,7 +729,7 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a) {
             for (int oo = 0; oo < out; ++oo)
                 if (h == 0) DY[oo * 32 + c] = ok ? a.dy[row * out + oo] : 0.f;
         }
-        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);     // in flight during this tile's arithmetic
+        if (kPrefetch && tile + gridDim.x < ntiles) fetch(tile + gridDim.x);     // in flight during this tile's arithmetic
         MAPPO_BWD_STAMP(1);
 
         // T[feature][c] = output of layer l = nhat * gamma + beta  (transposed into wave-private LDS)

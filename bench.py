@@ -349,7 +349,7 @@ def main():
             # launches averaged, as rocprofv3 --stats averages them), f32 matrix-core bound
             "roofline": roof_mfma("mappo_mlp_forward", "mlp_fwd_kernel (mappo_mlp_forward)") or roof("mappo_gae_f32"),
             "roofline_mlp_backward": roof_mfma("mappo_mlp_backward",
-                                               "mlp_bwd_kernel + mlp_dw1_kernel + reduce (mappo_mlp_backward)"),
+                                               "mlp_bwd_kernel + mlp_dw1_{direct,rows}_kernel + reduce (mappo_mlp_backward)"),
             # the kernel BASELINE.json's north star names (>= 70 % of HBM in the GAE scan), HBM bound
             "roofline_gae": roof("mappo_gae_f32"),
             "roofline_gather": roof("mappo_gather_chunks" if wl["recurrent"] else "mappo_gather_rows"),

@@ -68,6 +68,16 @@ def main():
     r = time_launches(lambda i: y.copy_(x), 1, 10)
     out["copy_1GiB_GBps"] = 2 * x.numel() * 4 / (r["b2b_us"] * 1e-6) / 1e9
     del x, y
+    # ... and a device copy that moves as many bytes as one fused GAE launch at THIS size (24 B / element): what a plain
+    # streaming kernel reaches when the whole launch lasts a few microseconds
+    n_small = 24 * T * C // 8
+    xs = [torch.empty(n_small, dtype=torch.float32, device=dev) for _ in range(opt.sets)]
+    ys = [torch.empty(n_small, dtype=torch.float32, device=dev) for _ in range(opt.sets)]
+    r = time_launches(lambda i: ys[i].copy_(xs[i]), opt.sets, opt.iters)
+    out["copy_same_bytes"] = {"bytes": 8 * n_small, "median_us": r["median_us"], "b2b_us": r["b2b_us"],
+                              "GBps_median": 8 * n_small / (r["median_us"] * 1e-6) / 1e9,
+                              "GBps_b2b": 8 * n_small / (r["b2b_us"] * 1e-6) / 1e9}
+    del xs, ys
 
     sets = []
     for s in range(opt.sets):

@@ -47,11 +47,11 @@ def main():
                 "and critic launches averaged; FETCH_SIZE doubled (gfx950 counts 64 B per 128 B request of a wide "
                 "coalesced read, MI355X_MICROARCH.md)"}
     alg_b = (_work(rows, 48, 2, 5, True)[1] + _work(rows, 384, 2, 1, True)[1]) / 2
-    fb = sum(mean_of(fetch, k)[0] for k in ("mlp_bwd_kernel", "mlp_dw1_kernel")) + 2 * mean_of(fetch, "mlp_reduce_kernel")[0]
-    wb = sum(mean_of(write, k)[0] for k in ("mlp_bwd_kernel", "mlp_dw1_kernel")) + 2 * mean_of(write, "mlp_reduce_kernel")[0]
+    fb = sum(mean_of(fetch, k)[0] for k in ("mlp_bwd_kernel", "mlp_dw1_")) + 2 * mean_of(fetch, "mlp_reduce_kernel")[0]
+    wb = sum(mean_of(write, k)[0] for k in ("mlp_bwd_kernel", "mlp_dw1_")) + 2 * mean_of(write, "mlp_reduce_kernel")[0]
     out["mappo_mlp_backward"] = {
         "algorithmic_bytes": alg_b, "fetch_size_bytes_raw": fb, "write_size_bytes": wb, "hbm_bytes": 2 * fb + wb,
-        "kernel": "mlp::mlp_bwd_kernel<2, 1> + mlp::mlp_dw1_kernel + 2 x mlp::mlp_reduce_kernel",
+        "kernel": "mlp::mlp_bwd_kernel<2, 1> + mlp::mlp_dw1_direct_kernel (critic) / mlp::mlp_dw1_rows_kernel<2> (actor) + 2 x mlp::mlp_reduce_kernel",
         "note": "one mappo_mlp_backward call = chain kernel + first-layer weight-gradient kernel + two reductions"}
     f, n = mean_of(fetch, "gae_")
     w, _ = mean_of(write, "gae_")

@@ -81,6 +81,20 @@ def test_trunk_vs_float64_modules(case):
     _compare(*case)
 
 
+@pytest.mark.parametrize("din", [384, 400, 48, 30])
+def test_persistent_loops_in_steady_state(din):
+    """With the grid capped at 2 workgroups every workgroup walks dozens of tiles: the software pipelines of all K9 kernels
+    (register chunk buffers of the forward, the direct-to-LDS slot rings and their counted waits in the weight-gradient
+    kernels: direct (384, two k slabs at 400), row-split (48), loader version (30)) run through their steady state with
+    the values checked, which the uncapped cases -- one or two tiles per workgroup -- do not exercise."""
+    from onpolicy import _native
+    _native.lib().mappo_mlp_set_grid_cap(2)
+    try:
+        _compare(din, 1, False, 3, 128 * 24 + 16 * 3 + 5, 9000)
+    finally:
+        _native.lib().mappo_mlp_set_grid_cap(0)
+
+
 def test_trunk_without_input_layernorm():
     _compare(40, 1, False, 4, 450, 450, feature_norm=False)
 

@@ -5,7 +5,8 @@ pick (hipBLASLt's heuristic) is 15-35 % slower on these shapes than the best ker
 offer (e.g. 1151 -> 925 us for the 384 -> 64 critic layer at 2.6 M rows, 358 -> 243 us for the 64 -> 64 layers).
 PyTorch's own TunableOp benchmarks the candidates the first time a shape is seen and remembers the winner;
 this module switches it on, pre-loads the winners for the shapes of the shipped workloads
-(``tuned_gemms_gfx950.csv``: north star at 1 / 2 / 4 / 8 GPUs, SMAC, Hanabi shapes) so that no tuning is needed
+(``tuned_gemms_gfx950.csv``: recurrent north star incl. its 8-GPU shard, SMAC, cfg2, Hanabi shapes -- the hidden-64 MLP
+trunks no longer reach the BLAS libraries; refresh with tools/tune_gemms.sh + tools/merge_tuned_gemms.py) so that no tuning is needed
 for them, and keeps whatever gets tuned later in a per-user cache file (one per device ordinal).
 
 The maths is unchanged (float32 GEMMs; only the tile configuration / summation order differs).

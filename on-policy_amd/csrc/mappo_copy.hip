@@ -516,7 +516,7 @@ extern "C" int mappo_gather_set_variant(int variant) {
 extern "C" int mappo_abi_version(void) { return MAPPO_ABI_VERSION; }
 
 extern "C" const char* mappo_build_info(void) {
-    return "libmappo_hip gfx950 (CDNA4) fp-contract=off " __DATE__;
+    return "libmappo_hip gfx950 (CDNA4) fp-contract=off (fused trunk: fast) " __DATE__;
 }
 
 extern "C" const char* mappo_error_string(int code) {

@@ -1,6 +1,7 @@
 // Fused actor / critic trunk for hidden width 64 (K9): sampler gather + input standardisation + Linear + act + LayerNorm
 // chain + head in one forward kernel; the matching backward as two kernels (row-parallel chain, first-layer weight
-// gradient as a gather-fused split-K GEMM).  Reference maths: onpolicy/algorithms/utils/mlp.py:6-58 (MLPLayer / MLPBase:
+// gradient as a gather-fused split-K GEMM in three forms: direct-to-LDS loads for wide aligned inputs, row-split for
+// narrow ones, loader waves for the rest).  Reference maths: onpolicy/algorithms/utils/mlp.py:6-58 (MLPLayer / MLPBase:
 // [LayerNorm] -> (Linear -> Tanh|ReLU -> LayerNorm) x (1 + layer_N)), act.py:44-60 / distributions.py:55-68 (Categorical
 // head = Linear), r_actor_critic.py:147-175 (v_out = Linear(hidden, 1)), rows drawn by the samplers of
 // onpolicy/utils/shared_buffer.py:340-400 (feed-forward) and :499-608 (recurrent chunks).
@@ -8,11 +9,12 @@
 // Why: at the north-star size the update was bound by [rows, 64] activation round trips between separate GEMM, bias,
 // activation and LayerNorm launches (47 % library GEMMs + 23 % LayerNorm passes + 17 % gathers of a 528 ms step).  Here a
 // row tile stays in registers from the gathered observation to the head's output; the only per-row HBM traffic is the
-// observation row itself, two saved [64] pre-activation rows and the head output.  All products run on the f32 MFMA
+// observation row itself, the saved normalised activations ([64] per row and layer) and the head output.  All products run on the f32 MFMA
 // (v_mfma_f32_32x32x2_f32: exact float32 fma chains, 64 flop / clk / SIMD), so this path is MFMA-bound, not HBM-bound.
 //
 // This header is the whole implementation, written against a handful of primitives (prim::mfma32, prim::xhalf,
-// prim::lds, __syncthreads, MAPPO_LAUNCH).  mappo_mlp.hip binds them to gfx950; tests/simt/ binds them to a host SIMT
+// prim::lds, prim::load_lds16 / load_lds4 / wait_lds_loads for the direct-to-LDS loads, prim::wave_sync,
+// __syncthreads, MAPPO_LAUNCH).  mappo_mlp.hip binds them to gfx950; tests/simt/ binds them to a host SIMT
 // emulator so that the fragment-layout logic is checked without a GPU (test infrastructure, never linked into the
 // product library).
 //

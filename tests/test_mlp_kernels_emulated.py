@@ -94,7 +94,7 @@ def _run(emu, rng, din, n_layers, act, out, rows, src_rows, standardize=True, ch
 
 
 # (din, n_layers, act, out, rows, src_rows): tails in every dimension -- rows not a multiple of the 128-row tile / the
-# 32-row wave tile, din not a multiple of the 64-wide chunk / of 4, several workgroups per launch
+# 32-row wave tile, din not a multiple of the 32-wide chunk / of 4, several workgroups per launch
 CASES = [
     (48, 2, 1, 5, 70, 200),        # north-star actor shapes (tanh, Discrete(5))
     (30, 2, 2, 1, 128, 128),       # cfg2 actor width, ReLU, value head, exactly one tile

@@ -59,3 +59,64 @@ def test_reference_flags_are_accepted_by_our_scripts():
         our_args = ours.parse_args([], get_config())
         extra = EXTRA_FLAGS.get(script, {})
         assert dict(vars(ref_args), **extra) == vars(our_args), script
+
+
+def _run_reference_main(script, argv, tmp_path, monkeypatch):
+    """Executes the reference's own ``main()`` (its source, compiled under a scratch ``__file__`` so that its run
+    directory lands in tmp_path, not in /root/reference) with this package on the import path.  ``wandb`` and
+    ``setproctitle`` (absent here; imported at the top of the script, unused with --use_wandb) are empty stand-ins."""
+    import sys
+    import types
+    for name in ("wandb", "setproctitle"):
+        if name not in sys.modules:
+            stub = types.ModuleType(name)
+            stub.setproctitle = lambda *_a, **_k: None
+            monkeypatch.setitem(sys.modules, name, stub)
+    fake = tmp_path / "onpolicy" / "scripts" / "train" / script
+    fake.parent.mkdir(parents=True)
+    src = open(os.path.join(REF_SCRIPTS, script)).read()
+    ns = {"__file__": str(fake), "__name__": "reference_" + script[:-3]}
+    exec(compile(src, str(fake), "exec"), ns)
+    ns["main"](argv)
+    return tmp_path / "onpolicy" / "scripts" / "results"
+
+
+def test_reference_train_mpe_main_runs_against_this_package(tmp_path, monkeypatch):
+    """The boundary, dynamically: the reference's scripts/train/train_mpe.py main() -- parser, env factory, runner
+    selection, run(), post-processing -- drives THIS package's config / VecEnv / MPE env / runner / policy / trainer for
+    two episodes on the CPU.  The rollout buffer of the product lives in HBM and has no CPU form, so the runner's buffer
+    class is the oracle-backed host stand-in of the other CPU runner tests (test infrastructure); everything else is the
+    product code the script imports."""
+    import json
+    import onpolicy.runner.shared.base_runner as base
+    from host_buffer import HostSharedBuffer
+    monkeypatch.setattr(base, "SharedReplayBuffer", HostSharedBuffer)
+    results = _run_reference_main("train_mpe.py", [
+        "--env_name", "MPE", "--algorithm_name", "mappo", "--experiment_name", "boundary", "--scenario_name",
+        "simple_spread", "--num_agents", "3", "--num_landmarks", "3", "--seed", "1", "--n_training_threads", "1",
+        "--n_rollout_threads", "2", "--num_mini_batch", "1", "--episode_length", "10", "--num_env_steps", "40",
+        "--ppo_epoch", "2", "--use_ReLU", "--gain", "0.01", "--lr", "7e-4", "--critic_lr", "7e-4",
+        "--use_wandb", "--cuda", "--log_interval", "1", "--save_interval", "1"], tmp_path, monkeypatch)
+    run = results / "MPE" / "simple_spread" / "mappo" / "boundary" / "run1"
+    assert (run / "models" / "actor.pt").exists() and (run / "models" / "critic.pt").exists()
+    summary = json.load(open(run / "logs" / "summary.json"))
+    assert any("average_episode_rewards" in k for k in summary), sorted(summary)[:5]
+
+
+def test_reference_train_hanabi_main_runs_against_this_package(tmp_path, monkeypatch):
+    """Same for scripts/train/train_hanabi_forward.py: the reference's main() builds ChooseDummyVecEnv over this package's
+    HanabiEnv (the batched native stepper) and runs the turn-based forward runner for two episodes."""
+    import json
+    import onpolicy.runner.shared.base_runner as base
+    from host_buffer import HostSharedBuffer
+    monkeypatch.setattr(base, "SharedReplayBuffer", HostSharedBuffer)
+    results = _run_reference_main("train_hanabi_forward.py", [
+        "--env_name", "Hanabi", "--algorithm_name", "mappo", "--experiment_name", "boundary", "--hanabi_name",
+        "Hanabi-Very-Small", "--num_agents", "2", "--seed", "1", "--n_training_threads", "1", "--n_rollout_threads", "1",
+        "--n_eval_rollout_threads", "1", "--num_mini_batch", "1", "--episode_length", "12", "--num_env_steps", "24",
+        "--ppo_epoch", "2", "--gain", "0.01", "--lr", "7e-4", "--critic_lr", "1e-3", "--hidden_size", "64",
+        "--layer_N", "1", "--entropy_coef", "0.015", "--use_wandb", "--cuda", "--log_interval", "1",
+        "--save_interval", "1"], tmp_path, monkeypatch)
+    run = results / "Hanabi" / "Hanabi-Very-Small" / "mappo" / "boundary" / "run1"
+    assert (run / "models" / "actor.pt").exists()
+    assert json.load(open(run / "logs" / "summary.json")) is not None

@@ -439,6 +439,11 @@ int64_t mappo_mlp_workspace_floats(int din, int n_layers, int out);
 /* dst[r, :] = (src[r, :] - mean_r) / sqrt(var_r + eps) for every row of a [rows, D] matrix (population variance: the
  * parameter-free half of nn.LayerNorm, reference onpolicy/algorithms/utils/mlp.py:47-48, 56-57) */
 int     mappo_standardize_rows(const float* src, int64_t rows, int D, float eps, float* dst, mappo_stream_t stream);
+/* ... with the rows of dst `ld` >= D floats apart and zeros in columns D .. ld - 1: a copy padded to a multiple of 4
+ * floats lets the trunk kernels take their 16-byte aligned paths for odd observation widths (pass din = ld and a
+ * first-layer weight matrix padded with zero columns; the zero products change no bit of the result) */
+int     mappo_standardize_rows_ld(const float* src, int64_t rows, int D, float eps, float* dst, int ld,
+                                  mappo_stream_t stream);
 
 /* --------------------------------------------------------------- K11: simple_spread worlds on the device ----
  * One env step of `n_worlds` cooperative-navigation worlds (the env of BASELINE.json configs[0] / configs[2]; reference

@@ -125,5 +125,10 @@ extern "C" int64_t mappo_mlp_workspace_floats(int din, int n_layers, int out) {
 }
 extern "C" int mappo_standardize_rows(const float* src, int64_t rows, int D, float eps, float* dst, mappo_stream_t stream) {
     g_launch_error = 0;
-    return mlp::standardize_rows(src, rows, D, eps, dst, static_cast<hipStream_t>(stream));
+    return mlp::standardize_rows(src, rows, D, eps, dst, D, static_cast<hipStream_t>(stream));
+}
+extern "C" int mappo_standardize_rows_ld(const float* src, int64_t rows, int D, float eps, float* dst, int ld,
+                                         mappo_stream_t stream) {
+    g_launch_error = 0;
+    return mlp::standardize_rows(src, rows, D, eps, dst, ld, static_cast<hipStream_t>(stream));
 }

@@ -1079,7 +1079,10 @@ __global__ void __launch_bounds__(kPipeThreads) mlp_dw1_kernel(Dw1Args a) {
 constexpr int kD2Rows = 16;
 constexpr int kD2Slots = 4;
 constexpr int kD2GridCap = 256;
-constexpr int kD2MinWidth = 192;                 // narrower inputs leave half of the waves without a k tile: loader version
+#ifndef MAPPO_D2_MIN_WIDTH
+#define MAPPO_D2_MIN_WIDTH 128                   // (tuning: tools/ab_build.sh; 152 columns: 2.01 ms per 2.6 M rows against 2.16)
+#endif
+constexpr int kD2MinWidth = MAPPO_D2_MIN_WIDTH;  // narrower inputs leave most waves without a k tile: loader version
 constexpr int kD2XSlot = 3 * kD2Rows * 32;       // floats: [k tile i < 3][16 rows][32]
 constexpr int kD2DzSlot = kD2Rows * 64;          // floats: [16 rows][64 features], shared by the 4 waves
 constexpr int kD2Lds = 4 * kD2Slots * kD2XSlot + kD2Slots * kD2DzSlot;       // floats, + the row-table rings:
@@ -1337,9 +1340,11 @@ __global__ void __launch_bounds__(kThreads) mlp_reduce_kernel(const float* parti
 // and for the output.
 // NV = 16-byte pieces per lane kept in registers (rows up to 64 * NV floats are read from HBM exactly once); NV = 0:
 // any width, the row is re-read from cache for the second moment and for the output.
+// Rows of dst are `ld` >= D floats apart; columns D .. ld - 1 (padding to a 16-byte multiple, so that the trunk kernels
+// take their aligned paths for odd observation widths) are written as zeros.
 template <int NV>
 __global__ void __launch_bounds__(kThreads) standardize_rows_kernel(const float* src, long long rows, int D, float eps,
-                                                                    float* dst) {
+                                                                    float* dst, int ld) {
     const int sub = threadIdx.x & 15;
     const long long groups = ((long long)gridDim.x * kThreads) >> 4;
     const long long first = ((long long)blockIdx.x * kThreads + threadIdx.x) >> 4;
@@ -1389,7 +1394,9 @@ __global__ void __launch_bounds__(kThreads) standardize_rows_kernel(const float*
         q = prim::sum16(q);
         const float rstd = 1.f / sqrtf(q / (float)D + eps);
         if (ok) {
-            float* o = dst + r * D;
+            float* o = dst + r * ld;
+            if (sub == 0)
+                for (int k = D; k < ld; ++k) o[k] = 0.f;
             if (NV > 0) {
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
@@ -1598,19 +1605,19 @@ inline int row_table(const long long* idx, long long rows, long long mb, int chu
     return MAPPO_LAUNCH_ERROR();
 }
 
-inline int standardize_rows(const float* src, long long rows, int D, float eps, float* dst, hipStream_t stream) {
+inline int standardize_rows(const float* src, long long rows, int D, float eps, float* dst, int ld, hipStream_t stream) {
     if (!src || !dst) return MAPPO_E_NULL;
-    if (rows <= 0 || D <= 0) return MAPPO_E_SHAPE;
+    if (rows <= 0 || D <= 0 || ld < D) return MAPPO_E_SHAPE;
     long long grid = ceil_div(rows * 16, kThreads);
     if (grid > 256 * 8) grid = 256 * 8;
     if (D <= 64) {
-        MAPPO_LAUNCH(standardize_rows_kernel<1>, (unsigned)grid, kThreads, 0, stream, src, rows, D, eps, dst);
+        MAPPO_LAUNCH(standardize_rows_kernel<1>, (unsigned)grid, kThreads, 0, stream, src, rows, D, eps, dst, ld);
     } else if (D <= 256) {
-        MAPPO_LAUNCH(standardize_rows_kernel<4>, (unsigned)grid, kThreads, 0, stream, src, rows, D, eps, dst);
+        MAPPO_LAUNCH(standardize_rows_kernel<4>, (unsigned)grid, kThreads, 0, stream, src, rows, D, eps, dst, ld);
     } else if (D <= 512) {
-        MAPPO_LAUNCH(standardize_rows_kernel<8>, (unsigned)grid, kThreads, 0, stream, src, rows, D, eps, dst);
+        MAPPO_LAUNCH(standardize_rows_kernel<8>, (unsigned)grid, kThreads, 0, stream, src, rows, D, eps, dst, ld);
     } else {
-        MAPPO_LAUNCH(standardize_rows_kernel<0>, (unsigned)grid, kThreads, 0, stream, src, rows, D, eps, dst);
+        MAPPO_LAUNCH(standardize_rows_kernel<0>, (unsigned)grid, kThreads, 0, stream, src, rows, D, eps, dst, ld);
     }
     return MAPPO_LAUNCH_ERROR();
 }

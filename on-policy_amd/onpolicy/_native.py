@@ -100,6 +100,7 @@ SIGNATURES = {
     "mappo_mlp_set_debug": (_int, [_vp]),
     "mappo_mlp_row_table": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _vp, _vp]),
     "mappo_standardize_rows": (_int, [_vp, _i64, _int, ctypes.c_float, _vp, _vp]),
+    "mappo_standardize_rows_ld": (_int, [_vp, _i64, _int, ctypes.c_float, _vp, _int, _vp]),
     "mappo_simple_spread_step": (_int, [_vp] * 11 + [_i64, _int, _int, _int, _int, _vp]),
     "mappo_abi_version": (_int, []),
     "mappo_build_info": (ctypes.c_char_p, []),

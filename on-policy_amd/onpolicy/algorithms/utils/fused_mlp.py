@@ -86,8 +86,10 @@ class RowSource(object):
     ``idx``   int64 device indices; ``chunk`` = (L, T, N, A) for recurrent_generator's chunk rows, None for row indices
     """
 
-    def __init__(self, src, idx, chunk=None, standardized=False):
+    def __init__(self, src, idx, chunk=None, standardized=False, width=None):
         self.src, self.idx, self.chunk, self.standardized = src, idx, chunk, bool(standardized)
+        # columns that carry data: a standardised copy may be padded with zero columns (``standardize_rows``)
+        self.width = int(src.shape[1]) if width is None else int(width)
         self.mb = int(idx.shape[0])
         self.rows = self.mb * (chunk[0] if chunk else 1)
         self._tab = None
@@ -106,7 +108,7 @@ class RowSource(object):
 
     @property
     def shape(self):
-        return (self.rows, int(self.src.shape[1]))
+        return (self.rows, self.width)
 
     @property
     def device(self):
@@ -117,7 +119,7 @@ class RowSource(object):
     def rows_slice(self, lo, hi):
         """Row span [lo, hi) of a rows-mode minibatch / chunk span [lo, hi) of a chunk-mode one (every span keeps all
         L steps of its chunks, row l * (hi - lo) + j)."""
-        return RowSource(self.src, self.idx[lo:hi], self.chunk, self.standardized)
+        return RowSource(self.src, self.idx[lo:hi], self.chunk, self.standardized, self.width)
 
     def __getitem__(self, key):
         if not (isinstance(key, slice) and key.step in (None, 1)) or self.chunk:
@@ -139,16 +141,20 @@ class RowSource(object):
 
     def materialize(self):
         """The [rows, din] tensor an eager sampler would have produced from ``src``."""
-        return self.src[self.source_rows()]
+        return self.src[self.source_rows()][:, :self.width]
 
 
-def standardize_rows(src2d, eps=1e-5):
-    """(x - mean) / sqrt(var + eps) of every row of a float32 device matrix (``mappo_standardize_rows``): the
-    parameter-free half of the networks' input LayerNorm, applied to a whole observation field once per train()."""
+def standardize_rows(src2d, eps=1e-5, pad=True):
+    """(x - mean) / sqrt(var + eps) of every row of a float32 device matrix (``mappo_standardize_rows_ld``): the
+    parameter-free half of the networks' input LayerNorm, applied to a whole observation field once per train().
+    ``pad``: the copy's rows are padded with zero columns to a multiple of 4 floats (16 bytes), so that the trunk
+    kernels take their aligned paths (direct-to-LDS weight gradient, no tail shifting) for odd observation widths;
+    ``RowSource(..., width=D)`` remembers the true width."""
     rows, D = src2d.shape
-    out = torch.empty_like(src2d)
-    _native.check(_native.lib().mappo_standardize_rows(src2d.data_ptr(), rows, D, float(eps), out.data_ptr(),
-                                                       _native.stream_of(src2d.device)), "mappo_standardize_rows")
+    ld = (D + 3) // 4 * 4 if pad and os.environ.get("MAPPO_PAD_STANDARDIZED", "1") != "0" else D
+    out = torch.empty((rows, ld), dtype=src2d.dtype, device=src2d.device)
+    _native.check(_native.lib().mappo_standardize_rows_ld(src2d.data_ptr(), rows, D, float(eps), out.data_ptr(), ld,
+                                                          _native.stream_of(src2d.device)), "mappo_standardize_rows_ld")
     return out
 
 
@@ -294,6 +300,9 @@ def trunk_forward(base, rs, head=None):
         if rs.standardized:
             raise ValueError("the trunk has no input LayerNorm: the RowSource must read the rows as they are")
         w1, b1 = lin0.weight, lin0.bias
+    ld = int(rs.src.shape[1])
+    if ld != w1.shape[1]:           # zero-padded standardised copy: zero columns in the first Linear, exact zeros in the sums
+        w1 = torch.nn.functional.pad(w1, (0, ld - w1.shape[1]))
     params = [w1, b1]
     for blk in blocks:
         params += [blk[2].weight, blk[2].bias]

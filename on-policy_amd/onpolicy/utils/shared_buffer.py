@@ -620,7 +620,8 @@ class SharedReplayBuffer(object):
             if lazy_obs and name in ("share_obs", "obs") and len(tail) == 1:
                 from onpolicy.algorithms.utils.fused_mlp import RowSource
                 chunk = None if chunk_len is None else (int(chunk_len), T, N, A)
-                outs.append(RowSource(self._obs_rows(name, standardize_obs), idx, chunk, standardized=standardize_obs))
+                outs.append(RowSource(self._obs_rows(name, standardize_obs), idx, chunk, standardized=standardize_obs,
+                                      width=width))
                 continue
             if is_state and not self._recurrent:
                 outs.append(src[0, 0, 0].expand((mb,) + tail))  # zeros, no traffic

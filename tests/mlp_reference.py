@@ -33,6 +33,8 @@ def bind(lib):
     lib.mappo_mlp_row_table.argtypes = [_vp, _i64, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp]
     lib.mappo_standardize_rows.restype = ctypes.c_int
     lib.mappo_standardize_rows.argtypes = [_vp, _i64, ctypes.c_int, ctypes.c_float, _vp, _vp]
+    lib.mappo_standardize_rows_ld.restype = ctypes.c_int
+    lib.mappo_standardize_rows_ld.argtypes = [_vp, _i64, ctypes.c_int, ctypes.c_float, _vp, ctypes.c_int, _vp]
     lib.mappo_mlp_set_grid_cap.restype = ctypes.c_int
     lib.mappo_mlp_set_grid_cap.argtypes = [ctypes.c_int]
     return lib

@@ -65,6 +65,10 @@ extern "C" int64_t mappo_mlp_workspace_floats(int din, int n_layers, int out) {
     return mlp::workspace_floats(din, n_layers, out);
 }
 extern "C" int mappo_standardize_rows(const float* src, int64_t rows, int D, float eps, float* dst, mappo_stream_t stream) {
-    return mlp::standardize_rows(src, rows, D, eps, dst, stream);
+    return mlp::standardize_rows(src, rows, D, eps, dst, D, stream);
+}
+extern "C" int mappo_standardize_rows_ld(const float* src, int64_t rows, int D, float eps, float* dst, int ld,
+                                         mappo_stream_t stream) {
+    return mlp::standardize_rows(src, rows, D, eps, dst, ld, stream);
 }
 extern "C" unsigned long long simt_mfma_count() { return simt::st().n_mfma; }

@@ -43,7 +43,7 @@ def _compare(din, layer_N, relu, out, rows, src_rows, chunk=None, feature_norm=T
         idx = torch.randperm(src_rows // L, generator=g)[:rows // L]
     src_d = src.to(DEV)
     xin = fused_mlp.standardize_rows(src_d) if feature_norm else src_d      # once per train() in the trainer
-    rs = fused_mlp.RowSource(xin, idx.to(DEV), chunk, standardized=feature_norm)
+    rs = fused_mlp.RowSource(xin, idx.to(DEV), chunk, standardized=feature_norm, width=din)     # (xin may be zero-padded)
     y = fused_mlp.trunk_forward(base, rs, head)
     dy = torch.randn(y.shape, generator=g)
     y.backward(dy.to(DEV))
@@ -132,10 +132,12 @@ def test_trunk_at_scale_is_deterministic_and_finite():
 def test_row_source_materialize_equals_eager_gather():
     from onpolicy.algorithms.utils import fused_mlp
     src = torch.randn(500, 54, device=DEV) * 3 + 1
-    xhat = fused_mlp.standardize_rows(src)
-    torch.testing.assert_close(xhat, torch.nn.functional.layer_norm(src, (54,)), rtol=1e-4, atol=1e-5)
+    xhat = fused_mlp.standardize_rows(src)          # 54 -> rows of 56 floats, two zero columns
+    assert xhat.shape == (500, 56) and not xhat[:, 54:].any()
+    assert torch.equal(xhat[:, :54], fused_mlp.standardize_rows(src, pad=False))
+    torch.testing.assert_close(xhat[:, :54], torch.nn.functional.layer_norm(src, (54,)), rtol=1e-4, atol=1e-5)
     idx = torch.randperm(500, device=DEV)[:123]
-    rs = fused_mlp.RowSource(xhat, idx, standardized=True)
-    assert torch.equal(rs.materialize(), xhat[idx])
+    rs = fused_mlp.RowSource(xhat, idx, standardized=True, width=54)
+    assert rs.shape == (123, 54) and torch.equal(rs.materialize(), xhat[idx][:, :54])
     assert rs[10:20].rows == 10 and torch.equal(rs[10:20].idx, idx[10:20])
     assert rs.table().dtype == torch.int32 and torch.equal(rs.table()[:123].long(), idx)

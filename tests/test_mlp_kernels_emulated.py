@@ -127,6 +127,22 @@ def test_workgroups_looping_over_many_tiles(emu, cap, din, tiles):
         emu.mappo_mlp_set_grid_cap(0)
 
 
+@pytest.mark.parametrize("D", [30, 19, 150, 600])
+def test_standardised_copy_padded_to_16_bytes(emu, D):
+    """mappo_standardize_rows_ld: the rows of the copy are ld = D rounded up to 4 floats apart, the padding is zero, the
+    data columns equal the unpadded call bit for bit."""
+    rng = np.random.default_rng(D)
+    rows, ld = 37, (D + 3) // 4 * 4
+    src = (rng.standard_normal((rows, D)) * 2 + 0.5).astype(np.float32)
+    plain = np.full((rows, D), np.nan, np.float32)
+    padded = np.full((rows, ld), np.nan, np.float32)
+    assert emu.mappo_standardize_rows(_ptr(src), rows, D, 1e-5, _ptr(plain), None) == 0
+    assert emu.mappo_standardize_rows_ld(_ptr(src), rows, D, 1e-5, _ptr(padded), ld, None) == 0
+    np.testing.assert_array_equal(padded[:, :D], plain)
+    np.testing.assert_array_equal(padded[:, D:], 0.0)
+    np.testing.assert_allclose(plain, R.standardize_ref(torch.tensor(src, dtype=torch.float64), 1e-5).numpy(), rtol=2e-5, atol=2e-6)
+
+
 def test_unstandardised_input_and_identity_rows(emu):
     rng = np.random.default_rng(3)
     _run(emu, rng, 40, 2, 1, 4, 45, 45, standardize=False)

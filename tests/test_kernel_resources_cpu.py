@@ -1,7 +1,7 @@
 """Compile-time guard on the kernels' register / LDS budgets (no GPU needed: hipcc cross-compiles and reports each
 kernel's resource usage).  profiles/kernel_resources.json is the committed snapshot (tools/kernel_resources.py
 --write); here: no kernel may spill to scratch memory, the hot kernels keep the occupancy they were tuned for, and the
-quick-to-compile sources still produce exactly the snapshot (all five with MAPPO_CHECK_ALL_KERNEL_RESOURCES=1)."""
+quick-to-compile sources still produce exactly the snapshot (all eight with MAPPO_CHECK_ALL_KERNEL_RESOURCES=1)."""
 import importlib.util
 import json
 import os
@@ -48,7 +48,7 @@ def test_sources_still_compile_to_the_snapshot():
     tool = _tool()
     table = json.load(open(SNAPSHOT))
     sources = tool.SOURCES if os.environ.get("MAPPO_CHECK_ALL_KERNEL_RESOURCES") == "1" else \
-        ("mappo_copy.hip", "mappo_loss.hip", "mappo_rnn.hip", "mappo_mlp.hip", "mappo_perm.hip", "mappo_env.hip")
+        ("mappo_copy.hip", "mappo_loss.hip", "mappo_rnn.hip", "mappo_mlp.hip", "mappo_perm.hip")     # (gae, env: ~100 s each)
     for src in sources:
         fresh = {"%s :: %s" % (src, k.pop("kernel")): k for k in tool.analyse(src)}
         committed = {k: v for k, v in table.items() if k.startswith(src + " :: ")}

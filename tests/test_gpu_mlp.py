@@ -104,6 +104,32 @@ def test_trunk_on_recurrent_chunk_rows():
     _compare(24, 1, False, 0, L * 100, T * N * A, chunk=(L, T, N, A))
 
 
+@pytest.mark.parametrize("din,out", [(384, 1), (48, 5)])
+def test_trunk_at_scale_vs_float64(din, out):
+    """One million rows (every workgroup of every K9 kernel deep in its persistent loop -- 30 to 250 tiles each) against
+    the float64 modules on the device: outputs and every gradient."""
+    from onpolicy.algorithms.utils import fused_mlp
+    base, head = _modules(din, 1, False, out, seed=5)
+    ref_base, ref_head = copy.deepcopy(base).double().to(DEV), copy.deepcopy(head).double().to(DEV)
+    base, head = base.to(DEV), head.to(DEV)
+    rows, src_rows = (1 << 20) + 77, (1 << 20) + 5000
+    g = torch.Generator(device=DEV).manual_seed(din)
+    src = torch.randn(src_rows, din, device=DEV, generator=g) * 1.5 + 0.7
+    idx = torch.randperm(src_rows, device=DEV, generator=g)[:rows]
+    rs = fused_mlp.RowSource(fused_mlp.standardize_rows(src), idx, standardized=True, width=din)
+    dy = torch.randn(rows, out, device=DEV, generator=g) / rows ** 0.5
+    y = fused_mlp.trunk_forward(base, rs, head)
+    y.backward(dy)
+    y_ref = ref_head(ref_base(src.double()[idx]))
+    y_ref.backward(dy.double())
+    torch.testing.assert_close(y.detach().double(), y_ref.detach(), rtol=0, atol=1e-5 * float(y_ref.abs().max()))
+    for (name, p), q in list(zip(base.named_parameters(), ref_base.parameters())) + \
+            list(zip(head.named_parameters(), ref_head.parameters())):
+        # sums of a million float32 terms against float64, judged against the tensor's largest entry (measured: 1e-6)
+        torch.testing.assert_close(p.grad.double(), q.grad, rtol=0, atol=2e-5 * float(q.grad.abs().max()) + 1e-9,
+                                   msg=lambda m: name + ": " + m)
+
+
 def test_trunk_at_scale_is_deterministic_and_finite():
     """2.6 M rows through every workgroup's persistent loop: finite, identical run to run (fixed reduction order), and
     the row-sum gradient of the output bias equals the column sums of dy."""

@@ -13,10 +13,18 @@ from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy
 from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO
 
 CASES = ["mlp", "mlp_relu", "gru", "mlp_nonorm"]
+# hidden 64 (oracle/make_golden_trainer.py: CASES_H64): the width of every shipped MPE / SMAC configuration, the one the
+# fused trunk kernels take on the device (tests/test_gpu_trainer_h64.py); here the same fixtures pin the torch modules
+CASES_H64 = ["h64_ns", "h64_relu2", "h64_nofeat", "h64_odd", "h64_gru", "h64_gru_straddle"]
+ALL_CASES = CASES + CASES_H64
+
+
+def _file(cname):
+    return "trainer_h64_cases" if cname.startswith("h64_") else "trainer_cases"
 
 
 def _build(gold, cname):
-    meta = gold.meta("trainer_cases")[cname]
+    meta = gold.meta(_file(cname))[cname]
     spec = meta["spec"]
     args = make_args(episode_length=spec["T"], n_rollout_threads=spec["N"], **spec["args"])
     spaces = Box((spec["Do"],)), Box((spec["Ds"],)), Discrete(spec["na"])
@@ -35,18 +43,18 @@ def _check_sd(z, prefix, module, rtol=0.0, atol=0.0):
         np.testing.assert_allclose(sd[k].numpy(), z[prefix + k], rtol=rtol, atol=atol, err_msg=prefix + k)
 
 
-@pytest.mark.parametrize("cname", CASES)
+@pytest.mark.parametrize("cname", ALL_CASES)
 def test_init_matches_reference_seed(gold, cname):
     """Same seed => bit-identical initial weights and identical state_dict keys (checkpoint compat)."""
-    z = gold.npz("trainer_cases")
+    z = gold.npz(_file(cname))
     _, _, _, _, policy, _ = _build(gold, cname)
     _check_sd(z, "trn_%s_init_actor." % cname, policy.actor)
     _check_sd(z, "trn_%s_init_critic." % cname, policy.critic)
 
 
-@pytest.mark.parametrize("cname", CASES)
+@pytest.mark.parametrize("cname", ALL_CASES)
 def test_forward_matches_reference(gold, cname):
-    z = gold.npz("trainer_cases")
+    z = gold.npz(_file(cname))
     key = "trn_%s_" % cname
     _, spec, args, _, policy, trainer = _build(gold, cname)
     B = spec["N"] * spec["A"]
@@ -72,11 +80,11 @@ def test_forward_matches_reference(gold, cname):
         np.testing.assert_allclose(float(ev_ent), float(z[key + "eval_entropy"]), **tol)
 
 
-@pytest.mark.parametrize("cname", CASES)
+@pytest.mark.parametrize("cname", ALL_CASES)
 def test_train_matches_reference(gold, cname):
     """compute_returns + R_MAPPO.train on the same seeds: same permutations, train_info and final
     parameters as the reference within float32 tolerance."""
-    z = gold.npz("trainer_cases")
+    z = gold.npz(_file(cname))
     key = "trn_%s_" % cname
     meta, spec, args, spaces, policy, trainer = _build(gold, cname)
     buf = oracle.OracleBuffer(args, spec["A"], *spaces)
@@ -101,6 +109,12 @@ def test_train_matches_reference(gold, cname):
         vn = trainer.value_normalizer
         got = np.array([float(vn.running_mean), float(vn.running_mean_sq), float(vn.debiasing_term)])
         np.testing.assert_allclose(got, z[key + "final_norm"], rtol=1e-5, atol=1e-9)
+    if cname in CASES_H64:      # what the last ppo_update left in .grad (clipped), relative to each tensor's largest entry
+        for net, pre in ((policy.actor, "last_grad_actor."), (policy.critic, "last_grad_critic.")):
+            for k, p in net.named_parameters():
+                ref = z[key + pre + k]
+                np.testing.assert_allclose(p.grad.numpy(), ref, rtol=0, atol=2e-4 * max(1e-12, np.abs(ref).max()),
+                                           err_msg=pre + k)
 
 
 @pytest.mark.parametrize("cname", ["mlp", "gru"])

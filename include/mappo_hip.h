@@ -396,7 +396,7 @@ int     mappo_minibatch_indices(int64_t n, int64_t mb, int n_mb, const uint32_t*
  *   = {mean, rstd} per row, room for the same padded row count (both NULL in rollouts).
  * mappo_mlp_backward reads dy [rows, out] (or [rows, 64] for out = 0), z[l] and ln_stats[l]; writes `grads`, the parameter gradients
  *   as one flat array [w1 64*din | per layer: bias 64, ln weight 64, ln bias 64 | per hidden layer: w 64*64 | wh out*64 |
- *   bh out] (mappo_mlp_grad_floats), using dz1 [rows, 64] and workspace [mappo_mlp_workspace_floats] as scratch.
+ *   bh out] (mappo_mlp_grad_floats), using dz1 [mappo_mlp_row_table_ints(rows), 64] and workspace [mappo_mlp_workspace_floats] as scratch.
  *   Gradients are plain sums over the rows in a fixed order (deterministic run to run).
  * mappo_mlp_row_table: idx [mb] int64 sampler indices (NULL: launch row r = source row r);
  *   chunk_len 0: rows mode (rows = mb, row r <- idx[r]); L > 0: chunk mode, rows = L * mb, row l * mb + j <- element

@@ -65,6 +65,8 @@ __device__ __forceinline__ void load_lds4(const int* g, int* lds_wave_base) {
         : "memory");
 }
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+// the value is produced here, in program order: the compiler may neither sink its load into a later branch nor merge it
+__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void wait_loads_14() { asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }   // (stamps only)
 __device__ __forceinline__ long long clock() { return (long long)__builtin_readcyclecounter(); }
 __device__ __forceinline__ int f2i(float v) { return __float_as_int(v); }

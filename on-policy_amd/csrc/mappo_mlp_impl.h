@@ -597,7 +597,7 @@ struct BwdArgs {
     const float* z[3];  // saved normalised activations / {mean, rstd} of every layer (forward kernel)
     const float* st[3];
     const float* dy;    // [rows, out] (head) or [rows, 64] (out == 0)
-    float* dz1;         // [rows, 64]
+    float* dz1;         // [rows128(rows), 64]
     float* partials;    // [gridDim.x * 4][p_main]
     long long* dbg;     // tuning hook (mappo_mlp_set_debug): cycle stamps of workgroup 0's first tiles at [1024 ...], or NULL
 };
@@ -900,6 +900,577 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a) {
                 }
 }
 
+// ================================================================== backward: row-parallel chain, version 2 ====
+// The same chain with most of its per-tile LDS / VALU work removed.  Measured on gfx950 (cycle stamps, round 3): an LDS
+// instruction costs a wave ~30 cycles of issue whatever it moves, a second wave per SIMD does not hide them (its MFMA
+// stream starves the partner's LDS / vector-memory instructions: every phase of a tile just took twice as long), and
+// global-load latency (3 - 6 k cycles under load) was exposed three times per tile.  So: ONE wave per SIMD with the whole
+// register file, as few LDS instructions as possible, every global load issued a tile (or a layer) ahead.
+//
+// (1) Only the weight-gradient operands are transposed.  With h_l = nhat_l * gamma_l + beta_l the input of hidden layer
+//     l + 1 and dz_{l+1} the gradient at its pre-activation, accumulate per tile only
+//         G_{l+1}[f][k] = sum_rows dz_{l+1}[row][f] * nhat_l[row][k]      (MFMA; both operands transposed through LDS)
+//         db_{l+1}[f]   = sum_rows dz_{l+1}[row][f]
+//     and derive, once per launch after the cross-workgroup reduction (mlp_finish_kernel):
+//         dW_{l+1}[f][k] = gamma_l[k] G[f][k] + beta_l[k] db[f]
+//         dgamma_l[k]    = sum_f W_{l+1}[f][k] G[f][k]       (= sum_rows dh_l * nhat_l with dh_l = W^T dz)
+//         dbeta_l[k]     = sum_f W_{l+1}[f][k] db[f]         (= sum_rows dh_l)
+//     -- the same for the head (Gh[o][k] = sum_rows dy[row][o] nhat_{L-1}[row][k], dbh[o] = sum_rows dy[row][o]).  The
+//     per-tile transposes of dh and dh * nhat of every layer with their row sums are gone; the first layer's bias
+//     gradient (column sums of dz1) moves into the first-layer weight-gradient kernels, which read dz1 with lane =
+//     feature anyway.  Only a trunk without a head (out == 0: the features feed a GRU) still transposes its top layer.
+// (2) Sums over rows that are not MFMA operands stay in ROW layout (lane = row position, one register per slot) across all
+//     tiles of the wave and are reduced over the lanes once, at the end: the bias gradients db_l (32 registers per hidden
+//     layer) and, for heads of up to HR outputs (template parameter: 1 = value head, 5 = the MPE action heads), Gh
+//     (32 HR registers, out x 32 fused multiply-adds per tile, no LDS at all).  Wider heads go through LDS: dy tile,
+//     transposed nhat, lane = feature dot products.
+// (3) gamma is folded into the staged weights: dnhat_l = (gamma_l (.) W_{l+1}^T) dz_{l+1} comes straight out of the MFMA;
+//     the head's dnhat = (gamma (.) Wh^T) dy is an MFMA too (K = out, B operand = the dy values as loaded).
+// (4) One transposed scratch tile per wave: the A operands of the weight-gradient MFMAs (dz^T) are parked in 32 registers
+//     while nhat^T takes the tile over.  Between its last use in a tile and its first use in the next the tile receives
+//     the next tile's top-layer activations by direct-to-LDS loads (no registers); dy and the row statistics of the next
+//     tile are prefetched in registers, the lower layers' activations are loaded one layer ahead of their use.
+// (5) Waves own 32-row tiles individually (no workgroup tile, no barrier in the loop); the waves' sums are added through
+//     LDS once at the end, so the partial buffer has one row per workgroup.
+constexpr int kB2Waves = 4;
+
+constexpr int kSS = 68;          // LDS row stride of that staging tile: 16-byte slot (17 row + piece) mod 16 -- rows c .. c + 15 at
+                                // one piece (the writes) and one row's 16 pieces (the reads) both cover all 64 banks
+struct Bwd2Lds {
+    int gam, w2t, whg, wave0, dy, hacc, stg, per_wave, total;
+};
+template <int NW>
+__host__ __device__ __forceinline__ Bwd2Lds bwd2_lds(int L, int out) {
+    Bwd2Lds o;
+    const int outp = (out + 1) & ~1;                 // head rows padded to a whole MFMA k step
+    o.gam = 0;                                       // [64] LayerNorm weight of the top layer (out == 0)
+    o.w2t = 64;                                      // [L - 1][64][kWS]: gamma-scaled, transposed + permuted hidden weights
+    o.whg = o.w2t + (L - 1) * 64 * kWS;              // [outp][64]: gamma-scaled head weights (zero row for odd out)
+    o.wave0 = (o.whg + outp * 64 + 3) & ~3;
+    o.dy = 64 * kTS;                                 // per wave: T[64][kTS] | DY[out][32] | head sums [out][64] + [out] | S
+    o.hacc = o.dy + ((out * 32 + 3) & ~3);
+    o.stg = o.hacc + ((65 * out + 3) & ~3);          // S[32][kSS]: row-major staging of the dz1 tile (coalesced stores)
+    o.per_wave = o.stg + 32 * kSS;
+    o.total = o.wave0 + NW * o.per_wave;
+    const int red = o.wave0 + (NW / 2) * 4096;       // the end-of-kernel reduction parks NW / 2 accumulator sets here
+    if (o.total < red) o.total = red;
+    return o;
+}
+// raw per-workgroup sums: [db_l 64 x L (l = 0 unused)] [top dgamma 64 | top dbeta 64 (out == 0)] [G_l 4096 x (L - 1)]
+// [Gh out x 64] [dbh out]
+__host__ __device__ __forceinline__ long long r_g(int L, int l) { return 64LL * L + 128 + 4096LL * (l - 1); }
+__host__ __device__ __forceinline__ long long r_gh(int L) { return 64LL * L + 128 + 4096LL * (L - 1); }
+__host__ __device__ __forceinline__ long long r_total(int L, int out) { return r_gh(L) + 65LL * out; }
+
+// d loss / d nhat (in dn) -> d loss / d z (in dn) of one layer on this lane's row: LayerNorm backward (mlp.py:17-22)
+// and the activation's derivative from the saved normalised activations (see layer_tail)
+template <int ACT>
+__device__ __forceinline__ void ln_act_backward(float* dn, const float* nh, float mean, float rstd) {
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        m1 += dn[s];
+        m2 += dn[s] * nh[s];
+    }
+    m1 += prim::xhalf(m1);
+    m2 += prim::xhalf(m2);
+    m1 *= (1.f / 64.f);
+    m2 *= (1.f / 64.f);
+    const float sd = prim::rcp_fast(rstd);
+    const float thr = (0.f - mean) * rstd;      // every zero of a ReLU row maps to this nhat (the forward's own operations)
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        const float t = (dn[s] - m1) - nh[s] * m2;
+        float dact = rstd;
+        if (ACT == 1) {
+            const float av = nh[s] * sd + mean;          // the activation output of the forward pass
+            dact = rstd * (1.f - av * av);
+        } else if (ACT == 2) {
+            dact = nh[s] > thr ? rstd : 0.f;
+        }
+        dn[s] = t * dact;
+    }
+}
+
+template <int L, int ACT, int HR>
+__global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd2_kernel(BwdArgs a) {
+    constexpr int NW = kB2Waves;
+    float* lds = prim::lds();
+    const Net& n = a.net;
+    const int out = n.out, outp = (out + 1) & ~1;
+    const Bwd2Lds o = bwd2_lds<NW>(L, out);
+    const int tid = threadIdx.x, lane = tid & 63, wave = prim::uniform(tid >> 6), c = lane & 31, h = lane >> 5;
+    constexpr int kThr = 64 * NW;
+    // ---- parameters
+    for (int e = tid; e < 64; e += kThr) lds[o.gam + e] = n.ln_g[L - 1][e];
+    // w2t[l-1][ki][h * 32 + s] = gamma_{l-1}[ki] * W_l[f(h, s)][ki]: A operand (lane = input feature ki) of
+    // dnhat_{l-1} = (gamma (.) W^T) dz
+    for (int l = 1; l < L; ++l)
+        for (int e = tid; e < 64 * 64; e += kThr) {
+            const int ki = e >> 6, hs = e & 63;
+            lds[o.w2t + (l - 1) * 64 * kWS + ki * kWS + hs] =
+                n.w2[l - 1][feat_of(hs >> 5, hs & 31) * 64 + ki] * n.ln_g[l - 1][ki];
+        }
+    for (int e = tid; e < outp * 64; e += kThr) {
+        const int oo = e >> 6, f = e & 63;
+        lds[o.whg + e] = oo < out ? n.wh[oo * 64 + f] * n.ln_g[L - 1][f] : 0.f;
+    }
+    float* T = lds + o.wave0 + wave * o.per_wave;
+    float* DY = T + o.dy;
+    float* hacc = T + o.hacc;       // [out][64] sums of dy * nhat | [out] sums of dy (lane = feature / lane = o)
+    float* S = T + o.stg;
+    for (int e = lane; e < 65 * out; e += 64) hacc[e] = 0.f;
+    constexpr int NG = L > 1 ? L - 1 : 1;
+    f32x16 G[NG][4];                // hidden layer l: tile 2 t + t' = (output feature tile t, input feature tile t')
+    // bias gradients of layers >= 1: row layout (slot s of this lane's row position, reduced over the lanes at the end)
+    // where the registers are there (<= 2 layers), else lane = feature row sums of the transposed tile
+    constexpr bool kRowDb = L <= 2;
+    float dbr[NG][32], db[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) db[l] = 0.f;
+#pragma unroll
+    for (int l = 0; l < NG; ++l) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) G[l][t][v] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) dbr[l][s] = 0.f;
+    }
+    constexpr int NH = HR > 0 ? HR : 1;
+    float ghr[NH][32], dbhr[NH];    // row layout: head sums (HR > 0)
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        dbhr[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) ghr[i][s] = 0.f;
+    }
+    float dgt = 0.f, dbt = 0.f;     // lane = feature: LayerNorm gradients of the top layer (out == 0)
+    // HR == 0 and a head of <= kHQ outputs: Gh (lane = feature) and dbh (lane = o) stay in registers too
+    constexpr int kHQ = 8;
+    float hsum[kHQ], dbq = 0.f;
+#pragma unroll
+    for (int i = 0; i < kHQ; ++i) hsum[i] = 0.f;
+    __syncthreads();
+    // A operands of the head's dnhat MFMAs (constant over the tiles): step j takes outputs o = 2 j + h
+    constexpr int kDyQ = 8;
+    constexpr int NJ = HR > 0 ? (HR + 1) / 2 : kDyQ;
+    float wa[NJ][2];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int oo = 2 * j + h < outp ? 2 * j + h : 0;
+        wa[j][0] = 2 * j + h < outp ? lds[o.whg + oo * 64 + c] : 0.f;
+        wa[j][1] = 2 * j + h < outp ? lds[o.whg + oo * 64 + 32 + c] : 0.f;
+    }
+
+    const long long rows = a.rs.rows;
+    const long long ntiles = (rows + 31) / 32;
+    const long long gw = (long long)blockIdx.x * NW + wave, nw = (long long)gridDim.x * NW;
+    // ---- what is fetched a tile ahead
+    auto prefetch_top = [&](long long t) {          // top layer's nhat -> T (direct-to-LDS: no registers)
+        if (t < ntiles) {
+#pragma unroll
+            for (int bq = 0; bq < 8; ++bq) prim::load_lds16(a.z[L - 1] + t * 2048 + 4 * lane + 256 * bq, T + 256 * bq);
+        }
+    };
+    float dyv[NH];                  // HR > 0: this row's dy[0 .. out)
+    float dyq[kDyQ];                // HR == 0, out > 0: this lane's dy values o = 2 j + h, j < kDyQ (wider heads: loaded at use)
+    float dhn[32];                  // out == 0: this row's gradient at the trunk's output
+    f2 stn;                         // the top layer's {mean, rstd} of this row
+    // (raw values: the selects on `live` / `o < out` happen where the values are used, one iteration later.  Next to
+    // the load the compiler turns such a select into a branch around the load and follows it with a full vmcnt(0) wait --
+    // the latency of everything the tile has in flight)
+    bool livn = false;
+    auto prefetch_row = [&](long long t) {
+        long long r = t * 32 + c;
+        if (t >= ntiles) r = rows - 1;              // (past the last tile: loaded, never used)
+        stn = *reinterpret_cast<const f2*>(a.st[L - 1] + 2 * r);
+        livn = r < rows;
+        const long long rr = livn ? r : rows - 1;
+        if (HR > 0) {
+#pragma unroll
+            for (int i = 0; i < HR; ++i) dyv[i] = a.dy[rr * out + (i < out ? i : 0)];
+        } else if (out > 0) {
+#pragma unroll
+            for (int j = 0; j < kDyQ; ++j) dyq[j] = a.dy[rr * out + (2 * j + h < out ? 2 * j + h : 0)];
+        } else {
+            load_row64(a.dy + rr * 64, dhn, h);
+        }
+    };
+    // dz1 [rows128(rows), 64] row-major (what the weight-gradient kernels read): staged in S by layer 0, stored by whole
+    // rows (4 per wave instruction; straight from the registers an instruction would touch 32 rows x 32 bytes)
+    long long staged = -1;
+    auto flush_dz1 = [&]() {
+        if (staged >= 0) {
+            v4 sv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sv[i] = *reinterpret_cast<const v4*>(S + (4 * i + (lane >> 4)) * kSS + 4 * (lane & 15));
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                *reinterpret_cast<v4*>(a.dz1 + (staged * 32 + 4 * i + (lane >> 4)) * 64 + 4 * (lane & 15)) = sv[i];
+            prim::wave_sync();
+        }
+    };
+    prefetch_row(gw);
+    prefetch_top(gw);
+    const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+    int n_stamp = 0;
+#define MAPPO_B2_STAMP(k) if (stamp && n_stamp < 12) a.dbg[1024 + 16 * n_stamp + (k)] = prim::clock()
+    for (long long tile = gw; tile < ntiles; tile += nw) {
+        const long long row = tile * 32 + c;
+        const bool ok = row < rows;
+        float nh[32], dn[32], nxt[32];
+        const bool liv = livn;      // this tile's prefetched row is a row of the launch
+        MAPPO_B2_STAMP(0);
+        // The prefetch into T has landed.  It is the youngest vector-memory instruction in flight -- a counted wait
+        // that lets younger stores pass is not safe: stores and loads complete out of order with respect to each other
+        // -- which is why the previous tile's dz1 leaves its staging tile only now, and before this tile's own loads
+        // are issued (the counter would wait for them too).
+        prim::wait_lds_loads<0>();
+        load_frag64(T, lane, nh);
+        flush_dz1();
+        // (z and the statistics are padded to the 128-row tile: rows past the end repeat the last row and meet dy = 0)
+        f2 st = stn, stx = stn;
+        if (L > 1) {
+            load_frag64(a.z[L > 1 ? L - 2 : 0] + tile * 2048, lane, nxt);
+            stx = *reinterpret_cast<const f2*>(a.st[L > 1 ? L - 2 : 0] + 2 * row);
+        }
+        prim::wave_sync();          // every lane has its copy before T is written again
+        MAPPO_B2_STAMP(1);
+        if (out > 0) {
+            // ---- head.  dnhat[f][row] = sum_o (gamma (.) Wh)[o][f] dy[row][o] on the MFMA: this lane's dy values
+            // (o = 2 j + h) are the B operand
+            f32x16 acc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+            if (HR > 0) {
+#pragma unroll
+                for (int i = 0; i < HR; ++i) dyv[i] = (liv && i < out) ? dyv[i] : 0.f;
+#pragma unroll
+                for (int j = 0; 2 * j < HR; ++j) {
+                    if (2 * j < out) {
+                        const float d1 = 2 * j + 1 < HR ? dyv[2 * j + 1 < HR ? 2 * j + 1 : 0] : 0.f;
+                        const float d = h ? d1 : dyv[2 * j];
+                        acc[0] = prim::mfma32(wa[j][0], d, acc[0]);
+                        acc[1] = prim::mfma32(wa[j][1], d, acc[1]);
+                    }
+                }
+                // head sums in row layout: no LDS
+#pragma unroll
+                for (int i = 0; i < HR; ++i) {
+                    dbhr[i] += dyv[i];
+#pragma unroll
+                    for (int s = 0; s < 32; ++s) ghr[i][s] += dyv[i] * nh[s];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < kDyQ; ++j) {
+                    if (2 * j < out) {
+                        const int oo = 2 * j + h;
+                        const float d = (liv && oo < out) ? dyq[j] : 0.f;
+                        if (oo < out) DY[oo * 32 + c] = d;
+                        acc[0] = prim::mfma32(wa[j < NJ ? j : 0][0], d, acc[0]);
+                        acc[1] = prim::mfma32(wa[j < NJ ? j : 0][1], d, acc[1]);
+                    }
+                }
+                for (int j = kDyQ; 2 * j < out; ++j) {
+                    const int oo = 2 * j + h;
+                    const float d = (ok && oo < out) ? a.dy[row * out + oo] : 0.f;
+                    if (oo < out) DY[oo * 32 + c] = d;
+                    const float* wp = lds + o.whg + oo * 64 + c;
+                    acc[0] = prim::mfma32(wp[0], d, acc[0]);
+                    acc[1] = prim::mfma32(wp[32], d, acc[1]);
+                }
+                // head sums, lane = feature k: Gh[o][k] += sum_rows dy[row][o] nhat[row][k]
+                put_transposed(T, nh, c, h);
+                prim::wave_sync();        // DY and T of this wave are complete
+                float hrow[32];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const v4 t = *reinterpret_cast<const v4*>(T + lane * kTS + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hrow[4 * q + e] = t[e];
+                }
+                auto dot_o = [&](int oo) {
+                    float sm = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const v4 d = *reinterpret_cast<const v4*>(DY + oo * 32 + 4 * q);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sm += d[e] * hrow[4 * q + e];
+                    }
+                    return sm;
+                };
+                if (out <= kHQ) {       // (unrolled: the reads of output o + 1 are in flight behind the products of o)
+#pragma unroll
+                    for (int oo = 0; oo < kHQ; ++oo)
+                        if (oo < out) hsum[oo] += dot_o(oo);
+                } else {
+                    for (int oo = 0; oo < out; ++oo) hacc[oo * 64 + lane] += dot_o(oo);
+                }
+                if (lane < out) dbq += rowsum32(DY + lane * 32);
+                prim::wave_sync();
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) dn[16 * t + v] = acc[t][v];
+        } else {
+            // ---- no head: dy is the gradient at the trunk's output h = nhat * gamma + beta
+            float dh[32];
+#pragma unroll
+            for (int s = 0; s < 32; ++s) dh[s] = liv ? dhn[s] : 0.f;
+            put_transposed(T, dh, c, h);
+            prim::wave_sync();
+            dbt += rowsum32(T + lane * kTS);
+            prim::wave_sync();
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const v4 g = *reinterpret_cast<const v4*>(lds + o.gam + 32 * t + 8 * q + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int s = 16 * t + 4 * q + e;
+                        dn[s] = dh[s] * g[e];
+                        dh[s] *= nh[s];
+                    }
+                }
+            put_transposed(T, dh, c, h);
+            prim::wave_sync();
+            dgt += rowsum32(T + lane * kTS);
+            prim::wave_sync();
+        }
+        prefetch_row(tile + nw);
+        if (L == 1) prefetch_top(tile + nw);     // (T's last use of this tile)
+        MAPPO_B2_STAMP(3);
+        // ---- layers, top down
+#pragma unroll
+        for (int l = L - 1; l >= 0; --l) {
+            ln_act_backward<ACT>(dn, nh, st[0], st[1]);      // dn now holds dz_l
+            MAPPO_B2_STAMP(l == L - 1 ? 4 : 10);
+            if (l == 0) {
+                // -> the row-major staging tile
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = dn[16 * t + 4 * q + e];
+                        *reinterpret_cast<v4*>(S + c * kSS + 32 * t + 8 * q + 4 * h) = v;
+                    }
+                prim::wave_sync();
+                staged = tile;          // (stored at the top of the next iteration, see flush_dz1)
+            } else {
+                if (kRowDb) {
+#pragma unroll
+                    for (int s = 0; s < 32; ++s) dbr[l > 0 ? l - 1 : 0][s] += dn[s];
+                }
+                put_transposed(T, dn, c, h);
+                // dnhat_{l-1} = (gamma (.) W^T) dz: the last use of dz in row order
+                f32x16 dx[2];
+                dense64(lds + o.w2t + (l - 1) * 64 * kWS, c, h, dn, dx);
+                MAPPO_B2_STAMP(5);
+                prim::wave_sync();
+                if (!kRowDb) db[l] += rowsum32(T + lane * kTS);
+                // A operands of G += dz^T nhat (lane = output feature, rows 16 h + ..): parked in registers while the
+                // input of this layer, nhat of layer l - 1 (loaded one layer ahead), takes the tile over
+                v4 a0[4], a1[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a0[q] = *reinterpret_cast<const v4*>(T + c * kTS + 16 * h + 4 * q);
+                    a1[q] = *reinterpret_cast<const v4*>(T + (32 + c) * kTS + 16 * h + 4 * q);
+                }
+                prim::wave_sync();
+                MAPPO_B2_STAMP(6);
+                put_transposed(T, nxt, c, h);
+                prim::wave_sync();
+                MAPPO_B2_STAMP(7);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const v4 b0 = *reinterpret_cast<const v4*>(T + c * kTS + 16 * h + 4 * q);
+                    const v4 b1 = *reinterpret_cast<const v4*>(T + (32 + c) * kTS + 16 * h + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        G[l > 0 ? l - 1 : 0][0] = prim::mfma32(a0[q][e], b0[e], G[l > 0 ? l - 1 : 0][0]);
+                        G[l > 0 ? l - 1 : 0][1] = prim::mfma32(a0[q][e], b1[e], G[l > 0 ? l - 1 : 0][1]);
+                        G[l > 0 ? l - 1 : 0][2] = prim::mfma32(a1[q][e], b0[e], G[l > 0 ? l - 1 : 0][2]);
+                        G[l > 0 ? l - 1 : 0][3] = prim::mfma32(a1[q][e], b1[e], G[l > 0 ? l - 1 : 0][3]);
+                    }
+                }
+                MAPPO_B2_STAMP(8);
+                prim::wave_sync();          // T's last use of this tile (l == 1): the next tile's prefetch may land
+                if (l == 1) {
+                    // (the compiler does not count the prefetch's loads: a wait for one of ITS older loads placed after
+                    // this point would wait for the prefetch too.  Settle them here, where they have long arrived.)
+                    float m0 = stx[0], m1 = stx[1];
+                    prim::pin(m0);
+                    prim::pin(m1);
+                    stx = f2{m0, m1};
+                    prefetch_top(tile + nw);
+                }
+#pragma unroll
+                for (int s = 0; s < 32; ++s) nh[s] = nxt[s];
+                st = stx;
+                if (l >= 2) {
+                    load_frag64(a.z[l >= 2 ? l - 2 : 0] + tile * 2048, lane, nxt);
+                    stx = *reinterpret_cast<const f2*>(a.st[l >= 2 ? l - 2 : 0] + 2 * row);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) dn[16 * t + v] = dx[t][v];
+                MAPPO_B2_STAMP(9);
+            }
+        }
+        MAPPO_B2_STAMP(15);
+        ++n_stamp;
+    }
+#undef MAPPO_B2_STAMP
+    prim::wait_lds_loads<0>();
+    flush_dz1();
+    // ---- row-layout sums -> lane = feature (sum over the 32 row positions of each half-wave's features)
+    if (kRowDb) {
+#pragma unroll
+        for (int l = 1; l < L; ++l) {
+            prim::wave_sync();
+            put_transposed(T, dbr[l - 1], c, h);
+            prim::wave_sync();
+            db[l] = rowsum32(T + lane * kTS);
+        }
+    }
+    if (HR == 0 && out > 0) {
+        if (out <= kHQ) {
+#pragma unroll
+            for (int oo = 0; oo < kHQ; ++oo)
+                if (oo < out) hacc[oo * 64 + lane] = hsum[oo];
+        }
+        if (lane < out) hacc[64 * out + lane] = dbq;
+    }
+    if (HR > 0) {
+#pragma unroll
+        for (int i = 0; i < HR; ++i) {
+            if (i < out) {
+                prim::wave_sync();
+                put_transposed(T, ghr[i], c, h);
+                prim::wave_sync();
+                hacc[i * 64 + lane] = rowsum32(T + lane * kTS);
+                prim::wave_sync();
+                if (h == 0) T[c] = dbhr[i];         // both half-waves hold the same rows' dy
+                prim::wave_sync();
+                if (lane == 0) hacc[64 * out + i] = rowsum32(T);
+            }
+        }
+    }
+    // ---- add the waves' sums through LDS and write this workgroup's partial row
+    float* prow = a.partials + (long long)blockIdx.x * r_total(L, out);
+    __syncthreads();                // every wave is done with its scratch
+    {
+        // vectors: [wave][L + 2][64] in the waves' own T tiles (64 * kTS >= (L + 2) * 64)
+#pragma unroll
+        for (int l = 0; l < L; ++l) T[64 * l + lane] = db[l];
+        T[64 * L + lane] = dgt;
+        T[64 * (L + 1) + lane] = dbt;
+        __syncthreads();
+        for (int e = tid; e < (L + 2) * 64; e += kThr) {
+            float sm = 0.f;
+            for (int w = 0; w < NW; ++w) sm += lds[o.wave0 + w * o.per_wave + e];
+            prow[e] = sm;
+        }
+        for (int e = tid; e < 65 * out; e += kThr) {
+            float sm = 0.f;
+            for (int w = 0; w < NW; ++w) sm += lds[o.wave0 + w * o.per_wave + o.hacc + e];
+            prow[r_gh(L) + e] = sm;
+        }
+    }
+    float* red = lds + o.wave0;     // [NW / 2][4096]: slot i of set w at w * 4096 + i * 64 + lane
+#pragma unroll
+    for (int l = 1; l < L; ++l) {
+#pragma unroll
+        for (int half = NW / 2; half >= 1; half >>= 1) {
+            __syncthreads();
+            if (wave >= half && wave < 2 * half) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) red[(wave - half) * 4096 + (16 * t + v) * 64 + lane] = G[l - 1][t][v];
+            }
+            __syncthreads();
+            if (wave < half) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) G[l - 1][t][v] += red[wave * 4096 + (16 * t + v) * 64 + lane];
+            }
+        }
+        if (wave == 0) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int f = 32 * t + (v & 3) + 8 * (v >> 2) + 4 * h;
+                        prow[r_g(L, l) + f * 64 + 32 * tp + c] = G[l - 1][2 * t + tp][v];
+                    }
+        }
+    }
+}
+
+// The parameter gradients of the chain from the reduced raw sums R (see mlp_bwd2_kernel): one workgroup.
+struct FinishArgs {
+    Net net;
+    const float* R;
+    float* grads;
+};
+__global__ void __launch_bounds__(kThreads) mlp_finish_kernel(FinishArgs a) {
+    const Net& n = a.net;
+    const int L = n.L, out = n.out, din = n.din, tid = threadIdx.x;
+    for (int l = 1; l < L; ++l) {
+        const float* G = a.R + r_g(L, l);
+        const float* dbl = a.R + 64 * l;
+        const float* g = n.ln_g[l - 1];
+        const float* be = n.ln_b[l - 1];
+        const float* W = n.w2[l - 1];
+        float* dW = a.grads + g_w2(din, L, l);
+        for (int e = tid; e < 4096; e += kThreads) dW[e] = g[e & 63] * G[e] + be[e & 63] * dbl[e >> 6];
+        if (tid < 64) {
+            float sg = 0.f, sb = 0.f;
+            for (int f = 0; f < 64; ++f) {
+                sg += W[f * 64 + tid] * G[f * 64 + tid];
+                sb += W[f * 64 + tid] * dbl[f];
+            }
+            a.grads[g_vec(din, l - 1) + 64 + tid] = sg;
+            a.grads[g_vec(din, l - 1) + 128 + tid] = sb;
+            a.grads[g_vec(din, l) + tid] = dbl[tid];
+        }
+    }
+    const float* g = n.ln_g[L - 1];
+    const float* be = n.ln_b[L - 1];
+    if (out > 0) {
+        const float* Gh = a.R + r_gh(L);
+        const float* dbh = Gh + 64 * out;
+        float* dWh = a.grads + g_wh(din, L);
+        for (int e = tid; e < 64 * out; e += kThreads) dWh[e] = g[e & 63] * Gh[e] + be[e & 63] * dbh[e >> 6];
+        for (int e = tid; e < out; e += kThreads) dWh[64 * out + e] = dbh[e];
+        if (tid < 64) {
+            float sg = 0.f, sb = 0.f;
+            for (int oo = 0; oo < out; ++oo) {
+                sg += n.wh[oo * 64 + tid] * Gh[oo * 64 + tid];
+                sb += n.wh[oo * 64 + tid] * dbh[oo];
+            }
+            a.grads[g_vec(din, L - 1) + 64 + tid] = sg;
+            a.grads[g_vec(din, L - 1) + 128 + tid] = sb;
+        }
+    } else if (tid < 64) {
+        a.grads[g_vec(din, L - 1) + 64 + tid] = a.R[64 * L + tid];
+        a.grads[g_vec(din, L - 1) + 128 + tid] = a.R[64 * L + 64 + tid];
+    }
+}
+
 // ================================================================== backward: first-layer weight gradient ====
 // dW1[f][k] = sum over rows dz1[row][f] * xhat[row][k] with xhat gathered and standardised on the fly: a split-K GEMM
 // (K = rows) whose B operand is read through the sampler's row table.  A workgroup owns a slab of <= 384 k columns
@@ -910,7 +1481,7 @@ __global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a) {
 struct Dw1Args {
     RowSrc rs;
     const float* dz1;
-    float* partials;    // [gridDim.x][64 * din]
+    float* partials;    // [gridDim.x][64 * din + 64]: weight gradient | column sums of dz1 (the first layer's bias gradient)
     long long* dbg;     // tuning hook (mappo_mlp_set_debug): cycle stamps of workgroup 0's first tiles at [512 ...], or NULL
 };
 constexpr int kDw1StageX = kDw1Rows * kDw1Slab;                        // floats
@@ -1014,6 +1585,8 @@ __global__ void __launch_bounds__(kPipeThreads) mlp_dw1_kernel(Dw1Args a) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][t][v] = 0.f;
+    const bool bias_sum = wave == 0 && blockIdx.y == 0;     // ... also sums the columns of dz1: first-layer bias gradient
+    float s0 = 0.f, s1 = 0.f;
     for (long long j = 0; j < n_it; ++j) {
         __syncthreads();
         const float* xt = lds + (j & 1) * kDw1Stage;
@@ -1046,9 +1619,18 @@ __global__ void __launch_bounds__(kPipeThreads) mlp_dw1_kernel(Dw1Args a) {
                 acc[2][0] = prim::mfma32(a0, b2, acc[2][0]);
                 acc[2][1] = prim::mfma32(a1, b2, acc[2][1]);
             }
+            if (bias_sum) {
+                s0 += a0;
+                s1 += a1;
+            }
         }
     }
-    float* prow = a.partials + (long long)blockIdx.x * 64 * din;
+    float* prow = a.partials + (long long)blockIdx.x * (64LL * din + 64);
+    if (bias_sum) {
+        s0 += prim::xhalf(s0);
+        s1 += prim::xhalf(s1);
+        prow[64LL * din + lane] = h == 0 ? s0 : s1;       // lane = feature
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int nt = wave + 4 * i;
@@ -1089,8 +1671,11 @@ constexpr int kD2Lds = 4 * kD2Slots * kD2XSlot + kD2Slots * kD2DzSlot;       // 
 constexpr int kD2TabRing = 2 * kD2Slots;         // 256-byte slots per wave
 
 // the 8 MFMA steps of one 16-row tile (step s contracts rows s and 8 + s) for a wave that owns NT k tiles
-template <int NT>
-__device__ __forceinline__ void dw1_tile_steps(const float* xt, const float* dzt, int c, int h, f32x16 (*acc)[2]) {
+// SUM: also accumulate the column sums of the dz1 tile (the first layer's bias gradient: the A operands are the dz1
+// values with lane = feature) -- s0: feature c, s1: feature 32 + c, over the rows this half-wave reads
+template <int NT, bool SUM>
+__device__ __forceinline__ void dw1_tile_steps(const float* xt, const float* dzt, int c, int h, f32x16 (*acc)[2], float& s0,
+                                               float& s1) {
     constexpr int NB = NT > 0 ? NT : 1;
     float a0n, a1n, bn[NB];
     auto rd_step = [&](int st, float& ra0, float& ra1, float* rb) {
@@ -1114,6 +1699,10 @@ __device__ __forceinline__ void dw1_tile_steps(const float* xt, const float* dzt
         for (int i = 0; i < NT; ++i) {
             acc[i][0] = prim::mfma32(a0, b[i], acc[i][0]);
             acc[i][1] = prim::mfma32(a1, b[i], acc[i][1]);
+        }
+        if (SUM) {
+            s0 += a0;
+            s1 += a1;
         }
     }
 }
@@ -1168,7 +1757,14 @@ __device__ __forceinline__ void dw1_direct_body(const Dw1Args& a, float* lds, in
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][t][v] = 0.f;
-    if (n_it == 0) return;
+    // wave 0 of the first slab also sums the columns of dz1: the first layer's bias gradient (partial row tail)
+    const bool bias_sum = wave == 0 && blockIdx.y == 0;
+    float s0 = 0.f, s1 = 0.f;
+    float* prow = a.partials + (long long)blockIdx.x * (64LL * din + 64);
+    if (n_it == 0) {
+        if (bias_sum) prow[64LL * din + lane] = 0.f;
+        return;
+    }
     for (int t = 0; t < kD2Slots - 1; ++t) issue_table(t);
     prim::wait_lds_loads<0>();
     for (int m = 0; m < kD2Slots - 1; ++m) issue(m);
@@ -1187,10 +1783,15 @@ __device__ __forceinline__ void dw1_direct_body(const Dw1Args& a, float* lds, in
         if (stamp && m < 40) a.dbg[512 + 4 * m + 3] = prim::clock();
         const float* xt = xs + (int)(m % kD2Slots) * kD2XSlot;
         const float* dzt = dzs + (int)(m % kD2Slots) * kD2DzSlot;
-        dw1_tile_steps<NT>(xt, dzt, c, h, acc);
+        if (bias_sum) dw1_tile_steps<NT, true>(xt, dzt, c, h, acc, s0, s1);
+        else dw1_tile_steps<NT, false>(xt, dzt, c, h, acc, s0, s1);
     }
     prim::wait_lds_loads<0>();      // (the groups issued past the end)
-    float* prow = a.partials + (long long)blockIdx.x * 64 * din;
+    if (bias_sum) {
+        s0 += prim::xhalf(s0);
+        s1 += prim::xhalf(s1);
+        prow[64LL * din + lane] = h == 0 ? s0 : s1;       // lane = feature
+    }
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int k = k0 + 32 * (wave + 4 * i) + c;
@@ -1272,6 +1873,7 @@ __global__ void __launch_bounds__(kThreads) mlp_dw1_rows_kernel(Dw1Args a) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][t][v] = 0.f;
+    float s0 = 0.f, s1 = 0.f;
     if (n_it > 0) {
         for (int t = 0; t < kD2Slots - 1; ++t) issue_table(t);
         prim::wait_lds_loads<0>();
@@ -1288,10 +1890,12 @@ __global__ void __launch_bounds__(kThreads) mlp_dw1_rows_kernel(Dw1Args a) {
                 prim::wave_sync();      // (a wave's LDS operations execute in order: only the compiler / the emulator care)
             }
             issue(m + kD2Slots - 1);
-            dw1_tile_steps<NT>(slot, slot + NT * (kD2Rows * 32), c, h, acc);
+            dw1_tile_steps<NT, true>(slot, slot + NT * (kD2Rows * 32), c, h, acc, s0, s1);
         }
         prim::wait_lds_loads<0>();
     }
+    s0 += prim::xhalf(s0);          // column sums of this wave's dz1 tiles: the first layer's bias gradient
+    s1 += prim::xhalf(s1);
     // ---- add the four waves' tiles: [wave][i][t][v][lane]
     __syncthreads();
     float* red = lds;
@@ -1302,7 +1906,7 @@ __global__ void __launch_bounds__(kThreads) mlp_dw1_rows_kernel(Dw1Args a) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) red[wave * (NT * 2048) + ((i * 2 + t) * 16 + v) * 64 + lane] = acc[i][t][v];
     __syncthreads();
-    float* prow = a.partials + (long long)blockIdx.x * 64 * din;
+    float* prow = a.partials + (long long)blockIdx.x * (64LL * din + 64);
     for (int e = tid; e < NT * 2048; e += kThreads) {
         const float sum = (red[e] + red[NT * 2048 + e]) + (red[2 * NT * 2048 + e] + red[3 * NT * 2048 + e]);
         const int ln = e & 63, v = (e >> 6) & 15, t = (e >> 10) & 1, i = e >> 11;
@@ -1310,6 +1914,10 @@ __global__ void __launch_bounds__(kThreads) mlp_dw1_rows_kernel(Dw1Args a) {
         const int k = 32 * i + (ln & 31);
         if (k < din) prow[(long long)f * din + k] = sum;
     }
+    __syncthreads();
+    red[wave * 64 + lane] = h == 0 ? s0 : s1;       // lane = feature
+    __syncthreads();
+    if (tid < 64) prow[64LL * din + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
 }
 
 // out[e] = sum over n partial rows (row stride `stride`); fixed order.  A block handles 32 consecutive elements with 8
@@ -1513,7 +2121,10 @@ inline int forward(const mappo_mlp_t* m, hipStream_t stream) {
 }
 
 inline long long workspace_floats(int din, int n_layers, int out) {
-    return (long long)kBwdGridCap * 4 * p_main(n_layers, out) + (long long)kD2GridCap * 64 * din;
+    // chain partials (one row per workgroup; the version-1 kernel: per wave) | reduced raw sums | first-layer partials
+    const long long v1 = (long long)kBwdGridCap * 4 * p_main(n_layers, out);
+    const long long v2 = (long long)(kBwdGridCap + 1) * r_total(n_layers, out);
+    return (v1 > v2 ? v1 : v2) + (long long)kD2GridCap * (64LL * din + 64);
 }
 
 inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
@@ -1531,16 +2142,35 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
     b.dy = m->dy;
     b.dz1 = m->dz1;
     b.partials = m->workspace;
-    const BwdLds o = bwd_lds(L, out);
-    const long long grid = capped(ceil_div(m->rows, kTR), kBwdGridCap);
+    const bool v1 = (tuning_flags() & 4) != 0;      // MAPPO_MLP_FLAGS=4: the version-1 chain kernel (A / B measurements)
+    long long grid;
+    if (v1) {
+        const BwdLds o = bwd_lds(L, out);
+        grid = capped(ceil_div(m->rows, kTR), kBwdGridCap);
 #define MAPPO_BWD_CASE(LL, AA)                                                                             \
     if (L == LL && m->act == AA) {                                                                         \
         MAPPO_LAUNCH((mlp_bwd_kernel<LL, AA>), (unsigned)grid, kThreads, (size_t)o.total * 4, stream, b);  \
     }
-    MAPPO_BWD_CASE(1, 0) MAPPO_BWD_CASE(1, 1) MAPPO_BWD_CASE(1, 2)
-    MAPPO_BWD_CASE(2, 0) MAPPO_BWD_CASE(2, 1) MAPPO_BWD_CASE(2, 2)
-    MAPPO_BWD_CASE(3, 0) MAPPO_BWD_CASE(3, 1) MAPPO_BWD_CASE(3, 2)
+        MAPPO_BWD_CASE(1, 0) MAPPO_BWD_CASE(1, 1) MAPPO_BWD_CASE(1, 2)
+        MAPPO_BWD_CASE(2, 0) MAPPO_BWD_CASE(2, 1) MAPPO_BWD_CASE(2, 2)
+        MAPPO_BWD_CASE(3, 0) MAPPO_BWD_CASE(3, 1) MAPPO_BWD_CASE(3, 2)
 #undef MAPPO_BWD_CASE
+    } else {
+        // head sums in registers for the value head (HR = 1)
+        const int hr = (out == 1 && L <= 2) ? 1 : 0;
+        const Bwd2Lds o = bwd2_lds<kB2Waves>(L, out);
+        grid = capped(ceil_div(m->rows, 32 * kB2Waves), kBwdGridCap);
+#define MAPPO_BWD_CASE(LL, AA, HH)                                                                                    \
+    if (L == LL && m->act == AA && hr == HH) {                                                                        \
+        MAPPO_LAUNCH((mlp_bwd2_kernel<LL, AA, HH>), (unsigned)grid, 64 * kB2Waves, (size_t)o.total * 4, stream, b);   \
+    }
+#define MAPPO_BWD_CASES(LL, AA) MAPPO_BWD_CASE(LL, AA, 0) MAPPO_BWD_CASE(LL, AA, 1)
+        MAPPO_BWD_CASES(1, 0) MAPPO_BWD_CASES(1, 1) MAPPO_BWD_CASES(1, 2)
+        MAPPO_BWD_CASES(2, 0) MAPPO_BWD_CASES(2, 1) MAPPO_BWD_CASES(2, 2)
+        MAPPO_BWD_CASE(3, 0, 0) MAPPO_BWD_CASE(3, 1, 0) MAPPO_BWD_CASE(3, 2, 0)
+#undef MAPPO_BWD_CASES
+#undef MAPPO_BWD_CASE
+    }
     code = MAPPO_LAUNCH_ERROR();
     if (code) return code;
 
@@ -1548,7 +2178,9 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
     d.dbg = debug_buffer();
     d.rs = b.rs;
     d.dz1 = m->dz1;
-    d.partials = m->workspace + (long long)kBwdGridCap * 4 * p_main(L, out);
+    const long long rt = r_total(L, out);
+    float* raw = m->workspace + (long long)kBwdGridCap * rt;        // reduced raw sums of the version-2 chain
+    d.partials = m->workspace + workspace_floats(din, L, out) - (long long)kD2GridCap * (64LL * din + 64);
     const int gy = (int)ceil_div(din, kDw1Slab);
     long long gx;
     if (din % 4 == 0 && din <= 64) {
@@ -1574,12 +2206,22 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
     code = MAPPO_LAUNCH_ERROR();
     if (code) return code;
 
-    // every slab's workgroups write disjoint k columns of their partial row; rows of unused workgroups do not exist
-    const long long pm = p_main(L, out);
-    MAPPO_LAUNCH(mlp_reduce_kernel, (unsigned)ceil_div(64LL * din, 32), kThreads, 1024, stream, d.partials, gx,
-                 64LL * din, 64LL * din, m->grads);
-    MAPPO_LAUNCH(mlp_reduce_kernel, (unsigned)ceil_div(pm, 32), kThreads, 1024, stream, b.partials, grid * 4, pm, pm,
-                 m->grads + 64LL * din);
+    // every slab's workgroups write disjoint k columns of their partial row; rows of unused workgroups do not exist.
+    // The first-layer partials end with the column sums of dz1: w1 and the first bias are adjacent in the flat layout
+    const long long p1 = 64LL * din + 64;
+    MAPPO_LAUNCH(mlp_reduce_kernel, (unsigned)ceil_div(p1, 32), kThreads, 1024, stream, d.partials, gx, p1, p1, m->grads);
+    if (v1) {
+        const long long pm = p_main(L, out);
+        MAPPO_LAUNCH(mlp_reduce_kernel, (unsigned)ceil_div(pm, 32), kThreads, 1024, stream, b.partials, grid * 4, pm, pm,
+                     m->grads + 64LL * din);
+        return MAPPO_LAUNCH_ERROR();
+    }
+    MAPPO_LAUNCH(mlp_reduce_kernel, (unsigned)ceil_div(rt, 32), kThreads, 1024, stream, b.partials, grid, rt, rt, raw);
+    FinishArgs f;
+    f.net = b.net;
+    f.R = raw;
+    f.grads = m->grads;
+    MAPPO_LAUNCH(mlp_finish_kernel, 1u, kThreads, 0, stream, f);
     return MAPPO_LAUNCH_ERROR();
 }
 

@@ -239,7 +239,7 @@ class _FusedTrunkFn(torch.autograd.Function):
         dy = dy.contiguous()
         grads = torch.empty(lib.mappo_mlp_grad_floats(din, n_layers, out), dtype=torch.float32, device=dev)
         ws = torch.empty(lib.mappo_mlp_workspace_floats(din, n_layers, out), dtype=torch.float32, device=dev)
-        dz1 = torch.empty((rs.rows, HIDDEN), dtype=torch.float32, device=dev)
+        dz1 = torch.empty((lib.mappo_mlp_row_table_ints(rs.rows), HIDDEN), dtype=torch.float32, device=dev)   # padded to the tile
         m.dy, m.dz1, m.workspace, m.grads = dy.data_ptr(), dz1.data_ptr(), ws.data_ptr(), grads.data_ptr()
         with _Timed("mappo_mlp_backward", *_work(rs.rows, din, n_layers, out, True)):
             _native.check(lib.mappo_mlp_backward(m, _native.stream_of(dev)), "mappo_mlp_backward")

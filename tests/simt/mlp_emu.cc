@@ -13,6 +13,7 @@ inline void set_priority_high() {}
 inline long long clock() { return 0; }
 inline void wait_loads_14() {}
 inline void wave_sync() { simt::wait(my_wave().bar); }
+inline void pin(float&) {}
 inline int uniform(int v) { return v; }
 // direct-to-LDS load: lane l's 16 bytes land at base + 16 l.  The copy happens at once; wait_lds_loads() is a wave
 // barrier, so that no lane reads a slot before every lane of its wave has issued its part.

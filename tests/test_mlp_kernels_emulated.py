@@ -83,7 +83,7 @@ def _run(emu, rng, din, n_layers, act, out, rows, src_rows, standardize=True, ch
     n_g = emu.mappo_mlp_grad_floats(din, n_layers, out)
     grads = np.full(n_g, np.nan, np.float32)
     ws = np.full(emu.mappo_mlp_workspace_floats(din, n_layers, out), np.nan, np.float32)
-    dz1 = np.full((rows, 64), np.nan, np.float32)
+    dz1 = np.full((emu.mappo_mlp_row_table_ints(rows), 64), np.nan, np.float32)     # padded to the 128-row tile
     m.dy, m.dz1, m.workspace, m.grads = _ptr(dy), _ptr(dz1), _ptr(ws), _ptr(grads)
     assert emu.mappo_mlp_backward(ctypes.byref(m), None) == 0
     (y_ref * torch.tensor(dy, dtype=torch.float64)).sum().backward()
@@ -104,6 +104,9 @@ CASES = [
     (388, 1, 2, 1, 45, 64),        # two k slabs in the first-layer weight gradient (din > 384), 16-byte aligned rows
     (28, 1, 2, 2, 16 * 9 + 1, 300),   # one k tile (row-split weight-gradient kernel), a tile with a single live row
     (200, 2, 1, 1, 16 * 7 + 5, 200),  # direct-to-LDS weight-gradient kernel: waves with two and with one k tile
+    (40, 2, 2, 7, 32 * 9 + 3, 400),   # a head wider than the backward chain keeps in registers (sums through LDS), odd width
+    (64, 1, 1, 18, 100, 128),         # SMAC-sized action head on a single layer
+    (36, 3, 1, 6, 32 * 5, 200),       # three layers with a head
 ]
 
 

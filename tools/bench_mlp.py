@@ -110,6 +110,15 @@ def main():
                     for m in range(4, 12):
                         print(m, d[m][1] - d[m][0], d[m][2] - d[m][1], d[m][3] - d[m][2], d[m + 1][0] - d[m][3])
                 b = dall[1024:1024 + 192].reshape(12, 16)
+                if not (int(os.environ.get("MAPPO_MLP_FLAGS", "0")) & 4):
+                    print("chain v2 (wave 0): tile | wait prefetch + issue loads | head | ln bwd | put dz + dX mfma | A regs |"
+                          " put nhat' | G mfma | copies | ln bwd 0 | store | total")
+                    ks = [0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 15]
+                    for t in range(1, 10):
+                        r = b[t]
+                        print(t, " ".join("%6d" % (r[ks[i + 1]] - r[ks[i]]) for i in range(len(ks) - 1)), "|", r[15] - r[0],
+                              "| gap to next", b[t + 1][0] - r[15])
+                    continue
                 print("chain kernel (thread 0): tile | inputs+fetch | head | L1: ln+dz, sums, transposes+bias, dW+dX | "
                       "L0: ln+dz, sums | rest | total")
                 for t in range(2, 10):

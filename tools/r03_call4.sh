@@ -1,0 +1,11 @@
+#!/bin/bash
+set -u
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$REPO"
+OUT=gpurun_out/r03_c4; mkdir -p $OUT
+timeout 900 python -m pytest tests/test_gpu_mlp.py tests/test_gpu_trainer_h64.py -q > $OUT/tests.log 2>&1
+tail -5 $OUT/tests.log
+echo "--- stamps critic"; timeout 300 python tools/bench_mlp.py --reps 3 --stamps --din 384 2>&1 | tail -11 | tee $OUT/stamps_critic.txt
+echo "--- stamps actor"; timeout 300 python tools/bench_mlp.py --reps 3 --stamps --din 48 2>&1 | tail -11 | tee $OUT/stamps_actor.txt
+echo "--- v3"; timeout 300 python tools/bench_mlp.py --reps 7 2>&1 | tail -2 | tee $OUT/mlp_v3.jsonl
+echo "--- v1"; MAPPO_MLP_FLAGS=4 timeout 300 python tools/bench_mlp.py --reps 7 2>&1 | tail -2 | tee $OUT/mlp_v1.jsonl
+echo "--- prof"; bash tools/profile_mlp.sh --reps 5 2>&1 | tail -12 | tee $OUT/mlp_prof.txt

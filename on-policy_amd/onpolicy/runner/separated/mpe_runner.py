@@ -44,7 +44,7 @@ class MPERunner(Runner):
     def run(self):
         self.warmup()
         start = time.time()
-        episodes = int(self.num_env_steps) // self.episode_length // self.n_rollout_threads
+        episodes = int(self.num_env_steps) // self.episode_length // self.n_rollout_threads_job
         infos = []
         for episode in range(episodes):
             if self.use_linear_lr_decay:
@@ -60,7 +60,7 @@ class MPERunner(Runner):
             self.compute()
             train_infos = self.train()
 
-            total_num_steps = (episode + 1) * self.episode_length * self.n_rollout_threads
+            total_num_steps = (episode + 1) * self.episode_length * self.n_rollout_threads_job
             if episode % self.save_interval == 0 or episode == episodes - 1:
                 self.save()
             if episode % self.log_interval == 0:

@@ -93,6 +93,11 @@ class Runner(object):
         self.num_env_steps = a.num_env_steps
         self.episode_length = a.episode_length
         self.n_rollout_threads = a.n_rollout_threads
+        # a data-parallel job (scripts/train/_launch.py: device_of) keeps this rank's share in n_rollout_threads;
+        # --num_env_steps is a budget of the WHOLE job, so episode counts, the learning-rate schedule and the step
+        # counters of the logs use the job-wide count -- identical on every rank (they must agree on the number of
+        # train() calls: every one of them is a collective)
+        self.n_rollout_threads_job = getattr(a, "global_n_rollout_threads", a.n_rollout_threads)
         self.n_eval_rollout_threads = a.n_eval_rollout_threads
         self.n_render_rollout_threads = a.n_render_rollout_threads
         self.use_linear_lr_decay = a.use_linear_lr_decay

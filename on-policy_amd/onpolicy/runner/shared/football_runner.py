@@ -25,7 +25,7 @@ class FootballRunner(Runner):
     def run(self):
         self.warmup()
         start = time.time()
-        episodes = int(self.num_env_steps) // self.episode_length // self.n_rollout_threads
+        episodes = int(self.num_env_steps) // self.episode_length // self.n_rollout_threads_job
         for episode in range(episodes):
             if self.use_linear_lr_decay:
                 self.trainer.policy.lr_decay(episode, episodes)
@@ -37,7 +37,7 @@ class FootballRunner(Runner):
             self.compute()
             train_infos = self.train()
 
-            total_num_steps = (episode + 1) * self.episode_length * self.n_rollout_threads
+            total_num_steps = (episode + 1) * self.episode_length * self.n_rollout_threads_job
             if total_num_steps % self.save_interval == 0 or episode == episodes - 1:
                 self.save()
             if total_num_steps % self.log_interval == 0:

@@ -86,7 +86,7 @@ class HanabiRunner(Runner):
         self._stage = _HostStage(self.buffer.device)
         self.warmup()
         start = time.time()
-        episodes = int(self.num_env_steps) // self.episode_length // self.n_rollout_threads
+        episodes = int(self.num_env_steps) // self.episode_length // self.n_rollout_threads_job
         T = self.episode_length
         b, turn = self.buffer, self.turn
         train_infos = {}
@@ -124,7 +124,7 @@ class HanabiRunner(Runner):
                     self.use_available_actions[rows] = a_d
                     self.avail_host[rc] = available_actions[rc]
 
-            total_num_steps = (episode + 1) * T * self.n_rollout_threads
+            total_num_steps = (episode + 1) * T * self.n_rollout_threads_job
             if episode % self.save_interval == 0 or episode == episodes - 1:
                 self.save()
             if episode % self.log_interval == 0 and episode > 0:

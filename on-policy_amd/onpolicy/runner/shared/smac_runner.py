@@ -25,7 +25,8 @@ class SMACRunner(Runner):
         self.warmup()
         started = time.time()
         T, N = self.episode_length, self.n_rollout_threads
-        episodes = int(self.num_env_steps) // T // N
+        NJ = self.n_rollout_threads_job     # job-wide thread count (== N in a single-process run)
+        episodes = int(self.num_env_steps) // T // NJ
         battles = common.BattleLog(N)
         infos = []
         for episode in range(episodes):
@@ -39,7 +40,7 @@ class SMACRunner(Runner):
             self.compute()
             train_infos = self.train()
 
-            steps_done = (episode + 1) * T * N
+            steps_done = (episode + 1) * T * NJ
             if episode % self.save_interval == 0 or episode == episodes - 1:
                 self.save()
             if episode % self.log_interval == 0:

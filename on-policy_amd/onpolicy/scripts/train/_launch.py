@@ -36,7 +36,9 @@ def device_of(all_args):
     RCCL process group and keeps its contiguous share of ``--n_rollout_threads`` -- ``all_args.n_rollout_threads``
     becomes the LOCAL count, ``all_args.rollout_thread_offset`` the index of its first thread (env seeds are
     offset by it so that the union of the ranks' envs is the single-process set) -- and R_MAPPO all-reduces the
-    gradients (onpolicy/utils/dist.py).  Step counters and logs of a rank count its own threads."""
+    gradients (onpolicy/utils/dist.py).  ``--num_env_steps`` remains the budget of the WHOLE job: the runners derive
+    episode counts, the learning-rate schedule and the logged step counters from ``all_args.global_n_rollout_threads``,
+    so every rank makes the same number of train() calls; thread counts that do not divide evenly are rejected."""
     if not (all_args.cuda and torch.cuda.is_available()):
         raise RuntimeError("the rollout buffer of this implementation lives in HBM: a HIP device is required")
     print("choose to use gpu...")
@@ -50,10 +52,12 @@ def device_of(all_args):
     device = torch.device("cuda", 0 if single else int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(device)
     mdist.init_from_env(device)
-    lo, hi = mdist.shard_threads(all_args.n_rollout_threads)
-    if hi == lo:
-        raise ValueError("--n_rollout_threads %d is smaller than the number of ranks %d"
+    if all_args.n_rollout_threads < world or all_args.n_rollout_threads % world != 0:
+        # equal shards only: every rank then runs the same number of episodes and train() calls (each one a collective),
+        # and --num_env_steps stays a budget of the whole job (the runners count the job-wide threads)
+        raise ValueError("--n_rollout_threads %d must be a positive multiple of the number of ranks %d"
                          % (all_args.n_rollout_threads, world))
+    lo, hi = mdist.shard_threads(all_args.n_rollout_threads)
     all_args.global_n_rollout_threads = all_args.n_rollout_threads
     all_args.n_rollout_threads, all_args.rollout_thread_offset = hi - lo, lo
     return device

@@ -97,3 +97,35 @@ def test_two_rank_transformer_update_equals_single_process(tmp_path, args_over):
     for k, rel in (("actor_grad_norm", 2e-3), ("value_loss", 2e-3), ("policy_loss", 2e-3), ("dist_entropy", 2e-3)):
         assert ranks[0]["info"][k] == pytest.approx(ranks[1]["info"][k], rel=1e-6)
         assert ranks[0]["info"][k] == pytest.approx(info[k], rel=rel, abs=2e-3), k
+
+
+def test_job_wide_episode_budget_and_even_shards(monkeypatch):
+    """Under a one-process-per-GPU launcher ``--num_env_steps`` is the budget of the whole job: every rank derives the
+    same episode count from the job-wide thread count (unequal counts would leave a rank waiting in a collective), and
+    thread counts that do not divide over the ranks are refused."""
+    import types
+    import torch
+    from onpolicy.scripts.train import _launch
+    from onpolicy.utils import dist as mdist
+    from onpolicy.runner.shared import base_runner
+
+    with monkeypatch.context() as m:     # (undone before the session fixtures look at torch.cuda again)
+        m.setenv("WORLD_SIZE", "4")
+        m.setenv("RANK", "1")
+        m.setenv("LOCAL_RANK", "0")
+        m.setenv("MAPPO_SINGLE_DEVICE", "1")
+        m.setattr(torch.cuda, "is_available", lambda: True)
+        m.setattr(torch.cuda, "set_device", lambda d: None)
+        m.setattr(mdist, "init_from_env", lambda device: None)
+        m.setattr(mdist, "shard_threads", lambda n, rank=1, world=4: (n // world * rank, n // world * (rank + 1)))
+        args = types.SimpleNamespace(cuda=True, n_training_threads=1, n_rollout_threads=10)
+        with pytest.raises(ValueError, match="multiple of the number of ranks"):
+            _launch.device_of(args)
+        args.n_rollout_threads = 12
+        _launch.device_of(args)
+    assert (args.n_rollout_threads, args.rollout_thread_offset, args.global_n_rollout_threads) == (3, 3, 12)
+    # the runners' episode count: job-wide threads (12), not this rank's 3
+    src = open(base_runner.__file__).read()
+    assert 'getattr(a, "global_n_rollout_threads", a.n_rollout_threads)' in src
+    from onpolicy.runner.shared import mpe_runner
+    assert "// self.n_rollout_threads_job" in open(mpe_runner.__file__).read()

@@ -205,6 +205,9 @@ class R_MAPPO():
         # reference's order (r_mappo.py:120 evaluate_actions, then :65 update inside cal_value_loss).  It matters
         # under PopArt, whose update rescales the value head the forward pass runs through.  ``pending`` is what
         # the update will be fed: None = nothing to do, () = the local minibatch, (mean, mean_sq) = global moments.
+        # (A minibatch cut into several row spans -- MAX_TENSOR_ELEMENTS, unfused routes only -- evaluates span 1 before the
+        # update and the others after it; under PopArt, whose update rescales v_out, that deviates from a single pass by
+        # the one EMA step (beta = 0.99999).  The fused route never cuts a minibatch.)
         pending = () if normalized else None
         if self.dp.active:      # one small collective for the loss denominators and the normaliser moments
             w_actor, w_critic, moments = self.dp.minibatch_stats(
@@ -416,7 +419,7 @@ class R_MAPPO():
             gen_kwargs["lazy_obs"] = True
 
         if hasattr(buffer, "plan_epochs"):
-            buffer.plan_epochs(self.ppo_epoch)      # lets the sampler draw the next permutation ahead
+            buffer.plan_epochs(self.ppo_epoch)      # (a no-op of the device sampler; kept for foreign buffers)
 
         keys = ('value_loss', 'policy_loss', 'dist_entropy', 'actor_grad_norm', 'critic_grad_norm', 'ratio')
         totals = torch.zeros(len(keys), dtype=torch.float32, device=self.device)

@@ -75,7 +75,9 @@ class SharedReplayBuffer(object):
         self._sampler_rng = getattr(args, "sampler_rng", "device")
         # --gae_exact (or MAPPO_GAE_EXACT=1): bit-identical returns for every buffer shape; by default narrow buffers
         # (2048 <= N * A < 16384) take the time-parallel GAE scan, which agrees with the reference to ~1e-6 relative
-        self._gae_exact = bool(getattr(args, "gae_exact", False)) or os.environ.get("MAPPO_GAE_EXACT", "0") == "1"
+        # (tolerance mode).  --sampler_rng host is the integer-parity mode of the whole path: it implies the exact kernels.
+        self._gae_exact = bool(getattr(args, "gae_exact", False)) or os.environ.get("MAPPO_GAE_EXACT", "0") == "1" \
+            or self._sampler_rng == "host"
 
         self.device = dev = self._resolve_device(args, device)
         self._lib = _native.lib()  # raises if the HIP library is not built
@@ -220,7 +222,8 @@ class SharedReplayBuffer(object):
         ``insert()`` then returns as soon as the host memcpy into the staging buffer is done: the DMA (57 MB per step at
         the north star) overlaps the next env step.  Two staging buffers alternate; an event per buffer keeps a step
         from overwriting data whose copy is still in flight.  -> pairs with host values replaced by device views."""
-        host = [(i, v) for i, (_, v) in enumerate(pairs) if not (torch.is_tensor(v) and v.device == self.device)]
+        # (host values only: a tensor that lives on another GPU takes the ordinary device-to-device path of _dev())
+        host = [(i, v) for i, (_, v) in enumerate(pairs) if not (torch.is_tensor(v) and v.device.type != "cpu")]
         if not host or not self._pinned_insert:
             return pairs
         arrays = []
@@ -324,6 +327,7 @@ class SharedReplayBuffer(object):
         if self.available_actions is not None:
             fields.append(self.available_actions)
         self._write_slabs([(f[0], f[-1]) for f in fields])
+        self._release_update_scratch()
 
     def chooseafter_update(self):
         """Hanabi variant (reference shared_buffer.py:172-177)."""
@@ -331,6 +335,13 @@ class SharedReplayBuffer(object):
         if self._recurrent:
             fields += [self.rnn_states, self.rnn_states_critic]
         self._write_slabs([(f[0], f[-1]) for f in fields])
+        self._release_update_scratch()
+
+    def _release_update_scratch(self):
+        """The row-standardised observation copies the fused trunk kernels read during train() (as large as the
+        observation fields themselves: 23.5 GB at the north star) go back to the allocator for the rollout; the next
+        train() takes the same blocks from its cache."""
+        self._std_rows.clear()
 
     # ------------------------------------------------------------------ returns
     def _denorm_scalars(self, value_normalizer):

@@ -56,7 +56,7 @@ constexpr int kFwdThreads = 512;     // forward kernel: 4 compute waves + 4 load
 constexpr int kFwdDepth = 3;         // chunk loads a loader thread of the forward keeps in flight
 constexpr int kFwdGridCap = 512;     // 2 workgroups per CU (each 2 LDS stages of 27 KB + 19 KB of parameters; <= 128 VGPRs):
                                      // while one workgroup's wave on a SIMD runs a layer tail (VALU), the other's feeds the MFMA
-constexpr int kBwdGridCap = 256;     // 1 workgroup per CU (108 KB of LDS)
+constexpr int kBwdGridCap = 256;     // 1 workgroup per CU
 constexpr int kDw1Rows = 32;         // rows per iteration of the first-layer weight-gradient kernel
 constexpr int kDw1Slab = 384;        // k columns per workgroup of that kernel (6 accumulator tiles per wave)
 constexpr int kDw1GridCap = 256;
@@ -72,8 +72,6 @@ __host__ __device__ __forceinline__ long long g_vec(int din, int l) { return 64L
 __host__ __device__ __forceinline__ long long g_w2(int din, int L, int l) { return 64LL * din + 192LL * L + 4096LL * (l - 1); }
 __host__ __device__ __forceinline__ long long g_wh(int din, int L) { return 64LL * din + 192LL * L + 4096LL * (L - 1); }
 __host__ __device__ __forceinline__ long long g_total(int din, int L, int out) { return g_wh(din, L) + 65LL * out; }
-// the chain kernel's per-wave partial row is the same layout without w1
-__host__ __device__ __forceinline__ long long p_main(int L, int out) { return 192LL * L + 4096LL * (L - 1) + 65LL * out; }
 
 // The rows of a launch: row r reads row srow[r] of `src`.  The table is the sampler's row map (shared_buffer.py:379-396
 // rows mode, :554-604 chunk mode) resolved once per minibatch by rowtab_kernel (int32, padded to the 128-row tile with
@@ -569,28 +567,6 @@ __global__ void __launch_bounds__(kFwdThreads, 4) mlp_fwd_kernel(FwdArgs a) {
 }
 
 // ================================================================== backward: row-parallel chain ====
-// (TA / TB / DY / the vector accumulators are private to a wave: the synchronisation points inside the tile loop are
-// wave-level -- a wave's LDS operations execute in order -- and the four waves of a workgroup drift freely.)
-// Per 32-row wave tile: recompute act / LayerNorm of every layer from the saved pre-activations, walk the chain
-// backwards in registers, write d loss / d z of the first layer to HBM (consumed by the weight-gradient kernel below)
-// and accumulate every other parameter gradient: hidden-layer weights in accumulator registers (MFMA over the rows of
-// the tile, operands transposed through wave-private LDS scratch), vectors and the head in per-wave LDS accumulators.
-struct BwdLds {
-    int vec, w2t, whp, scratch, acc, scratch_per_wave, acc_per_wave, total;
-};
-__host__ __device__ __forceinline__ BwdLds bwd_lds(int L, int out) {
-    BwdLds o;
-    o.vec = 0;                                    // [L][bias | g | beta][64]
-    o.w2t = o.vec + 192 * L;                      // [L - 1][2][32][kWS]: transposed + permuted hidden weights
-    o.whp = o.w2t + (L - 1) * 2 * 32 * kWS;       // [out][64] permuted head weights
-    o.scratch = (o.whp + out * 64 + 3) & ~3;
-    o.scratch_per_wave = 2 * 64 * kTS + ((out * 32 + 3) & ~3);   // TA | TB | DY[out][32]
-    o.acc = o.scratch + 4 * o.scratch_per_wave;
-    o.acc_per_wave = 192 * L + 65 * out;          // vectors per layer | head weight [out][64] | head bias [out]
-    o.total = o.acc + 4 * o.acc_per_wave;
-    return o;
-}
-
 struct BwdArgs {
     RowSrc rs;          // only rows is used here
     Net net;
@@ -598,7 +574,7 @@ struct BwdArgs {
     const float* st[3];
     const float* dy;    // [rows, out] (head) or [rows, 64] (out == 0)
     float* dz1;         // [rows128(rows), 64]
-    float* partials;    // [gridDim.x * 4][p_main]
+    float* partials;    // [gridDim.x][r_total]
     long long* dbg;     // tuning hook (mappo_mlp_set_debug): cycle stamps of workgroup 0's first tiles at [1024 ...], or NULL
 };
 
@@ -619,289 +595,9 @@ __device__ __forceinline__ void put_transposed(float* T, const float* reg, int c
     for (int s = 0; s < 32; ++s) T[feat_of(h, s) * kTS + c] = reg[s];
 }
 
-constexpr int kDyRegs = 8;      // prefetch registers for the next tile's dy block: covers out <= 16 (32 * out / 64 floats per lane)
-
-template <int L, int ACT>
-__global__ void __launch_bounds__(kThreads) mlp_bwd_kernel(BwdArgs a) {
-    float* lds = prim::lds();
-    const Net& n = a.net;
-    const int out = n.out;
-    const BwdLds o = bwd_lds(L, out);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5;
-    // ---- parameters
-    for (int e = tid; e < 192 * L; e += kThreads) {
-        const int l = e / 192, q = (e - 192 * l) >> 6, cc = e & 63;
-        const float* p = q == 0 ? n.bias[l] : (q == 1 ? n.ln_g[l] : n.ln_b[l]);
-        lds[o.vec + e] = p[cc];
-    }
-    // w2t[l-1][t][i][h * 32 + s] = W2_l[f(h, s)][32 t + i]: A operand of dX = W^T dZ (lane i = input feature)
-    for (int l = 1; l < L; ++l)
-        for (int e = tid; e < 64 * 64; e += kThreads) {
-            const int ki = e >> 6, hs = e & 63;
-            lds[o.w2t + (l - 1) * 2 * 32 * kWS + ki * kWS + hs] = n.w2[l - 1][feat_of(hs >> 5, hs & 31) * 64 + ki];
-        }
-    for (int e = tid; e < out * 64; e += kThreads) {
-        const int oo = e >> 6, hs = e & 63;
-        lds[o.whp + e] = n.wh[oo * 64 + feat_of(hs >> 5, hs & 31)];
-    }
-    const int wave_u = prim::uniform(wave);
-    float* TA = lds + o.scratch + wave * o.scratch_per_wave;
-    float* TB = TA + 64 * kTS;
-    float* DY = TB + 64 * kTS;
-    float* vacc = lds + o.acc + wave * o.acc_per_wave;      // [L][db | dg | dbeta][64] | dwh[out][64] | dbh[out]
-    for (int e = lane; e < o.acc_per_wave; e += 64) vacc[e] = 0.f;
-    // hidden layers 1 .. L - 1: tile 2 t + t' = (output feature tile t, input feature tile t').  L is a template
-    // parameter so that every index into this array is a compile-time constant (registers, not scratch memory)
-    constexpr int NW = L > 1 ? L - 1 : 1;
-    f32x16 dw2[NW][4];
-#pragma unroll
-    for (int l = 0; l < NW; ++l)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) dw2[l][t][v] = 0.f;
-    __syncthreads();
-
-    const long long rows = a.rs.rows;
-    const long long ntiles = (rows + kTR - 1) / kTR;
-    const bool dy_regs = out > 0 && 32 * out <= 64 * kDyRegs;
-    // ---- global inputs of a tile, fetched one tile ahead: the saved normalised activations / statistics of this lane's
-    // row and (head case) this wave's [32, out] block of dy, which is contiguous in memory
-    float zn[L][32], dyn[kDyRegs], dhn[32];
-    f2 stn[L];
-    auto fetch = [&](long long tile) {
-        const long long row = tile * kTR + 32 * wave + c;
-        const long long rrow = row < rows ? row : rows - 1;
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
-            // (padded to the tile: rows past the end repeat the last row)
-            load_frag64(a.z[l] + (tile * kTR + 32 * wave_u) * 64, lane, zn[l]);
-            stn[l] = *reinterpret_cast<const f2*>(a.st[l] + 2 * rrow);
-        }
-        if (out == 0) {
-            load_row64(a.dy + rrow * 64, dhn, h);
-            if (row >= rows) {
-#pragma unroll
-                for (int s = 0; s < 32; ++s) dhn[s] = 0.f;
-            }
-        } else if (dy_regs) {
-            const long long base = (tile * kTR + 32 * wave) * out;
-#pragma unroll
-            for (int i = 0; i < kDyRegs; ++i) {
-                const long long e = base + lane + 64 * i;
-                dyn[i] = (lane + 64 * i < 32 * out && e < rows * out) ? a.dy[e] : 0.f;
-            }
-        }
-    };
-    // (three layers: 96 prefetch registers on top of three layers of live state do not fit; the tile's inputs are then
-    // fetched when it starts)
-    constexpr bool kPrefetch = L <= 2;
-    if (kPrefetch && blockIdx.x < ntiles) fetch(blockIdx.x);
-
-    const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
-    int n_stamp = 0;
-#define MAPPO_BWD_STAMP(k) if (stamp && n_stamp < 12) a.dbg[1024 + 16 * n_stamp + (k)] = prim::clock()
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long long row = tile * kTR + 32 * wave + c;
-        const bool ok = row < rows;
-        MAPPO_BWD_STAMP(0);
-        if (!kPrefetch) fetch(tile);
-        float nc[L][32];        // this tile's normalised activations
-        float mean[L], rstd[L], sd[L];
-        float dh[32];           // gradient w.r.t. the output of the layer being processed (slot order)
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
-#pragma unroll
-            for (int s = 0; s < 32; ++s) nc[l][s] = zn[l][s];
-            mean[l] = stn[l][0];
-            rstd[l] = stn[l][1];
-            sd[l] = 1.f / rstd[l];
-        }
-        if (out == 0) {
-#pragma unroll
-            for (int s = 0; s < 32; ++s) dh[s] = dhn[s];
-        } else if (dy_regs) {
-            // dy block -> DY[o][row] (wave-private LDS)
-#pragma unroll
-            for (int i = 0; i < kDyRegs; ++i) {
-                const int e = lane + 64 * i;
-                if (e < 32 * out) DY[(e % out) * 32 + e / out] = dyn[i];
-            }
-        } else {
-            for (int oo = 0; oo < out; ++oo)
-                if (h == 0) DY[oo * 32 + c] = ok ? a.dy[row * out + oo] : 0.f;
-        }
-        if (kPrefetch && tile + gridDim.x < ntiles) fetch(tile + gridDim.x);     // in flight during this tile's arithmetic
-        MAPPO_BWD_STAMP(1);
-
-        // T[feature][c] = output of layer l = nhat * gamma + beta  (transposed into wave-private LDS)
-        auto put_output = [&](float* T, int l) {
-            const float* vec = lds + o.vec + 192 * l;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const v4 g = *reinterpret_cast<const v4*>(vec + 64 + 32 * t + 8 * q + 4 * h);
-                    const v4 be = *reinterpret_cast<const v4*>(vec + 128 + 32 * t + 8 * q + 4 * h);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int s = 16 * t + 4 * q + e;
-                        T[feat_of(h, s) * kTS + c] = nc[l][s] * g[e] + be[e];
-                    }
-                }
-        };
-        // ---- head
-        if (out > 0) {
-            put_output(TA, L - 1);
-            prim::wave_sync();        // DY and TA of this wave are complete
-#pragma unroll
-            for (int s = 0; s < 32; ++s) dh[s] = 0.f;
-            for (int oo = 0; oo < out; ++oo) {
-                const float d = DY[oo * 32 + c];
-                const float* wp = lds + o.whp + oo * 64 + 32 * h;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const v4 w = *reinterpret_cast<const v4*>(wp + 4 * q);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) dh[4 * q + e] += w[e] * d;
-                }
-            }
-            // lane = feature: d loss / d Wh[o][lane] += sum over the tile's rows of dy[row][o] * h[lane][row]
-            {
-                float hrow[32];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const v4 t = *reinterpret_cast<const v4*>(TA + lane * kTS + 4 * q);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) hrow[4 * q + e] = t[e];
-                }
-                for (int oo = 0; oo < out; ++oo) {
-                    float s = 0.f;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const v4 d = *reinterpret_cast<const v4*>(DY + oo * 32 + 4 * q);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) s += d[e] * hrow[4 * q + e];
-                    }
-                    vacc[192 * L + oo * 64 + lane] += s;
-                }
-                if (lane < out) vacc[192 * L + 64 * out + lane] += rowsum32(DY + lane * 32);
-            }
-            prim::wave_sync();
-        }
-        MAPPO_BWD_STAMP(2);
-        // ---- layers, top down
-#pragma unroll
-        for (int l = L - 1; l >= 0; --l) {
-            const float* vec = lds + o.vec + 192 * l;
-            float* va = vacc + 192 * l;
-            // LayerNorm backward: d beta = sum dh, d gamma = sum dh * nhat; then d a, d z
-            float m1 = 0.f, m2 = 0.f;
-#pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                TA[feat_of(h, s) * kTS + c] = dh[s];
-                TB[feat_of(h, s) * kTS + c] = dh[s] * nc[l][s];
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const v4 g = *reinterpret_cast<const v4*>(vec + 64 + 32 * t + 8 * q + 4 * h);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int s = 16 * t + 4 * q + e;
-                        dh[s] *= g[e];                      // dh now holds d nhat
-                        m1 += dh[s];
-                        m2 += dh[s] * nc[l][s];
-                    }
-                }
-            m1 += prim::xhalf(m1);
-            m2 += prim::xhalf(m2);
-            m1 *= (1.f / 64.f);
-            m2 *= (1.f / 64.f);
-            float dz[32];
-#pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                const float da = rstd[l] * (dh[s] - m1 - nc[l][s] * m2);
-                float dact = 1.f;
-                if (ACT == 1) {
-                    const float av = nc[l][s] * sd[l] + mean[l];     // the activation output of the forward pass
-                    dact = 1.f - av * av;
-                } else if (ACT == 2) {
-                    // every zero of a ReLU row maps to the same nhat, (0 - mean) * rstd, evaluated here with the forward's
-                    // own operations (no contraction): the active entries are exactly those above it
-                    dact = nc[l][s] > (0.f - mean[l]) * rstd[l] ? 1.f : 0.f;
-                }
-                dz[s] = da * dact;
-            }
-            MAPPO_BWD_STAMP(3 + 4 * (L - 1 - l));
-            prim::wave_sync();
-            va[128 + lane] += rowsum32(TA + lane * kTS);      // d beta
-            va[64 + lane] += rowsum32(TB + lane * kTS);       // d gamma
-            prim::wave_sync();
-            MAPPO_BWD_STAMP(4 + 4 * (L - 1 - l));
-            put_transposed(TA, dz, c, h);
-            if (l == 0) {
-                if (ok) store_row64(a.dz1 + row * 64, dz, h);
-                prim::wave_sync();
-                va[lane] += rowsum32(TA + lane * kTS);        // d bias
-                prim::wave_sync();
-            } else {
-                // hidden layer l >= 1: its input is the output of layer l - 1
-                put_output(TB, l > 0 ? l - 1 : 0);
-                prim::wave_sync();
-                va[lane] += rowsum32(TA + lane * kTS);            // d bias
-                MAPPO_BWD_STAMP(5 + 4 * (L - 1 - l));
-                // dW[f][k] += sum over rows dz[f][row] * hin[k][row]: A = TA (lane = f), B = TB (lane = k), rows 16 h + s
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const v4 a0 = *reinterpret_cast<const v4*>(TA + c * kTS + 16 * h + 4 * q);
-                    const v4 a1 = *reinterpret_cast<const v4*>(TA + (32 + c) * kTS + 16 * h + 4 * q);
-                    const v4 b0 = *reinterpret_cast<const v4*>(TB + c * kTS + 16 * h + 4 * q);
-                    const v4 b1 = *reinterpret_cast<const v4*>(TB + (32 + c) * kTS + 16 * h + 4 * q);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        dw2[l > 0 ? l - 1 : 0][0] = prim::mfma32(a0[e], b0[e], dw2[l > 0 ? l - 1 : 0][0]);
-                        dw2[l > 0 ? l - 1 : 0][1] = prim::mfma32(a0[e], b1[e], dw2[l > 0 ? l - 1 : 0][1]);
-                        dw2[l > 0 ? l - 1 : 0][2] = prim::mfma32(a1[e], b0[e], dw2[l > 0 ? l - 1 : 0][2]);
-                        dw2[l > 0 ? l - 1 : 0][3] = prim::mfma32(a1[e], b1[e], dw2[l > 0 ? l - 1 : 0][3]);
-                    }
-                }
-                // d hin = W^T dz
-                f32x16 dx[2];
-                dense64(lds + o.w2t + (l - 1) * 2 * 32 * kWS, c, h, dz, dx);
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) dh[16 * t + v] = dx[t][v];
-                prim::wave_sync();
-                MAPPO_BWD_STAMP(6 + 4 * (L - 1 - l));
-            }
-        }
-        MAPPO_BWD_STAMP(15);
-        ++n_stamp;
-    }
-#undef MAPPO_BWD_STAMP
-    // ---- flush this wave's partial sums
-    float* prow = a.partials + ((long long)blockIdx.x * 4 + wave) * p_main(L, out);
-    for (int e = lane; e < 192 * L; e += 64) prow[e] = vacc[e];
-    for (int e = lane; e < 65 * out; e += 64) prow[192 * L + 4096 * (L - 1) + e] = vacc[192 * L + e];
-#pragma unroll
-    for (int l = 1; l < L; ++l)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int tp = 0; tp < 2; ++tp)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int f = 32 * t + (v & 3) + 8 * (v >> 2) + 4 * h;
-                    const int k = 32 * tp + c;
-                    prow[192 * L + 4096 * (l - 1) + f * 64 + k] = dw2[l - 1][2 * t + tp][v];
-                }
-}
-
-// ================================================================== backward: row-parallel chain, version 2 ====
-// The same chain with most of its per-tile LDS / VALU work removed.  Measured on gfx950 (cycle stamps, round 3): an LDS
+// The chain kernel.  Its first version (round 2) transposed dh, dh * nhat, dz and the layer input of every layer through two
+// scratch tiles per wave and prefetched a whole tile in registers (416 registers, 23 k cycles per tile).  This one keeps
+// most of that per-tile LDS / VALU work out of the loop.  Measured on gfx950 (cycle stamps, round 3): an LDS
 // instruction costs a wave ~30 cycles of issue whatever it moves, a second wave per SIMD does not hide them (its MFMA
 // stream starves the partner's LDS / vector-memory instructions: every phase of a tile just took twice as long), and
 // global-load latency (3 - 6 k cycles under load) was exposed three times per tile.  So: ONE wave per SIMD with the whole
@@ -993,7 +689,7 @@ __device__ __forceinline__ void ln_act_backward(float* dn, const float* nh, floa
 }
 
 template <int L, int ACT, int HR>
-__global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd2_kernel(BwdArgs a) {
+__global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
     constexpr int NW = kB2Waves;
     float* lds = prim::lds();
     const Net& n = a.net;
@@ -1420,7 +1116,7 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd2_kernel(BwdArgs a) {
     }
 }
 
-// The parameter gradients of the chain from the reduced raw sums R (see mlp_bwd2_kernel): one workgroup.
+// The parameter gradients of the chain from the reduced raw sums R (see mlp_bwd_kernel): one workgroup.
 struct FinishArgs {
     Net net;
     const float* R;
@@ -1509,7 +1205,7 @@ __global__ void __launch_bounds__(kPipeThreads) mlp_dw1_kernel(Dw1Args a) {
         const int lt = tid - 256, lr = lt >> 3, sub = lt & 7;
         const int np = kw >> 5;                  // 16-byte pieces per thread: piece sub + 8 p, p < np (<= 12)
         long long issued = 0;
-        auto row_of = [&](long long m) {         // launch row this thread serves in its m-th tile (clamped past the end)
+            auto row_of = [&](long long m) {         // launch row this thread serves in its m-th tile (clamped past the end)
             if (m >= n_it) m = n_it - 1;
             return (blockIdx.x + m * gridDim.x) * kDw1Rows + lr;     // < rows128
         };
@@ -2107,9 +1803,9 @@ inline int forward(const mappo_mlp_t* m, hipStream_t stream) {
         a.st[l] = l < m->n_layers ? m->ln_stats[l] : nullptr;
         if (a.z[l] != nullptr && a.st[l] == nullptr) return MAPPO_E_NULL;
     }
+    const bool al = m->din % 4 == 0;
     const FwdLds o = fwd_lds(m->n_layers, m->out);
     const long long grid = capped(ceil_div(m->rows, kTR), kFwdGridCap);
-    const bool al = m->din % 4 == 0;
 #define MAPPO_FWD_CASE(AA, AL)                                                                                 \
     if (m->act == AA && al == AL) {                                                                            \
         MAPPO_LAUNCH((mlp_fwd_kernel<AA, AL>), (unsigned)grid, kFwdThreads, (size_t)o.total * 4, stream, a);   \
@@ -2121,10 +1817,8 @@ inline int forward(const mappo_mlp_t* m, hipStream_t stream) {
 }
 
 inline long long workspace_floats(int din, int n_layers, int out) {
-    // chain partials (one row per workgroup; the version-1 kernel: per wave) | reduced raw sums | first-layer partials
-    const long long v1 = (long long)kBwdGridCap * 4 * p_main(n_layers, out);
-    const long long v2 = (long long)(kBwdGridCap + 1) * r_total(n_layers, out);
-    return (v1 > v2 ? v1 : v2) + (long long)kD2GridCap * (64LL * din + 64);
+    // chain partials (one row per workgroup) | reduced raw sums | first-layer partials
+    return (long long)(kBwdGridCap + 1) * r_total(n_layers, out) + (long long)kD2GridCap * (64LL * din + 64);
 }
 
 inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
@@ -2142,27 +1836,15 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
     b.dy = m->dy;
     b.dz1 = m->dz1;
     b.partials = m->workspace;
-    const bool v1 = (tuning_flags() & 4) != 0;      // MAPPO_MLP_FLAGS=4: the version-1 chain kernel (A / B measurements)
     long long grid;
-    if (v1) {
-        const BwdLds o = bwd_lds(L, out);
-        grid = capped(ceil_div(m->rows, kTR), kBwdGridCap);
-#define MAPPO_BWD_CASE(LL, AA)                                                                             \
-    if (L == LL && m->act == AA) {                                                                         \
-        MAPPO_LAUNCH((mlp_bwd_kernel<LL, AA>), (unsigned)grid, kThreads, (size_t)o.total * 4, stream, b);  \
-    }
-        MAPPO_BWD_CASE(1, 0) MAPPO_BWD_CASE(1, 1) MAPPO_BWD_CASE(1, 2)
-        MAPPO_BWD_CASE(2, 0) MAPPO_BWD_CASE(2, 1) MAPPO_BWD_CASE(2, 2)
-        MAPPO_BWD_CASE(3, 0) MAPPO_BWD_CASE(3, 1) MAPPO_BWD_CASE(3, 2)
-#undef MAPPO_BWD_CASE
-    } else {
+    {
         // head sums in registers for the value head (HR = 1)
         const int hr = (out == 1 && L <= 2) ? 1 : 0;
         const Bwd2Lds o = bwd2_lds<kB2Waves>(L, out);
         grid = capped(ceil_div(m->rows, 32 * kB2Waves), kBwdGridCap);
 #define MAPPO_BWD_CASE(LL, AA, HH)                                                                                    \
     if (L == LL && m->act == AA && hr == HH) {                                                                        \
-        MAPPO_LAUNCH((mlp_bwd2_kernel<LL, AA, HH>), (unsigned)grid, 64 * kB2Waves, (size_t)o.total * 4, stream, b);   \
+        MAPPO_LAUNCH((mlp_bwd_kernel<LL, AA, HH>), (unsigned)grid, 64 * kB2Waves, (size_t)o.total * 4, stream, b);   \
     }
 #define MAPPO_BWD_CASES(LL, AA) MAPPO_BWD_CASE(LL, AA, 0) MAPPO_BWD_CASE(LL, AA, 1)
         MAPPO_BWD_CASES(1, 0) MAPPO_BWD_CASES(1, 1) MAPPO_BWD_CASES(1, 2)
@@ -2210,12 +1892,6 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
     // The first-layer partials end with the column sums of dz1: w1 and the first bias are adjacent in the flat layout
     const long long p1 = 64LL * din + 64;
     MAPPO_LAUNCH(mlp_reduce_kernel, (unsigned)ceil_div(p1, 32), kThreads, 1024, stream, d.partials, gx, p1, p1, m->grads);
-    if (v1) {
-        const long long pm = p_main(L, out);
-        MAPPO_LAUNCH(mlp_reduce_kernel, (unsigned)ceil_div(pm, 32), kThreads, 1024, stream, b.partials, grid * 4, pm, pm,
-                     m->grads + 64LL * din);
-        return MAPPO_LAUNCH_ERROR();
-    }
     MAPPO_LAUNCH(mlp_reduce_kernel, (unsigned)ceil_div(rt, 32), kThreads, 1024, stream, b.partials, grid, rt, rt, raw);
     FinishArgs f;
     f.net = b.net;

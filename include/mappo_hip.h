@@ -352,6 +352,55 @@ int mappo_gru_step_fwd(const float* gi, const float* hm, const float* w_hh, cons
                        const float* mask_next, float* h_out, float* hm_next, float* ws, int64_t B, int H,
                        mappo_stream_t stream);
 
+/* --------------------------------------------------------------- K12: the GRU over a whole chunk ----
+ * RNNLayer of the recurrent policies (reference onpolicy/algorithms/utils/rnn.py:7-80: nn.GRU, gates r | z | n, state
+ * multiplied by the episode mask before every step, LayerNorm on the outputs) for H = 64, ONE launch per direction over
+ * the [L * mb, 64] chunk rows of recurrent_generator (shared_buffer.py:499-608; row l * mb + j = step l of chunk j; the
+ * rollout is the case L = 1).  A wave walks the L steps of 32 chunks with the state in registers; both projections of a
+ * step run on the f32 MFMA against weights held in LDS; gates, mask reset and the output LayerNorm on the accumulators.
+ * mappo_gru_seq_forward: x, h0 [mb, 64], masks [L * mb] -> y = LayerNorm(h_l) [L * mb, 64], h_last [mb, 64] (optional).
+ *   For the backward (all three or none): gates [mappo_gru_seq_gates_floats(L, mb)] (r, z, n, W_hn hm + b_hn and the
+ *   normalised output per row and step, opaque order), hm [L * mb, 64] (the masked previous state of every step),
+ *   stats [mappo_gru_seq_stats_floats(L, mb)].
+ * mappo_gru_seq_backward (truncated BPTT inside the launch): dy [L * mb, 64] (+ dh_last [mb, 64], optional) -> dx [L * mb, 64], dh0 [mb, 64] (optional),
+ *   dgi [L * mb, 192] = gradient at W_ih x + b_ih, dq [L * mb, 64] = gradient at W_hn hm + b_hn (the r and z thirds of the
+ *   hidden side's gradient are dgi's) -- the caller forms dW_ih = dgi^T x, dW_hh = [dgi_rz | dq]^T hm and the bias
+ *   gradients (column sums) from them -- and ln_grads [128] = LayerNorm weight | bias gradients; workspace
+ *   [mappo_gru_seq_workspace_floats()] scratch.  Deterministic run to run. */
+typedef struct mappo_gru_seq {
+    const float* x;
+    const float* h0;
+    const float* masks;
+    const float* w_ih;      /* [192, 64] */
+    const float* w_hh;      /* [192, 64] */
+    const float* b_ih;      /* [192] */
+    const float* b_hh;      /* [192] */
+    const float* ln_g;      /* [64] */
+    const float* ln_b;      /* [64] */
+    float ln_eps;
+    int32_t H;              /* 64 */
+    int32_t L;
+    int64_t mb;
+    float* y;
+    float* h_last;
+    float* gates;
+    float* hm;
+    float* stats;
+    const float* dy;
+    float* dx;
+    float* dgi;
+    float* dq;
+    float* dh0;
+    const float* dh_last;   /* [mb, 64] gradient at h_last, or NULL */
+    float* ln_grads;
+    float* workspace;
+} mappo_gru_seq_t;
+int64_t mappo_gru_seq_gates_floats(int L, int64_t mb);
+int64_t mappo_gru_seq_stats_floats(int L, int64_t mb);
+int64_t mappo_gru_seq_workspace_floats(void);
+int     mappo_gru_seq_forward(const mappo_gru_seq_t* seq, mappo_stream_t stream);
+int     mappo_gru_seq_backward(const mappo_gru_seq_t* seq, mappo_stream_t stream);
+
 /* --------------------------------------------------------------- K10: sort-free minibatch index lists ----
  * Device-side replacement of `rand = torch.randperm(B); slices = [rand[i*mb:(i+1)*mb] for i in range(n_mb)]`
  * (reference onpolicy/utils/shared_buffer.py:360-361 feed-forward, :415-416 whole trajectories, :511-512 chunks).

@@ -1,0 +1,443 @@
+// K12: the GRU of the recurrent policies over a whole chunk in one launch per direction (hidden width 64).
+// Reference: onpolicy/algorithms/utils/rnn.py:7-80 -- RNNLayer = nn.GRU (gates stacked r | z | n, PyTorch cell)
+//     r = sigmoid(W_ir x + b_ir + W_hr hm + b_hr),  z = sigmoid(W_iz x + b_iz + W_hz hm + b_hz),
+//     n = tanh(W_in x + b_in + r * (W_hn hm + b_hn)),  h' = n + z * (hm - n),   hm = h * mask   (rnn.py:43-77: the
+//     state is reset where an episode ended; multiplying by the mask at every step is the same function)
+// followed by LayerNorm(h') (rnn.py:22, :79), driven over the [L * mb, 64] chunk rows of recurrent_generator
+// (shared_buffer.py:499-608: row l * mb + j = step l of chunk j).
+//
+// Why: round 2 walked the L = 10 steps of a chunk with one gate kernel + one hidden GEMM per step and direction, plus
+// library GEMMs for the input projection / its gradient, bias reductions and a separate LayerNorm pair -- ~55 launches
+// per network and minibatch, 65 % of the ns_rnn step, the [rows, 192] projections and gate gradients making round trips
+// through HBM between them.  Here a wave owns 32 chunks (lane = chunk, like a row of K9) and walks their L steps with the
+// state in registers: both projections of a step run on the f32 MFMA against weights held in LDS (2 x 52 KB, staged once
+// per workgroup in the order the accumulator registers feed the next MFMA: mappo_mlp_impl.h, "orientation"), the gates,
+// the mask reset and the output LayerNorm are evaluated on the accumulators.  The backward walks the steps in reverse
+// (truncated BPTT inside the launch): LayerNorm and gate backward in registers, d x and d hm on the MFMA against the
+// transposed weights; it writes the gate gradients once ([rows, 192] + the n third of the hidden side) for the two
+// weight-gradient GEMMs, which stay split-K library GEMMs over all L * mb rows.
+//
+// Written against the primitives of mappo_mlp_impl.h (included before this header); tests/simt runs the same source on
+// the host SIMT emulator.
+#ifndef MAPPO_GRU_IMPL_H
+#define MAPPO_GRU_IMPL_H
+
+namespace gru {
+
+using mlp::feat_of;
+using mlp::kTS;
+using mlp::kWS;
+using mlp::f2;
+
+constexpr int kWaves = 4;
+constexpr int kThreads = 64 * kWaves;
+constexpr int kGridCap = 256;        // one workgroup per CU (104 KB of weights in LDS)
+constexpr int kSaved = 5;            // fragments saved per row and step: r, z, n, q = W_hn hm + b_hn, nhat
+
+struct Args {
+    const float* x;         // [L * mb, 64] layer input, row l * mb + j
+    const float* h0;        // [mb, 64]
+    const float* masks;     // [L * mb]
+    const float* w_ih;      // [192, 64]
+    const float* w_hh;      // [192, 64]
+    const float* b_ih;      // [192]
+    const float* b_hh;      // [192]
+    const float* ln_g;      // [64]
+    const float* ln_b;      // [64]
+    float eps;
+    long long mb;
+    int L;
+    float* y;               // [L * mb, 64] LayerNorm(h_l)
+    float* h_last;          // [mb, 64] or NULL
+    float* gates;           // [L][tiles][kSaved][2048] fragment order (NULL: nothing is saved)
+    float* hm;              // [L * mb, 64] masked previous state of every step (NULL with gates)
+    float* stats;           // [L * tiles * 32, 2] {mean, rstd} of the output LayerNorm
+    // backward only
+    const float* dy;        // [L * mb, 64]
+    float* dx;              // [L * mb, 64]
+    float* dgi;             // [L * mb, 192] gradient at W_ih x + b_ih (r | z | n)
+    float* dq;              // [L * mb, 64]  gradient at W_hn hm + b_hn (the r and z thirds of the hidden side equal dgi's)
+    float* dh0;             // [mb, 64] or NULL
+    const float* dh_last;   // [mb, 64] gradient at h_last, or NULL (none)
+    float* partials;        // [gridDim.x][128]: LayerNorm weight | bias gradient sums per workgroup
+};
+
+__host__ __device__ __forceinline__ long long tiles_of(long long mb) { return (mb + 31) / 32; }
+
+// acc[t] += sum over (h, s) of Wp[t][lane & 31][h * 32 + s] * reg[s] for the two 32-feature tiles at wp, wp + 32 kWS
+__device__ __forceinline__ void dense64_acc(const float* wp, int c, int h, const float* reg, f32x16* acc) {
+    const float* w0 = wp + c * kWS + 32 * h;
+    const float* w1 = wp + (32 + c) * kWS + 32 * h;
+    v4 a0n = *reinterpret_cast<const v4*>(w0), a1n = *reinterpret_cast<const v4*>(w1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const v4 a0 = a0n, a1 = a1n;
+        if (q < 7) {
+            a0n = *reinterpret_cast<const v4*>(w0 + 4 * q + 4);
+            a1n = *reinterpret_cast<const v4*>(w1 + 4 * q + 4);
+        }
+        prim::sched_fence();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[0] = prim::mfma32(a0[e], reg[4 * q + e], acc[0]);
+            acc[1] = prim::mfma32(a1[e], reg[4 * q + e], acc[1]);
+        }
+    }
+}
+
+__device__ __forceinline__ void zero2(f32x16* acc) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+}
+
+// slot-order registers <-> one 2048-float fragment tile (see mlp::load_frag64)
+__device__ __forceinline__ void store_frag64(float* tile, int lane, const float* reg) {
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        v4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = reg[4 * b + e];
+        *reinterpret_cast<v4*>(tile + 4 * lane + 256 * b) = o;
+    }
+}
+
+// a per-feature vector [64] in LDS -> this lane's 32 slots
+__device__ __forceinline__ void slots_of(const float* vec, int h, float* out) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const v4 b = *reinterpret_cast<const v4*>(vec + 32 * t + 8 * q + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[16 * t + 4 * q + e] = b[e];
+        }
+}
+
+__device__ __forceinline__ float sigmoid_fast(float x) {
+    return prim::rcp_fast(1.f + prim::exp2_fast(x * -1.4426950408889634f));
+}
+
+// LDS (floats): forward  wih [6][32][kWS] | whh [6][32][kWS] | vec [6][64] = b_ir + b_hr, b_iz + b_hz, b_in, b_hn, gamma, beta
+//               backward wihT [3][2][32][kWS] | whhT [3][2][32][kWS] | gamma [64] | per wave T [64][kTS]
+constexpr int kW = 6 * 32 * kWS;
+constexpr int kFwdLds = 2 * kW + 6 * 64;
+constexpr int kBwdLds = 2 * kW + 64 + kWaves * 64 * kTS;
+
+__global__ void __launch_bounds__(kThreads, 1) gru_seq_fwd_kernel(Args a) {
+    float* lds = prim::lds();
+    const int tid = threadIdx.x, lane = tid & 63, wave = prim::uniform(tid >> 6), c = lane & 31, h = lane >> 5;
+    // w[T][i][h * 32 + s] = W[32 T + i][f(h, s)]: A operand (lane = output feature) of the step that consumes slot s
+    for (int e = tid; e < 192 * 64; e += kThreads) {
+        const int fo = e >> 6, hs = e & 63, k = feat_of(hs >> 5, hs & 31);
+        lds[fo * kWS + hs] = a.w_ih[fo * 64 + k];
+        lds[kW + fo * kWS + hs] = a.w_hh[fo * 64 + k];
+    }
+    float* vec = lds + 2 * kW;
+    for (int e = tid; e < 64; e += kThreads) {
+        vec[e] = a.b_ih[e] + a.b_hh[e];
+        vec[64 + e] = a.b_ih[64 + e] + a.b_hh[64 + e];
+        vec[128 + e] = a.b_ih[128 + e];
+        vec[192 + e] = a.b_hh[128 + e];
+        vec[256 + e] = a.ln_g[e];
+        vec[320 + e] = a.ln_b[e];
+    }
+    __syncthreads();
+    const long long mb = a.mb, ntiles = tiles_of(mb);
+    const int L = a.L;
+    for (long long tile = (long long)blockIdx.x * kWaves + wave; tile < ntiles; tile += (long long)gridDim.x * kWaves) {
+        const long long j = tile * 32 + c;
+        const bool ok = j < mb;
+        const long long jj = ok ? j : mb - 1;       // rows past the end repeat the last chunk (never stored row-major)
+        float hcur[32], xn[32];
+        mlp::load_row64(a.h0 + jj * 64, hcur, h);
+        mlp::load_row64(a.x + jj * 64, xn, h);
+        float mk = a.masks[jj];
+        for (int l = 0; l < L; ++l) {
+            const long long row = (long long)l * mb + jj;
+            float x[32], hm[32];
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                x[s] = xn[s];
+                hm[s] = hcur[s] * mk;
+            }
+            if (l + 1 < L) {                        // the next step's input and mask, in flight behind this step's MFMAs
+                mlp::load_row64(a.x + (row + mb) * 64, xn, h);
+                mk = a.masks[row + mb];
+            }
+            if (a.hm != nullptr && ok) mlp::store_row64(a.hm + row * 64, hm, h);
+            f32x16 ar[2], az[2], ai[2], ah[2];
+            zero2(ar);
+            zero2(az);
+            zero2(ai);
+            zero2(ah);
+            dense64_acc(lds + 0 * 64 * kWS, c, h, x, ar);
+            dense64_acc(lds + kW + 0 * 64 * kWS, c, h, hm, ar);
+            dense64_acc(lds + 1 * 64 * kWS, c, h, x, az);
+            dense64_acc(lds + kW + 1 * 64 * kWS, c, h, hm, az);
+            dense64_acc(lds + 2 * 64 * kWS, c, h, x, ai);
+            dense64_acc(lds + kW + 2 * 64 * kWS, c, h, hm, ah);
+            float r[32], z[32], n[32], q[32];
+            {
+                float b0[32], b1[32];
+                slots_of(vec, h, b0);
+                slots_of(vec + 64, h, b1);
+#pragma unroll
+                for (int s = 0; s < 32; ++s) {
+                    r[s] = sigmoid_fast(ar[s >> 4][s & 15] + b0[s]);
+                    z[s] = sigmoid_fast(az[s >> 4][s & 15] + b1[s]);
+                }
+                slots_of(vec + 128, h, b0);
+                slots_of(vec + 192, h, b1);
+#pragma unroll
+                for (int s = 0; s < 32; ++s) {
+                    q[s] = ah[s >> 4][s & 15] + b1[s];
+                    n[s] = mlp::fast_tanh(ai[s >> 4][s & 15] + b0[s] + r[s] * q[s]);
+                    hcur[s] = n[s] + z[s] * (hm[s] - n[s]);
+                }
+            }
+            // output LayerNorm on this lane's row (rnn.py:79)
+            float sum = 0.f;
+#pragma unroll
+            for (int s = 0; s < 32; ++s) sum += hcur[s];
+            sum += prim::xhalf(sum);
+            const float mean = sum * (1.f / 64.f);
+            float var = 0.f, nh[32];
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                nh[s] = hcur[s] - mean;
+                var += nh[s] * nh[s];
+            }
+            var += prim::xhalf(var);
+            const float rstd = 1.f / sqrtf(var * (1.f / 64.f) + a.eps);
+            {
+                float g[32], be[32];
+                slots_of(vec + 256, h, g);
+                slots_of(vec + 320, h, be);
+                float yv[32];
+#pragma unroll
+                for (int s = 0; s < 32; ++s) {
+                    nh[s] *= rstd;
+                    yv[s] = nh[s] * g[s] + be[s];
+                }
+                if (ok) mlp::store_row64(a.y + row * 64, yv, h);
+            }
+            if (a.gates != nullptr) {
+                float* gt = a.gates + ((long long)l * ntiles + tile) * (kSaved * 2048);
+                store_frag64(gt, lane, r);
+                store_frag64(gt + 2048, lane, z);
+                store_frag64(gt + 2 * 2048, lane, n);
+                store_frag64(gt + 3 * 2048, lane, q);
+                store_frag64(gt + 4 * 2048, lane, nh);
+                *reinterpret_cast<f2*>(a.stats + 2 * (((long long)l * ntiles + tile) * 32 + c)) = f2{mean, rstd};
+            }
+        }
+        if (a.h_last != nullptr && ok) mlp::store_row64(a.h_last + j * 64, hcur, h);
+    }
+}
+
+__global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
+    float* lds = prim::lds();
+    const int tid = threadIdx.x, lane = tid & 63, wave = prim::uniform(tid >> 6), c = lane & 31, h = lane >> 5;
+    // wT[g][t][i][h * 32 + s] = W[64 g + f(h, s)][32 t + i]: A operand (lane = input feature) of d input = W_g^T d gate_g
+    for (int e = tid; e < 3 * 64 * 64; e += kThreads) {
+        const int g = e >> 12, ki = (e >> 6) & 63, hs = e & 63, fo = 64 * g + feat_of(hs >> 5, hs & 31);
+        lds[g * 64 * kWS + ki * kWS + hs] = a.w_ih[fo * 64 + ki];
+        lds[kW + g * 64 * kWS + ki * kWS + hs] = a.w_hh[fo * 64 + ki];
+    }
+    float* gam = lds + 2 * kW;
+    for (int e = tid; e < 64; e += kThreads) gam[e] = a.ln_g[e];
+    float* T = gam + 64 + wave * 64 * kTS;
+    __syncthreads();
+    float dgam[32], dbet[32];       // row layout (this lane's row position): LayerNorm weight / bias gradient sums
+#pragma unroll
+    for (int s = 0; s < 32; ++s) dgam[s] = dbet[s] = 0.f;
+    const long long mb = a.mb, ntiles = tiles_of(mb);
+    const int L = a.L;
+    for (long long tile = (long long)blockIdx.x * kWaves + wave; tile < ntiles; tile += (long long)gridDim.x * kWaves) {
+        const long long j = tile * 32 + c;
+        const bool ok = j < mb;
+        const long long jj = ok ? j : mb - 1;
+        float carry[32];            // d loss / d h_l arriving from step l + 1 (from the caller's use of h_last at l = L - 1)
+#pragma unroll
+        for (int s = 0; s < 32; ++s) carry[s] = 0.f;
+        if (a.dh_last != nullptr) {
+            mlp::load_row64(a.dh_last + jj * 64, carry, h);
+            if (!ok) {
+#pragma unroll
+                for (int s = 0; s < 32; ++s) carry[s] = 0.f;
+            }
+        }
+        // What a step reads first (the normalised output, the gradient from above, the masked previous state: the last
+        // two row-major, i.e. the slow ones) is fetched one step ahead into the registers the previous step has finished
+        // with, so that the loads fly under the step's 384 MFMAs; the four gate fragments are loaded at the top of their
+        // step, behind the LayerNorm backward (all seven streams a step ahead need more registers than a wave has)
+        float r[32], z[32], n[32], q[32], nh[32], hm[32], g[32];
+        f2 st;
+        float mk;
+        auto fetch = [&](int l) {
+            const long long row = (long long)l * mb + jj;
+            const float* gt = a.gates + ((long long)l * ntiles + tile) * (kSaved * 2048);
+            mlp::load_frag64(gt + 4 * 2048, lane, nh);
+            st = *reinterpret_cast<const f2*>(a.stats + 2 * (((long long)l * ntiles + tile) * 32 + c));
+            mlp::load_row64(a.hm + row * 64, hm, h);
+            mlp::load_row64(a.dy + row * 64, g, h);
+            mk = a.masks[row];
+        };
+        fetch(L - 1);
+        for (int l = L - 1; l >= 0; --l) {
+            const long long row = (long long)l * mb + jj;
+            const float mkl = mk;
+            {
+                const float* gt = a.gates + ((long long)l * ntiles + tile) * (kSaved * 2048);
+                mlp::load_frag64(gt + 2048, lane, z);
+                mlp::load_frag64(gt + 2 * 2048, lane, n);
+                mlp::load_frag64(gt, lane, r);
+                mlp::load_frag64(gt + 3 * 2048, lane, q);
+            }
+            // output LayerNorm backward (rows past the end: dy = 0 -> every gradient below is 0)
+            float m1 = 0.f, m2 = 0.f;
+            {
+                float gslot[32];
+                slots_of(gam, h, gslot);
+#pragma unroll
+                for (int s = 0; s < 32; ++s) {
+                    if (!ok) g[s] = 0.f;
+                    dbet[s] += g[s];
+                    dgam[s] += g[s] * nh[s];
+                    g[s] *= gslot[s];
+                    m1 += g[s];
+                    m2 += g[s] * nh[s];
+                }
+            }
+            m1 += prim::xhalf(m1);
+            m2 += prim::xhalf(m2);
+            m1 *= (1.f / 64.f);
+            m2 *= (1.f / 64.f);
+            float dar[32], daz[32], dan[32], dqq[32], gz[32];
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                const float gg = st[1] * ((g[s] - m1) - nh[s] * m2) + carry[s];        // d loss / d h_l
+                gz[s] = gg * z[s];
+                dan[s] = gg * (1.f - z[s]) * (1.f - n[s] * n[s]);
+                daz[s] = gg * (hm[s] - n[s]) * z[s] * (1.f - z[s]);
+                dqq[s] = dan[s] * r[s];
+                dar[s] = dan[s] * q[s] * r[s] * (1.f - r[s]);
+            }
+            if (l > 0) fetch(l - 1);
+            if (ok) {
+                mlp::store_row64(a.dgi + row * 192, dar, h);
+                mlp::store_row64(a.dgi + row * 192 + 64, daz, h);
+                mlp::store_row64(a.dgi + row * 192 + 128, dan, h);
+                mlp::store_row64(a.dq + row * 64, dqq, h);
+            }
+            f32x16 acc[2];
+            zero2(acc);
+            dense64_acc(lds + 0 * 64 * kWS, c, h, dar, acc);
+            dense64_acc(lds + 1 * 64 * kWS, c, h, daz, acc);
+            dense64_acc(lds + 2 * 64 * kWS, c, h, dan, acc);
+            {
+                float dxv[32];
+#pragma unroll
+                for (int s = 0; s < 32; ++s) dxv[s] = acc[s >> 4][s & 15];
+                if (ok) mlp::store_row64(a.dx + row * 64, dxv, h);
+            }
+            zero2(acc);
+            dense64_acc(lds + kW + 0 * 64 * kWS, c, h, dar, acc);
+            dense64_acc(lds + kW + 1 * 64 * kWS, c, h, daz, acc);
+            dense64_acc(lds + kW + 2 * 64 * kWS, c, h, dqq, acc);
+#pragma unroll
+            for (int s = 0; s < 32; ++s) carry[s] = (acc[s >> 4][s & 15] + gz[s]) * mkl;     // d loss / d h_{l-1}
+        }
+        if (a.dh0 != nullptr && ok) mlp::store_row64(a.dh0 + j * 64, carry, h);
+    }
+    // ---- LayerNorm parameter gradients: row layout -> lane = feature, waves added through LDS
+    prim::wave_sync();
+    mlp::put_transposed(T, dgam, c, h);
+    prim::wave_sync();
+    const float sg = mlp::rowsum32(T + lane * kTS);
+    prim::wave_sync();
+    mlp::put_transposed(T, dbet, c, h);
+    prim::wave_sync();
+    const float sb = mlp::rowsum32(T + lane * kTS);
+    prim::wave_sync();
+    T[lane] = sg;
+    T[64 + lane] = sb;
+    __syncthreads();
+    if (tid < 128) {
+        float s = 0.f;
+        for (int w = 0; w < kWaves; ++w) s += gam[64 + w * 64 * kTS + tid];
+        a.partials[(long long)blockIdx.x * 128 + tid] = s;
+    }
+}
+
+inline long long grid_of(long long mb) {
+    long long g = (tiles_of(mb) + kWaves - 1) / kWaves;
+    const int cap = mlp::grid_cap_override() > 0 && mlp::grid_cap_override() < kGridCap ? mlp::grid_cap_override() : kGridCap;
+    return g > cap ? cap : g;
+}
+
+inline int check(const mappo_gru_seq_t* m, bool backward) {
+    if (!m || !m->x || !m->h0 || !m->masks || !m->w_ih || !m->w_hh || !m->b_ih || !m->b_hh || !m->ln_g || !m->ln_b)
+        return MAPPO_E_NULL;
+    if (m->mb <= 0 || m->L <= 0 || m->H != 64) return MAPPO_E_SHAPE;
+    if (!backward && !m->y) return MAPPO_E_NULL;
+    if ((m->gates != nullptr) != (m->hm != nullptr) || (m->gates != nullptr) != (m->stats != nullptr)) return MAPPO_E_NULL;
+    if (backward && (!m->gates || !m->dy || !m->dx || !m->dgi || !m->dq || !m->ln_grads || !m->workspace)) return MAPPO_E_NULL;
+    const void* al[] = {m->x, m->h0, m->y, m->h_last, m->gates, m->hm, m->stats, m->dy, m->dx, m->dgi, m->dq, m->dh0, m->dh_last};
+    for (const void* p : al)
+        if (p && (reinterpret_cast<uintptr_t>(p) & 15) != 0) return MAPPO_E_ALIGN;
+    return 0;
+}
+
+inline void fill(const mappo_gru_seq_t* m, Args& a) {
+    a.x = m->x;
+    a.h0 = m->h0;
+    a.masks = m->masks;
+    a.w_ih = m->w_ih;
+    a.w_hh = m->w_hh;
+    a.b_ih = m->b_ih;
+    a.b_hh = m->b_hh;
+    a.ln_g = m->ln_g;
+    a.ln_b = m->ln_b;
+    a.eps = m->ln_eps;
+    a.mb = m->mb;
+    a.L = m->L;
+    a.y = m->y;
+    a.h_last = m->h_last;
+    a.gates = m->gates;
+    a.hm = m->hm;
+    a.stats = m->stats;
+    a.dy = m->dy;
+    a.dx = m->dx;
+    a.dgi = m->dgi;
+    a.dq = m->dq;
+    a.dh0 = m->dh0;
+    a.dh_last = m->dh_last;
+    a.partials = m->workspace;
+}
+
+inline int forward(const mappo_gru_seq_t* m, hipStream_t stream) {
+    int code = check(m, false);
+    if (code) return code;
+    Args a;
+    fill(m, a);
+    MAPPO_LAUNCH(gru_seq_fwd_kernel, (unsigned)grid_of(m->mb), kThreads, (size_t)kFwdLds * 4, stream, a);
+    return MAPPO_LAUNCH_ERROR();
+}
+
+inline int backward(const mappo_gru_seq_t* m, hipStream_t stream) {
+    int code = check(m, true);
+    if (code) return code;
+    Args a;
+    fill(m, a);
+    const long long grid = grid_of(m->mb);
+    MAPPO_LAUNCH(gru_seq_bwd_kernel, (unsigned)grid, kThreads, (size_t)kBwdLds * 4, stream, a);
+    MAPPO_LAUNCH(mlp::mlp_reduce_kernel, 4u, mlp::kThreads, 1024, stream, (const float*)m->workspace, grid, 128LL, 128LL,
+                 m->ln_grads);
+    return MAPPO_LAUNCH_ERROR();
+}
+
+}  // namespace gru
+#endif

@@ -98,6 +98,7 @@ void grant_lds(K kernel, size_t bytes) {
 #define MAPPO_LAUNCH_ERROR() (g_launch_error ? g_launch_error : (int)hipGetLastError())
 
 #include "mappo_mlp_impl.h"
+#include "mappo_gru_impl.h"
 
 extern "C" int mappo_mlp_forward(const mappo_mlp_t* net, mappo_stream_t stream) {
     g_launch_error = 0;
@@ -133,4 +134,17 @@ extern "C" int mappo_standardize_rows_ld(const float* src, int64_t rows, int D, 
                                          mappo_stream_t stream) {
     g_launch_error = 0;
     return mlp::standardize_rows(src, rows, D, eps, dst, ld, static_cast<hipStream_t>(stream));
+}
+
+// K12: the GRU over a whole chunk (mappo_gru_impl.h, same primitives)
+extern "C" int64_t mappo_gru_seq_gates_floats(int L, int64_t mb) { return (int64_t)L * gru::tiles_of(mb) * gru::kSaved * 2048; }
+extern "C" int64_t mappo_gru_seq_stats_floats(int L, int64_t mb) { return (int64_t)L * gru::tiles_of(mb) * 64; }
+extern "C" int64_t mappo_gru_seq_workspace_floats(void) { return (int64_t)gru::kGridCap * 128; }
+extern "C" int mappo_gru_seq_forward(const mappo_gru_seq_t* seq, mappo_stream_t stream) {
+    g_launch_error = 0;
+    return gru::forward(seq, static_cast<hipStream_t>(stream));
+}
+extern "C" int mappo_gru_seq_backward(const mappo_gru_seq_t* seq, mappo_stream_t stream) {
+    g_launch_error = 0;
+    return gru::backward(seq, static_cast<hipStream_t>(stream));
 }

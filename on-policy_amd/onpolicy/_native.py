@@ -56,6 +56,14 @@ class MLP(ctypes.Structure):
                 ("workspace", _vp), ("grads", _vp)]
 
 
+class GRUSeq(ctypes.Structure):
+    """struct mappo_gru_seq (include/mappo_hip.h): the GRU of a recurrent policy over a whole chunk."""
+    _fields_ = [(n, _vp) for n in ("x", "h0", "masks", "w_ih", "w_hh", "b_ih", "b_hh", "ln_g", "ln_b")] + \
+               [("ln_eps", ctypes.c_float), ("H", ctypes.c_int32), ("L", ctypes.c_int32), ("mb", _i64)] + \
+               [(n, _vp) for n in ("y", "h_last", "gates", "hm", "stats", "dy", "dx", "dgi", "dq", "dh0", "dh_last",
+                                   "ln_grads", "workspace")]
+
+
 LOSS_HUBER, LOSS_CLIPPED_VALUE, LOSS_POLICY_ACTIVE_MASKS, LOSS_VALUE_ACTIVE_MASKS = 1, 2, 4, 8
 
 # symbol -> (restype, argtypes); must list every function include/mappo_hip.h declares
@@ -88,6 +96,11 @@ SIGNATURES = {
     "mappo_gru_cell_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]),
     "mappo_gru_cell_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]),
     "mappo_gru_step_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]),
+    "mappo_gru_seq_gates_floats": (_i64, [_int, _i64]),
+    "mappo_gru_seq_stats_floats": (_i64, [_int, _i64]),
+    "mappo_gru_seq_workspace_floats": (_i64, []),
+    "mappo_gru_seq_forward": (_int, [ctypes.POINTER(GRUSeq), _vp]),
+    "mappo_gru_seq_backward": (_int, [ctypes.POINTER(GRUSeq), _vp]),
     "mappo_ppo_loss_f32": (_int, [ctypes.POINTER(PPOLoss), _vp]),
     "mappo_minibatch_workspace_ints": (_i64, [_i64, _int]),
     "mappo_minibatch_indices": (_int, [_i64, _i64, _int, _vp, _vp, _vp, _vp]),

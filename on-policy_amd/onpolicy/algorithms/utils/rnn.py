@@ -96,6 +96,69 @@ class _GRUSequenceFn(torch.autograd.Function):
         return dgi_all, dh0, None, dw, db_ih, db_hh
 
 
+class _GRUChunkFn(torch.autograd.Function):
+    """RNNLayer (one GRU layer of width 64 + its output LayerNorm) over a whole chunk as ONE launch per direction
+    (K12, ``mappo_gru_seq_forward`` / ``_backward``): x [L * B, 64], h0 [B, 64], masks [L * B] -> (y [L * B, 64] =
+    LayerNorm(h_l), h_last [B, 64]).  The backward kernel walks the chunk in reverse (truncated BPTT inside the launch)
+    and hands back d x, d h0, the LayerNorm gradients and the gate gradients; the two weight gradients are split-K GEMMs
+    over all L * B rows here, the bias gradients column sums."""
+
+    @staticmethod
+    def forward(ctx, x, h0, masks, w_ih, w_hh, b_ih, b_hh, ln_g, ln_b, eps, L):
+        from onpolicy import _native
+        lib, p = _native.lib(), _native.ptr
+        B = h0.shape[0]
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        x, h0, masks = x.contiguous(), h0.contiguous(), masks.reshape(-1).contiguous()
+        params = [t.detach().contiguous() for t in (w_ih, w_hh, b_ih, b_hh, ln_g, ln_b)]
+        y = torch.empty(L * B, 64, **f32)
+        h_last = torch.empty(B, 64, **f32)
+        need = any(ctx.needs_input_grad)
+        gates = torch.empty(lib.mappo_gru_seq_gates_floats(L, B), **f32) if need else None
+        stats = torch.empty(lib.mappo_gru_seq_stats_floats(L, B), **f32) if need else None
+        hm = torch.empty(L * B, 64, **f32) if need else None
+        m = _native.GRUSeq(x=p(x), h0=p(h0), masks=p(masks), w_ih=p(params[0]), w_hh=p(params[1]), b_ih=p(params[2]),
+                           b_hh=p(params[3]), ln_g=p(params[4]), ln_b=p(params[5]), ln_eps=float(eps), H=64, L=L, mb=B,
+                           y=p(y), h_last=p(h_last), gates=p(gates), hm=p(hm), stats=p(stats))
+        _native.check(lib.mappo_gru_seq_forward(m, _native.stream_of(dev)), "mappo_gru_seq_forward")
+        if need:
+            ctx.save_for_backward(x, h0, masks, gates, stats, hm, *params)
+            ctx.cfg = (float(eps), L)
+        return y, h_last
+
+    @staticmethod
+    def backward(ctx, dy, dh_last):
+        from onpolicy import _native
+        lib, p = _native.lib(), _native.ptr
+        x, h0, masks, gates, stats, hm, w_ih, w_hh, b_ih, b_hh, ln_g, ln_b = ctx.saved_tensors
+        eps, L = ctx.cfg
+        B = h0.shape[0]
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        dy = torch.zeros(L * B, 64, **f32) if dy is None else dy.contiguous()
+        dh_last = None if dh_last is None else dh_last.contiguous()
+        dx = torch.empty(L * B, 64, **f32)
+        dgi = torch.empty(L * B, 192, **f32)
+        dq = torch.empty(L * B, 64, **f32)
+        dh0 = torch.empty(B, 64, **f32) if ctx.needs_input_grad[1] else None
+        ln_grads = torch.empty(128, **f32)
+        ws = torch.empty(lib.mappo_gru_seq_workspace_floats(), **f32)
+        m = _native.GRUSeq(x=p(x), h0=p(h0), masks=p(masks), w_ih=p(w_ih), w_hh=p(w_hh), b_ih=p(b_ih), b_hh=p(b_hh),
+                           ln_g=p(ln_g), ln_b=p(ln_b), ln_eps=eps, H=64, L=L, mb=B, gates=p(gates), hm=p(hm),
+                           stats=p(stats), dy=p(dy), dx=p(dx), dgi=p(dgi), dq=p(dq), dh0=p(dh0), dh_last=p(dh_last),
+                           ln_grads=p(ln_grads), workspace=p(ws))
+        _native.check(lib.mappo_gru_seq_backward(m, _native.stream_of(dev)), "mappo_gru_seq_backward")
+        # dW_ih = dgi^T x; the hidden side's gate gradient is [dgi_r | dgi_z | dq]
+        dw_ih = splitk_weight_grad(dgi, x)
+        dw_hh = torch.cat([splitk_weight_grad(dgi[:, :128], hm), splitk_weight_grad(dq, hm)], 0)
+        db_ih = column_sums(dgi)
+        db_hh = torch.cat([db_ih[:128], column_sums(dq)])
+        return dx, dh0, None, dw_ih, dw_hh, db_ih, db_hh, ln_grads[:64], ln_grads[64:], None, None
+
+
+# MAPPO_GRU_CHUNK=0 keeps the step-by-step kernels below for the update (one launch per step and direction)
+_CHUNK_KERNEL = __import__("os").environ.get("MAPPO_GRU_CHUNK", "1") != "0"
 # MAPPO_GRU_SEQUENCE=0 falls back to aten::_thnn_fused_gru_cell driven step by step through autograd
 _SEQUENCE_KERNELS = __import__("os").environ.get("MAPPO_GRU_SEQUENCE", "1") != "0"
 # MAPPO_GRU_FUSED_STEP=0 keeps the forward hidden projection a library GEMM next to the K8 cell kernel
@@ -174,7 +237,19 @@ class RNNLayer(nn.Module):
             finals.append(h)
         return layer_in, torch.stack(finals, 1)
 
+    def _chunk_kernel_ok(self, x):
+        """One GRU layer of width 64 on float32 HIP tensors, LayerNorm with affine parameters: K12 takes the whole layer."""
+        return _CHUNK_KERNEL and x.is_cuda and x.dtype == torch.float32 and self._recurrent_N == 1 and x.size(-1) == 64 \
+            and self.rnn.hidden_size == 64 and self.norm.elementwise_affine and self.norm.bias is not None
+
     def forward(self, x, hxs, masks):
+        if self._chunk_kernel_ok(x):
+            B = hxs.size(0)
+            L = x.size(0) // B
+            w_ih, w_hh, b_ih, b_hh = self._layer_weights(0)
+            y, h_last = _GRUChunkFn.apply(x, hxs[:, 0], masks, w_ih, w_hh, b_ih, b_hh, self.norm.weight, self.norm.bias,
+                                          self.norm.eps, L)
+            return y, h_last.unsqueeze(1)
         if x.size(0) == hxs.size(0):
             # rollout: one step for every (env, agent) row
             y, hxs = self._run(x.unsqueeze(0), hxs, masks.reshape(1, -1, 1))

@@ -45,6 +45,7 @@ inline float sum16(float v) {
 }  // namespace prim
 
 #include "../../on-policy_amd/csrc/mappo_mlp_impl.h"
+#include "../../on-policy_amd/csrc/mappo_gru_impl.h"
 
 extern "C" int mappo_mlp_forward(const mappo_mlp_t* net, mappo_stream_t stream) { return mlp::forward(net, stream); }
 extern "C" int mappo_mlp_backward(const mappo_mlp_t* net, mappo_stream_t stream) { return mlp::backward(net, stream); }
@@ -73,3 +74,9 @@ extern "C" int mappo_standardize_rows_ld(const float* src, int64_t rows, int D, 
     return mlp::standardize_rows(src, rows, D, eps, dst, ld, stream);
 }
 extern "C" unsigned long long simt_mfma_count() { return simt::st().n_mfma; }
+
+extern "C" int64_t mappo_gru_seq_gates_floats(int L, int64_t mb) { return (int64_t)L * gru::tiles_of(mb) * gru::kSaved * 2048; }
+extern "C" int64_t mappo_gru_seq_stats_floats(int L, int64_t mb) { return (int64_t)L * gru::tiles_of(mb) * 64; }
+extern "C" int64_t mappo_gru_seq_workspace_floats(void) { return (int64_t)gru::kGridCap * 128; }
+extern "C" int mappo_gru_seq_forward(const mappo_gru_seq_t* seq, mappo_stream_t stream) { return gru::forward(seq, stream); }
+extern "C" int mappo_gru_seq_backward(const mappo_gru_seq_t* seq, mappo_stream_t stream) { return gru::backward(seq, stream); }

@@ -1,0 +1,66 @@
+"""-m gpu: K12, the GRU of the recurrent policies over a whole chunk in one launch per direction
+(mappo_gru_seq_forward / _backward), through RNNLayer and autograd on the device against a float64 restatement of the
+reference's RNNLayer (onpolicy/algorithms/utils/rnn.py:7-80).  The reference-generated fixtures that run through it are
+tests/test_gpu_trainer_h64.py::test_fused_trunk_update_vs_reference[h64_gru*]."""
+import numpy as np
+import pytest
+import torch
+
+from test_gru_kernels_emulated import reference
+
+pytestmark = pytest.mark.gpu
+
+
+def _layer(dev, seed):
+    from onpolicy.algorithms.utils.rnn import RNNLayer
+    torch.manual_seed(seed)
+    layer = RNNLayer(64, 64, 1, True)
+    with torch.no_grad():
+        for p in layer.parameters():        # biases and LayerNorm parameters away from their 0 / 1 defaults
+            p.add_(0.1 * torch.randn_like(p))
+    return layer.to(dev)
+
+
+@pytest.mark.parametrize("L,B", [(1, 200), (10, 96), (10, 32 * 1024 + 17), (4, 33)])
+def test_chunk_kernel_layer_vs_float64(L, B):
+    dev = torch.device("cuda", 0)
+    layer = _layer(dev, L + B)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(L * B, 64, generator=g)
+    h0 = torch.randn(B, 1, 64, generator=g)
+    masks = (torch.rand(L * B, 1, generator=g) > 0.1).float()
+    dy = torch.randn(L * B, 64, generator=g)
+    xd, hd = x.to(dev).requires_grad_(), h0.to(dev).requires_grad_()
+    assert layer._chunk_kernel_ok(xd)
+    y, h_last = layer(xd, hd, masks.to(dev))
+    (y * dy.to(dev)).sum().backward()
+
+    P = {"w_ih": layer.rnn.weight_ih_l0, "w_hh": layer.rnn.weight_hh_l0, "b_ih": layer.rnn.bias_ih_l0,
+         "b_hh": layer.rnn.bias_hh_l0, "ln_g": layer.norm.weight, "ln_b": layer.norm.bias}
+    tp = {k: v.detach().cpu().double().requires_grad_() for k, v in P.items()}
+    tx, th = x.double().requires_grad_(), h0[:, 0].double().requires_grad_()
+    y_ref, h_ref = reference(tp, tx, th, masks[:, 0].double(), L, B)
+    (y_ref * dy.double()).sum().backward()
+    torch.testing.assert_close(y.detach().cpu().double(), y_ref.detach(), rtol=0, atol=2e-5 * float(y_ref.abs().max()))
+    torch.testing.assert_close(h_last[:, 0].detach().cpu().double(), h_ref.detach(), rtol=0, atol=2e-5)
+    pairs = [("dx", xd.grad, tx.grad), ("dh0", hd.grad[:, 0], th.grad)] + [(k, P[k].grad, tp[k].grad) for k in P]
+    for name, got, ref in pairs:
+        torch.testing.assert_close(got.cpu().double(), ref, rtol=0, atol=1e-4 * float(ref.abs().max()) + 1e-9, msg=name)
+
+
+def test_chunk_kernel_is_deterministic():
+    dev = torch.device("cuda", 0)
+    layer = _layer(dev, 5)
+    L, B = 10, 50000
+    g = torch.Generator().manual_seed(4)
+    x, h0 = torch.randn(L * B, 64, generator=g).to(dev), torch.randn(B, 1, 64, generator=g).to(dev)
+    masks = (torch.rand(L * B, 1, generator=g) > 0.05).float().to(dev)
+    outs = []
+    for _ in range(2):
+        layer.zero_grad()
+        xd = x.clone().requires_grad_()
+        y, _ = layer(xd, h0, masks)
+        y.square().sum().backward()
+        outs.append([y.detach().clone(), xd.grad.clone()] + [p.grad.clone() for p in layer.parameters()])
+    for a, b in zip(*outs):
+        assert torch.isfinite(a).all() and torch.equal(a, b)

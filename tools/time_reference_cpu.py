@@ -75,14 +75,94 @@ def time_one(name, threads):
             "value_loss": float(info["value_loss"])}
 
 
+def time_port(name, threads):
+    """The PORT that bench.py's live ``cpu_baseline`` leg runs on the GPU box's host (oracle buffer: C restatement of
+    compute_returns + numpy gathers; this repo's R_MAPPO / networks on CPU tensors), here at the SAME n_rollout_threads and
+    thread count as the reference run above and on the same machine: port / reference ties the two numbers together."""
+    import importlib.util
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "on-policy_amd"))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from oracle import oracle
+    from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO
+    from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy
+    wl = bench.WORKLOADS[name]
+    n = SAMPLE_N[name]
+    torch.set_num_threads(threads)
+    args = bench.make_args(wl, n)
+    spaces = bench.Box((wl["Do"],)), bench.Box((wl["Ds"],)), bench.Discrete(wl["na"])
+    torch.manual_seed(1)
+    np.random.seed(1)
+    policy = R_MAPPOPolicy(args, *spaces)
+    trainer = R_MAPPO(args, policy)
+    buf = oracle.OracleBuffer(args, wl["A"], *spaces)
+    rng = np.random.default_rng(0)
+    f32 = np.float32
+    for field in ("share_obs", "obs", "rewards", "rnn_states", "rnn_states_critic"):
+        getattr(buf, field)[...] = rng.standard_normal(getattr(buf, field).shape, dtype=f32)
+    buf.value_preds[:-1] = rng.standard_normal(buf.value_preds[:-1].shape, dtype=f32)
+    buf.actions[...] = rng.integers(0, wl["na"], buf.actions.shape).astype(f32)
+    buf.action_log_probs[...] = -np.log(wl["na"])
+    buf.masks[...] = (rng.random(buf.masks.shape) >= 1.0 / 25).astype(f32)
+    nv = rng.standard_normal(buf.value_preds.shape[1:], dtype=f32)
+    trainer.prep_training()
+    t0 = time.perf_counter()
+    buf.compute_returns(nv, trainer.value_normalizer)
+    t1 = time.perf_counter()
+    info = trainer.train(buf)
+    buf.after_update()
+    t2 = time.perf_counter()
+    return {"workload": name, "kind": "port", "T": wl["T"], "n_rollout_threads_timed": n, "torch_threads": threads,
+            "compute_returns_s": round(t1 - t0, 4), "train_s": round(t2 - t1, 3),
+            "env_steps_per_s": round(wl["T"] * n / (t2 - t0), 1), "value_loss": float(info["value_loss"])}
+
+
+def port_vs_reference(workloads, out_path):
+    """Reference and port back to back on this machine, same N, 1 thread and all cores -> out_path."""
+    runs = []
+    for name in workloads:
+        for threads in (1, os.cpu_count() or 1):
+            pair = {}
+            for mode in ("--one", "--one-port"):
+                out = subprocess.run([sys.executable, os.path.abspath(__file__), mode, name, str(threads)],
+                                     capture_output=True, text=True, check=True)
+                rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+                pair["port" if mode == "--one-port" else "reference"] = rec
+                print(rec, flush=True)
+            pair["port_over_reference"] = round(pair["port"]["env_steps_per_s"] / pair["reference"]["env_steps_per_s"], 3)
+            runs.append(pair)
+    cpu = ""
+    try:
+        cpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        pass
+    doc = {"what": "bench.py's CPU port (oracle buffer + this repo's trainer on CPU tensors) and the reference's own "
+                   "compute_returns + R_MAPPO.train, same machine, same n_rollout_threads, same thread count",
+           "host": {"cpu": cpu, "logical_cores": os.cpu_count(), "where": "build container"}, "runs": runs}
+    with open(out_path, "w") as f:
+        json.dump(doc, f, indent=1)
+    print("wrote", out_path)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
+    ap.add_argument("--port-vs-reference", metavar="OUT", help="time the port next to the reference, write OUT")
+    ap.add_argument("--one-port", nargs=2, metavar=("WORKLOAD", "THREADS"), help=argparse.SUPPRESS)
     ap.add_argument("--workloads", nargs="+", default=["ns", "ns_rnn", "cfg2"])
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_cpu_reference.json"))
     ap.add_argument("--one", nargs=2, metavar=("WORKLOAD", "THREADS"), help=argparse.SUPPRESS)
     opt = ap.parse_args()
     if opt.one:
         print("RESULT " + json.dumps(time_one(opt.one[0], int(opt.one[1]))))
+        sys.exit(0)
+    if opt.one_port:
+        print("RESULT " + json.dumps(time_port(opt.one_port[0], int(opt.one_port[1]))))
+        sys.exit(0)
+    if opt.port_vs_reference:
+        port_vs_reference(opt.workloads, opt.port_vs_reference)
         sys.exit(0)
     import torch
     runs = []

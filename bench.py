@@ -12,10 +12,14 @@ Multi-GPU (launched by torch.distributed.run, one rank per GPU): the global N ro
 sharded N / world per rank (strong scaling, fixed total work); per update one RCCL all-reduce of the
 flat actor+critic gradient bucket plus two tiny statistic all-reduces.
 
-Rank 0 prints ONE JSON line.  ``roofline`` describes the GAE scan kernel (HBM-bound; algorithmic
-bytes from SURVEY.md section 8d), timed with events on the launch stream inside the timed region;
-``roofline_gather`` the same for the fused minibatch gather; ``cpu_baseline`` is the CPU port of the
-same path (oracle buffer + the same PyTorch trainer on host cores) on a bounded sample.
+Rank 0 prints ONE JSON line.  ``roofline`` describes the dominant kernel of the step, the fused trunk's forward launch
+(K9, f32 matrix-core bound: algorithmic FLOPs / launch time against the dense f32 MFMA peak), timed with events on the
+launch stream inside the timed region; ``roofline_mlp_backward`` the same for the backward call, ``roofline_gae`` the GAE
+scan BASELINE.json's north star names (HBM bound; algorithmic bytes from SURVEY.md section 8d), ``roofline_gather`` the
+fused minibatch gather.  ``traffic`` fields quote the committed rocprofv3 PMC passes (``traffic_source`` names the file
+each one came from).  ``cpu_baseline`` is the CPU port of the same path (oracle buffer + the same PyTorch trainer on
+host cores) on a bounded sample, next to the recorded timings of the reference itself and the port / reference factor
+measured on one machine.
 """
 import argparse
 import json
@@ -172,7 +176,21 @@ def reference_recorded(workload):
     runs = [r for r in doc["runs"] if r["workload"] == workload]
     if not runs:
         return None
+    pair = None
+    try:        # round 3: reference and port back to back on one machine, same N, same thread count
+        with open(os.path.join(ROOT, "profiles", "r03_cpu_port_vs_reference.json")) as f:
+            pairs = [r for r in json.load(f)["runs"] if r["reference"]["workload"] == workload]
+        pair = [{"torch_threads": r["reference"]["torch_threads"],
+                 "reference_env_steps_per_s": r["reference"]["env_steps_per_s"],
+                 "port_env_steps_per_s": r["port"]["env_steps_per_s"],
+                 "port_over_reference": r["port_over_reference"]} for r in pairs] or None
+    except Exception:
+        pass
     return {"kind": "reference", "source": "profiles/r02_cpu_reference.json (tools/time_reference_cpu.py)",
+            "port_vs_reference_same_machine": pair,
+            "port_vs_reference_source": "profiles/r03_cpu_port_vs_reference.json (tools/time_reference_cpu.py "
+                                        "--port-vs-reference): the live `port` figure above times this ratio ~ the "
+                                        "reference on the GPU box's host",
             "host": doc["host"]["cpu"] + ", %d logical cores, build container" % doc["host"]["logical_cores"],
             "n_rollout_threads_timed": runs[0]["n_rollout_threads_timed"],
             "note": "same T / agents / dims / ppo_epoch as the GPU run, fewer rollout threads (host memory); env-steps/s "
@@ -287,30 +305,28 @@ def main():
         value = wl["T"] * wl["N"] * opt.steps / elapsed
 
         def pmc_traffic(name, nbytes):
-            """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_summary.json:
-            2 x FETCH_SIZE + WRITE_SIZE, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950) --
-            only quoted when the profiled launch had the same algorithmic byte count."""
-            try:
-                rec = None
-                for fn in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
-                    path = os.path.join(ROOT, "profiles", fn)
-                    if rec is None and os.path.exists(path):
-                        with open(path) as f:
-                            rec = json.load(f).get(name)
-                if rec and abs(rec["algorithmic_bytes"] - nbytes) <= 0.01 * nbytes:
-                    return rec["hbm_bytes"]
-            except Exception:
-                pass
-            return None
+            """(HBM bytes per launch, file) from the committed rocprofv3 PMC passes (profiles/r0N_pmc_summary.json, newest
+            first: 2 x FETCH_SIZE + WRITE_SIZE, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950) -- only
+            quoted when the profiled launch had the same algorithmic byte count."""
+            for fn in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+                try:
+                    with open(os.path.join(ROOT, "profiles", fn)) as f:
+                        rec = json.load(f).get(name)
+                    if rec and abs(rec["algorithmic_bytes"] - nbytes) <= 0.01 * nbytes:
+                        return rec["hbm_bytes"], "committed rocprofv3 PMC passes (profiles/%s), not this run" % fn
+                except Exception:
+                    pass
+            return None, None
 
         def roof(name):
             if name not in kt:
                 return None
             launches, ms, nbytes = kt[name]
             achieved = nbytes / (ms * 1e-3) / 1e9
+            traffic, source = pmc_traffic(name, nbytes)
             return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(name, nbytes),
-                    "traffic_source": "committed rocprofv3 PMC passes (profiles/r01_pmc_summary.json), not this run",
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_source": source,
                     "launch_ms": round(ms, 5), "launches": launches, "algorithmic_bytes": int(nbytes)}
 
         def roof_mfma(name, what):
@@ -321,10 +337,10 @@ def main():
                 return None
             launches, ms, flops, nbytes = mt[name]
             tf = flops / launches / (ms * 1e-3) / 1e12
+            traffic, source = pmc_traffic(name, nbytes / launches)
             return {"kernel": what, "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
-                    "traffic": pmc_traffic(name, nbytes / launches), "traffic_source":
-                    "committed rocprofv3 PMC passes (profiles/r02_pmc_summary.json), not this run",
+                    "traffic": traffic, "traffic_source": source,
                     "launch_ms": round(ms, 4), "launches": launches, "flop_per_launch": int(flops / launches),
                     "algorithmic_bytes": int(nbytes / launches),
                     "hbm_gbs": round(nbytes / launches / (ms * 1e-3) / 1e9, 1),
@@ -349,7 +365,7 @@ def main():
             # launches averaged, as rocprofv3 --stats averages them), f32 matrix-core bound
             "roofline": roof_mfma("mappo_mlp_forward", "mlp_fwd_kernel (mappo_mlp_forward)") or roof("mappo_gae_f32"),
             "roofline_mlp_backward": roof_mfma("mappo_mlp_backward",
-                                               "mlp_bwd_kernel + mlp_dw1_{direct,rows}_kernel + reduce (mappo_mlp_backward)"),
+                                               "mlp_bwd_kernel + mlp_dw1_{direct,rows}_kernel + reduce / finish (mappo_mlp_backward)"),
             # the kernel BASELINE.json's north star names (>= 70 % of HBM in the GAE scan), HBM bound
             "roofline_gae": roof("mappo_gae_f32"),
             "roofline_gather": roof("mappo_gather_chunks" if wl["recurrent"] else "mappo_gather_rows"),

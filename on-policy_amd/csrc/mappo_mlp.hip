@@ -65,6 +65,9 @@ __device__ __forceinline__ void load_lds4(const int* g, int* lds_wave_base) {
         : "memory");
 }
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+// device-wide release of this thread's earlier writes / a ticket from a counter in device memory (mlp_tail_kernel)
+__device__ __forceinline__ void fence() { __threadfence(); }
+__device__ __forceinline__ unsigned ticket(unsigned* counter) { return atomicAdd(counter, 1u); }
 // the value is produced here, in program order: the compiler may neither sink its load into a later branch nor merge it
 __device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void wait_loads_14() { asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }   // (stamps only)
@@ -74,6 +77,16 @@ __device__ __forceinline__ float i2f(int v) { return __int_as_float(v); }
 __device__ __forceinline__ float* lds() {
     extern __shared__ __attribute__((aligned(16))) float mappo_dyn_lds[];
     return mappo_dyn_lds;
+}
+}  // namespace prim
+
+namespace prim {
+// one ticket counter per process and device context: the K9 backward calls of a process are ordered on one stream
+__device__ unsigned g_ticket_counter = 0;
+inline unsigned* ticket_counter() {
+    unsigned* p = nullptr;
+    (void)hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(g_ticket_counter));
+    return p;
 }
 }  // namespace prim
 

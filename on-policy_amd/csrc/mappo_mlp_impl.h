@@ -612,9 +612,7 @@ __device__ __forceinline__ void put_transposed(float* T, const float* reg, int c
 //         dgamma_l[k]    = sum_f W_{l+1}[f][k] G[f][k]       (= sum_rows dh_l * nhat_l with dh_l = W^T dz)
 //         dbeta_l[k]     = sum_f W_{l+1}[f][k] db[f]         (= sum_rows dh_l)
 //     -- the same for the head (Gh[o][k] = sum_rows dy[row][o] nhat_{L-1}[row][k], dbh[o] = sum_rows dy[row][o]).  The
-//     per-tile transposes of dh and dh * nhat of every layer with their row sums are gone; the first layer's bias
-//     gradient (column sums of dz1) moves into the first-layer weight-gradient kernels, which read dz1 with lane =
-//     feature anyway.  Only a trunk without a head (out == 0: the features feed a GRU) still transposes its top layer.
+//     per-tile transposes of dh and dh * nhat of every layer with their row sums are gone.  Only a trunk without a head (out == 0: the features feed a GRU) still transposes its top layer.
 // (2) Sums over rows that are not MFMA operands stay in ROW layout (lane = row position, one register per slot) across all
 //     tiles of the wave and are reduced over the lanes once, at the end: the bias gradients db_l (32 registers per hidden
 //     layer) and, for heads of up to HR outputs (template parameter: 1 = value head, 5 = the MPE action heads), Gh
@@ -652,7 +650,7 @@ __host__ __device__ __forceinline__ Bwd2Lds bwd2_lds(int L, int out) {
     if (o.total < red) o.total = red;
     return o;
 }
-// raw per-workgroup sums: [db_l 64 x L (l = 0 unused)] [top dgamma 64 | top dbeta 64 (out == 0)] [G_l 4096 x (L - 1)]
+// raw per-workgroup sums: [db_l 64 x L] [top dgamma 64 | top dbeta 64 (out == 0)] [G_l 4096 x (L - 1)]
 // [Gh out x 64] [dbh out]
 __host__ __device__ __forceinline__ long long r_g(int L, int l) { return 64LL * L + 128 + 4096LL * (l - 1); }
 __host__ __device__ __forceinline__ long long r_gh(int L) { return 64LL * L + 128 + 4096LL * (L - 1); }
@@ -721,18 +719,20 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
     // bias gradients of layers >= 1: row layout (slot s of this lane's row position, reduced over the lanes at the end)
     // where the registers are there (<= 2 layers), else lane = feature row sums of the transposed tile
     constexpr bool kRowDb = L <= 2;
-    float dbr[NG][32], db[L];
+    constexpr int NDB = kRowDb ? L : 1;
+    float dbr[NDB][32], db[L];      // (layer 0 included: the column sums of dz1)
 #pragma unroll
     for (int l = 0; l < L; ++l) db[l] = 0.f;
 #pragma unroll
-    for (int l = 0; l < NG; ++l) {
+    for (int l = 0; l < NG; ++l)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int v = 0; v < 16; ++v) G[l][t][v] = 0.f;
 #pragma unroll
+    for (int l = 0; l < NDB; ++l)
+#pragma unroll
         for (int s = 0; s < 32; ++s) dbr[l][s] = 0.f;
-    }
     constexpr int NH = HR > 0 ? HR : 1;
     float ghr[NH][32], dbhr[NH];    // row layout: head sums (HR > 0)
 #pragma unroll
@@ -948,6 +948,17 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
             ln_act_backward<ACT>(dn, nh, st[0], st[1]);      // dn now holds dz_l
             MAPPO_B2_STAMP(l == L - 1 ? 4 : 10);
             if (l == 0) {
+                if (kRowDb) {
+#pragma unroll
+                    for (int s = 0; s < 32; ++s) dbr[0][s] += dn[s];
+                } else {
+                    prim::wave_sync();
+                    put_transposed(T, dn, c, h);        // (three layers: no registers left for row-layout sums)
+                    prim::wave_sync();
+                    db[0] += rowsum32(T + lane * kTS);
+                    prim::wave_sync();
+                    prefetch_top(tile + nw);            // (T's last use of this tile comes here in this variant)
+                }
                 // -> the row-major staging tile
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
@@ -963,7 +974,7 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
             } else {
                 if (kRowDb) {
 #pragma unroll
-                    for (int s = 0; s < 32; ++s) dbr[l > 0 ? l - 1 : 0][s] += dn[s];
+                    for (int s = 0; s < 32; ++s) dbr[kRowDb ? l : 0][s] += dn[s];
                 }
                 put_transposed(T, dn, c, h);
                 // dnhat_{l-1} = (gamma (.) W^T) dz: the last use of dz in row order
@@ -999,7 +1010,7 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
                 }
                 MAPPO_B2_STAMP(8);
                 prim::wave_sync();          // T's last use of this tile (l == 1): the next tile's prefetch may land
-                if (l == 1) {
+                if (l == 1 && kRowDb) {
                     // (the compiler does not count the prefetch's loads: a wait for one of ITS older loads placed after
                     // this point would wait for the prefetch too.  Settle them here, where they have long arrived.)
                     float m0 = stx[0], m1 = stx[1];
@@ -1031,9 +1042,9 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
     // ---- row-layout sums -> lane = feature (sum over the 32 row positions of each half-wave's features)
     if (kRowDb) {
 #pragma unroll
-        for (int l = 1; l < L; ++l) {
+        for (int l = 0; l < L; ++l) {
             prim::wave_sync();
-            put_transposed(T, dbr[l - 1], c, h);
+            put_transposed(T, dbr[kRowDb ? l : 0], c, h);
             prim::wave_sync();
             db[l] = rowsum32(T + lane * kTS);
         }
@@ -1122,7 +1133,7 @@ struct FinishArgs {
     const float* R;
     float* grads;
 };
-__global__ void __launch_bounds__(kThreads) mlp_finish_kernel(FinishArgs a) {
+__device__ __forceinline__ void finish_grads(const FinishArgs& a) {
     const Net& n = a.net;
     const int L = n.L, out = n.out, din = n.din, tid = threadIdx.x;
     for (int l = 1; l < L; ++l) {
@@ -1144,6 +1155,7 @@ __global__ void __launch_bounds__(kThreads) mlp_finish_kernel(FinishArgs a) {
             a.grads[g_vec(din, l) + tid] = dbl[tid];
         }
     }
+    if (tid < 64) a.grads[g_vec(din, 0) + tid] = a.R[tid];       // first layer's bias: column sums of dz1
     const float* g = n.ln_g[L - 1];
     const float* be = n.ln_b[L - 1];
     if (out > 0) {
@@ -1167,6 +1179,37 @@ __global__ void __launch_bounds__(kThreads) mlp_finish_kernel(FinishArgs a) {
     }
 }
 
+// The tail of a backward call as ONE launch (three in round 2/3a: 40 us of launches per call, 2 % of a step on an 8-GPU
+// shard): blocks [0, nb1) add the first-layer weight-gradient partials into `grads`, blocks [nb1, nb1 + nb2) the chain's
+// partial rows into the raw sums R; the block that finishes last (a ticket counter in device memory, reset by that block)
+// derives the remaining parameter gradients from R.
+__device__ __forceinline__ void reduce_chunk(const float* partials, long long n, long long stride, long long count,
+                                             float* out, long long chunk, float* sh);
+struct TailArgs {
+    FinishArgs fin;             // fin.R = reduced raw sums (written here), fin.grads
+    const float* p1;            // [n1][c1] first-layer partials -> grads[0 .. c1)
+    long long n1, c1;
+    const float* p2;            // [n2][c2] chain partials -> R
+    long long n2, c2;
+    float* raw;
+    unsigned* ticket;
+    int nb1, nb2;
+};
+__global__ void __launch_bounds__(kThreads) mlp_tail_kernel(TailArgs a) {
+    float* sh = prim::lds();        // [8][32] | ticket
+    const int b = blockIdx.x;
+    if (b < a.nb1) reduce_chunk(a.p1, a.n1, a.c1, a.c1, a.fin.grads, b, sh);
+    else reduce_chunk(a.p2, a.n2, a.c2, a.c2, a.raw, b - a.nb1, sh);
+    prim::fence();                  // this block's sums are visible device-wide before its ticket is drawn
+    __syncthreads();
+    if (threadIdx.x == 0) sh[256] = prim::i2f((int)prim::ticket(a.ticket));
+    __syncthreads();
+    if (prim::f2i(sh[256]) != a.nb1 + a.nb2 - 1) return;
+    if (threadIdx.x == 0) *a.ticket = 0u;
+    prim::fence();
+    finish_grads(a.fin);
+}
+
 // ================================================================== backward: first-layer weight gradient ====
 // dW1[f][k] = sum over rows dz1[row][f] * xhat[row][k] with xhat gathered and standardised on the fly: a split-K GEMM
 // (K = rows) whose B operand is read through the sampler's row table.  A workgroup owns a slab of <= 384 k columns
@@ -1177,7 +1220,7 @@ __global__ void __launch_bounds__(kThreads) mlp_finish_kernel(FinishArgs a) {
 struct Dw1Args {
     RowSrc rs;
     const float* dz1;
-    float* partials;    // [gridDim.x][64 * din + 64]: weight gradient | column sums of dz1 (the first layer's bias gradient)
+    float* partials;    // [gridDim.x][64 * din]
     long long* dbg;     // tuning hook (mappo_mlp_set_debug): cycle stamps of workgroup 0's first tiles at [512 ...], or NULL
 };
 constexpr int kDw1StageX = kDw1Rows * kDw1Slab;                        // floats
@@ -1281,8 +1324,6 @@ __global__ void __launch_bounds__(kPipeThreads) mlp_dw1_kernel(Dw1Args a) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][t][v] = 0.f;
-    const bool bias_sum = wave == 0 && blockIdx.y == 0;     // ... also sums the columns of dz1: first-layer bias gradient
-    float s0 = 0.f, s1 = 0.f;
     for (long long j = 0; j < n_it; ++j) {
         __syncthreads();
         const float* xt = lds + (j & 1) * kDw1Stage;
@@ -1315,18 +1356,9 @@ __global__ void __launch_bounds__(kPipeThreads) mlp_dw1_kernel(Dw1Args a) {
                 acc[2][0] = prim::mfma32(a0, b2, acc[2][0]);
                 acc[2][1] = prim::mfma32(a1, b2, acc[2][1]);
             }
-            if (bias_sum) {
-                s0 += a0;
-                s1 += a1;
-            }
         }
     }
-    float* prow = a.partials + (long long)blockIdx.x * (64LL * din + 64);
-    if (bias_sum) {
-        s0 += prim::xhalf(s0);
-        s1 += prim::xhalf(s1);
-        prow[64LL * din + lane] = h == 0 ? s0 : s1;       // lane = feature
-    }
+    float* prow = a.partials + (long long)blockIdx.x * 64 * din;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int nt = wave + 4 * i;
@@ -1367,11 +1399,8 @@ constexpr int kD2Lds = 4 * kD2Slots * kD2XSlot + kD2Slots * kD2DzSlot;       // 
 constexpr int kD2TabRing = 2 * kD2Slots;         // 256-byte slots per wave
 
 // the 8 MFMA steps of one 16-row tile (step s contracts rows s and 8 + s) for a wave that owns NT k tiles
-// SUM: also accumulate the column sums of the dz1 tile (the first layer's bias gradient: the A operands are the dz1
-// values with lane = feature) -- s0: feature c, s1: feature 32 + c, over the rows this half-wave reads
-template <int NT, bool SUM>
-__device__ __forceinline__ void dw1_tile_steps(const float* xt, const float* dzt, int c, int h, f32x16 (*acc)[2], float& s0,
-                                               float& s1) {
+template <int NT>
+__device__ __forceinline__ void dw1_tile_steps(const float* xt, const float* dzt, int c, int h, f32x16 (*acc)[2]) {
     constexpr int NB = NT > 0 ? NT : 1;
     float a0n, a1n, bn[NB];
     auto rd_step = [&](int st, float& ra0, float& ra1, float* rb) {
@@ -1395,10 +1424,6 @@ __device__ __forceinline__ void dw1_tile_steps(const float* xt, const float* dzt
         for (int i = 0; i < NT; ++i) {
             acc[i][0] = prim::mfma32(a0, b[i], acc[i][0]);
             acc[i][1] = prim::mfma32(a1, b[i], acc[i][1]);
-        }
-        if (SUM) {
-            s0 += a0;
-            s1 += a1;
         }
     }
 }
@@ -1453,14 +1478,7 @@ __device__ __forceinline__ void dw1_direct_body(const Dw1Args& a, float* lds, in
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][t][v] = 0.f;
-    // wave 0 of the first slab also sums the columns of dz1: the first layer's bias gradient (partial row tail)
-    const bool bias_sum = wave == 0 && blockIdx.y == 0;
-    float s0 = 0.f, s1 = 0.f;
-    float* prow = a.partials + (long long)blockIdx.x * (64LL * din + 64);
-    if (n_it == 0) {
-        if (bias_sum) prow[64LL * din + lane] = 0.f;
-        return;
-    }
+    if (n_it == 0) return;
     for (int t = 0; t < kD2Slots - 1; ++t) issue_table(t);
     prim::wait_lds_loads<0>();
     for (int m = 0; m < kD2Slots - 1; ++m) issue(m);
@@ -1479,15 +1497,10 @@ __device__ __forceinline__ void dw1_direct_body(const Dw1Args& a, float* lds, in
         if (stamp && m < 40) a.dbg[512 + 4 * m + 3] = prim::clock();
         const float* xt = xs + (int)(m % kD2Slots) * kD2XSlot;
         const float* dzt = dzs + (int)(m % kD2Slots) * kD2DzSlot;
-        if (bias_sum) dw1_tile_steps<NT, true>(xt, dzt, c, h, acc, s0, s1);
-        else dw1_tile_steps<NT, false>(xt, dzt, c, h, acc, s0, s1);
+        dw1_tile_steps<NT>(xt, dzt, c, h, acc);
     }
     prim::wait_lds_loads<0>();      // (the groups issued past the end)
-    if (bias_sum) {
-        s0 += prim::xhalf(s0);
-        s1 += prim::xhalf(s1);
-        prow[64LL * din + lane] = h == 0 ? s0 : s1;       // lane = feature
-    }
+    float* prow = a.partials + (long long)blockIdx.x * 64 * din;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int k = k0 + 32 * (wave + 4 * i) + c;
@@ -1569,7 +1582,6 @@ __global__ void __launch_bounds__(kThreads) mlp_dw1_rows_kernel(Dw1Args a) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][t][v] = 0.f;
-    float s0 = 0.f, s1 = 0.f;
     if (n_it > 0) {
         for (int t = 0; t < kD2Slots - 1; ++t) issue_table(t);
         prim::wait_lds_loads<0>();
@@ -1586,12 +1598,10 @@ __global__ void __launch_bounds__(kThreads) mlp_dw1_rows_kernel(Dw1Args a) {
                 prim::wave_sync();      // (a wave's LDS operations execute in order: only the compiler / the emulator care)
             }
             issue(m + kD2Slots - 1);
-            dw1_tile_steps<NT, true>(slot, slot + NT * (kD2Rows * 32), c, h, acc, s0, s1);
+            dw1_tile_steps<NT>(slot, slot + NT * (kD2Rows * 32), c, h, acc);
         }
         prim::wait_lds_loads<0>();
     }
-    s0 += prim::xhalf(s0);          // column sums of this wave's dz1 tiles: the first layer's bias gradient
-    s1 += prim::xhalf(s1);
     // ---- add the four waves' tiles: [wave][i][t][v][lane]
     __syncthreads();
     float* red = lds;
@@ -1602,7 +1612,7 @@ __global__ void __launch_bounds__(kThreads) mlp_dw1_rows_kernel(Dw1Args a) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) red[wave * (NT * 2048) + ((i * 2 + t) * 16 + v) * 64 + lane] = acc[i][t][v];
     __syncthreads();
-    float* prow = a.partials + (long long)blockIdx.x * (64LL * din + 64);
+    float* prow = a.partials + (long long)blockIdx.x * 64 * din;
     for (int e = tid; e < NT * 2048; e += kThreads) {
         const float sum = (red[e] + red[NT * 2048 + e]) + (red[2 * NT * 2048 + e] + red[3 * NT * 2048 + e]);
         const int ln = e & 63, v = (e >> 6) & 15, t = (e >> 10) & 1, i = e >> 11;
@@ -1610,19 +1620,14 @@ __global__ void __launch_bounds__(kThreads) mlp_dw1_rows_kernel(Dw1Args a) {
         const int k = 32 * i + (ln & 31);
         if (k < din) prow[(long long)f * din + k] = sum;
     }
-    __syncthreads();
-    red[wave * 64 + lane] = h == 0 ? s0 : s1;       // lane = feature
-    __syncthreads();
-    if (tid < 64) prow[64LL * din + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
 }
 
 // out[e] = sum over n partial rows (row stride `stride`); fixed order.  A block handles 32 consecutive elements with 8
 // row groups (group g sums rows g, g + 8, ...), combined through LDS.
-__global__ void __launch_bounds__(kThreads) mlp_reduce_kernel(const float* partials, long long n, long long stride,
-                                                              long long count, float* out) {
-    float* sh = prim::lds();        // [8][32]
+__device__ __forceinline__ void reduce_chunk(const float* partials, long long n, long long stride, long long count,
+                                             float* out, long long chunk, float* sh /* [8][32] */) {
     const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const long long e = (long long)blockIdx.x * 32 + el;
+    const long long e = chunk * 32 + el;
     float s = 0.f;
     if (e < count)
         for (long long r = g; r < n; r += 8) s += partials[r * stride + e];
@@ -1634,6 +1639,10 @@ __global__ void __launch_bounds__(kThreads) mlp_reduce_kernel(const float* parti
         for (int q = 0; q < 8; ++q) t += sh[q * 32 + el];
         out[e] = t;
     }
+}
+__global__ void __launch_bounds__(kThreads) mlp_reduce_kernel(const float* partials, long long n, long long stride,
+                                                              long long count, float* out) {
+    reduce_chunk(partials, n, stride, count, out, blockIdx.x, prim::lds());
 }
 
 // ================================================================== input LayerNorm, parameter-free half ====
@@ -1818,7 +1827,7 @@ inline int forward(const mappo_mlp_t* m, hipStream_t stream) {
 
 inline long long workspace_floats(int din, int n_layers, int out) {
     // chain partials (one row per workgroup) | reduced raw sums | first-layer partials
-    return (long long)(kBwdGridCap + 1) * r_total(n_layers, out) + (long long)kD2GridCap * (64LL * din + 64);
+    return (long long)(kBwdGridCap + 1) * r_total(n_layers, out) + (long long)kD2GridCap * 64LL * din;
 }
 
 inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
@@ -1862,7 +1871,7 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
     d.dz1 = m->dz1;
     const long long rt = r_total(L, out);
     float* raw = m->workspace + (long long)kBwdGridCap * rt;        // reduced raw sums of the version-2 chain
-    d.partials = m->workspace + workspace_floats(din, L, out) - (long long)kD2GridCap * (64LL * din + 64);
+    d.partials = m->workspace + workspace_floats(din, L, out) - (long long)kD2GridCap * 64LL * din;
     const int gy = (int)ceil_div(din, kDw1Slab);
     long long gx;
     if (din % 4 == 0 && din <= 64) {
@@ -1888,16 +1897,23 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
     code = MAPPO_LAUNCH_ERROR();
     if (code) return code;
 
-    // every slab's workgroups write disjoint k columns of their partial row; rows of unused workgroups do not exist.
-    // The first-layer partials end with the column sums of dz1: w1 and the first bias are adjacent in the flat layout
-    const long long p1 = 64LL * din + 64;
-    MAPPO_LAUNCH(mlp_reduce_kernel, (unsigned)ceil_div(p1, 32), kThreads, 1024, stream, d.partials, gx, p1, p1, m->grads);
-    MAPPO_LAUNCH(mlp_reduce_kernel, (unsigned)ceil_div(rt, 32), kThreads, 1024, stream, b.partials, grid, rt, rt, raw);
-    FinishArgs f;
-    f.net = b.net;
-    f.R = raw;
-    f.grads = m->grads;
-    MAPPO_LAUNCH(mlp_finish_kernel, 1u, kThreads, 0, stream, f);
+    // every slab's workgroups write disjoint k columns of their partial row; rows of unused workgroups do not exist
+    const long long p1 = 64LL * din;
+    TailArgs t;
+    t.fin.net = b.net;
+    t.fin.R = raw;
+    t.fin.grads = m->grads;
+    t.p1 = d.partials;
+    t.n1 = gx;
+    t.c1 = p1;
+    t.p2 = b.partials;
+    t.n2 = grid;
+    t.c2 = rt;
+    t.raw = raw;
+    t.ticket = prim::ticket_counter();
+    t.nb1 = (int)ceil_div(p1, 32);
+    t.nb2 = (int)ceil_div(rt, 32);
+    MAPPO_LAUNCH(mlp_tail_kernel, (unsigned)(t.nb1 + t.nb2), kThreads, 1028, stream, t);
     return MAPPO_LAUNCH_ERROR();
 }
 

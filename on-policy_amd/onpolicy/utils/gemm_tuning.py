@@ -10,7 +10,8 @@ trunks no longer reach the BLAS libraries; refresh with tools/tune_gemms.sh + to
 for them, and keeps whatever gets tuned later in a per-user cache file (one per device ordinal).
 
 The maths is unchanged (float32 GEMMs; only the tile configuration / summation order differs).
-``MAPPO_GEMM_TUNING=0`` disables it; ``MAPPO_GEMM_TUNING_CACHE`` moves the cache directory.
+``MAPPO_GEMM_TUNING=0`` disables it, ``=tune`` also benchmarks shapes that have no stored winner yet (inside the update
+phase only); ``MAPPO_GEMM_TUNING_CACHE`` moves the cache directory.
 """
 import os
 import tempfile
@@ -20,10 +21,25 @@ import torch
 SHIPPED = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tuned_gemms_gfx950.csv")
 
 
+# whether shapes without a stored winner are benchmarked inside R_MAPPO.train() (``with tuning():``)
+_TUNE_NEW_SHAPES = False
+
+
 def enable(tune_new=True):
-    """Turn TunableOp on for this process.  -> True if it is active."""
-    if os.environ.get("MAPPO_GEMM_TUNING", "1") == "0" or not torch.cuda.is_available():
+    """Turn TunableOp on for this process.  -> True if it is active.
+
+    ``tune_new=False`` (the train scripts): stored winners only -- the shipped table and the per-user cache -- and
+    nothing is ever benchmarked on line: tuning the GEMM shapes of an unseen configuration costs tens of seconds per
+    shape, which made the FIRST update of e.g. ``train_hanabi_forward.py`` at 1024 tables take four minutes (round 2).
+    ``MAPPO_GEMM_TUNING=tune`` (or ``tune_new=True``: bench.py, tools/tune_gemms.sh) benchmarks new shapes inside the
+    update phase and stores the winners in the cache for later runs."""
+    global _TUNE_NEW_SHAPES
+    mode = os.environ.get("MAPPO_GEMM_TUNING", "1")
+    if mode == "0" or not torch.cuda.is_available():
         return False
+    if mode == "tune":
+        tune_new = True
+    _TUNE_NEW_SHAPES = bool(tune_new)
     t = torch.cuda.tunable
     try:
         t.enable(True)
@@ -48,14 +64,14 @@ def enable(tune_new=True):
 
 
 class tuning(object):
-    """``with gemm_tuning.tuning():`` -- shapes first seen inside the block are benchmarked (when TunableOp is on);
-    outside it only stored winners are used.  The update phase runs the same few shapes every iteration and is worth
+    """``with gemm_tuning.tuning():`` -- shapes first seen inside the block are benchmarked when the process asked for
+    on-line tuning (``enable(tune_new=True)`` / ``MAPPO_GEMM_TUNING=tune``); outside it only stored winners are used.  The update phase runs the same few shapes every iteration and is worth
     tuning; a rollout is not: e.g. the turn-based Hanabi loop evaluates the policy on a different number of rows at
     almost every move, and benchmarking each of them (seconds per shape) stalls it for minutes."""
 
     def __enter__(self):
         self.was = None
-        if torch.cuda.is_available() and torch.cuda.tunable.is_enabled():
+        if _TUNE_NEW_SHAPES and torch.cuda.is_available() and torch.cuda.tunable.is_enabled():
             self.was = torch.cuda.tunable.tuning_is_enabled()
             torch.cuda.tunable.tuning_enable(True)
         return self

@@ -485,6 +485,12 @@ class SharedReplayBuffer(object):
             return torch.randperm(n).to(self.device, non_blocking=True) if self._sampler_rng == "host" \
                 else torch.randperm(n, device=self.device)
         keys = torch.randint(0, 1 << 32, (6,), dtype=torch.int64).tolist()
+        if n_mb == 1 and mb == n:
+            # one slice that takes every sample: K10 would emit 0 .. n - 1 (slices come out in ascending order) whatever
+            # the keys -- three launches per epoch saved (the generator's draw above still happens: same random stream)
+            if getattr(self, "_identity_idx", None) is None or self._identity_idx.numel() != n:
+                self._identity_idx = torch.arange(n, dtype=torch.int64, device=self.device)
+            return self._identity_idx
         idx = torch.empty(n_mb * mb, dtype=torch.int64, device=self.device)
         ws = torch.empty(self._lib.mappo_minibatch_workspace_ints(n, n_mb), dtype=torch.int32, device=self.device)
         _native.check(self._lib.mappo_minibatch_indices(n, mb, n_mb, (ctypes.c_uint32 * 6)(*keys), idx.data_ptr(),

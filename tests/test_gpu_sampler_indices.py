@@ -115,3 +115,21 @@ def test_buffer_generators_use_the_device_sampler():
     assert all(np.array_equal(x, y) for x, y in zip(e1, e3))
     chunks = [s[1].shape[0] for s in buf.recurrent_generator(adv, 2, 4)]
     assert chunks == [T * N * A // 4 // 2 * 4] * 2
+
+
+def test_single_minibatch_shortcut_equals_the_kernel():
+    """One minibatch that takes every sample: the buffer hands out a cached 0 .. n - 1 list instead of running K10 -- which
+    is exactly what K10 emits for one slice, whatever the keys (and the CPU generator still advances by the same draw)."""
+    from helpers import Box, Discrete, make_args
+    from onpolicy.utils.shared_buffer import SharedReplayBuffer
+    n = 6 * 50 * 3
+    for keys in ([1, 2, 3, 4, 5, 6], [0xDEADBEEF, 7, 0, M32, 99, 12345]):
+        np.testing.assert_array_equal(_indices(n, n, 1, keys), np.arange(n))
+    buf = SharedReplayBuffer(make_args(episode_length=6, n_rollout_threads=50), 3, Box((4,)), Box((5,)), Discrete(3), device=DEV)
+    torch.manual_seed(5)
+    a = buf._sampler_indices(n, n, 1)
+    after_shortcut = torch.randint(0, 1 << 30, (1,)).item()
+    torch.manual_seed(5)
+    buf._sampler_indices(n, n // 2, 2)           # the kernel path draws the same six keys
+    assert torch.randint(0, 1 << 30, (1,)).item() == after_shortcut
+    np.testing.assert_array_equal(a.cpu().numpy(), np.arange(n))

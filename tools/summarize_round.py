@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Turns gpurun_out/r02/ (tools/profile_r02.sh on the MI355X box) into the committed evidence under profiles/:
-kernel-statistics CSVs, the bench lines of every workload and profiles/r02_pmc_summary.json -- HBM bytes per launch of
+"""Turns gpurun_out/<round>/ (tools/profile_r02.sh / tools/profile_r03.sh on the MI355X box) into the committed evidence
+under profiles/ (python tools/summarize_round.py r03): kernel-statistics CSVs, the bench lines of every workload and
+profiles/<round>_pmc_summary.json -- HBM bytes per launch of
 the dominant kernels from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as
 MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE reports half the bytes of wide coalesced reads: doubled)."""
 import collections
@@ -12,7 +13,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r02")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+SRC = os.path.join(ROOT, "gpurun_out", TAG)
 DST = os.path.join(ROOT, "profiles")
 sys.path.insert(0, os.path.join(ROOT, "on-policy_amd"))
 
@@ -47,30 +49,34 @@ def main():
                 "and critic launches averaged; FETCH_SIZE doubled (gfx950 counts 64 B per 128 B request of a wide "
                 "coalesced read, MI355X_MICROARCH.md)"}
     alg_b = (_work(rows, 48, 2, 5, True)[1] + _work(rows, 384, 2, 1, True)[1]) / 2
-    fb = sum(mean_of(fetch, k)[0] for k in ("mlp_bwd_kernel", "mlp_dw1_")) + 2 * mean_of(fetch, "mlp_reduce_kernel")[0]
-    wb = sum(mean_of(write, k)[0] for k in ("mlp_bwd_kernel", "mlp_dw1_")) + 2 * mean_of(write, "mlp_reduce_kernel")[0]
+    small = ("mlp_reduce_kernel", "mlp_reduce_kernel") + (("mlp_finish_kernel",) if any("mlp_finish" in k for k in fetch) else ())
+    fb = sum(mean_of(fetch, k)[0] for k in ("mlp_bwd_kernel", "mlp_dw1_") + small)
+    wb = sum(mean_of(write, k)[0] for k in ("mlp_bwd_kernel", "mlp_dw1_") + small)
     out["mappo_mlp_backward"] = {
         "algorithmic_bytes": alg_b, "fetch_size_bytes_raw": fb, "write_size_bytes": wb, "hbm_bytes": 2 * fb + wb,
-        "kernel": "mlp::mlp_bwd_kernel<2, 1> + mlp::mlp_dw1_direct_kernel (critic) / mlp::mlp_dw1_rows_kernel<2> (actor) + 2 x mlp::mlp_reduce_kernel",
-        "note": "one mappo_mlp_backward call = chain kernel + first-layer weight-gradient kernel + two reductions"}
+        "kernel": "mlp::mlp_bwd_kernel + mlp::mlp_dw1_direct_kernel (critic) / mlp::mlp_dw1_rows_kernel<2> (actor) + 2 x mlp::mlp_reduce_kernel (+ mlp::mlp_finish_kernel from round 3)",
+        "note": "one mappo_mlp_backward call = chain kernel + first-layer weight-gradient kernel + the small reductions"}
     f, n = mean_of(fetch, "gae_")
     w, _ = mean_of(write, "gae_")
     out["mappo_gae_f32"] = {"algorithmic_bytes": 24 * rows, "fetch_size_bytes_raw": f, "write_size_bytes": w,
                             "hbm_bytes": 2 * f + w, "dispatches_averaged": n,
                             "note": "north-star size, fused advantages epilogue (24 B / element)"}
-    with open(os.path.join(DST, "r02_pmc_summary.json"), "w") as fh:
+    with open(os.path.join(DST, TAG + "_pmc_summary.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     for k, v in out.items():
         print(k, "algorithmic %.3f GB, HBM %.3f GB (%.2fx)" % (v["algorithmic_bytes"] / 1e9, v["hbm_bytes"] / 1e9,
                                                               v["hbm_bytes"] / v["algorithmic_bytes"]))
-    for w in ("ns", "cfg2", "smac"):
+    for w in ("ns", "cfg2", "smac", "ns_rnn"):
         for f in glob.glob(os.path.join(SRC, "prof_" + w, "*kernel_stats.csv")):
-            shutil.copy(f, os.path.join(DST, "r02_bench_%s_kernel_stats.csv" % w))
+            shutil.copy(f, os.path.join(DST, "%s_bench_%s_kernel_stats.csv" % (TAG, w)))
     lines = {}
     for f in sorted(glob.glob(os.path.join(SRC, "bench_*.json"))):
         name = os.path.basename(f)[6:-5]
-        lines[name] = json.loads(open(f).read())
-    with open(os.path.join(DST, "r02_bench_lines.json"), "w") as fh:
+        try:
+            lines[name] = json.loads(open(f).read())
+        except ValueError:
+            print("skipped (no JSON line):", f)
+    with open(os.path.join(DST, TAG + "_bench_lines.json"), "w") as fh:
         json.dump(lines, fh, indent=1)
     print("bench lines:", {k: (round(v["value"]), v["ms_per_step"]) for k, v in lines.items()})
 

@@ -97,7 +97,19 @@ def main():
                              args=dict(algorithm_name="mat_dec", dec_actor=True, share_actor=True, n_embd=16, n_head=1,
                                        n_block=1, ppo_epoch=1, num_mini_batch=1)),
     }
-    for cname, sp in specs.items():
+    # hidden 64 (the width of every shipped MPE / SMAC configuration: on the device these go through the fused trunk, K9,
+    # and -- recurrent -- the GRU chunk kernels, K12); generated after everything else so that the older cases keep their
+    # place in the run
+    h64_specs = {
+        "mpe_mlp_h64": dict(env="MPE", runner=MPERunner, T=12, N=6, A=3, Do=18, na=5,
+                            args=dict(algorithm_name="mappo", hidden_size=64, layer_N=1, use_ReLU=False, ppo_epoch=2,
+                                      num_mini_batch=1)),
+        "smac_rnn_h64": dict(env="StarCraft2", runner=SMACRunner, T=10, N=5, A=4, Do=22, Ds=30, na=6,
+                             args=dict(algorithm_name="rmappo", use_recurrent_policy=True, hidden_size=64, layer_N=1,
+                                       ppo_epoch=1, num_mini_batch=1, data_chunk_length=5, gain=1.0)),
+    }
+
+    def shared_case(cname, sp):
         T, N, A = sp["T"], sp["N"], sp["A"]
         args = mg.make_args(env_name=sp["env"], episode_length=T, n_rollout_threads=N, num_env_steps=T * N,
                             use_wandb=False, use_eval=True, n_eval_rollout_threads=2, eval_episodes=4, **sp["args"])
@@ -136,6 +148,9 @@ def main():
         runner.eval(777)                      # deterministic policy on the eval envs; what it logs is the result
         meta[cname] = dict(spec={k: v for k, v in sp.items() if k != "runner"},
                            train_info={k: float(v) for k, v in info.items()}, eval_logged=logged_since(mark))
+
+    for cname, sp in specs.items():
+        shared_case(cname, sp)
 
     # ---- separated policies (one policy / trainer / buffer per agent, HAPPO factor bookkeeping in train())
     from onpolicy.runner.separated.mpe_runner import MPERunner as SepMPERunner
@@ -225,6 +240,8 @@ def main():
     runner.eval(888)
     meta["hanabi"] = dict(spec=dict(T=T, N=N, A=A, Do=Do, Ds=Ds, na=na), true_total_num_steps=int(runner.true_total_num_steps),
                           env_steps=int(envs.steps), games=int(envs.games), eval_logged=logged_since(mark))
+    for cname, sp in h64_specs.items():
+        shared_case(cname, sp)
     np.savez_compressed(os.path.join(mg.GOLD, "runner_cases.npz"), **out)
     with open(os.path.join(mg.GOLD, "runner_cases.json"), "w") as f:
         json.dump(meta, f, indent=1)

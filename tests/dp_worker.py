@@ -95,7 +95,57 @@ def run_update(N_global, lo, hi, args_over, device=None):
     return info, sd, trainer.dp.world_size
 
 
-def worker(rank, world, port, N_global, args_over, out_dir, device=None, mat=False):
+def run_fixture(cname, lo, hi, device=None):
+    """compute_returns + train on rollout threads [lo, hi) of a REFERENCE-generated hidden-64 case
+    (tests/golden/trainer_h64_cases.npz, oracle/make_golden_trainer.py), starting from the reference's initial weights.
+    With one minibatch per epoch the union of the ranks' minibatches is the reference's batch, so the data-parallel result
+    is comparable with what the reference's single process produced."""
+    import json
+    from helpers import Box, Discrete, make_args
+    from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy
+    from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO
+    z = np.load(os.path.join(HERE, "golden", "trainer_h64_cases.npz"))
+    spec = json.load(open(os.path.join(HERE, "golden", "trainer_h64_cases.json")))[cname]["spec"]
+    key = "trn_%s_" % cname
+    extra = {} if device is None else {"sampler_rng": "host"}
+    args = make_args(episode_length=spec["T"], n_rollout_threads=hi - lo, **dict(spec["args"], **extra))
+    spaces = Box((spec["Do"],)), Box((spec["Ds"],)), Discrete(spec["na"])
+    torch.manual_seed(1)
+    np.random.seed(1)
+    if device is None:
+        from oracle import oracle
+        policy = R_MAPPOPolicy(args, *spaces)
+        trainer = R_MAPPO(args, policy)
+        buf = oracle.OracleBuffer(args, spec["A"], *spaces)
+    else:
+        from onpolicy.utils.shared_buffer import SharedReplayBuffer
+        policy = R_MAPPOPolicy(args, *spaces, device=device)
+        trainer = R_MAPPO(args, policy, device=device)
+        buf = SharedReplayBuffer(args, spec["A"], *spaces, device=device)
+    with torch.no_grad():
+        for net, pre in ((policy.actor, "init_actor."), (policy.critic, "init_critic.")):
+            for k, v in net.state_dict().items():
+                v.copy_(torch.from_numpy(z[key + pre + k]))
+    for name in ("share_obs", "obs", "rnn_states", "rnn_states_critic", "actions", "value_preds", "masks", "bad_masks",
+                 "active_masks", "action_log_probs", "available_actions", "rewards"):
+        dst, src = getattr(buf, name), z[key + "buf_" + name][:, lo:hi]
+        if device is None:
+            dst[...] = src
+        elif dst.stride()[0] != 0:
+            dst.copy_(torch.from_numpy(np.ascontiguousarray(src)))
+    buf.compute_returns(z[key + "next_value"][lo:hi], trainer.value_normalizer)
+    trainer.prep_training()
+    torch.manual_seed(21)
+    info = trainer.train(buf)
+    sd = {"final_actor." + k: v.detach().cpu().clone() for k, v in policy.actor.state_dict().items()}
+    sd.update({"final_critic." + k: v.detach().cpu().clone() for k, v in policy.critic.state_dict().items()})
+    vn = trainer.value_normalizer
+    sd["final_norm"] = torch.tensor([float(vn.running_mean), float(vn.running_mean_sq), float(vn.debiasing_term)],
+                                    dtype=torch.float64)
+    return info, sd, trainer.dp.world_size
+
+
+def worker(rank, world, port, N_global, args_over, out_dir, device=None, mat=False, fixture=None):
     """``device``: None = CPU ranks; "cuda:0" = every rank on GPU 0 with the gloo backend (RCCL refuses
     duplicate devices), which exercises the device buffer + fused loss under data parallelism."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -108,7 +158,10 @@ def worker(rank, world, port, N_global, args_over, out_dir, device=None, mat=Fal
     mdist.init_from_env(torch.device("cpu") if device is None else device)
     assert dist.get_backend() == "gloo"
     lo, hi = mdist.shard_threads(N_global, rank, world)
-    info, sd, ws = run_update_mat(N_global, lo, hi, args_over) if mat else run_update(N_global, lo, hi, args_over, device)
+    if fixture is not None:
+        info, sd, ws = run_fixture(fixture, lo, hi, device)
+    else:
+        info, sd, ws = run_update_mat(N_global, lo, hi, args_over) if mat else run_update(N_global, lo, hi, args_over, device)
     assert ws == world
     torch.save({"info": info, "sd": sd, "span": (lo, hi)}, os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()

@@ -129,3 +129,38 @@ def test_job_wide_episode_budget_and_even_shards(monkeypatch):
     assert 'getattr(a, "global_n_rollout_threads", a.n_rollout_threads)' in src
     from onpolicy.runner.shared import mpe_runner
     assert "// self.n_rollout_threads_job" in open(mpe_runner.__file__).read()
+
+
+def _two_ranks_on_reference_fixture(tmp_path, cname, device):
+    """Two data-parallel ranks (gloo), each with half of the rollout threads of a reference-generated hidden-64 trainer
+    case, against what the REFERENCE's single process produced (tests/golden/trainer_h64_cases.npz)."""
+    import json
+    spec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trainer_h64_cases.json")))[cname]
+    N, world, port = spec["spec"]["N"], 2, _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=dp_worker.worker, args=(r, world, port, N, {}, str(tmp_path), device, False, cname))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    ranks = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=False) for r in range(world)]
+    assert [r["span"] for r in ranks] == [(0, N // 2), (N // 2, N)]
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trainer_h64_cases.npz"))
+    for k in ranks[0]["sd"]:
+        assert torch.equal(ranks[0]["sd"][k], ranks[1]["sd"][k]), k                  # replicas stay identical
+        ref = z["trn_%s_%s" % (cname, k)]
+        if k == "final_norm":
+            np.testing.assert_allclose(ranks[0]["sd"][k].numpy(), ref, rtol=1e-5, atol=1e-9)
+        else:
+            np.testing.assert_allclose(ranks[0]["sd"][k].numpy(), ref, rtol=1e-3, atol=5e-5, err_msg=k)
+    # global-batch quantities of the log: the gradient norms (the losses are rank means of per-rank means)
+    for k in ("actor_grad_norm", "critic_grad_norm"):
+        assert ranks[0]["info"][k] == pytest.approx(spec["train_info"][k], rel=2e-3), k
+
+
+def test_two_rank_update_on_hidden64_reference_fixture(tmp_path):
+    """(CPU ranks: the PyTorch modules at width 64; the device variant with the fused trunk is
+    tests/test_gpu_bench.py::test_two_rank_device_update_on_hidden64_reference_fixture.)"""
+    _two_ranks_on_reference_fixture(tmp_path, "h64_ns", None)

@@ -122,6 +122,14 @@ def test_two_rank_device_update_equals_single_process(tmp_path, args_over):
         assert ranks[0]["info"][k] == pytest.approx(ranks[1]["info"][k], rel=1e-6, abs=1e-9)
 
 
+def test_two_rank_device_update_on_hidden64_reference_fixture(tmp_path):
+    """Two ranks sharing GPU 0 (gloo), each with half of the rollout threads of the reference-generated north-star-flag
+    case at hidden 64: HBM buffers, lazy-obs samplers, K9 forward / backward, fused loss with global denominators, one
+    gradient all-reduce per update -- against the weights the REFERENCE's single process ended with."""
+    from test_data_parallel_cpu import _two_ranks_on_reference_fixture
+    _two_ranks_on_reference_fixture(tmp_path, "h64_ns", "cuda:0")
+
+
 def test_gemm_tuning_preloads_shipped_winners(tmp_path):
     """onpolicy.utils.gemm_tuning: TunableOp comes up with the shipped winners for the bench shapes loaded (no
     tuning needed for them), and a bench run with it reports gemm_tuning = true."""

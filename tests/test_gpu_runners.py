@@ -253,6 +253,26 @@ def test_rollout_and_update_vs_reference_runner(gold, tmp_path, cname):
     assert next(runner.policy.actor.parameters()).is_cuda
 
 
+@pytest.mark.parametrize("cname", ["mpe_mlp_h64", "smac_rnn_h64"])
+def test_hidden64_rollout_and_update_vs_reference_runner(gold, tmp_path, cname):
+    """The same replay at hidden size 64, where the device update runs through the fused trunk (K9) and, for the recurrent
+    SMAC case, the GRU chunk kernels (K12); the test asserts that those kernels were launched."""
+    import runner_replay
+    from onpolicy.algorithms.utils import fused_mlp
+    fused_mlp.profile(True)
+    try:
+        runner = runner_replay.replay_shared_case(gold, tmp_path, cname, device=torch.device("cuda", 0), init_exact=False,
+                                                  sampler_rng="host")
+        torch.cuda.synchronize()
+        launches = fused_mlp.profile_times()
+    finally:
+        fused_mlp.profile(False)
+    assert launches.get("mappo_mlp_forward", (0,))[0] > 0 and launches.get("mappo_mlp_backward", (0,))[0] > 0, launches
+    assert runner.buffer.obs.is_cuda
+    if cname == "smac_rnn_h64":
+        assert runner.policy.actor.rnn._chunk_kernel_ok(torch.zeros(4, 64, device="cuda"))
+
+
 def test_hanabi_turn_loop_vs_reference_runner(gold, tmp_path):
     """The reference's whole turn-based Hanabi loop (chooseinsert / reward shift / chooseafter_update, four episodes with
     lr decay) replayed on the HBM buffer."""

@@ -24,7 +24,7 @@ def host_buffer(monkeypatch):
     monkeypatch.setattr(base, "SharedReplayBuffer", HostSharedBuffer)
 
 
-@pytest.mark.parametrize("cname", ["mpe_mlp", "mpe_rnn", "smac_rnn", "smac_mat", "smac_mat_dec"])
+@pytest.mark.parametrize("cname", ["mpe_mlp", "mpe_rnn", "smac_rnn", "smac_mat", "smac_mat_dec", "mpe_mlp_h64", "smac_rnn_h64"])
 def test_rollout_and_update_match_reference_runner(gold, host_buffer, tmp_path, cname):
     runner_replay.replay_shared_case(gold, tmp_path, cname)
 

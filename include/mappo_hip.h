@@ -401,6 +401,30 @@ int64_t mappo_gru_seq_workspace_floats(void);
 int     mappo_gru_seq_forward(const mappo_gru_seq_t* seq, mappo_stream_t stream);
 int     mappo_gru_seq_backward(const mappo_gru_seq_t* seq, mappo_stream_t stream);
 
+/* --------------------------------------------------------------- K13: gradient clipping + Adam of one network ----
+ * What the reference does between backward() and the next minibatch for each network (r_mappo.py:146-167:
+ * nn.utils.clip_grad_norm_(parameters, max_grad_norm) or get_gard_norm, then optimizer.step(); the optimiser is
+ * torch.optim.Adam(lr, eps = opti_eps, weight_decay), rMAPPOPolicy.py:31-37) as two launches over all tensors of the
+ * network: total L2 norm of the gradients -> grad_norm [1] (before clipping), gradients scaled in place by
+ * min(1, max_grad_norm / (norm + 1e-6)) (max_grad_norm <= 0: no clipping), then Adam without amsgrad on the optimiser's
+ * own state tensors: step[t] (float32 scalar, incremented), exp_avg[t], exp_avg_sq[t], param[t], all float32 and
+ * contiguous.  workspace [mappo_adam_workspace_floats()]. */
+#define MAPPO_ADAM_MAX_TENSORS 64
+typedef struct mappo_adam {
+    float*  param[MAPPO_ADAM_MAX_TENSORS];
+    float*  grad[MAPPO_ADAM_MAX_TENSORS];
+    float*  exp_avg[MAPPO_ADAM_MAX_TENSORS];
+    float*  exp_avg_sq[MAPPO_ADAM_MAX_TENSORS];
+    float*  step[MAPPO_ADAM_MAX_TENSORS];
+    int64_t numel[MAPPO_ADAM_MAX_TENSORS];
+    int32_t n;
+    double  lr, beta1, beta2, eps, weight_decay, max_grad_norm;     /* doubles, as torch.optim.Adam holds them */
+    float*  grad_norm;
+    float*  workspace;
+} mappo_adam_t;
+int64_t mappo_adam_workspace_floats(void);
+int     mappo_clip_adam(const mappo_adam_t* adam, mappo_stream_t stream);
+
 /* --------------------------------------------------------------- K10: sort-free minibatch index lists ----
  * Device-side replacement of `rand = torch.randperm(B); slices = [rand[i*mb:(i+1)*mb] for i in range(n_mb)]`
  * (reference onpolicy/utils/shared_buffer.py:360-361 feed-forward, :415-416 whole trajectories, :511-512 chunks).

@@ -1,0 +1,146 @@
+// K13: gradient clipping + Adam for one network as two launches (hidden work of a PPO update that is not a network):
+// the reference clips each network's gradients to a global L2 norm and takes one Adam step per minibatch
+// (onpolicy/algorithms/r_mappo/r_mappo.py:146-167: clip_grad_norm_(max_grad_norm) or get_gard_norm, optimizer.step();
+// rMAPPOPolicy.py:31-37: torch.optim.Adam(lr, eps = opti_eps, weight_decay)).  In PyTorch that is ~8 launches per
+// network (foreach norms, stack, norm, clamp, multiply, the fused Adam kernel, the step counters) -- 16 of the ~70 tiny
+// launches of an update, each ~4.5 us on an idle queue: 3 % of a step on one rank's shard of an 8-GPU north-star job and
+// 10 % of the 25 ms config-2 step.  Here: one launch sums the squares (and advances the step counters), one applies
+// clip coefficient + Adam to every tensor of the network.  Same arithmetic as torch.optim.Adam (no amsgrad, no
+// maximize) on float32 tensors; the optimiser's own state tensors (exp_avg, exp_avg_sq, step) are updated in place, so
+// torch.optim.Adam.state_dict() / lr schedules keep working.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mappo_hip.h"
+#include "mappo_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 256;
+
+struct Desc {
+    mappo_adam_t a;
+    long long total;
+};
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < kThreads / 64; ++w) t += sh[w];
+    return t;       // valid on thread 0
+}
+
+// prefix[t] = elements of tensors 0 .. t - 1, in LDS; -> tensor of flat element e
+__device__ __forceinline__ int tensor_of(const long long* prefix, int n, long long e) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (prefix[mid] <= e) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(kThreads) adam_norm_kernel(Desc d) {
+    __shared__ long long prefix[MAPPO_ADAM_MAX_TENSORS + 1];
+    __shared__ float sh[kThreads / 64];
+    if (threadIdx.x == 0) {
+        long long s = 0;
+        for (int t = 0; t < d.a.n; ++t) {
+            prefix[t] = s;
+            s += d.a.numel[t];
+        }
+        prefix[d.a.n] = s;
+    }
+    __syncthreads();
+    const long long per = (d.total + gridDim.x - 1) / gridDim.x;
+    const long long lo = (long long)blockIdx.x * per, hi = lo + per < d.total ? lo + per : d.total;
+    float s = 0.f;
+    for (long long e = lo + threadIdx.x; e < hi; e += kThreads) {
+        const int t = tensor_of(prefix, d.a.n, e);
+        const float g = d.a.grad[t][e - prefix[t]];
+        s += g * g;
+    }
+    const float tot = block_sum(s, sh);
+    if (threadIdx.x == 0) d.a.workspace[blockIdx.x] = tot;
+    // the step counters advance here, so that every block of the second launch reads the new value
+    if (blockIdx.x == 0 && threadIdx.x < d.a.n) d.a.step[threadIdx.x][0] += 1.f;
+}
+
+__global__ void __launch_bounds__(kThreads) adam_step_kernel(Desc d, int n_partials) {
+    __shared__ long long prefix[MAPPO_ADAM_MAX_TENSORS + 1];
+    __shared__ float sh[kThreads / 64];
+    __shared__ float coef_s;
+    if (threadIdx.x == 0) {
+        long long s = 0;
+        for (int t = 0; t < d.a.n; ++t) {
+            prefix[t] = s;
+            s += d.a.numel[t];
+        }
+        prefix[d.a.n] = s;
+    }
+    float p = threadIdx.x < n_partials ? d.a.workspace[threadIdx.x] : 0.f;      // (n_partials <= kThreads, fixed order)
+    __syncthreads();
+    const float sq = block_sum(p, sh);
+    if (threadIdx.x == 0) {
+        const float norm = sqrtf(sq);
+        float c = 1.f;
+        if (d.a.max_grad_norm > 0.0) {                  // torch.nn.utils.clip_grad_norm_: max_norm / (total + 1e-6), <= 1
+            c = (float)d.a.max_grad_norm / (norm + 1e-6f);
+            c = c < 1.f ? c : 1.f;
+        }
+        coef_s = c;
+        if (blockIdx.x == 0 && d.a.grad_norm != nullptr) d.a.grad_norm[0] = norm;
+    }
+    __syncthreads();
+    const float coef = coef_s;
+    const long long per = (d.total + gridDim.x - 1) / gridDim.x;
+    const long long lo = (long long)blockIdx.x * per, hi = lo + per < d.total ? lo + per : d.total;
+    for (long long e = lo + threadIdx.x; e < hi; e += kThreads) {
+        const int t = tensor_of(prefix, d.a.n, e);
+        const long long i = e - prefix[t];
+        // (torch's fused Adam kernel: the hyper-parameters are doubles, so the products with them are formed in double and
+        // rounded to float32 once)
+        const double step = (double)d.a.step[t][0];
+        const float bc1 = (float)(1.0 - pow(d.a.beta1, step)), bc2 = (float)(1.0 - pow(d.a.beta2, step));
+        float g = d.a.grad[t][i] * coef;
+        d.a.grad[t][i] = g;                             // the clipped gradient stays in .grad, as clip_grad_norm_ leaves it
+        float w = d.a.param[t][i];
+        if (d.a.weight_decay != 0.0) g = (float)(g + w * d.a.weight_decay);
+        float m = d.a.exp_avg[t][i], v = d.a.exp_avg_sq[t][i];
+        m = (float)(d.a.beta1 * m + (1.0 - d.a.beta1) * g);
+        v = (float)(d.a.beta2 * v + (1.0 - d.a.beta2) * g * g);
+        d.a.exp_avg[t][i] = m;
+        d.a.exp_avg_sq[t][i] = v;
+        const float step_size = (float)(d.a.lr / bc1);
+        const float denom = (float)(sqrtf(v) / sqrtf(bc2) + d.a.eps);
+        d.a.param[t][i] = w - step_size * m / denom;
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t mappo_adam_workspace_floats(void) { return kMaxBlocks; }
+
+extern "C" int mappo_clip_adam(const mappo_adam_t* a, mappo_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!a || !a->workspace) return MAPPO_E_NULL;
+    if (a->n <= 0 || a->n > MAPPO_ADAM_MAX_TENSORS) return MAPPO_E_SHAPE;
+    Desc d;
+    d.a = *a;
+    d.total = 0;
+    for (int t = 0; t < a->n; ++t) {
+        if (!a->param[t] || !a->grad[t] || !a->exp_avg[t] || !a->exp_avg_sq[t] || !a->step[t]) return MAPPO_E_NULL;
+        if (a->numel[t] <= 0) return MAPPO_E_SHAPE;
+        d.total += a->numel[t];
+    }
+    long long blocks = (d.total + kThreads * 8 - 1) / (kThreads * 8);
+    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+    hipLaunchKernelGGL(adam_norm_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, d);
+    hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, d, (int)blocks);
+    return (int)hipGetLastError();
+}

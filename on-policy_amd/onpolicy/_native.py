@@ -64,6 +64,17 @@ class GRUSeq(ctypes.Structure):
                                    "ln_grads", "workspace")]
 
 
+ADAM_MAX_TENSORS = 64
+
+
+class Adam(ctypes.Structure):
+    """struct mappo_adam (include/mappo_hip.h): gradient clipping + Adam over all tensors of one network."""
+    _fields_ = [(n, _vp * ADAM_MAX_TENSORS) for n in ("param", "grad", "exp_avg", "exp_avg_sq", "step")] + \
+               [("numel", _i64 * ADAM_MAX_TENSORS), ("n", ctypes.c_int32)] + \
+               [(n, ctypes.c_double) for n in ("lr", "beta1", "beta2", "eps", "weight_decay", "max_grad_norm")] + \
+               [("grad_norm", _vp), ("workspace", _vp)]
+
+
 LOSS_HUBER, LOSS_CLIPPED_VALUE, LOSS_POLICY_ACTIVE_MASKS, LOSS_VALUE_ACTIVE_MASKS = 1, 2, 4, 8
 
 # symbol -> (restype, argtypes); must list every function include/mappo_hip.h declares
@@ -101,6 +112,8 @@ SIGNATURES = {
     "mappo_gru_seq_workspace_floats": (_i64, []),
     "mappo_gru_seq_forward": (_int, [ctypes.POINTER(GRUSeq), _vp]),
     "mappo_gru_seq_backward": (_int, [ctypes.POINTER(GRUSeq), _vp]),
+    "mappo_adam_workspace_floats": (_i64, []),
+    "mappo_clip_adam": (_int, [ctypes.POINTER(Adam), _vp]),
     "mappo_ppo_loss_f32": (_int, [ctypes.POINTER(PPOLoss), _vp]),
     "mappo_minibatch_workspace_ints": (_i64, [_i64, _int]),
     "mappo_minibatch_indices": (_int, [_i64, _i64, _int, _vp, _vp, _vp, _vp]),

@@ -301,18 +301,27 @@ class R_MAPPO():
 
         self.dp.all_reduce_grads()  # no-op for world size 1
 
-        if self._use_max_grad_norm:
-            actor_grad_norm = nn.utils.clip_grad_norm_(self.policy.actor.parameters(), self.max_grad_norm)
-            critic_grad_norm = nn.utils.clip_grad_norm_(self.policy.critic.parameters(), self.max_grad_norm)
-        else:
-            actor_grad_norm = get_gard_norm(self.policy.actor.parameters())
-            critic_grad_norm = get_gard_norm(self.policy.critic.parameters())
-
-        if update_actor or not self.dp.active:
-            self.policy.actor_optimizer.step()
-        self.policy.critic_optimizer.step()
+        actor_grad_norm = self._clip_and_step(self.policy.actor, self.policy.actor_optimizer,
+                                              update_actor or not self.dp.active)
+        critic_grad_norm = self._clip_and_step(self.policy.critic, self.policy.critic_optimizer, True)
 
         return value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights
+
+    def _clip_and_step(self, net, optimizer, step):
+        """Clip the network's gradients to ``max_grad_norm`` (or only measure them) and take the optimiser step
+        (reference r_mappo.py:146-153, :160-167) -> the gradient norm before clipping.  On a HIP device the whole thing is
+        K13 (two launches instead of ~8); otherwise, or when a parameter has no gradient, the PyTorch calls."""
+        from onpolicy.algorithms.utils import fused_optim
+        params = [p for p in net.parameters() if p.requires_grad]
+        if step and params and params[0].is_cuda and fused_optim.supported(optimizer, params):
+            return fused_optim.clip_and_step(optimizer, params, self.max_grad_norm if self._use_max_grad_norm else None)
+        if self._use_max_grad_norm:
+            norm = nn.utils.clip_grad_norm_(net.parameters(), self.max_grad_norm)
+        else:
+            norm = get_gard_norm(net.parameters())
+        if step:
+            optimizer.step()
+        return norm
 
     def _fused_spans(self, spans, cut, tensors, w_actor, w_critic, feed_normalizer, update_actor):
         """The span loop of ppo_update through the fused loss kernel (K7): per span one forward to the

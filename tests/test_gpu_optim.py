@@ -1,0 +1,67 @@
+"""-m gpu: K13 (mappo_clip_adam): gradient clipping + Adam of one network as two launches, against
+torch.nn.utils.clip_grad_norm_ + torch.optim.Adam (the calls of the reference's ppo_update, r_mappo.py:146-167;
+optimiser of rMAPPOPolicy.py:31-37) on the same tensors over several steps."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _nets(seed, shapes, dev):
+    g = torch.Generator().manual_seed(seed)
+    make = lambda: [torch.nn.Parameter(torch.randn(s, generator=g).to(dev)) for s in shapes]
+    g.manual_seed(seed)
+    a = make()
+    g.manual_seed(seed)
+    b = make()
+    return a, b
+
+
+@pytest.mark.parametrize("max_norm,wd", [(10.0, 0.0), (0.05, 0.0), (None, 0.0), (0.5, 0.01)])
+def test_clip_adam_matches_torch(max_norm, wd):
+    from onpolicy.algorithms.utils import fused_optim
+    dev = torch.device("cuda", 0)
+    shapes = [(64, 48), (64,), (64,), (64,), (64, 64), (64,), (5, 64), (5,), (192, 64), (3, 1000, 7)]
+    pa, pb = _nets(3, shapes, dev)
+    kw = dict(lr=7e-4, eps=1e-5, weight_decay=wd)
+    oa = torch.optim.Adam(pa, fused=True, **kw)
+    ob = torch.optim.Adam(pb, fused=True, **kw)
+    g = torch.Generator().manual_seed(11)
+    for step in range(5):
+        grads = [torch.randn(s, generator=g).to(dev) * (0.1 if step % 2 else 3.0) for s in shapes]
+        for p, q, gr in zip(pa, pb, grads):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        if step == 3:
+            for o in (oa, ob):
+                o.param_groups[0]["lr"] = 3e-4          # lr_decay between updates
+        assert fused_optim.supported(oa, pa)
+        na = fused_optim.clip_and_step(oa, pa, max_norm)
+        if max_norm:
+            nb = torch.nn.utils.clip_grad_norm_(pb, max_norm)
+        else:
+            nb = torch.sqrt(sum(q.grad.norm() ** 2 for q in pb))
+        ob.step()
+        torch.testing.assert_close(na, nb.reshape(()), rtol=2e-6, atol=0)
+        for i, (p, q) in enumerate(zip(pa, pb)):
+            torch.testing.assert_close(p.grad, q.grad, rtol=2e-6, atol=1e-9, msg="grad %d step %d" % (i, step))
+            torch.testing.assert_close(p.data, q.data, rtol=3e-7, atol=1e-8, msg="param %d step %d" % (i, step))      # ~2 ulp
+            for k in ("exp_avg", "exp_avg_sq", "step"):     # (sums that can cancel: absolute floor of a few ulp of the terms)
+                torch.testing.assert_close(oa.state[p][k], ob.state[q][k], rtol=2e-6, atol=3e-7, msg=k)
+    # the state is torch.optim.Adam's own: a plain step() continues from it
+    for p, q in zip(pa, pb):
+        p.grad, q.grad = torch.ones_like(p), torch.ones_like(q)
+    oa.step()
+    ob.step()
+    for p, q in zip(pa, pb):
+        torch.testing.assert_close(p.data, q.data, rtol=5e-7, atol=1e-8)
+
+
+def test_unsupported_optimisers_fall_back():
+    from onpolicy.algorithms.utils import fused_optim
+    dev = torch.device("cuda", 0)
+    p = [torch.nn.Parameter(torch.randn(4, 4, device=dev))]
+    p[0].grad = torch.randn(4, 4, device=dev)
+    assert not fused_optim.supported(torch.optim.Adam(p, amsgrad=True), p)
+    assert not fused_optim.supported(torch.optim.SGD(p, lr=0.1), p)
+    q = [torch.nn.Parameter(torch.randn(4, 4, device=dev))]
+    assert not fused_optim.supported(torch.optim.Adam(q), q)        # no gradient

@@ -425,6 +425,17 @@ typedef struct mappo_adam {
 int64_t mappo_adam_workspace_floats(void);
 int     mappo_clip_adam(const mappo_adam_t* adam, mappo_stream_t stream);
 
+/* ValueNorm.update + running_mean_var as two launches (reference onpolicy/utils/valuenorm.py:32-55): the mean and mean of
+ * squares of x [n] (or batch_moments [2] = {mean, mean_sq} when the caller all-reduced them over the ranks; x is then
+ * ignored) are folded into the scalar statistics in place, m <- weight * m + (1 - weight) * E[.], debiasing_term <-
+ * weight * d + (1 - weight), and denorm [2] receives {sigma, mu} = {sqrt(max(m2 / max(d, eps) - mu^2, 1e-2)), m1 / max(d,
+ * eps)} -- what the loss normalises returns with and the GAE scan de-normalises values with.
+ * workspace [mappo_valuenorm_workspace_doubles()] float64. */
+int64_t mappo_valuenorm_workspace_doubles(void);
+int     mappo_valuenorm_update(const float* x, int64_t n, const float* batch_moments, double weight, float eps,
+                               float* running_mean, float* running_mean_sq, float* debiasing_term, float* denorm,
+                               double* workspace, mappo_stream_t stream);
+
 /* --------------------------------------------------------------- K10: sort-free minibatch index lists ----
  * Device-side replacement of `rand = torch.randperm(B); slices = [rand[i*mb:(i+1)*mb] for i in range(n_mb)]`
  * (reference onpolicy/utils/shared_buffer.py:360-361 feed-forward, :415-416 whole trajectories, :511-512 chunks).

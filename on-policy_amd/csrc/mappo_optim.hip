@@ -122,7 +122,91 @@ __global__ void __launch_bounds__(kThreads) adam_step_kernel(Desc d, int n_parti
     }
 }
 
+// ---------------------------------------------------------------- ValueNorm update + de-normalisation scalars ----
+// ValueNorm.update (onpolicy/utils/valuenorm.py:39-55: batch mean and mean of squares folded into the debiased running
+// moments with weight beta) followed by running_mean_var / the [sigma, mu] pair the loss and the GAE scan read
+// (valuenorm.py:32-37): ~17 launches and an n-element temporary (x ** 2) in PyTorch per minibatch.  Launch 1: per-block
+// float64 partial sums of x and x^2; launch 2 (one block): batch moments -> the three statistics in place -> [sigma, mu].
+__global__ void __launch_bounds__(kThreads) vn_sums_kernel(const float* x, long long n, double* partials) {
+    __shared__ double sh[2][kThreads / 64];
+    double s = 0.0, q = 0.0;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+        const double v = x[i];
+        s += v;
+        q += v * v;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off);
+        q += __shfl_down(q, off);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        sh[0][wave] = s;
+        sh[1][wave] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < kThreads / 64; ++w) {
+            a += sh[0][w];
+            b += sh[1][w];
+        }
+        partials[2 * blockIdx.x] = a;
+        partials[2 * blockIdx.x + 1] = b;
+    }
+}
+
+__global__ void vn_fold_kernel(const double* partials, int n_partials, double count, const float* batch_moments,
+                               double weight, float eps, float* m1, float* m2, float* d, float* denorm) {
+    if (threadIdx.x != 0) return;
+    float mean, mean_sq;
+    if (batch_moments != nullptr) {         // data parallel: the all-reduced moments of the global minibatch
+        mean = batch_moments[0];
+        mean_sq = batch_moments[1];
+    } else {
+        double a = 0.0, b = 0.0;
+        for (int i = 0; i < n_partials; ++i) {
+            a += partials[2 * i];
+            b += partials[2 * i + 1];
+        }
+        mean = (float)(a / count);
+        mean_sq = (float)(b / count);
+    }
+    // m <- w m + (1 - w) E[.] in float32 with the Python float weight, like the in-place tensor ops of the reference
+    const float w = (float)weight, u = (float)(1.0 - weight);
+    const float n1 = m1[0] * w + mean * u, n2 = m2[0] * w + mean_sq * u, nd = d[0] * w + u;
+    m1[0] = n1;
+    m2[0] = n2;
+    d[0] = nd;
+    const float dd = nd > eps ? nd : eps;
+    const float mu = n1 / dd;
+    float var = n2 / dd - mu * mu;
+    var = var > 1e-2f ? var : 1e-2f;
+    denorm[0] = sqrtf(var);
+    denorm[1] = mu;
+}
+
 }  // namespace
+
+extern "C" int64_t mappo_valuenorm_workspace_doubles(void) { return 2 * kMaxBlocks; }
+
+extern "C" int mappo_valuenorm_update(const float* x, int64_t n, const float* batch_moments, double weight, float eps,
+                                      float* running_mean, float* running_mean_sq, float* debiasing_term, float* denorm,
+                                      double* workspace, mappo_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!running_mean || !running_mean_sq || !debiasing_term || !denorm) return MAPPO_E_NULL;
+    if (!batch_moments && (!x || !workspace)) return MAPPO_E_NULL;
+    if (!batch_moments && n <= 0) return MAPPO_E_SHAPE;
+    long long blocks = 0;
+    if (!batch_moments) {
+        blocks = (n + kThreads * 16 - 1) / (kThreads * 16);
+        if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+        hipLaunchKernelGGL(vn_sums_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, x, (long long)n, workspace);
+    }
+    hipLaunchKernelGGL(vn_fold_kernel, dim3(1), dim3(64), 0, stream, (const double*)workspace, (int)blocks, (double)n,
+                       batch_moments, weight, eps, running_mean, running_mean_sq, debiasing_term, denorm);
+    return (int)hipGetLastError();
+}
 
 extern "C" int64_t mappo_adam_workspace_floats(void) { return kMaxBlocks; }
 

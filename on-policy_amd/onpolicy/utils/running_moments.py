@@ -48,8 +48,43 @@ class DebiasedMoments(object):
         axes = tuple(range(self.norm_axes))
         return x.mean(dim=axes), (x ** 2).mean(dim=axes)
 
+    # -- the HIP route for scalar statistics (ValueNorm(1) on the device): update + [sigma, mu] as two launches
+    def _fused_ok(self, input_vector, batch_moments):
+        import os
+        m1 = getattr(self, self._first_moment)
+        if not (m1.is_cuda and m1.numel() == 1 and self.norm_axes == 1 and os.environ.get("MAPPO_FUSED_VALUENORM", "1") != "0"
+                and type(self).__name__ == "ValueNorm"):
+            return False
+        if batch_moments is not None:
+            return all(torch.is_tensor(t) and t.is_cuda and t.numel() == 1 for t in batch_moments)
+        return torch.is_tensor(input_vector) and input_vector.is_cuda and input_vector.dtype == torch.float32 \
+            and input_vector.dim() == 2 and input_vector.shape[1] == 1 and input_vector.is_contiguous()
+
+    def _stats_versions(self):
+        return tuple((b.data_ptr(), b._version) for b in self._moments())
+
+    @torch.no_grad()
+    def _fold_in_fused(self, input_vector, batch_moments, weight):
+        from onpolicy import _native
+        lib, p = _native.lib(), _native.ptr
+        m1, m2, d = self._moments()
+        dev = m1.device
+        if getattr(self, "_denorm_cache", None) is None or self._denorm_cache.device != dev:
+            self._denorm_cache = torch.empty(2, dtype=torch.float32, device=dev)
+            self._vn_ws = torch.empty(lib.mappo_valuenorm_workspace_doubles(), dtype=torch.float64, device=dev)
+        bm = None if batch_moments is None else torch.cat([t.reshape(1).float() for t in batch_moments])
+        x = None if batch_moments is not None else input_vector
+        _native.check(lib.mappo_valuenorm_update(p(x), 0 if x is None else x.numel(), p(bm), float(weight), float(self.epsilon),
+                                                 p(m1), p(m2), p(d), p(self._denorm_cache), p(self._vn_ws),
+                                                 _native.stream_of(dev)), "mappo_valuenorm_update")
+        # (the kernel writes the statistics through raw pointers: the tensors' version counters stay put, so any later
+        # in-place torch edit of them -- load_state_dict, zero_moments, a test poking values in -- invalidates the cache)
+        self._denorm_key = self._stats_versions()
+
     @torch.no_grad()
     def _fold_in(self, input_vector, batch_moments, weight):
+        if self._fused_ok(input_vector, batch_moments):
+            return self._fold_in_fused(input_vector, batch_moments, weight)
         mean, mean_sq = batch_moments if batch_moments is not None \
             else self._batch_moments(self._as_tensor(input_vector))
         m1, m2, d = self._moments()
@@ -59,6 +94,8 @@ class DebiasedMoments(object):
 
     def denorm_scalars(self):
         """float32 device tensor [sigma, mu] (scalar statistics, input_shape == 1)."""
+        if getattr(self, "_denorm_key", None) is not None and self._denorm_key == self._stats_versions():
+            return self._denorm_cache        # written by the update kernel, statistics untouched since
         mean, var = self._mean_var()
         return torch.stack([torch.sqrt(var).reshape(()), mean.reshape(())])
 

@@ -65,3 +65,30 @@ def test_unsupported_optimisers_fall_back():
     assert not fused_optim.supported(torch.optim.SGD(p, lr=0.1), p)
     q = [torch.nn.Parameter(torch.randn(4, 4, device=dev))]
     assert not fused_optim.supported(torch.optim.Adam(q), q)        # no gradient
+
+
+def test_fused_valuenorm_update_matches_the_tensor_ops():
+    """mappo_valuenorm_update (ValueNorm.update + running_mean_var, valuenorm.py:32-55) against the same module on the
+    CPU: statistics and the [sigma, mu] pair after several batches, local batches and given (all-reduced) moments; the
+    cached pair is dropped as soon as somebody edits the statistics."""
+    from onpolicy.utils.valuenorm import ValueNorm
+    dev = torch.device("cuda", 0)
+    a, b = ValueNorm(1, device=dev), ValueNorm(1)
+    g = torch.Generator().manual_seed(2)
+    for i in range(6):
+        x = torch.randn(100003 if i % 2 else 257, 1, generator=g) * (3.0 + i) + 1.5
+        if i == 4:
+            mom = (x.mean(0), (x ** 2).mean(0))
+            a.update(None, batch_moments=tuple(t.to(dev) for t in mom))
+            b.update(None, batch_moments=mom)
+        else:
+            a.update(x.to(dev))
+            b.update(x)
+        assert a._denorm_key is not None
+        for name in ("running_mean", "running_mean_sq", "debiasing_term"):
+            torch.testing.assert_close(getattr(a, name).cpu(), getattr(b, name), rtol=2e-5, atol=1e-10, msg=name)
+        torch.testing.assert_close(a.denorm_scalars().cpu(), b.denorm_scalars(), rtol=2e-5, atol=1e-8)
+        torch.testing.assert_close(a.normalize(x.to(dev)).cpu(), b.normalize(x), rtol=1e-4, atol=1e-5)
+    a.running_mean.fill_(7.0)       # an in-place edit: the cached pair must not be served any more
+    b.running_mean.fill_(7.0)
+    torch.testing.assert_close(a.denorm_scalars().cpu(), b.denorm_scalars(), rtol=2e-5, atol=1e-8)

@@ -25,7 +25,7 @@ def test_snapshot_has_no_spills_and_expected_occupancy():
     table = json.load(open(SNAPSHOT))
     assert len(table) > 300 and {k.split(" :: ")[0] for k in table} == {
         "mappo_gae.hip", "mappo_copy.hip", "mappo_norm.hip", "mappo_loss.hip", "mappo_rnn.hip", "mappo_mlp.hip",
-        "mappo_perm.hip", "mappo_env.hip"}
+        "mappo_perm.hip", "mappo_env.hip", "mappo_optim.hip"}
     # no spills, except: the 64-wide time-parallel GAE scan with time limits (a tuning variant, never selected
     # automatically), the identity-activation forward trunk (<= 32 bytes: loop-invariant addresses reloaded once per tile)
     # and the GRU chunk backward (<= 128 bytes: its gate arithmetic wants ~480 values in the 256 VALU-addressable
@@ -55,7 +55,7 @@ def test_sources_still_compile_to_the_snapshot():
     tool = _tool()
     table = json.load(open(SNAPSHOT))
     sources = tool.SOURCES if os.environ.get("MAPPO_CHECK_ALL_KERNEL_RESOURCES") == "1" else \
-        ("mappo_copy.hip", "mappo_loss.hip", "mappo_rnn.hip", "mappo_mlp.hip", "mappo_perm.hip")     # (gae, env: ~100 s each)
+        ("mappo_copy.hip", "mappo_loss.hip", "mappo_rnn.hip", "mappo_mlp.hip", "mappo_perm.hip", "mappo_optim.hip")     # (gae, env: ~100 s each)
     for src in sources:
         fresh = {"%s :: %s" % (src, k.pop("kernel")): k for k in tool.analyse(src)}
         committed = {k: v for k, v in table.items() if k.startswith(src + " :: ")}

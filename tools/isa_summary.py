@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "on-policy_amd", "csrc")
 SNAPSHOT = os.path.join(ROOT, "profiles", "isa_summary.json")
 SOURCES = ("mappo_gae.hip", "mappo_copy.hip", "mappo_norm.hip", "mappo_loss.hip", "mappo_rnn.hip", "mappo_mlp.hip",
-           "mappo_perm.hip", "mappo_env.hip")
+           "mappo_perm.hip", "mappo_env.hip", "mappo_optim.hip")
 FAMILIES = {
     "lds_dma_128bit": r"^\s*global_load_lds_dwordx4\b",
     "lds_dma_other": r"^\s*(global_load_lds_(?!dwordx4)\w+|buffer_load_\w+ .*\blds\b)",

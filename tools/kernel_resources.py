@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "on-policy_amd", "csrc")
 SNAPSHOT = os.path.join(ROOT, "profiles", "kernel_resources.json")
 SOURCES = ("mappo_gae.hip", "mappo_copy.hip", "mappo_norm.hip", "mappo_loss.hip", "mappo_rnn.hip", "mappo_mlp.hip",
-           "mappo_perm.hip", "mappo_env.hip")
+           "mappo_perm.hip", "mappo_env.hip", "mappo_optim.hip")
 FIELDS = {"VGPRs": "vgprs", "AGPRs": "agprs", "SGPRs": "sgprs", "ScratchSize [bytes/lane]": "scratch_bytes",
           "Occupancy [waves/SIMD]": "occupancy", "LDS Size [bytes/block]": "lds_bytes"}
 

@@ -29,7 +29,7 @@ def counters(name):
 
 def mean_of(acc, key):
     vals = [v for k, vs in acc.items() if key in k for v in vs]
-    return sum(vals) / len(vals), len(vals)
+    return (sum(vals) / len(vals) if vals else 0.0), len(vals)
 
 
 def main():
@@ -49,12 +49,14 @@ def main():
                 "and critic launches averaged; FETCH_SIZE doubled (gfx950 counts 64 B per 128 B request of a wide "
                 "coalesced read, MI355X_MICROARCH.md)"}
     alg_b = (_work(rows, 48, 2, 5, True)[1] + _work(rows, 384, 2, 1, True)[1]) / 2
-    small = ("mlp_reduce_kernel", "mlp_reduce_kernel") + (("mlp_finish_kernel",) if any("mlp_finish" in k for k in fetch) else ())
+    # the small kernels of a backward call: two reductions (round 2), + the finish kernel (early round 3), one tail kernel now
+    small = ("mlp_tail_kernel",) if any("mlp_tail" in k for k in fetch) else \
+        ("mlp_reduce_kernel", "mlp_reduce_kernel") + (("mlp_finish_kernel",) if any("mlp_finish" in k for k in fetch) else ())
     fb = sum(mean_of(fetch, k)[0] for k in ("mlp_bwd_kernel", "mlp_dw1_") + small)
     wb = sum(mean_of(write, k)[0] for k in ("mlp_bwd_kernel", "mlp_dw1_") + small)
     out["mappo_mlp_backward"] = {
         "algorithmic_bytes": alg_b, "fetch_size_bytes_raw": fb, "write_size_bytes": wb, "hbm_bytes": 2 * fb + wb,
-        "kernel": "mlp::mlp_bwd_kernel + mlp::mlp_dw1_direct_kernel (critic) / mlp::mlp_dw1_rows_kernel<2> (actor) + 2 x mlp::mlp_reduce_kernel (+ mlp::mlp_finish_kernel from round 3)",
+        "kernel": "mlp::mlp_bwd_kernel + mlp::mlp_dw1_direct_kernel (critic) / mlp::mlp_dw1_rows_kernel<2> (actor) + mlp::mlp_tail_kernel (round 2: two mlp::mlp_reduce_kernel)",
         "note": "one mappo_mlp_backward call = chain kernel + first-layer weight-gradient kernel + the small reductions"}
     f, n = mean_of(fetch, "gae_")
     w, _ = mean_of(write, "gae_")

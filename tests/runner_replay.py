@@ -84,7 +84,7 @@ def replay_shared_case(gold, tmp_path, cname, device=torch.device("cpu"), init_e
     key = "run_%s_" % cname
     # initial weights: drawn on the CPU generator on every device; bit-identical on the host that made the fixtures,
     # 1e-6 across hosts (orthogonal_'s LAPACK QR)
-    wide = kw.get("hidden_size", 64) >= 64      # (64-wide QR factors differ a little more between hosts)
+    wide = kw.get("hidden_size", 0) >= 64 and hasattr(runner.policy, "actor")     # (64-wide QR factors differ a little more between hosts)
     check_params(z, key + "init_", runner.policy, exact=init_exact and not wide, rtol=1e-4 if wide else 1e-5,
                  atol=5e-6 if wide else 1e-6)
     if wide:        # ... so a wide case starts from the reference's exact weights: its sampled actions must not depend on them

@@ -1185,6 +1185,8 @@ __device__ __forceinline__ void finish_grads(const FinishArgs& a) {
 // derives the remaining parameter gradients from R.
 __device__ __forceinline__ void reduce_chunk(const float* partials, long long n, long long stride, long long count,
                                              float* out, long long chunk, float* sh);
+__device__ __forceinline__ void reduce_chunk4(const float* partials, long long n, long long stride, long long count,
+                                              float* out, long long chunk, float* sh);
 struct TailArgs {
     FinishArgs fin;             // fin.R = reduced raw sums (written here), fin.grads
     const float* p1;            // [n1][c1] first-layer partials -> grads[0 .. c1)
@@ -1194,17 +1196,22 @@ struct TailArgs {
     float* raw;
     unsigned* ticket;
     int nb1, nb2;
+    int wide1;                  // p1 / grads are 16-byte aligned and c1 is a multiple of 4: blocks of 128 elements
 };
 __global__ void __launch_bounds__(kThreads) mlp_tail_kernel(TailArgs a) {
-    float* sh = prim::lds();        // [8][32] | ticket
+    float* sh = prim::lds();        // [8][128] | ticket
     const int b = blockIdx.x;
-    if (b < a.nb1) reduce_chunk(a.p1, a.n1, a.c1, a.c1, a.fin.grads, b, sh);
-    else reduce_chunk(a.p2, a.n2, a.c2, a.c2, a.raw, b - a.nb1, sh);
+    if (b < a.nb1) {
+        if (a.wide1) reduce_chunk4(a.p1, a.n1, a.c1, a.c1, a.fin.grads, b, sh);
+        else reduce_chunk(a.p1, a.n1, a.c1, a.c1, a.fin.grads, b, sh);
+    } else {
+        reduce_chunk(a.p2, a.n2, a.c2, a.c2, a.raw, b - a.nb1, sh);
+    }
     prim::fence();                  // this block's sums are visible device-wide before its ticket is drawn
     __syncthreads();
-    if (threadIdx.x == 0) sh[256] = prim::i2f((int)prim::ticket(a.ticket));
+    if (threadIdx.x == 0) sh[1024] = prim::i2f((int)prim::ticket(a.ticket));
     __syncthreads();
-    if (prim::f2i(sh[256]) != a.nb1 + a.nb2 - 1) return;
+    if (prim::f2i(sh[1024]) != a.nb1 + a.nb2 - 1) return;
     if (threadIdx.x == 0) *a.ticket = 0u;
     prim::fence();
     finish_grads(a.fin);
@@ -1628,16 +1635,53 @@ __device__ __forceinline__ void reduce_chunk(const float* partials, long long n,
                                              float* out, long long chunk, float* sh /* [8][32] */) {
     const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
     const long long e = chunk * 32 + el;
-    float s = 0.f;
-    if (e < count)
-        for (long long r = g; r < n; r += 8) s += partials[r * stride + e];
-    sh[g * 32 + el] = s;
+    // four independent chains: the loop is bound by load latency, not bandwidth (a single chain ran at ~0.4 TB/s)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < count) {
+        const float* p = partials + e;
+        long long r = g;
+        for (; r + 24 < n; r += 32) {
+            s0 += p[r * stride];
+            s1 += p[(r + 8) * stride];
+            s2 += p[(r + 16) * stride];
+            s3 += p[(r + 24) * stride];
+        }
+        for (; r < n; r += 8) s0 += p[r * stride];
+    }
+    sh[g * 32 + el] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (g == 0 && e < count) {
         float t = 0.f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) t += sh[q * 32 + el];
         out[e] = t;
+    }
+}
+// The same sums for 16-byte aligned partial rows (count, stride multiples of 4): a block owns 128 consecutive elements,
+// every load moves 16 bytes, four rows in flight per thread.  sh: [8][128].
+__device__ __forceinline__ void reduce_chunk4(const float* partials, long long n, long long stride, long long count,
+                                              float* out, long long chunk, float* sh) {
+    const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const long long e = chunk * 128 + 4 * el;
+    v4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (e < count) {
+        const float* p = partials + e;
+        long long r = g;
+        for (; r + 24 < n; r += 32) {
+            s0 += *reinterpret_cast<const v4*>(p + r * stride);
+            s1 += *reinterpret_cast<const v4*>(p + (r + 8) * stride);
+            s2 += *reinterpret_cast<const v4*>(p + (r + 16) * stride);
+            s3 += *reinterpret_cast<const v4*>(p + (r + 24) * stride);
+        }
+        for (; r < n; r += 8) s0 += *reinterpret_cast<const v4*>(p + r * stride);
+    }
+    *reinterpret_cast<v4*>(sh + g * 128 + 4 * el) = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && e < count) {
+        v4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += *reinterpret_cast<const v4*>(sh + q * 128 + 4 * el);
+        *reinterpret_cast<v4*>(out + e) = t;
     }
 }
 __global__ void __launch_bounds__(kThreads) mlp_reduce_kernel(const float* partials, long long n, long long stride,
@@ -1825,9 +1869,12 @@ inline int forward(const mappo_mlp_t* m, hipStream_t stream) {
     return MAPPO_LAUNCH_ERROR();
 }
 
+inline long long chain_floats(int n_layers, int out) {
+    return ((long long)(kBwdGridCap + 1) * r_total(n_layers, out) + 3) & ~3LL;
+}
 inline long long workspace_floats(int din, int n_layers, int out) {
-    // chain partials (one row per workgroup) | reduced raw sums | first-layer partials
-    return (long long)(kBwdGridCap + 1) * r_total(n_layers, out) + (long long)kD2GridCap * 64LL * din;
+    // chain partials (one row per workgroup) | reduced raw sums | (16-byte boundary) first-layer partials
+    return chain_floats(n_layers, out) + (long long)kD2GridCap * 64LL * din;
 }
 
 inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
@@ -1871,7 +1918,7 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
     d.dz1 = m->dz1;
     const long long rt = r_total(L, out);
     float* raw = m->workspace + (long long)kBwdGridCap * rt;        // reduced raw sums of the version-2 chain
-    d.partials = m->workspace + workspace_floats(din, L, out) - (long long)kD2GridCap * 64LL * din;
+    d.partials = m->workspace + chain_floats(L, out);
     const int gy = (int)ceil_div(din, kDw1Slab);
     long long gx;
     if (din % 4 == 0 && din <= 64) {
@@ -1911,9 +1958,10 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
     t.c2 = rt;
     t.raw = raw;
     t.ticket = prim::ticket_counter();
-    t.nb1 = (int)ceil_div(p1, 32);
+    t.wide1 = ((reinterpret_cast<uintptr_t>(t.p1) | reinterpret_cast<uintptr_t>(m->grads)) & 15) == 0 && p1 % 4 == 0;
+    t.nb1 = (int)ceil_div(p1, t.wide1 ? 128 : 32);
     t.nb2 = (int)ceil_div(rt, 32);
-    MAPPO_LAUNCH(mlp_tail_kernel, (unsigned)(t.nb1 + t.nb2), kThreads, 1028, stream, t);
+    MAPPO_LAUNCH(mlp_tail_kernel, (unsigned)(t.nb1 + t.nb2), kThreads, 4 * 1025, stream, t);
     return MAPPO_LAUNCH_ERROR();
 }
 

@@ -115,8 +115,9 @@ class R_MAPPO():
             self.value_normalizer.update(return_batch)
             return
         x = return_batch.detach()
+        # (torch.full, not torch.tensor(..., device=): a host scalar uploaded with a blocking copy drains the stream)
         stats = torch.stack([x.sum(0).reshape(()).double(), (x ** 2).sum(0).reshape(()).double(),
-                             torch.tensor(float(x.shape[0]), dtype=torch.float64, device=x.device)])
+                             torch.full((), float(x.shape[0]), dtype=torch.float64, device=x.device)])
         self.dp.all_reduce(stats)
         mean = (stats[0] / stats[2]).float().reshape(1)
         mean_sq = (stats[1] / stats[2]).float().reshape(1)
@@ -333,13 +334,24 @@ class R_MAPPO():
         f32 = dict(dtype=torch.float32, device=dev)
         actions = check(actions).to(**f32)
         avail = None if avail is None else check(avail).to(**f32)
+        # Nothing below may touch the host: a Python scalar turned into a device tensor (torch.as_tensor(1.0, device=...))
+        # is a blocking copy that drains the stream once per update -- the ~40 small launches up to the first trunk
+        # kernel then run at launch latency instead of from a filled queue (0.5 ms per update at a 512-thread shard).
         n_rows = torch.full((), float(rows), **f32)
-        active_total = active.sum()
-        inv_local = 1.0 / torch.stack([active_total if self._use_policy_active_masks else n_rows,
-                                       active_total if self._use_value_active_masks else n_rows])
+        masked = self._use_policy_active_masks or self._use_value_active_masks
+        active_total = active.sum() if masked else n_rows
+        # [1 / policy denominator, 1 / value denominator, 1 / rows] of THIS rank's minibatch
+        inv3 = 1.0 / torch.stack([active_total if self._use_policy_active_masks else n_rows,
+                                  active_total if self._use_value_active_masks else n_rows, n_rows])
+        inv_local = inv3[:2]
         # data-parallel weights are local / global denominators, so this is 1 / the GLOBAL denominators
-        inv = (inv_local * torch.stack([torch.as_tensor(w_actor, **f32).reshape(()),
-                                        torch.as_tensor(w_critic, **f32).reshape(())])).contiguous()
+        if torch.is_tensor(w_actor) or torch.is_tensor(w_critic):
+            inv = (inv_local * torch.stack([torch.as_tensor(w_actor, **f32).reshape(()),
+                                            torch.as_tensor(w_critic, **f32).reshape(())])).contiguous()
+        elif w_actor == 1.0 and w_critic == 1.0:
+            inv = inv_local
+        else:
+            inv = torch.stack([inv_local[0] * float(w_actor), inv_local[1] * float(w_critic)])
         sums = torch.zeros(4, dtype=torch.float64, device=dev)
         normalized = self._use_popart or self._use_valuenorm
         for lo, hi in spans:
@@ -360,8 +372,9 @@ class R_MAPPO():
             else:
                 values.backward(dvalues)
             del values, logits, dlogits, dvalues
-        means = sums.float()
-        return means[2] * inv_local[1], means[0] * inv_local[0], means[1] * inv_local[0], means[3] / n_rows
+        # sums = [policy loss, entropy, value loss, ratio] numerators -> local means, one launch
+        means = sums.float() * torch.stack([inv3[0], inv3[0], inv3[1], inv3[2]])
+        return means[2], means[0], means[1], means[3]
 
     def _fused_trunks(self, fold):
         """Both networks' trunks qualify for the fused kernels (K9) and expect the kind of rows the sampler would hand
@@ -450,12 +463,14 @@ class R_MAPPO():
                 finally:
                     self._obs_standardized = False
                 with torch.no_grad():
+                    ratio = imp_weights.detach()
+                    ratio = ratio.reshape(()) if ratio.numel() == 1 else ratio.mean()     # (the fused loss returns the mean)
                     totals += torch.stack([
                         value_loss.detach().reshape(()), policy_loss.detach().reshape(()),
                         dist_entropy.detach().reshape(()),
                         torch.as_tensor(actor_grad_norm, **self.tpdv).reshape(()),
                         torch.as_tensor(critic_grad_norm, **self.tpdv).reshape(()),
-                        imp_weights.detach().mean().reshape(())])
+                        ratio])
 
         num_updates = self.ppo_epoch * self.num_mini_batch
         totals = self.dp.average_info(totals / num_updates)

@@ -154,8 +154,8 @@ class DataParallel(object):
         if not self.active:
             return 1.0, 1.0
         local = torch.stack([active_masks.detach().sum().double(),
-                             torch.tensor(float(active_masks.shape[0]), dtype=torch.float64,
-                                          device=active_masks.device)])
+                             torch.full((), float(active_masks.shape[0]), dtype=torch.float64,
+                                        device=active_masks.device)])
         total = local.clone()
         self.all_reduce(total)
         w = (local / total).float()
@@ -168,7 +168,8 @@ class DataParallel(object):
         r_mappo.py:135-139, 84-87); the moments feed the ValueNorm / PopArt update (r_mappo.py:65)."""
         am = active_masks.detach()
         ret = return_batch.detach()
-        local = torch.stack([am.sum().double(), torch.tensor(float(am.shape[0]), dtype=torch.float64, device=am.device),
+        # (the row count goes up with torch.full: torch.tensor(x, device=...) is a blocking copy that drains the stream)
+        local = torch.stack([am.sum().double(), torch.full((), float(am.shape[0]), dtype=torch.float64, device=am.device),
                              ret.sum().double(), (ret * ret).sum().double()])
         total = local.clone()
         self.all_reduce(total)

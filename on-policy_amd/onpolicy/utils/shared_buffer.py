@@ -174,16 +174,19 @@ class SharedReplayBuffer(object):
     def profile_kernels(self, enabled=True):
         self._events = {} if enabled else None
 
-    def _timed(self, name, nbytes):
+    def _timed(self, name, nbytes, settle=False):
         if self._events is None:
             return None
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), nbytes)
         self._events.setdefault(name, []).append(ev)
-        # Keep the stream busy for ~0.1 ms first: on an idle stream the start event would fire at
-        # once and the interval would include the host's launch latency (tens of microseconds of
-        # Python / ctypes), not just the kernel.  Behind the spin, start event, kernel and end event
-        # are all queued before the GPU reaches them, so the interval is the kernel's duration.
-        torch.cuda._sleep(250000)
+        if settle:
+            # (the GAE launch, first kernel of a step:) keep the stream busy for ~0.1 ms first: on an idle stream the
+            # start event would fire at once and the interval would include the host's launch latency (tens of
+            # microseconds of Python / ctypes), not just the kernel.  Behind the spin, start event, kernel and end event
+            # are all queued before the GPU reaches them, so the interval is the kernel's duration.  Once per step:
+            # the sampler's gathers run from a filled queue and are timed without it (ten spins per step were 2.5 % of
+            # an 8-GPU shard's step).
+            torch.cuda._sleep(250000)
         ev[0].record(torch.cuda.current_stream(self.device))
         return ev
 
@@ -391,7 +394,7 @@ class SharedReplayBuffer(object):
         if self.algo in ("mat", "mat_dec") and self._use_gae and not self._use_proper_time_limits:
             # transformer branches (reference shared_buffer.py:222-232, :241-251): the advantages are the
             # GAE accumulator itself and, without a normaliser, the TD error uses the agent-mean value
-            ev = self._timed("mappo_gae_mat_f32", 24 * T * N * A)
+            ev = self._timed("mappo_gae_mat_f32", 24 * T * N * A, settle=True)
             code = self._lib.mappo_gae_mat_f32(
                 p(self.rewards), p(self.value_preds), p(nv), p(self.masks), p(self.returns), p(denorm),
                 p(self.advantages), p(self.active_masks), p(self._adv_partials), T, N * A, A,
@@ -409,7 +412,7 @@ class SharedReplayBuffer(object):
         self._adv_is_gae = False
         # algorithmic bytes: r, v, m reads + returns write (16 B) + advantages write + active read
         # (+8 B) [+ bad_masks read 4 B] per (t, n, a) element  
-        ev = self._timed("mappo_gae_f32", (24 + (4 if self._use_proper_time_limits else 0)) * T * N * A)
+        ev = self._timed("mappo_gae_f32", (24 + (4 if self._use_proper_time_limits else 0)) * T * N * A, settle=True)
         code = self._lib.mappo_gae_f32(
             p(self.rewards), p(self.value_preds), p(nv), p(self.masks),
             p(self.bad_masks) if self._use_proper_time_limits else None, p(self.returns), p(denorm),

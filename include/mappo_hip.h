@@ -364,9 +364,10 @@ int mappo_gru_step_fwd(const float* gi, const float* hm, const float* w_hh, cons
  *   stats [mappo_gru_seq_stats_floats(L, mb)].
  * mappo_gru_seq_backward (truncated BPTT inside the launch): dy [L * mb, 64] (+ dh_last [mb, 64], optional) -> dx [L * mb, 64], dh0 [mb, 64] (optional),
  *   dgi [L * mb, 192] = gradient at W_ih x + b_ih, dq [L * mb, 64] = gradient at W_hn hm + b_hn (the r and z thirds of the
- *   hidden side's gradient are dgi's) -- the caller forms dW_ih = dgi^T x, dW_hh = [dgi_rz | dq]^T hm and the bias
- *   gradients (column sums) from them -- and ln_grads [128] = LayerNorm weight | bias gradients; workspace
- *   [mappo_gru_seq_workspace_floats()] scratch.  Deterministic run to run. */
+ *   hidden side's gradient are dgi's) -- the caller forms dW_ih = dgi^T x and dW_hh = [dgi_rz | dq]^T hm from them -- and
+ *   ln_grads [384] = LayerNorm weight | bias gradients [128], then the column sums of dgi [192] (= db_ih; its first 128 are
+ *   also the r and z thirds of db_hh) and of dq [64] (= the n third of db_hh), folded over the rows inside the launch;
+ *   workspace [mappo_gru_seq_workspace_floats()] scratch.  Deterministic run to run. */
 typedef struct mappo_gru_seq {
     const float* x;
     const float* h0;
@@ -392,7 +393,7 @@ typedef struct mappo_gru_seq {
     float* dq;
     float* dh0;
     const float* dh_last;   /* [mb, 64] gradient at h_last, or NULL */
-    float* ln_grads;
+    float* ln_grads;        /* [384], see above */
     float* workspace;
 } mappo_gru_seq_t;
 int64_t mappo_gru_seq_gates_floats(int L, int64_t mb);

@@ -59,8 +59,10 @@ struct Args {
     float* dq;              // [L * mb, 64]  gradient at W_hn hm + b_hn (the r and z thirds of the hidden side equal dgi's)
     float* dh0;             // [mb, 64] or NULL
     const float* dh_last;   // [mb, 64] gradient at h_last, or NULL (none)
-    float* partials;        // [gridDim.x][128]: LayerNorm weight | bias gradient sums per workgroup
+    float* partials;        // [gridDim.x][kSums]: LayerNorm weight | bias gradient sums, then the column sums of the gate
+                            // gradients (r | z | n of dgi, then dq) per workgroup
 };
+constexpr int kSums = 128 + 256;
 
 __host__ __device__ __forceinline__ long long tiles_of(long long mb) { return (mb + 31) / 32; }
 
@@ -113,6 +115,22 @@ __device__ __forceinline__ void slots_of(const float* vec, int h, float* out) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) out[16 * t + 4 * q + e] = b[e];
         }
+}
+
+// Column sums over the wave's 32 rows of a slot-order array: lane (h, c) returns the sum over the 32 lanes of its
+// half-wave of slot c, i.e. of feature f(h, c) -- a reduce-scatter butterfly (31 exchange-and-add steps, each halving the
+// values a lane still carries), all in registers.
+__device__ __forceinline__ float colsum32(const float* v) {
+    float w[16], x[8], y[4], z[2];
+    prim::rs16_8(v, v + 16, w);
+    prim::rs16_8(v + 8, v + 24, w + 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = prim::rs_step<8, 3>(w[i], w[i + 8]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = prim::rs_step<7, 2>(x[i], x[i + 4]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) z[i] = prim::rs_step<2, 1>(y[i], y[i + 2]);
+    return prim::rs_step<1, 0>(z[0], z[1]);
 }
 
 __device__ __forceinline__ float sigmoid_fast(float x) {
@@ -250,9 +268,13 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
     for (int e = tid; e < 64; e += kThreads) gam[e] = a.ln_g[e];
     float* T = gam + 64 + wave * 64 * kTS;
     __syncthreads();
-    float dgam[32], dbet[32];       // row layout (this lane's row position): LayerNorm weight / bias gradient sums
-#pragma unroll
-    for (int s = 0; s < 32; ++s) dgam[s] = dbet[s] = 0.f;
+    // Parameter gradients that are column sums over every row and step -- the LayerNorm weight / bias gradients and the
+    // bias gradients (= column sums of the gate gradients) -- are folded over the wave's rows step by step (colsum32), so
+    // a lane carries ONE running sum per vector: that of feature f(h, c).  (Row-layout accumulators for the LayerNorm
+    // pair alone were 64 registers of a kernel that spills; as separate passes over the [rows, 192] + [rows, 64] arrays
+    // this kernel writes, the bias sums were 6 % of the recurrent north-star step.)
+    float sgam = 0.f, sbet = 0.f;
+    float sbr = 0.f, sbz = 0.f, sbn = 0.f, sbq = 0.f;
     const long long mb = a.mb, ntiles = tiles_of(mb);
     const int L = a.L;
     for (long long tile = (long long)blockIdx.x * kWaves + wave; tile < ntiles; tile += (long long)gridDim.x * kWaves) {
@@ -299,16 +321,20 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
             // output LayerNorm backward (rows past the end: dy = 0 -> every gradient below is 0)
             float m1 = 0.f, m2 = 0.f;
             {
-                float gslot[32];
+                float gslot[32], gn[32];
                 slots_of(gam, h, gslot);
 #pragma unroll
                 for (int s = 0; s < 32; ++s) {
                     if (!ok) g[s] = 0.f;
-                    dbet[s] += g[s];
-                    dgam[s] += g[s] * nh[s];
+                    gn[s] = g[s] * nh[s];
+                }
+                sbet += colsum32(g);
+                sgam += colsum32(gn);
+#pragma unroll
+                for (int s = 0; s < 32; ++s) {
                     g[s] *= gslot[s];
                     m1 += g[s];
-                    m2 += g[s] * nh[s];
+                    m2 += gn[s] * gslot[s];
                 }
             }
             m1 += prim::xhalf(m1);
@@ -332,6 +358,10 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
                 mlp::store_row64(a.dgi + row * 192 + 128, dan, h);
                 mlp::store_row64(a.dq + row * 64, dqq, h);
             }
+            sbr += colsum32(dar);       // (rows past the end carry zeros)
+            sbz += colsum32(daz);
+            sbn += colsum32(dan);
+            sbq += colsum32(dqq);
             f32x16 acc[2];
             zero2(acc);
             dense64_acc(lds + 0 * 64 * kWS, c, h, dar, acc);
@@ -352,23 +382,22 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
         }
         if (a.dh0 != nullptr && ok) mlp::store_row64(a.dh0 + j * 64, carry, h);
     }
-    // ---- LayerNorm parameter gradients: row layout -> lane = feature, waves added through LDS
+    // ---- the waves' sums added through LDS
     prim::wave_sync();
-    mlp::put_transposed(T, dgam, c, h);
-    prim::wave_sync();
-    const float sg = mlp::rowsum32(T + lane * kTS);
-    prim::wave_sync();
-    mlp::put_transposed(T, dbet, c, h);
-    prim::wave_sync();
-    const float sb = mlp::rowsum32(T + lane * kTS);
-    prim::wave_sync();
-    T[lane] = sg;
-    T[64 + lane] = sb;
+    {
+        const int f = feat_of(h, c);
+        T[f] = sgam;
+        T[64 + f] = sbet;
+        T[128 + f] = sbr;
+        T[192 + f] = sbz;
+        T[256 + f] = sbn;
+        T[320 + f] = sbq;
+    }
     __syncthreads();
-    if (tid < 128) {
+    for (int e = tid; e < kSums; e += kThreads) {
         float s = 0.f;
-        for (int w = 0; w < kWaves; ++w) s += gam[64 + w * 64 * kTS + tid];
-        a.partials[(long long)blockIdx.x * 128 + tid] = s;
+        for (int w = 0; w < kWaves; ++w) s += gam[64 + w * 64 * kTS + e];
+        a.partials[(long long)blockIdx.x * kSums + e] = s;
     }
 }
 
@@ -434,8 +463,8 @@ inline int backward(const mappo_gru_seq_t* m, hipStream_t stream) {
     fill(m, a);
     const long long grid = grid_of(m->mb);
     MAPPO_LAUNCH(gru_seq_bwd_kernel, (unsigned)grid, kThreads, (size_t)kBwdLds * 4, stream, a);
-    MAPPO_LAUNCH(mlp::mlp_reduce_kernel, 4u, mlp::kThreads, 1024, stream, (const float*)m->workspace, grid, 128LL, 128LL,
-                 m->ln_grads);
+    MAPPO_LAUNCH(mlp::mlp_reduce_kernel, (unsigned)(kSums / 32), mlp::kThreads, 1024, stream, (const float*)m->workspace, grid,
+                 (long long)kSums, (long long)kSums, m->ln_grads);
     return MAPPO_LAUNCH_ERROR();
 }
 

@@ -22,6 +22,64 @@ __device__ __forceinline__ float sum16(float v) {
     v += __shfl_xor(v, 1);
     return v;
 }
+// One step of a reduce-scatter over lanes: lanes whose bit BIT is clear return a + (a of lane ^ XOR), the others
+// b + (b of lane ^ XOR).  The exchanges are register-to-register (v_permlane16_swap between the 16-lane rows, DPP inside a
+// row: no LDS crossbar like __shfl_xor's ds_bpermute), so 31 of them fold a lane's 32 values over the 32 lanes of its
+// half-wave in ~90 VALU instructions.
+template <int XOR, int BIT>
+__device__ __forceinline__ float rs_step(float a, float b);
+#define MAPPO_DPP(v, ctrl) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+// The step between the 16-lane rows, eight pairs at a time: out[i] = rs_step<16, 4>(a[i], b[i]).  v_permlane16_swap_b32
+// exchanges rows 1 / 3 of its first operand with rows 0 / 2 of the second, after which every lane holds its own and
+// its partner's copy of the value it keeps.  Inline assembly: this compiler's __builtin_amdgcn_permlane16_swap returns its
+// FIRST result in both halves of the pair (tools/probes/probe_rs_step.hip); the leading s_nop covers the two wait states
+// the instruction needs after a VALU write of its operands (the compiler does not look inside the block).
+__device__ __forceinline__ void rs16_8(const float* a, const float* b, float* out) {
+    float x0 = a[0], x1 = a[1], x2 = a[2], x3 = a[3], x4 = a[4], x5 = a[5], x6 = a[6], x7 = a[7];
+    float y0 = b[0], y1 = b[1], y2 = b[2], y3 = b[3], y4 = b[4], y5 = b[5], y6 = b[6], y7 = b[7];
+    asm("s_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %8\n\t"
+        "v_permlane16_swap_b32 %1, %9\n\t"
+        "v_permlane16_swap_b32 %2, %10\n\t"
+        "v_permlane16_swap_b32 %3, %11\n\t"
+        "v_permlane16_swap_b32 %4, %12\n\t"
+        "v_permlane16_swap_b32 %5, %13\n\t"
+        "v_permlane16_swap_b32 %6, %14\n\t"
+        "v_permlane16_swap_b32 %7, %15\n\t"
+        "s_nop 0"
+        : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(y0), "+v"(y1), "+v"(y2),
+          "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7));
+    out[0] = x0 + y0;
+    out[1] = x1 + y1;
+    out[2] = x2 + y2;
+    out[3] = x3 + y3;
+    out[4] = x4 + y4;
+    out[5] = x5 + y5;
+    out[6] = x6 + y6;
+    out[7] = x7 + y7;
+}
+template <>
+__device__ __forceinline__ float rs_step<8, 3>(float a, float b) {        // row_ror:8
+    const float t = a + MAPPO_DPP(a, 0x128), u = b + MAPPO_DPP(b, 0x128);
+    return (threadIdx.x & 8) ? u : t;
+}
+template <>
+__device__ __forceinline__ float rs_step<7, 2>(float a, float b) {        // row_half_mirror: lane ^ 7
+    const float t = a + MAPPO_DPP(a, 0x141), u = b + MAPPO_DPP(b, 0x141);
+    return (threadIdx.x & 4) ? u : t;
+}
+template <>
+__device__ __forceinline__ float rs_step<2, 1>(float a, float b) {        // quad_perm [2, 3, 0, 1]
+    const float t = a + MAPPO_DPP(a, 0x4E), u = b + MAPPO_DPP(b, 0x4E);
+    return (threadIdx.x & 2) ? u : t;
+}
+template <>
+__device__ __forceinline__ float rs_step<1, 0>(float a, float b) {        // quad_perm [1, 0, 3, 2]
+    const float t = a + MAPPO_DPP(a, 0xB1), u = b + MAPPO_DPP(b, 0xB1);
+    return (threadIdx.x & 1) ? u : t;
+}
+#undef MAPPO_DPP
 __device__ __forceinline__ float exp2_fast(float v) { return __builtin_amdgcn_exp2f(v); }   // v_exp_f32
 __device__ __forceinline__ float rcp_fast(float v) { return __builtin_amdgcn_rcpf(v); }     // v_rcp_f32
 // scheduling barrier: the compiler may not move instructions across it (used to keep operand prefetches early)
@@ -152,7 +210,7 @@ extern "C" int mappo_standardize_rows_ld(const float* src, int64_t rows, int D, 
 // K12: the GRU over a whole chunk (mappo_gru_impl.h, same primitives)
 extern "C" int64_t mappo_gru_seq_gates_floats(int L, int64_t mb) { return (int64_t)L * gru::tiles_of(mb) * gru::kSaved * 2048; }
 extern "C" int64_t mappo_gru_seq_stats_floats(int L, int64_t mb) { return (int64_t)L * gru::tiles_of(mb) * 64; }
-extern "C" int64_t mappo_gru_seq_workspace_floats(void) { return (int64_t)gru::kGridCap * 128; }
+extern "C" int64_t mappo_gru_seq_workspace_floats(void) { return (int64_t)gru::kGridCap * gru::kSums; }
 extern "C" int mappo_gru_seq_forward(const mappo_gru_seq_t* seq, mappo_stream_t stream) {
     g_launch_error = 0;
     return gru::forward(seq, static_cast<hipStream_t>(stream));

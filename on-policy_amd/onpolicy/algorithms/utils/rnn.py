@@ -100,8 +100,9 @@ class _GRUChunkFn(torch.autograd.Function):
     """RNNLayer (one GRU layer of width 64 + its output LayerNorm) over a whole chunk as ONE launch per direction
     (K12, ``mappo_gru_seq_forward`` / ``_backward``): x [L * B, 64], h0 [B, 64], masks [L * B] -> (y [L * B, 64] =
     LayerNorm(h_l), h_last [B, 64]).  The backward kernel walks the chunk in reverse (truncated BPTT inside the launch)
-    and hands back d x, d h0, the LayerNorm gradients and the gate gradients; the two weight gradients are split-K GEMMs
-    over all L * B rows here, the bias gradients column sums."""
+    and hands back d x, d h0, the LayerNorm gradients, the bias gradients (column sums of the gate gradients, folded
+    over the rows inside the launch) and the gate gradients; the two weight gradients are split-K GEMMs over all L * B
+    rows here."""
 
     @staticmethod
     def forward(ctx, x, h0, masks, w_ih, w_hh, b_ih, b_hh, ln_g, ln_b, eps, L):
@@ -142,7 +143,7 @@ class _GRUChunkFn(torch.autograd.Function):
         dgi = torch.empty(L * B, 192, **f32)
         dq = torch.empty(L * B, 64, **f32)
         dh0 = torch.empty(B, 64, **f32) if ctx.needs_input_grad[1] else None
-        ln_grads = torch.empty(128, **f32)
+        ln_grads = torch.empty(384, **f32)        # LayerNorm weight | bias gradients, column sums of dgi [192] and dq [64]
         ws = torch.empty(lib.mappo_gru_seq_workspace_floats(), **f32)
         m = _native.GRUSeq(x=p(x), h0=p(h0), masks=p(masks), w_ih=p(w_ih), w_hh=p(w_hh), b_ih=p(b_ih), b_hh=p(b_hh),
                            ln_g=p(ln_g), ln_b=p(ln_b), ln_eps=eps, H=64, L=L, mb=B, gates=p(gates), hm=p(hm),
@@ -152,9 +153,9 @@ class _GRUChunkFn(torch.autograd.Function):
         # dW_ih = dgi^T x; the hidden side's gate gradient is [dgi_r | dgi_z | dq]
         dw_ih = splitk_weight_grad(dgi, x)
         dw_hh = torch.cat([splitk_weight_grad(dgi[:, :128], hm), splitk_weight_grad(dq, hm)], 0)
-        db_ih = column_sums(dgi)
-        db_hh = torch.cat([db_ih[:128], column_sums(dq)])
-        return dx, dh0, None, dw_ih, dw_hh, db_ih, db_hh, ln_grads[:64], ln_grads[64:], None, None
+        db_ih = ln_grads[128:320]
+        db_hh = torch.cat([ln_grads[128:256], ln_grads[320:384]])
+        return dx, dh0, None, dw_ih, dw_hh, db_ih, db_hh, ln_grads[:64], ln_grads[64:128], None, None
 
 
 # MAPPO_GRU_CHUNK=0 keeps the step-by-step kernels below for the update (one launch per step and direction)

@@ -50,6 +50,24 @@ inline float sum16(float v) {
     simt::wait(w.bar);
     return s;
 }
+// one step of a reduce-scatter over lanes: lanes whose bit BIT is clear return a + (a of lane ^ XOR), the others
+// b + (b of lane ^ XOR) (XOR always flips bit BIT)
+template <int XOR, int BIT>
+inline float rs_step(float a, float b) {
+    static_assert((XOR >> BIT) & 1, "the partner must sit on the other side");
+    simt::Wave& w = my_wave();
+    const unsigned lane = simt::st().cur->tid & 63;
+    w.a[lane] = a;
+    w.b[lane] = b;
+    simt::wait(w.bar);
+    const unsigned p = lane ^ XOR;
+    const float r = ((lane >> BIT) & 1) ? b + w.b[p] : a + w.a[p];
+    simt::wait(w.bar);
+    return r;
+}
+inline void rs16_8(const float* a, const float* b, float* out) {
+    for (int i = 0; i < 8; ++i) out[i] = rs_step<16, 4>(a[i], b[i]);
+}
 }  // namespace prim
 
 #include "../../on-policy_amd/csrc/mappo_mlp_impl.h"
@@ -85,6 +103,6 @@ extern "C" unsigned long long simt_mfma_count() { return simt::st().n_mfma; }
 
 extern "C" int64_t mappo_gru_seq_gates_floats(int L, int64_t mb) { return (int64_t)L * gru::tiles_of(mb) * gru::kSaved * 2048; }
 extern "C" int64_t mappo_gru_seq_stats_floats(int L, int64_t mb) { return (int64_t)L * gru::tiles_of(mb) * 64; }
-extern "C" int64_t mappo_gru_seq_workspace_floats(void) { return (int64_t)gru::kGridCap * 128; }
+extern "C" int64_t mappo_gru_seq_workspace_floats(void) { return (int64_t)gru::kGridCap * gru::kSums; }
 extern "C" int mappo_gru_seq_forward(const mappo_gru_seq_t* seq, mappo_stream_t stream) { return gru::forward(seq, stream); }
 extern "C" int mappo_gru_seq_backward(const mappo_gru_seq_t* seq, mappo_stream_t stream) { return gru::backward(seq, stream); }

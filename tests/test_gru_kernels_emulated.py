@@ -66,7 +66,7 @@ def run(emu, L, mb, seed, grid_cap=0):
     stats = nan(emu.mappo_gru_seq_stats_floats(L, mb))
     hm = nan(L * mb, 64)
     dx, dgi, dq, dh0 = nan(L * mb, 64), nan(L * mb, 192), nan(L * mb, 64), nan(mb, 64)
-    ln_grads, ws = nan(128), nan(emu.mappo_gru_seq_workspace_floats())
+    ln_grads, ws = nan(384), nan(emu.mappo_gru_seq_workspace_floats())
     ptr = lambda a: a.ctypes.data
     m = _native.GRUSeq(x=ptr(x), h0=ptr(h0), masks=ptr(masks), w_ih=ptr(P["w_ih"]), w_hh=ptr(P["w_hh"]), b_ih=ptr(P["b_ih"]),
                        b_hh=ptr(P["b_hh"]), ln_g=ptr(P["ln_g"]), ln_b=ptr(P["ln_b"]), ln_eps=1e-5, H=64, L=L, mb=mb,
@@ -95,7 +95,10 @@ def run(emu, L, mb, seed, grid_cap=0):
     close(dx, tx.grad, "dx")
     close(dh0, th0.grad, "dh0")
     close(ln_grads[:64], tp["ln_g"].grad, "ln weight")
-    close(ln_grads[64:], tp["ln_b"].grad, "ln bias")
+    close(ln_grads[64:128], tp["ln_b"].grad, "ln bias")
+    # the bias gradients come out of the launch (column sums of the gate gradients, folded over the rows in registers)
+    close(ln_grads[128:320], tp["b_ih"].grad, "b_ih (in-kernel)")
+    close(np.concatenate([ln_grads[128:256], ln_grads[320:384]]), tp["b_hh"].grad, "b_hh (in-kernel)")
     # what the caller forms from the gate gradients (onpolicy/algorithms/utils/rnn.py: _GRUChunkFn.backward)
     d64 = lambda a: a.astype(np.float64)
     close(d64(dgi).T @ d64(x), tp["w_ih"].grad, "w_ih")

@@ -1400,10 +1400,14 @@ constexpr int kD2GridCap = 256;
 #define MAPPO_D2_MIN_WIDTH 128                   // (tuning: tools/ab_build.sh; 152 columns: 2.01 ms per 2.6 M rows against 2.16)
 #endif
 constexpr int kD2MinWidth = MAPPO_D2_MIN_WIDTH;  // narrower inputs leave most waves without a k tile: loader version
-constexpr int kD2XSlot = 3 * kD2Rows * 32;       // floats: [k tile i < 3][16 rows][32]
+// A wave owns up to MAXNT k tiles of its workgroup's slab of 128 MAXNT columns.  MAXNT = 3 (384-column slabs, 120 KB of LDS)
+// or 4 (512 columns, 152 KB): the launcher takes 4 where that saves a slab -- widths in (384, 512] had a second slab of a
+// few k tiles whose workgroups idled most of the launch (SMAC's 436-wide critic input: 49 instead of 100 TFLOP/s).
+constexpr int d2_xslot(int maxnt) { return maxnt * kD2Rows * 32; }        // floats: [k tile i < MAXNT][16 rows][32]
 constexpr int kD2DzSlot = kD2Rows * 64;          // floats: [16 rows][64 features], shared by the 4 waves
-constexpr int kD2Lds = 4 * kD2Slots * kD2XSlot + kD2Slots * kD2DzSlot;       // floats, + the row-table rings:
+constexpr int d2_lds(int maxnt) { return 4 * kD2Slots * d2_xslot(maxnt) + kD2Slots * kD2DzSlot; }   // floats, + the row-table rings:
 constexpr int kD2TabRing = 2 * kD2Slots;         // 256-byte slots per wave
+inline int d2_maxnt(int din) { return (din + 511) / 512 < (din + 383) / 384 ? 4 : 3; }
 
 // the 8 MFMA steps of one 16-row tile (step s contracts rows s and 8 + s) for a wave that owns NT k tiles
 template <int NT>
@@ -1435,9 +1439,10 @@ __device__ __forceinline__ void dw1_tile_steps(const float* xt, const float* dzt
     }
 }
 
-// the whole kernel for a wave that owns NT (0 .. 3) k tiles: tiles wave, wave + 4, wave + 8 of the slab
-template <int NT>
+// the whole kernel for a wave that owns NT (0 .. MAXNT) k tiles: tiles wave, wave + 4, wave + 8 (, wave + 12) of the slab
+template <int NT, int MAXNT>
 __device__ __forceinline__ void dw1_direct_body(const Dw1Args& a, float* lds, int wave, int k0) {
+    constexpr int kD2XSlot = d2_xslot(MAXNT), kD2Lds = d2_lds(MAXNT);
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, h = lane >> 5;
     const int din = a.rs.din;
     const long long rows = a.rs.rows;
@@ -1523,18 +1528,21 @@ __device__ __forceinline__ void dw1_direct_body(const Dw1Args& a, float* lds, in
     }
 }
 
+template <int MAXNT>
 __global__ void __launch_bounds__(kThreads) mlp_dw1_direct_kernel(Dw1Args a) {
     float* lds = prim::lds();
     const int wave = prim::uniform(threadIdx.x >> 6);
     const int din = a.rs.din;
-    const int k0 = blockIdx.y * kDw1Slab;
-    const int kw = (din - k0 < kDw1Slab ? ((din - k0 + 31) / 32) * 32 : kDw1Slab);
+    constexpr int slab = 128 * MAXNT;
+    const int k0 = blockIdx.y * slab;
+    const int kw = (din - k0 < slab ? ((din - k0 + 31) / 32) * 32 : slab);
     const int ntk = kw / 32;
-    const int n_own = (wave < ntk) + (wave + 4 < ntk) + (wave + 8 < ntk);
-    if (n_own == 3) dw1_direct_body<3>(a, lds, wave, k0);
-    else if (n_own == 2) dw1_direct_body<2>(a, lds, wave, k0);
-    else if (n_own == 1) dw1_direct_body<1>(a, lds, wave, k0);
-    else dw1_direct_body<0>(a, lds, wave, k0);
+    const int n_own = (wave < ntk) + (wave + 4 < ntk) + (wave + 8 < ntk) + (MAXNT > 3 && wave + 12 < ntk);
+    if (MAXNT > 3 && n_own == 4) dw1_direct_body<MAXNT, MAXNT>(a, lds, wave, k0);
+    else if (n_own == 3) dw1_direct_body<3, MAXNT>(a, lds, wave, k0);
+    else if (n_own == 2) dw1_direct_body<2, MAXNT>(a, lds, wave, k0);
+    else if (n_own == 1) dw1_direct_body<1, MAXNT>(a, lds, wave, k0);
+    else dw1_direct_body<0, MAXNT>(a, lds, wave, k0);
 }
 
 // ---- narrow inputs (din <= 64, din % 4 == 0): one or two k tiles are not enough to split among four waves, so every wave
@@ -1919,7 +1927,9 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
     const long long rt = r_total(L, out);
     float* raw = m->workspace + (long long)kBwdGridCap * rt;        // reduced raw sums of the version-2 chain
     d.partials = m->workspace + chain_floats(L, out);
-    const int gy = (int)ceil_div(din, kDw1Slab);
+    const bool direct = din % 4 == 0 && din >= kD2MinWidth;
+    const int maxnt = d2_maxnt(din);
+    const int gy = (int)ceil_div(din, direct ? 128 * maxnt : kDw1Slab);
     long long gx;
     if (din % 4 == 0 && din <= 64) {
         gx = capped(ceil_div(m->rows, 4 * kD2Rows), kD2GridCap);
@@ -1932,10 +1942,15 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
             MAPPO_LAUNCH(mlp_dw1_rows_kernel<2>, (unsigned)gx, kThreads, (size_t)(4 * kD2Slots * SL + 4 * kD2TabRing * 64) * 4,
                          stream, d);
         }
-    } else if (din % 4 == 0 && din >= kD2MinWidth) {
+    } else if (direct) {
         gx = capped(ceil_div(m->rows, kD2Rows), kD2GridCap / gy > 0 ? kD2GridCap / gy : 1);
-        MAPPO_LAUNCH(mlp_dw1_direct_kernel, dim3((unsigned)gx, (unsigned)gy), kThreads,
-                     (size_t)(kD2Lds + 4 * kD2TabRing * 64) * 4, stream, d);
+        if (maxnt == 4) {
+            MAPPO_LAUNCH(mlp_dw1_direct_kernel<4>, dim3((unsigned)gx, (unsigned)gy), kThreads,
+                         (size_t)(d2_lds(4) + 4 * kD2TabRing * 64) * 4, stream, d);
+        } else {
+            MAPPO_LAUNCH(mlp_dw1_direct_kernel<3>, dim3((unsigned)gx, (unsigned)gy), kThreads,
+                         (size_t)(d2_lds(3) + 4 * kD2TabRing * 64) * 4, stream, d);
+        }
     } else {
         gx = capped(ceil_div(m->rows, kDw1Rows), kDw1GridCap / gy > 0 ? kDw1GridCap / gy : 1);
         const size_t dw1_lds = (size_t)2 * kDw1Stage * 4;

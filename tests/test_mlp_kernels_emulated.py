@@ -101,7 +101,10 @@ CASES = [
     (19, 1, 1, 3, 37, 64),         # single layer, odd width (unaligned rows)
     (130, 3, 1, 0, 150, 300),      # layer_N = 2, trunk only (features for the GRU), three chunks with a tail
     (70, 2, 1, 2, 128 * 5 + 9, 900),   # several tiles and two chunks: the loaders' in-flight chunks cross tile boundaries
-    (388, 1, 2, 1, 45, 64),        # two k slabs in the first-layer weight gradient (din > 384), 16-byte aligned rows
+    (388, 1, 2, 1, 45, 64),        # din just above 384: one 512-column slab, waves with four and with three k tiles
+    (436, 2, 1, 1, 45, 64),        # SMAC's critic input width (padded): one 512-column slab
+    (768, 1, 2, 1, 40, 64),        # two full 384-column slabs in the first-layer weight gradient
+    (900, 1, 1, 2, 40, 64),        # two 512-column slabs, the second partly filled
     (28, 1, 2, 2, 16 * 9 + 1, 300),   # one k tile (row-split weight-gradient kernel), a tile with a single live row
     (200, 2, 1, 1, 16 * 7 + 5, 200),  # direct-to-LDS weight-gradient kernel: waves with two and with one k tile
     (40, 2, 2, 7, 32 * 9 + 3, 400),   # a head wider than the backward chain keeps in registers (sums through LDS), odd width

@@ -437,6 +437,23 @@ int     mappo_valuenorm_update(const float* x, int64_t n, const float* batch_mom
                                float* running_mean, float* running_mean_sq, float* debiasing_term, float* denorm,
                                double* workspace, mappo_stream_t stream);
 
+/* What a minibatch needs before its loss is formed (reference onpolicy/algorithms/r_mappo/r_mappo.py:135-139 and :84-87: the
+ * masked means divide by active_masks.sum(), the unmasked ones by the row count; :65 feeds ValueNorm / PopArt with the batch
+ * moments of the returns), three launches instead of ~13 PyTorch ones (27 with the data-parallel bookkeeping).
+ * mappo_minibatch_sums: active_masks [n], returns [n] -> sums [4] float64 = {sum active_masks, n, sum returns,
+ *   sum returns^2} (fixed summation order).  A data-parallel caller all-reduces a copy of them over the ranks.
+ * mappo_minibatch_scales: local / global sums (the same array for one rank) -> out [8] float32 =
+ *   {1 / global policy denominator, 1 / global value denominator, 1 / local policy denominator (twice), 1 / local value
+ *   denominator, 1 / local rows, mean and mean of squares of the returns over the global minibatch}; a denominator is the
+ *   active-mask sum when the loss is masked (use_policy_active_masks / use_value_active_masks), else the row count.
+ *   out[0..1] scale the fused loss (K7: `inv`), out[2..5] turn its four sums into the logged means, out[6..7] are
+ *   mappo_valuenorm_update's batch_moments. */
+int64_t mappo_minibatch_sums_workspace_doubles(void);
+int     mappo_minibatch_sums(const float* active_masks, const float* returns, int64_t n, double* sums, double* workspace,
+                             mappo_stream_t stream);
+int     mappo_minibatch_scales(const double* local_sums, const double* global_sums, int policy_masked, int value_masked,
+                               float* out, mappo_stream_t stream);
+
 /* --------------------------------------------------------------- K10: sort-free minibatch index lists ----
  * Device-side replacement of `rand = torch.randperm(B); slices = [rand[i*mb:(i+1)*mb] for i in range(n_mb)]`
  * (reference onpolicy/utils/shared_buffer.py:360-361 feed-forward, :415-416 whole trajectories, :511-512 chunks).

@@ -186,7 +186,90 @@ __global__ void vn_fold_kernel(const double* partials, int n_partials, double co
     denorm[1] = mu;
 }
 
+// ---------------------------------------------------------------- what a minibatch needs before its loss is formed ----
+// Denominators of the masked means (r_mappo.py:135-139 policy loss, :84-87 value loss: sum of active_masks, or the row
+// count) and the batch moments of the returns for the ValueNorm / PopArt update (r_mappo.py:65) -- in a data-parallel job the
+// GLOBAL ones, so the four sums are all-reduced between the two halves below.  In PyTorch this was ~13 launches per update
+// (27 with the data-parallel bookkeeping): at an 8-GPU shard of the north star 3 % of the step.
+// Launch 1 + 2: float64 sums of active_masks, returns, returns^2 (per block, then in block order) -> [sum active, rows,
+// sum returns, sum returns^2].
+__global__ void __launch_bounds__(kThreads) mb_sums_kernel(const float* active, const float* returns, long long n,
+                                                           double* partials) {
+    __shared__ double sh[3][kThreads / 64];
+    double sa = 0.0, s = 0.0, q = 0.0;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+        const double v = returns[i];
+        sa += (double)active[i];
+        s += v;
+        q += v * v;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sa += __shfl_down(sa, off);
+        s += __shfl_down(s, off);
+        q += __shfl_down(q, off);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        sh[0][wave] = sa;
+        sh[1][wave] = s;
+        sh[2][wave] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double a = 0.0;
+        for (int w = 0; w < kThreads / 64; ++w) a += sh[threadIdx.x][w];
+        partials[3 * blockIdx.x + threadIdx.x] = a;
+    }
+}
+__global__ void mb_sums_finish_kernel(const double* partials, int n_partials, double rows, double* sums) {
+    if (threadIdx.x >= 3) return;
+    double a = 0.0;
+    for (int i = 0; i < n_partials; ++i) a += partials[3 * i + threadIdx.x];
+    sums[threadIdx.x == 0 ? 0 : threadIdx.x + 1] = a;
+    if (threadIdx.x == 0) sums[1] = rows;
+}
+// Launch 3: out = [1 / global policy denominator, 1 / global value denominator,
+//                  1 / local policy denominator (twice), 1 / local value denominator, 1 / local rows,
+//                  mean, mean of squares of the returns over the global minibatch]
+__global__ void mb_scales_kernel(const double* local, const double* global, int policy_masked, int value_masked, float* out) {
+    if (threadIdx.x != 0) return;
+    const double gp = policy_masked ? global[0] : global[1], gv = value_masked ? global[0] : global[1];
+    const double lp = policy_masked ? local[0] : local[1], lv = value_masked ? local[0] : local[1];
+    out[0] = (float)(1.0 / gp);
+    out[1] = (float)(1.0 / gv);
+    out[2] = (float)(1.0 / lp);
+    out[3] = (float)(1.0 / lp);
+    out[4] = (float)(1.0 / lv);
+    out[5] = (float)(1.0 / local[1]);
+    out[6] = (float)(global[2] / global[1]);
+    out[7] = (float)(global[3] / global[1]);
+}
+
 }  // namespace
+
+extern "C" int64_t mappo_minibatch_sums_workspace_doubles(void) { return 3 * kMaxBlocks; }
+
+extern "C" int mappo_minibatch_sums(const float* active_masks, const float* returns, int64_t n, double* sums,
+                                    double* workspace, mappo_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!active_masks || !returns || !sums || !workspace) return MAPPO_E_NULL;
+    if (n <= 0) return MAPPO_E_SHAPE;
+    long long blocks = (n + kThreads * 16 - 1) / (kThreads * 16);
+    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+    hipLaunchKernelGGL(mb_sums_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, active_masks, returns, (long long)n,
+                       workspace);
+    hipLaunchKernelGGL(mb_sums_finish_kernel, dim3(1), dim3(64), 0, stream, (const double*)workspace, (int)blocks, (double)n,
+                       sums);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mappo_minibatch_scales(const double* local_sums, const double* global_sums, int policy_masked, int value_masked,
+                                      float* out, mappo_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!local_sums || !global_sums || !out) return MAPPO_E_NULL;
+    hipLaunchKernelGGL(mb_scales_kernel, dim3(1), dim3(64), 0, stream, local_sums, global_sums, policy_masked, value_masked, out);
+    return (int)hipGetLastError();
+}
 
 extern "C" int64_t mappo_valuenorm_workspace_doubles(void) { return 2 * kMaxBlocks; }
 

@@ -210,13 +210,19 @@ class R_MAPPO():
         # update and the others after it; under PopArt, whose update rescales v_out, that deviates from a single pass by
         # the one EMA step (beta = 0.99999).  The fused route never cuts a minibatch.)
         pending = () if normalized else None
-        if self.dp.active:      # one small collective for the loss denominators and the normaliser moments
+        fused = self._fused_loss and adv_targ.is_cuda and actions_batch is not None
+        # fused loss on a HIP device: denominators, their reciprocals and the returns' batch moments in three launches
+        scales = self.dp.minibatch_scales(active_masks_batch, return_batch, self._use_policy_active_masks,
+                                          self._use_value_active_masks) if fused else None
+        w_actor = w_critic = 1.0
+        if scales is not None:
+            if normalized:
+                pending = (scales[6:7], scales[7:8])
+        elif self.dp.active:    # one small collective for the loss denominators and the normaliser moments
             w_actor, w_critic, moments = self.dp.minibatch_stats(
                 active_masks_batch, return_batch, self._use_policy_active_masks, self._use_value_active_masks)
             if normalized:
                 pending = moments
-        else:
-            w_actor = w_critic = 1.0
 
         self.dp.zero_grad(self.policy.actor_optimizer, self.policy.critic_optimizer)
 
@@ -243,13 +249,12 @@ class R_MAPPO():
 
         value_loss = policy_loss = dist_entropy = None
         ratios = []
-        fused = self._fused_loss and adv_targ.is_cuda and actions_batch is not None
         if fused:
             value_loss, policy_loss, dist_entropy, imp_weights = self._fused_spans(
                 spans, cut, (share_obs_batch, obs_batch, rnn_states_batch, rnn_states_critic_batch, actions_batch,
                              value_preds_batch, return_batch, masks_batch, active_masks_batch,
                              old_action_log_probs_batch, adv_targ, available_actions_batch, factor_batch),
-                w_actor, w_critic, feed_normalizer, update_actor)
+                w_actor, w_critic, feed_normalizer, update_actor, scales)
         for lo, hi in ([] if fused else spans):
             am = cut(active_masks_batch, lo, hi)
             values, action_log_probs, entropy = self.policy.evaluate_actions(
@@ -324,7 +329,7 @@ class R_MAPPO():
             optimizer.step()
         return norm
 
-    def _fused_spans(self, spans, cut, tensors, w_actor, w_critic, feed_normalizer, update_actor):
+    def _fused_spans(self, spans, cut, tensors, w_actor, w_critic, feed_normalizer, update_actor, scales=None):
         """The span loop of ppo_update through the fused loss kernel (K7): per span one forward to the
         head's logits / the critic's values, one ``mappo_ppo_loss_f32`` launch that evaluates the loss and
         its gradient, one backward from those gradients.  -> (value_loss, policy_loss, dist_entropy,
@@ -337,21 +342,25 @@ class R_MAPPO():
         # Nothing below may touch the host: a Python scalar turned into a device tensor (torch.as_tensor(1.0, device=...))
         # is a blocking copy that drains the stream once per update -- the ~40 small launches up to the first trunk
         # kernel then run at launch latency instead of from a filled queue (0.5 ms per update at a 512-thread shard).
-        n_rows = torch.full((), float(rows), **f32)
-        masked = self._use_policy_active_masks or self._use_value_active_masks
-        active_total = active.sum() if masked else n_rows
-        # [1 / policy denominator, 1 / value denominator, 1 / rows] of THIS rank's minibatch
-        inv3 = 1.0 / torch.stack([active_total if self._use_policy_active_masks else n_rows,
-                                  active_total if self._use_value_active_masks else n_rows, n_rows])
-        inv_local = inv3[:2]
-        # data-parallel weights are local / global denominators, so this is 1 / the GLOBAL denominators
-        if torch.is_tensor(w_actor) or torch.is_tensor(w_critic):
-            inv = (inv_local * torch.stack([torch.as_tensor(w_actor, **f32).reshape(()),
-                                            torch.as_tensor(w_critic, **f32).reshape(())])).contiguous()
-        elif w_actor == 1.0 and w_critic == 1.0:
-            inv = inv_local
+        if scales is not None:      # DataParallel.minibatch_scales: [inv (2) | scale of the four sums (4) | moments (2)]
+            inv, scale4 = scales[0:2], scales[2:6]
         else:
-            inv = torch.stack([inv_local[0] * float(w_actor), inv_local[1] * float(w_critic)])
+            n_rows = torch.full((), float(rows), **f32)
+            masked = self._use_policy_active_masks or self._use_value_active_masks
+            active_total = active.sum() if masked else n_rows
+            # [1 / policy denominator, 1 / value denominator, 1 / rows] of THIS rank's minibatch
+            inv3 = 1.0 / torch.stack([active_total if self._use_policy_active_masks else n_rows,
+                                      active_total if self._use_value_active_masks else n_rows, n_rows])
+            inv_local = inv3[:2]
+            # data-parallel weights are local / global denominators, so this is 1 / the GLOBAL denominators
+            if torch.is_tensor(w_actor) or torch.is_tensor(w_critic):
+                inv = (inv_local * torch.stack([torch.as_tensor(w_actor, **f32).reshape(()),
+                                                torch.as_tensor(w_critic, **f32).reshape(())])).contiguous()
+            elif w_actor == 1.0 and w_critic == 1.0:
+                inv = inv_local
+            else:
+                inv = torch.stack([inv_local[0] * float(w_actor), inv_local[1] * float(w_critic)])
+            scale4 = torch.stack([inv3[0], inv3[0], inv3[1], inv3[2]])
         sums = torch.zeros(4, dtype=torch.float64, device=dev)
         normalized = self._use_popart or self._use_valuenorm
         for lo, hi in spans:
@@ -373,7 +382,7 @@ class R_MAPPO():
                 values.backward(dvalues)
             del values, logits, dlogits, dvalues
         # sums = [policy loss, entropy, value loss, ratio] numerators -> local means, one launch
-        means = sums.float() * torch.stack([inv3[0], inv3[0], inv3[1], inv3[2]])
+        means = sums.float() * scale4
         return means[2], means[0], means[1], means[3]
 
     def _fused_trunks(self, fold):

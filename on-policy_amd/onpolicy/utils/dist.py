@@ -178,6 +178,35 @@ class DataParallel(object):
         mean_sq = (total[3] / total[1]).float().reshape(1)
         return (w[0] if policy_masked else w[1]), (w[0] if value_masked else w[1]), (mean, mean_sq)
 
+    def minibatch_scales(self, active_masks, return_batch, policy_masked, value_masked):
+        """The same quantities for the fused loss on a HIP device, three launches + one collective
+        (``mappo_minibatch_sums`` / ``mappo_minibatch_scales``) -> float32 [8] device tensor
+        ``[1 / global policy denominator, 1 / global value denominator, 1 / local policy denominator (twice),
+        1 / local value denominator, 1 / local rows, mean, mean of squares of the returns over the global minibatch]``,
+        or None when the columns do not qualify (then ``minibatch_stats`` / PyTorch do the work)."""
+        am, ret = active_masks.detach(), return_batch.detach()
+        ok = all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in (am, ret)) \
+            and am.numel() == ret.numel() and am.numel() > 0 and os.environ.get("MAPPO_FUSED_PROLOGUE", "1") != "0"
+        if not ok:
+            return None
+        from onpolicy import _native
+        lib, p = _native.lib(), _native.ptr
+        dev = am.device
+        if getattr(self, "_mb_ws", None) is None or self._mb_ws.device != dev:
+            self._mb_ws = torch.empty(lib.mappo_minibatch_sums_workspace_doubles(), dtype=torch.float64, device=dev)
+        stream = _native.stream_of(dev)
+        local = torch.empty(4, dtype=torch.float64, device=dev)
+        _native.check(lib.mappo_minibatch_sums(p(am), p(ret), am.numel(), p(local), p(self._mb_ws), stream),
+                      "mappo_minibatch_sums")
+        total = local
+        if self.active:
+            total = local.clone()
+            self.all_reduce(total)
+        out = torch.empty(8, dtype=torch.float32, device=dev)
+        _native.check(lib.mappo_minibatch_scales(p(local), p(total), int(bool(policy_masked)), int(bool(value_masked)),
+                                                 p(out), stream), "mappo_minibatch_scales")
+        return out
+
     def average_info(self, totals):
         """Logged scalars: mean over ranks of the per-rank means."""
         if self.active:

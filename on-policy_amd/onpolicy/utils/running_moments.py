@@ -72,7 +72,12 @@ class DebiasedMoments(object):
         if getattr(self, "_denorm_cache", None) is None or self._denorm_cache.device != dev:
             self._denorm_cache = torch.empty(2, dtype=torch.float32, device=dev)
             self._vn_ws = torch.empty(lib.mappo_valuenorm_workspace_doubles(), dtype=torch.float64, device=dev)
-        bm = None if batch_moments is None else torch.cat([t.reshape(1).float() for t in batch_moments])
+        bm = None
+        if batch_moments is not None:
+            a, b = batch_moments
+            # (mean, mean_sq) that already sit side by side in float32 -- DataParallel.minibatch_scales -- are read in place
+            bm = a if (a.dtype == torch.float32 and b.dtype == torch.float32 and a.data_ptr() + 4 == b.data_ptr()) \
+                else torch.cat([t.reshape(1).float() for t in batch_moments])
         x = None if batch_moments is not None else input_vector
         _native.check(lib.mappo_valuenorm_update(p(x), 0 if x is None else x.numel(), p(bm), float(weight), float(self.epsilon),
                                                  p(m1), p(m2), p(d), p(self._denorm_cache), p(self._vn_ws),

@@ -92,3 +92,26 @@ def test_fused_valuenorm_update_matches_the_tensor_ops():
     a.running_mean.fill_(7.0)       # an in-place edit: the cached pair must not be served any more
     b.running_mean.fill_(7.0)
     torch.testing.assert_close(a.denorm_scalars().cpu(), b.denorm_scalars(), rtol=2e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("policy_masked,value_masked", [(True, True), (True, False), (False, False)])
+def test_minibatch_scales_match_the_tensor_ops(policy_masked, value_masked):
+    """mappo_minibatch_sums / mappo_minibatch_scales (DataParallel.minibatch_scales: loss denominators of r_mappo.py:135-139,
+    :84-87 and the returns' batch moments of :65) against float64 tensor arithmetic, one rank."""
+    from onpolicy.utils.dist import DataParallel
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5)
+    for n in (1, 257, 1_000_003):
+        active = (torch.rand(n, 1, generator=g) > 0.3).float()
+        active[0] = 1.0
+        ret = torch.randn(n, 1, generator=g) * 4.0 + 2.0
+        dp = DataParallel(torch.nn.Linear(2, 2), torch.nn.Linear(2, 2), dev)
+        out = dp.minibatch_scales(active.to(dev), ret.to(dev), policy_masked, value_masked)
+        assert out is not None and out.shape == (8,)
+        a, r = active.double(), ret.double()
+        den_p = a.sum() if policy_masked else float(n)
+        den_v = a.sum() if value_masked else float(n)
+        want = torch.tensor([1 / den_p, 1 / den_v, 1 / den_p, 1 / den_p, 1 / den_v, 1 / n, r.mean(), (r * r).mean()])
+        torch.testing.assert_close(out.cpu().double(), want, rtol=3e-7, atol=0)
+    # columns that do not qualify fall back to the tensor ops
+    assert dp.minibatch_scales(active.to(dev).double(), ret.to(dev), True, True) is None

@@ -14,5 +14,5 @@ run --workload ns_rnn --threads 512
 run --workload smac
 run --workload smac --threads 64
 run --workload cfg2
-run --workload hanabi
+# (hanabi: its hidden-512 shapes are in the shipped table since round 2; run --workload hanabi to refresh them)
 wc -l $MAPPO_GEMM_TUNING_CACHE/*

@@ -546,6 +546,16 @@ int     mappo_standardize_rows(const float* src, int64_t rows, int D, float eps,
  * first-layer weight matrix padded with zero columns; the zero products change no bit of the result) */
 int     mappo_standardize_rows_ld(const float* src, int64_t rows, int D, float eps, float* dst, int ld,
                                   mappo_stream_t stream);
+/* The affine half of that LayerNorm folded into the Linear behind it (reference mlp.py:47-48 feature_norm, :20 fc1):
+ * Linear(LayerNorm(x)) = x^ w_folded^T + b_folded with w_folded[f][k] = w[f][k] gamma[k] (rows `ld` >= din floats apart,
+ * zero columns beyond din: the padded copy above), b_folded[f] = b[f] + sum_k w[f][k] beta[k].  One launch; the
+ * backward turns the gradients at (w_folded [out_features, ld], b_folded) into those of w [out_features, din], gamma,
+ * beta [din] (the gradient of b is db_folded itself), one launch. */
+int     mappo_fold_input_norm_forward(const float* w, const float* b, const float* gamma, const float* beta, int out_features,
+                                      int din, int ld, float* w_folded, float* b_folded, mappo_stream_t stream);
+int     mappo_fold_input_norm_backward(const float* w, const float* gamma, const float* beta, const float* dw_folded,
+                                       const float* db_folded, int out_features, int din, int ld, float* dw, float* dgamma,
+                                       float* dbeta, mappo_stream_t stream);
 
 /* --------------------------------------------------------------- K11: simple_spread worlds on the device ----
  * One env step of `n_worlds` cooperative-navigation worlds (the env of BASELINE.json configs[0] / configs[2]; reference

@@ -245,7 +245,74 @@ __global__ void mb_scales_kernel(const double* local, const double* global, int 
     out[7] = (float)(global[3] / global[1]);
 }
 
+// ---------------------------------------------------------------- input LayerNorm folded into the first Linear ----
+// A trunk that reads standardised rows x^ (mappo_standardize_rows) evaluates Linear(LayerNorm(x)) as x^ W'^T + b' with
+// W'[f][k] = W[f][k] gamma[k], b'[f] = b[f] + sum_k W[f][k] beta[k] (mlp.py:47-48 feature_norm, :20 fc1).  Forward: one
+// block per output feature writes its row of W' (zero columns up to ld) and b'[f].  Backward: one thread per input
+// column k walks the 64 features: dW[f][k] = dW'[f][k] gamma[k] + db'[f] beta[k], dgamma[k] = sum_f dW'[f][k] W[f][k],
+// dbeta[k] = sum_f db'[f] W[f][k]; db = db'.  (As tensor ops: 3 launches forward, 7 backward, per network and update.)
+__global__ void __launch_bounds__(kThreads) fold_fwd_kernel(const float* W, const float* b, const float* gamma, const float* beta,
+                                                            int out_f, int din, int ld, float* Wf, float* bf) {
+    __shared__ float sh[kThreads / 64];
+    const int f = blockIdx.x;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < ld; k += kThreads) {
+        float w = 0.f;
+        if (k < din) {
+            w = W[(long long)f * din + k];
+            s += w * beta[k];
+            w *= gamma[k];
+        }
+        Wf[(long long)f * ld + k] = w;
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < kThreads / 64; ++w) t += sh[w];
+        bf[f] = b[f] + t;
+    }
+}
+__global__ void __launch_bounds__(kThreads) fold_bwd_kernel(const float* W, const float* gamma, const float* beta, const float* dWf,
+                                                            const float* dbf, int out_f, int din, int ld, float* dW,
+                                                            float* dgamma, float* dbeta) {
+    const int k = blockIdx.x * kThreads + threadIdx.x;
+    if (k >= din) return;
+    const float g = gamma[k], be = beta[k];
+    float sg = 0.f, sb = 0.f;
+    for (int f = 0; f < out_f; ++f) {
+        const float w = W[(long long)f * din + k], dwf = dWf[(long long)f * ld + k], d = dbf[f];
+        dW[(long long)f * din + k] = dwf * g + d * be;
+        sg += dwf * w;
+        sb += d * w;
+    }
+    dgamma[k] = sg;
+    dbeta[k] = sb;
+}
+
 }  // namespace
+
+extern "C" int mappo_fold_input_norm_forward(const float* w, const float* b, const float* gamma, const float* beta, int out_features,
+                                             int din, int ld, float* w_folded, float* b_folded, mappo_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!w || !b || !gamma || !beta || !w_folded || !b_folded) return MAPPO_E_NULL;
+    if (out_features <= 0 || din <= 0 || ld < din) return MAPPO_E_SHAPE;
+    hipLaunchKernelGGL(fold_fwd_kernel, dim3((unsigned)out_features), dim3(kThreads), 0, stream, w, b, gamma, beta, out_features,
+                       din, ld, w_folded, b_folded);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mappo_fold_input_norm_backward(const float* w, const float* gamma, const float* beta, const float* dw_folded,
+                                              const float* db_folded, int out_features, int din, int ld, float* dw,
+                                              float* dgamma, float* dbeta, mappo_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!w || !gamma || !beta || !dw_folded || !db_folded || !dw || !dgamma || !dbeta) return MAPPO_E_NULL;
+    if (out_features <= 0 || din <= 0 || ld < din) return MAPPO_E_SHAPE;
+    hipLaunchKernelGGL(fold_bwd_kernel, dim3((unsigned)((din + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, w, gamma, beta,
+                       dw_folded, db_folded, out_features, din, ld, dw, dgamma, dbeta);
+    return (int)hipGetLastError();
+}
 
 extern "C" int64_t mappo_minibatch_sums_workspace_doubles(void) { return 3 * kMaxBlocks; }
 

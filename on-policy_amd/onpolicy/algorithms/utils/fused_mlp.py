@@ -284,6 +284,42 @@ def _split_grads(g, din, n_layers, out):
     return res
 
 
+class _FoldInputNormFn(torch.autograd.Function):
+    """(W [64, din], b [64], gamma [din], beta [din]) -> (W * gamma zero-padded to ld columns, b + W beta): the input
+    LayerNorm's affine half folded into the first Linear (``mappo_fold_input_norm_forward`` / ``_backward``, one launch per
+    direction; as tensor ops it was 3 launches forward and 7 backward per network and update)."""
+
+    @staticmethod
+    def forward(ctx, w, b, gamma, beta, ld):
+        lib, p = _native.lib(), _native.ptr
+        w, b, gamma, beta = (t.detach().contiguous() for t in (w, b, gamma, beta))
+        out_f, din = w.shape
+        wf = torch.empty((out_f, ld), dtype=torch.float32, device=w.device)
+        bf = torch.empty(out_f, dtype=torch.float32, device=w.device)
+        _native.check(lib.mappo_fold_input_norm_forward(p(w), p(b), p(gamma), p(beta), out_f, din, ld, p(wf), p(bf),
+                                                        _native.stream_of(w.device)), "mappo_fold_input_norm_forward")
+        ctx.save_for_backward(w, gamma, beta)
+        ctx.ld = ld
+        return wf, bf
+
+    @staticmethod
+    def backward(ctx, dwf, dbf):
+        lib, p = _native.lib(), _native.ptr
+        w, gamma, beta = ctx.saved_tensors
+        out_f, din = w.shape
+        dwf, dbf = dwf.contiguous(), dbf.contiguous()
+        dw = torch.empty_like(w)
+        dgb = torch.empty((2, din), dtype=torch.float32, device=w.device)
+        _native.check(lib.mappo_fold_input_norm_backward(p(w), p(gamma), p(beta), p(dwf), p(dbf), out_f, din, ctx.ld, p(dw),
+                                                         p(dgb[0]), p(dgb[1]), _native.stream_of(w.device)),
+                      "mappo_fold_input_norm_backward")
+        return dw, dbf, dgb[0], dgb[1], None
+
+
+def _fold_kernel_ok(*tensors):
+    return os.environ.get("MAPPO_FUSED_FOLD", "1") != "0" and all(t.is_cuda and t.dtype == torch.float32 for t in tensors)
+
+
 def trunk_forward(base, rs, head=None):
     """``head(base(rows))`` for an ``MLPBase`` (see ``trunk_supported``) on the rows of a ``RowSource``; ``head``: an
     ``nn.Linear``-like module with ``weight`` [out, 64] / ``bias`` [out] (out <= 64) or None for the trunk's features."""
@@ -294,8 +330,11 @@ def trunk_forward(base, rs, head=None):
         if not rs.standardized:
             raise ValueError("the trunk has an input LayerNorm: the RowSource must read standardised rows")
         fn = base.feature_norm
-        w1 = lin0.weight * fn.weight
-        b1 = lin0.bias + lin0.weight @ fn.bias
+        if _fold_kernel_ok(lin0.weight, lin0.bias, fn.weight, fn.bias):
+            w1, b1 = _FoldInputNormFn.apply(lin0.weight, lin0.bias, fn.weight, fn.bias, int(rs.src.shape[1]))
+        else:
+            w1 = lin0.weight * fn.weight
+            b1 = lin0.bias + lin0.weight @ fn.bias
     else:
         if rs.standardized:
             raise ValueError("the trunk has no input LayerNorm: the RowSource must read the rows as they are")

@@ -115,3 +115,25 @@ def test_minibatch_scales_match_the_tensor_ops(policy_masked, value_masked):
         torch.testing.assert_close(out.cpu().double(), want, rtol=3e-7, atol=0)
     # columns that do not qualify fall back to the tensor ops
     assert dp.minibatch_scales(active.to(dev).double(), ret.to(dev), True, True) is None
+
+
+@pytest.mark.parametrize("din,ld", [(48, 48), (30, 32), (435, 436), (7, 8)])
+def test_fold_input_norm_kernels_match_autograd(din, ld):
+    """mappo_fold_input_norm_forward / _backward (the input LayerNorm's affine half folded into the first Linear,
+    mlp.py:47-48 + :20) against the tensor expression they replace, values and all four gradients."""
+    from onpolicy.algorithms.utils.fused_mlp import _FoldInputNormFn
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(din)
+    mk = lambda *shape: torch.randn(*shape, generator=g).to(dev).requires_grad_(True)
+    w, b, gamma, beta = mk(64, din), mk(64), mk(din), mk(din)
+    wf, bf = _FoldInputNormFn.apply(w, b, gamma, beta, ld)
+    ref = [t.detach().double().requires_grad_(True) for t in (w, b, gamma, beta)]
+    wr = torch.nn.functional.pad(ref[0] * ref[2], (0, ld - din))
+    br = ref[1] + ref[0] @ ref[3]
+    torch.testing.assert_close(wf.double(), wr.detach(), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(bf.double(), br.detach(), rtol=1e-5, atol=1e-5)
+    dwf, dbf = torch.randn(64, ld, generator=g).to(dev), torch.randn(64, generator=g).to(dev)
+    torch.autograd.backward([wf, bf], [dwf, dbf])
+    torch.autograd.backward([wr, br], [dwf.double(), dbf.double()])
+    for got, want, name in zip((w, b, gamma, beta), ref, ("w", "b", "gamma", "beta")):
+        torch.testing.assert_close(got.grad.double(), want.grad, rtol=2e-5, atol=2e-5, msg=name)

@@ -395,6 +395,16 @@ typedef struct mappo_gru_seq {
     const float* dh_last;   /* [mb, 64] gradient at h_last, or NULL */
     float* ln_grads;        /* [384], see above */
     float* workspace;
+    /* Optional output Linear on y inside the launches (the Categorical head's Linear, distributions.py:55-68, or the
+     * critic's v_out, r_actor_critic.py:147-175): head_out > 0 makes the forward also write logits [L * mb, head_out] =
+     * y head_w^T + head_b (y may then be NULL), and the backward (head_out <= 18) form dy = dlogits head_w itself from
+     * dlogits [L * mb, head_out] -- dy is not read.  The head's own gradients are the caller's: dlogits^T y and the
+     * column sums of dlogits. */
+    const float* head_w;    /* [head_out, 64] or NULL */
+    const float* head_b;    /* [head_out] */
+    int32_t head_out;       /* 0: no head */
+    float* logits;
+    const float* dlogits;
 } mappo_gru_seq_t;
 int64_t mappo_gru_seq_gates_floats(int L, int64_t mb);
 int64_t mappo_gru_seq_stats_floats(int L, int64_t mb);

@@ -59,6 +59,12 @@ struct Args {
     float* dq;              // [L * mb, 64]  gradient at W_hn hm + b_hn (the r and z thirds of the hidden side equal dgi's)
     float* dh0;             // [mb, 64] or NULL
     const float* dh_last;   // [mb, 64] gradient at h_last, or NULL (none)
+    // optional output Linear on y (the Categorical head's Linear / v_out): logits = y head_w^T + head_b
+    const float* head_w;    // [head_out, 64] or NULL
+    const float* head_b;    // [head_out]
+    int head_out;
+    float* logits;          // [L * mb, head_out]
+    const float* dlogits;   // backward: [L * mb, head_out]; dy = dlogits head_w is formed in the launch (a.dy is not read)
     float* partials;        // [gridDim.x][kSums]: LayerNorm weight | bias gradient sums, then the column sums of the gate
                             // gradients (r | z | n of dgi, then dq) per workgroup
 };
@@ -140,8 +146,11 @@ __device__ __forceinline__ float sigmoid_fast(float x) {
 // LDS (floats): forward  wih [6][32][kWS] | whh [6][32][kWS] | vec [6][64] = b_ir + b_hr, b_iz + b_hz, b_in, b_hn, gamma, beta
 //               backward wihT [3][2][32][kWS] | whhT [3][2][32][kWS] | gamma [64] | per wave T [64][kTS]
 constexpr int kW = 6 * 32 * kWS;
-constexpr int kFwdLds = 2 * kW + 6 * 64;
-constexpr int kBwdLds = 2 * kW + 64 + kWaves * 64 * kTS;
+constexpr int kFwdLds = 2 * kW + 6 * 64;                 // + head_out * 65 with a head: whp [out][64] permuted | bias [out]
+constexpr int kMaxHeadSteps = 9;                         // backward with a head: head_out <= 18 (k steps of 2 on the MFMA)
+constexpr int kHeadA = 2 * kMaxHeadSteps * 64;           // whA [2 feature tiles][NJ][64 lanes]
+constexpr int kSumsPerWave = 512;                        // >= kSums
+constexpr int kBwdLds = 2 * kW + 64 + kHeadA + kWaves * kSumsPerWave;
 
 __global__ void __launch_bounds__(kThreads, 1) gru_seq_fwd_kernel(Args a) {
     float* lds = prim::lds();
@@ -161,6 +170,11 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_fwd_kernel(Args a) {
         vec[256 + e] = a.ln_g[e];
         vec[320 + e] = a.ln_b[e];
     }
+    // head weights in slot order: whp[o][h * 32 + s] = head_w[o][f(h, s)]
+    const int hout = a.head_out;
+    float* whp = vec + 384;
+    for (int e = tid; e < hout * 64; e += kThreads) whp[e] = a.head_w[(e >> 6) * 64 + feat_of((e & 63) >> 5, e & 31)];
+    for (int e = tid; e < hout; e += kThreads) whp[hout * 64 + e] = a.head_b[e];
     __syncthreads();
     const long long mb = a.mb, ntiles = tiles_of(mb);
     const int L = a.L;
@@ -239,7 +253,20 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_fwd_kernel(Args a) {
                     nh[s] *= rstd;
                     yv[s] = nh[s] * g[s] + be[s];
                 }
-                if (ok) mlp::store_row64(a.y + row * 64, yv, h);
+                if (ok && a.y != nullptr) mlp::store_row64(a.y + row * 64, yv, h);
+                // the output Linear on this lane's row: 32 in-lane terms per output + the other half-wave's
+                for (int o = 0; o < hout; ++o) {
+                    const float* wp = whp + o * 64 + 32 * h;
+                    float p = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const v4 w = *reinterpret_cast<const v4*>(wp + 4 * q);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) p += w[e] * yv[4 * q + e];
+                    }
+                    p += prim::xhalf(p);
+                    if (ok) a.logits[row * hout + o] = p + whp[hout * 64 + o];
+                }
             }
             if (a.gates != nullptr) {
                 float* gt = a.gates + ((long long)l * ntiles + tile) * (kSaved * 2048);
@@ -255,6 +282,9 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_fwd_kernel(Args a) {
     }
 }
 
+// NJ > 0: the gradient at y comes from an output Linear, dy = dlogits head_w, as NJ k steps of 2 outputs on the MFMA
+// (head_out <= 2 NJ; padded outputs have zero weights)
+template <int NJ>
 __global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
     float* lds = prim::lds();
     const int tid = threadIdx.x, lane = tid & 63, wave = prim::uniform(tid >> 6), c = lane & 31, h = lane >> 5;
@@ -266,7 +296,15 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
     }
     float* gam = lds + 2 * kW;
     for (int e = tid; e < 64; e += kThreads) gam[e] = a.ln_g[e];
-    float* T = gam + 64 + wave * 64 * kTS;
+    // whA[t][j][lane (i, hh)] = head_w[2 j + hh][32 t + i]: A operand (lane = feature 32 t + i) of k step j
+    float* whA = gam + 64;
+    constexpr int NJ1 = NJ > 0 ? NJ : 1;
+    const int hout = a.head_out;
+    for (int e = tid; e < 2 * NJ * 64; e += kThreads) {
+        const int t = e / (NJ1 * 64), jq = (e >> 6) % NJ1, ln = e & 63, o = 2 * jq + (ln >> 5);
+        whA[e] = o < hout ? a.head_w[o * 64 + 32 * t + (ln & 31)] : 0.f;
+    }
+    float* T = gam + 64 + kHeadA + wave * kSumsPerWave;
     __syncthreads();
     // Parameter gradients that are column sums over every row and step -- the LayerNorm weight / bias gradients and the
     // bias gradients (= column sums of the gate gradients) -- are folded over the wave's rows step by step (colsum32), so
@@ -296,6 +334,7 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
         // with, so that the loads fly under the step's 384 MFMAs; the four gate fragments are loaded at the top of their
         // step, behind the LayerNorm backward (all seven streams a step ahead need more registers than a wave has)
         float r[32], z[32], n[32], q[32], nh[32], hm[32], g[32];
+        float dl[NJ1];              // with a head: this lane's B operands, dlogits[row][2 j + h]
         f2 st;
         float mk;
         auto fetch = [&](int l) {
@@ -304,7 +343,16 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
             mlp::load_frag64(gt + 4 * 2048, lane, nh);
             st = *reinterpret_cast<const f2*>(a.stats + 2 * (((long long)l * ntiles + tile) * 32 + c));
             mlp::load_row64(a.hm + row * 64, hm, h);
-            mlp::load_row64(a.dy + row * 64, g, h);
+            if (NJ == 0) {
+                mlp::load_row64(a.dy + row * 64, g, h);
+            } else {
+                // (always a valid address and no select: outputs past head_out meet zero weights)
+#pragma unroll
+                for (int jq = 0; jq < NJ; ++jq) {
+                    const int o = 2 * jq + h;
+                    dl[jq] = a.dlogits[row * hout + (o < hout ? o : hout - 1)];
+                }
+            }
             mk = a.masks[row];
         };
         fetch(L - 1);
@@ -317,6 +365,17 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
                 mlp::load_frag64(gt + 2 * 2048, lane, n);
                 mlp::load_frag64(gt, lane, r);
                 mlp::load_frag64(gt + 3 * 2048, lane, q);
+            }
+            if (NJ > 0) {       // dy = dlogits head_w on the MFMA: D[feature][row] += whA[feature][o] dlogits[o][row]
+                f32x16 ag[2];
+                zero2(ag);
+#pragma unroll
+                for (int jq = 0; jq < NJ; ++jq) {
+                    ag[0] = prim::mfma32(whA[jq * 64 + lane], dl[jq], ag[0]);
+                    ag[1] = prim::mfma32(whA[(NJ + jq) * 64 + lane], dl[jq], ag[1]);
+                }
+#pragma unroll
+                for (int s = 0; s < 32; ++s) g[s] = ag[s >> 4][s & 15];
             }
             // output LayerNorm backward (rows past the end: dy = 0 -> every gradient below is 0)
             float m1 = 0.f, m2 = 0.f;
@@ -396,7 +455,7 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
     __syncthreads();
     for (int e = tid; e < kSums; e += kThreads) {
         float s = 0.f;
-        for (int w = 0; w < kWaves; ++w) s += gam[64 + w * 64 * kTS + e];
+        for (int w = 0; w < kWaves; ++w) s += gam[64 + kHeadA + w * kSumsPerWave + e];
         a.partials[(long long)blockIdx.x * kSums + e] = s;
     }
 }
@@ -411,9 +470,12 @@ inline int check(const mappo_gru_seq_t* m, bool backward) {
     if (!m || !m->x || !m->h0 || !m->masks || !m->w_ih || !m->w_hh || !m->b_ih || !m->b_hh || !m->ln_g || !m->ln_b)
         return MAPPO_E_NULL;
     if (m->mb <= 0 || m->L <= 0 || m->H != 64) return MAPPO_E_SHAPE;
-    if (!backward && !m->y) return MAPPO_E_NULL;
     if ((m->gates != nullptr) != (m->hm != nullptr) || (m->gates != nullptr) != (m->stats != nullptr)) return MAPPO_E_NULL;
-    if (backward && (!m->gates || !m->dy || !m->dx || !m->dgi || !m->dq || !m->ln_grads || !m->workspace)) return MAPPO_E_NULL;
+    if (m->head_out < 0 || m->head_out > 64 || (backward && m->head_out > 2 * kMaxHeadSteps)) return MAPPO_E_SHAPE;
+    if (m->head_out > 0 && (!m->head_w || !m->head_b || (backward ? !m->dlogits : !m->logits))) return MAPPO_E_NULL;
+    if (!backward && !m->y && m->head_out == 0) return MAPPO_E_NULL;
+    if (backward && (!m->gates || (!m->dy && m->head_out == 0) || !m->dx || !m->dgi || !m->dq || !m->ln_grads || !m->workspace))
+        return MAPPO_E_NULL;
     const void* al[] = {m->x, m->h0, m->y, m->h_last, m->gates, m->hm, m->stats, m->dy, m->dx, m->dgi, m->dq, m->dh0, m->dh_last};
     for (const void* p : al)
         if (p && (reinterpret_cast<uintptr_t>(p) & 15) != 0) return MAPPO_E_ALIGN;
@@ -445,6 +507,11 @@ inline void fill(const mappo_gru_seq_t* m, Args& a) {
     a.dh0 = m->dh0;
     a.dh_last = m->dh_last;
     a.partials = m->workspace;
+    a.head_w = m->head_w;
+    a.head_b = m->head_b;
+    a.head_out = m->head_out;
+    a.logits = m->logits;
+    a.dlogits = m->dlogits;
 }
 
 inline int forward(const mappo_gru_seq_t* m, hipStream_t stream) {
@@ -452,7 +519,7 @@ inline int forward(const mappo_gru_seq_t* m, hipStream_t stream) {
     if (code) return code;
     Args a;
     fill(m, a);
-    MAPPO_LAUNCH(gru_seq_fwd_kernel, (unsigned)grid_of(m->mb), kThreads, (size_t)kFwdLds * 4, stream, a);
+    MAPPO_LAUNCH(gru_seq_fwd_kernel, (unsigned)grid_of(m->mb), kThreads, (size_t)(kFwdLds + 65 * m->head_out) * 4, stream, a);
     return MAPPO_LAUNCH_ERROR();
 }
 
@@ -462,7 +529,16 @@ inline int backward(const mappo_gru_seq_t* m, hipStream_t stream) {
     Args a;
     fill(m, a);
     const long long grid = grid_of(m->mb);
-    MAPPO_LAUNCH(gru_seq_bwd_kernel, (unsigned)grid, kThreads, (size_t)kBwdLds * 4, stream, a);
+    const int ho = m->head_out;
+    if (ho == 0) {
+        MAPPO_LAUNCH(gru_seq_bwd_kernel<0>, (unsigned)grid, kThreads, (size_t)kBwdLds * 4, stream, a);
+    } else if (ho <= 2) {
+        MAPPO_LAUNCH(gru_seq_bwd_kernel<1>, (unsigned)grid, kThreads, (size_t)kBwdLds * 4, stream, a);
+    } else if (ho <= 6) {
+        MAPPO_LAUNCH(gru_seq_bwd_kernel<3>, (unsigned)grid, kThreads, (size_t)kBwdLds * 4, stream, a);
+    } else {
+        MAPPO_LAUNCH(gru_seq_bwd_kernel<9>, (unsigned)grid, kThreads, (size_t)kBwdLds * 4, stream, a);
+    }
     MAPPO_LAUNCH(mlp::mlp_reduce_kernel, (unsigned)(kSums / 32), mlp::kThreads, 1024, stream, (const float*)m->workspace, grid,
                  (long long)kSums, (long long)kSums, m->ln_grads);
     return MAPPO_LAUNCH_ERROR();

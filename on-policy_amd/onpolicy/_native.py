@@ -61,7 +61,8 @@ class GRUSeq(ctypes.Structure):
     _fields_ = [(n, _vp) for n in ("x", "h0", "masks", "w_ih", "w_hh", "b_ih", "b_hh", "ln_g", "ln_b")] + \
                [("ln_eps", ctypes.c_float), ("H", ctypes.c_int32), ("L", ctypes.c_int32), ("mb", _i64)] + \
                [(n, _vp) for n in ("y", "h_last", "gates", "hm", "stats", "dy", "dx", "dgi", "dq", "dh0", "dh_last",
-                                   "ln_grads", "workspace")]
+                                   "ln_grads", "workspace", "head_w", "head_b")] + \
+               [("head_out", ctypes.c_int32), ("logits", _vp), ("dlogits", _vp)]
 
 
 ADAM_MAX_TENSORS = 64

@@ -92,6 +92,11 @@ class R_Actor(nn.Module, _DeviceMixin):
         head = self.act.action_out.linear
         if self._fuses_head(obs, head):
             return self.base(obs, head=head)          # gather + trunk + head: one launch
+        if self._recurrent:        # the head inside the GRU chunk kernels (K12) where they take the layer
+            feats = self.base(obs, standardized=True) if obs_standardized else self.base(obs)
+            if self.rnn.head_ok(feats, head):
+                return self.rnn(feats, rnn_states, masks, head=head)[0]
+            return head(self.rnn(feats, rnn_states, masks)[0])
         feats, _ = self._features(obs, rnn_states, masks, obs_standardized)
         return head(feats)
 
@@ -126,5 +131,7 @@ class R_Critic(nn.Module, _DeviceMixin):
             return self.base(cent_obs, head=self.v_out), rnn_states
         feats = self.base(cent_obs, standardized=True) if obs_standardized else self.base(cent_obs)
         if self._recurrent:
+            if type(self.v_out) is not PopArt and self.rnn.head_ok(feats, self.v_out):
+                return self.rnn(feats, rnn_states, masks, head=self.v_out)      # v_out inside the GRU chunk kernels
             feats, rnn_states = self.rnn(feats, rnn_states, masks)
         return self.v_out(feats), rnn_states

@@ -105,7 +105,9 @@ class _GRUChunkFn(torch.autograd.Function):
     rows here."""
 
     @staticmethod
-    def forward(ctx, x, h0, masks, w_ih, w_hh, b_ih, b_hh, ln_g, ln_b, eps, L):
+    def forward(ctx, x, h0, masks, w_ih, w_hh, b_ih, b_hh, ln_g, ln_b, eps, L, head_w=None, head_b=None):
+        """``head_w`` [out, 64] / ``head_b`` [out] (out <= 18): an output Linear on y evaluated inside the launches -- the
+        first result is then ``y head_w^T + head_b`` instead of y (y itself is kept for the head's weight gradient)."""
         from onpolicy import _native
         lib, p = _native.lib(), _native.ptr
         B = h0.shape[0]
@@ -113,31 +115,37 @@ class _GRUChunkFn(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         x, h0, masks = x.contiguous(), h0.contiguous(), masks.reshape(-1).contiguous()
         params = [t.detach().contiguous() for t in (w_ih, w_hh, b_ih, b_hh, ln_g, ln_b)]
-        y = torch.empty(L * B, 64, **f32)
-        h_last = torch.empty(B, 64, **f32)
+        head = None if head_w is None else (head_w.detach().contiguous(), head_b.detach().contiguous())
+        out = 0 if head is None else int(head[0].shape[0])
         need = any(ctx.needs_input_grad)
+        y = torch.empty(L * B, 64, **f32) if (head is None or need) else None
+        logits = torch.empty(L * B, out, **f32) if head is not None else None
+        h_last = torch.empty(B, 64, **f32)
         gates = torch.empty(lib.mappo_gru_seq_gates_floats(L, B), **f32) if need else None
         stats = torch.empty(lib.mappo_gru_seq_stats_floats(L, B), **f32) if need else None
         hm = torch.empty(L * B, 64, **f32) if need else None
         m = _native.GRUSeq(x=p(x), h0=p(h0), masks=p(masks), w_ih=p(params[0]), w_hh=p(params[1]), b_ih=p(params[2]),
                            b_hh=p(params[3]), ln_g=p(params[4]), ln_b=p(params[5]), ln_eps=float(eps), H=64, L=L, mb=B,
-                           y=p(y), h_last=p(h_last), gates=p(gates), hm=p(hm), stats=p(stats))
+                           y=p(y), h_last=p(h_last), gates=p(gates), hm=p(hm), stats=p(stats),
+                           head_w=p(head[0]) if head else None, head_b=p(head[1]) if head else None, head_out=out,
+                           logits=p(logits))
         _native.check(lib.mappo_gru_seq_forward(m, _native.stream_of(dev)), "mappo_gru_seq_forward")
         if need:
-            ctx.save_for_backward(x, h0, masks, gates, stats, hm, *params)
-            ctx.cfg = (float(eps), L)
-        return y, h_last
+            ctx.save_for_backward(x, h0, masks, gates, stats, hm, *params, *((y,) + head if head else ()))
+            ctx.cfg = (float(eps), L, out)
+        return (logits if head is not None else y), h_last
 
     @staticmethod
     def backward(ctx, dy, dh_last):
         from onpolicy import _native
         lib, p = _native.lib(), _native.ptr
-        x, h0, masks, gates, stats, hm, w_ih, w_hh, b_ih, b_hh, ln_g, ln_b = ctx.saved_tensors
-        eps, L = ctx.cfg
+        x, h0, masks, gates, stats, hm, w_ih, w_hh, b_ih, b_hh, ln_g, ln_b = ctx.saved_tensors[:12]
+        eps, L, out = ctx.cfg
+        y, head_w, head_b = ctx.saved_tensors[12:] if out else (None, None, None)
         B = h0.shape[0]
         dev = x.device
         f32 = dict(dtype=torch.float32, device=dev)
-        dy = torch.zeros(L * B, 64, **f32) if dy is None else dy.contiguous()
+        dy = torch.zeros(L * B, out or 64, **f32) if dy is None else dy.contiguous()
         dh_last = None if dh_last is None else dh_last.contiguous()
         dx = torch.empty(L * B, 64, **f32)
         dgi = torch.empty(L * B, 192, **f32)
@@ -147,19 +155,26 @@ class _GRUChunkFn(torch.autograd.Function):
         ws = torch.empty(lib.mappo_gru_seq_workspace_floats(), **f32)
         m = _native.GRUSeq(x=p(x), h0=p(h0), masks=p(masks), w_ih=p(w_ih), w_hh=p(w_hh), b_ih=p(b_ih), b_hh=p(b_hh),
                            ln_g=p(ln_g), ln_b=p(ln_b), ln_eps=eps, H=64, L=L, mb=B, gates=p(gates), hm=p(hm),
-                           stats=p(stats), dy=p(dy), dx=p(dx), dgi=p(dgi), dq=p(dq), dh0=p(dh0), dh_last=p(dh_last),
-                           ln_grads=p(ln_grads), workspace=p(ws))
+                           stats=p(stats), dy=None if out else p(dy), dx=p(dx), dgi=p(dgi), dq=p(dq), dh0=p(dh0),
+                           dh_last=p(dh_last), ln_grads=p(ln_grads), workspace=p(ws),
+                           head_w=p(head_w), head_b=p(head_b), head_out=out, dlogits=p(dy) if out else None)
         _native.check(lib.mappo_gru_seq_backward(m, _native.stream_of(dev)), "mappo_gru_seq_backward")
         # dW_ih = dgi^T x; the hidden side's gate gradient is [dgi_r | dgi_z | dq]
         dw_ih = splitk_weight_grad(dgi, x)
         dw_hh = torch.cat([splitk_weight_grad(dgi[:, :128], hm), splitk_weight_grad(dq, hm)], 0)
         db_ih = ln_grads[128:320]
         db_hh = torch.cat([ln_grads[128:256], ln_grads[320:384]])
-        return dx, dh0, None, dw_ih, dw_hh, db_ih, db_hh, ln_grads[:64], ln_grads[64:128], None, None
+        d_head = (splitk_weight_grad(dy, y), column_sums(dy)) if out else (None, None)
+        return (dx, dh0, None, dw_ih, dw_hh, db_ih, db_hh, ln_grads[:64], ln_grads[64:128], None, None) + d_head
 
+
+# the widest output Linear the chunk kernels evaluate themselves (k steps of 2 on the MFMA in the backward)
+CHUNK_HEAD_MAX = 18
 
 # MAPPO_GRU_CHUNK=0 keeps the step-by-step kernels below for the update (one launch per step and direction)
 _CHUNK_KERNEL = __import__("os").environ.get("MAPPO_GRU_CHUNK", "1") != "0"
+# MAPPO_GRU_HEAD=0 keeps the output Linear behind the GRU (action head / v_out) a separate GEMM
+_CHUNK_HEAD = __import__("os").environ.get("MAPPO_GRU_HEAD", "1") != "0"
 # MAPPO_GRU_SEQUENCE=0 falls back to aten::_thnn_fused_gru_cell driven step by step through autograd
 _SEQUENCE_KERNELS = __import__("os").environ.get("MAPPO_GRU_SEQUENCE", "1") != "0"
 # MAPPO_GRU_FUSED_STEP=0 keeps the forward hidden projection a library GEMM next to the K8 cell kernel
@@ -243,14 +258,30 @@ class RNNLayer(nn.Module):
         return _CHUNK_KERNEL and x.is_cuda and x.dtype == torch.float32 and self._recurrent_N == 1 and x.size(-1) == 64 \
             and self.rnn.hidden_size == 64 and self.norm.elementwise_affine and self.norm.bias is not None
 
-    def forward(self, x, hxs, masks):
+    def head_ok(self, x, head):
+        """Whether ``forward(..., head=head)`` evaluates the output Linear inside the chunk kernels: K12 takes the layer,
+        ``head`` is Linear-like (weight [out <= 18, 64], bias [out]) and the ``MAPPO_GRU_HEAD`` switch is on."""
+        w, b = getattr(head, "weight", None), getattr(head, "bias", None)
+        return _CHUNK_HEAD and self._chunk_kernel_ok(x) and torch.is_tensor(w) and torch.is_tensor(b) and w.dim() == 2 \
+            and w.shape[1] == 64 and 0 < w.shape[0] <= CHUNK_HEAD_MAX and w.is_cuda and w.dtype == torch.float32
+
+    def forward(self, x, hxs, masks, head=None):
+        """-> (LayerNorm(h_l) rows, final states); with ``head`` (see ``head_ok``) the first result is ``head(...)`` of
+        those rows, evaluated inside the K12 launches."""
         if self._chunk_kernel_ok(x):
             B = hxs.size(0)
             L = x.size(0) // B
             w_ih, w_hh, b_ih, b_hh = self._layer_weights(0)
+            extra = ()
+            if head is not None:
+                if not self.head_ok(x, head):
+                    raise ValueError("this head cannot be evaluated inside the GRU chunk kernels (see head_ok)")
+                extra = (head.weight, head.bias)
             y, h_last = _GRUChunkFn.apply(x, hxs[:, 0], masks, w_ih, w_hh, b_ih, b_hh, self.norm.weight, self.norm.bias,
-                                          self.norm.eps, L)
+                                          self.norm.eps, L, *extra)
             return y, h_last.unsqueeze(1)
+        if head is not None:
+            raise ValueError("this head cannot be evaluated inside the GRU chunk kernels (see head_ok)")
         if x.size(0) == hxs.size(0):
             # rollout: one step for every (env, agent) row
             y, hxs = self._run(x.unsqueeze(0), hxs, masks.reshape(1, -1, 1))

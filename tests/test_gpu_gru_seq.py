@@ -64,3 +64,43 @@ def test_chunk_kernel_is_deterministic():
         outs.append([y.detach().clone(), xd.grad.clone()] + [p.grad.clone() for p in layer.parameters()])
     for a, b in zip(*outs):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("out,L,B", [(1, 10, 96), (5, 10, 2000), (18, 10, 777), (6, 1, 200), (2, 4, 33)])
+def test_output_linear_inside_the_chunk_kernels(out, L, B):
+    """RNNLayer.forward(..., head=Linear(64, out)): the head's output comes out of the forward launch and the backward
+    launch forms the gradient at the layer's output from the gradient at the head's output; the head's own gradients
+    (split-K GEMM on the kept features, column sums) and every other gradient against the float64 restatement."""
+    dev = torch.device("cuda", 0)
+    layer = _layer(dev, out + L + B)
+    torch.manual_seed(out)
+    head = torch.nn.Linear(64, out).to(dev)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(L * B, 64, generator=g)
+    h0 = torch.randn(B, 1, 64, generator=g)
+    masks = (torch.rand(L * B, 1, generator=g) > 0.1).float()
+    dlog = torch.randn(L * B, out, generator=g)
+    xd, hd = x.to(dev).requires_grad_(), h0.to(dev).requires_grad_()
+    assert layer.head_ok(xd, head)
+    logits, h_last = layer(xd, hd, masks.to(dev), head=head)
+    assert logits.shape == (L * B, out)
+    ((logits * dlog.to(dev)).sum() + 0.5 * h_last.sum()).backward()
+
+    P = {"w_ih": layer.rnn.weight_ih_l0, "w_hh": layer.rnn.weight_hh_l0, "b_ih": layer.rnn.bias_ih_l0,
+         "b_hh": layer.rnn.bias_hh_l0, "ln_g": layer.norm.weight, "ln_b": layer.norm.bias, "head_w": head.weight,
+         "head_b": head.bias}
+    tp = {k: v.detach().cpu().double().requires_grad_() for k, v in P.items()}
+    tx, th = x.double().requires_grad_(), h0[:, 0].double().requires_grad_()
+    y_ref, h_ref = reference(tp, tx, th, masks[:, 0].double(), L, B)
+    logits_ref = y_ref @ tp["head_w"].t() + tp["head_b"]
+    ((logits_ref * dlog.double()).sum() + 0.5 * h_ref.sum()).backward()
+    torch.testing.assert_close(logits.detach().cpu().double(), logits_ref.detach(), rtol=0,
+                               atol=3e-5 * float(logits_ref.abs().max()))
+    pairs = [("dx", xd.grad, tx.grad), ("dh0", hd.grad[:, 0], th.grad)] + [(k, P[k].grad, tp[k].grad) for k in P]
+    for name, got, ref in pairs:
+        torch.testing.assert_close(got.cpu().double(), ref, rtol=0, atol=1e-4 * float(ref.abs().max()) + 1e-9, msg=name)
+    # a head the kernels do not take is refused, not silently evaluated some other way
+    wide = torch.nn.Linear(64, 19).to(dev)
+    assert not layer.head_ok(xd, wide)
+    with pytest.raises(ValueError):
+        layer(xd, hd, masks.to(dev), head=wide)

@@ -47,7 +47,7 @@ def reference(p, x, h0, masks, L, mb):
     return y, h
 
 
-def run(emu, L, mb, seed, grid_cap=0):
+def run(emu, L, mb, seed, grid_cap=0, head_out=0):
     from onpolicy import _native
     rng = np.random.default_rng(seed)
     f32 = np.float32
@@ -58,7 +58,10 @@ def run(emu, L, mb, seed, grid_cap=0):
     x = rng.standard_normal((L * mb, 64)).astype(f32)
     h0 = rng.standard_normal((mb, 64)).astype(f32)
     masks = (rng.random(L * mb) > 0.2).astype(f32)
-    dy = rng.standard_normal((L * mb, 64)).astype(f32)
+    dy = rng.standard_normal((L * mb, head_out or 64)).astype(f32)     # with a head: the gradient at its output
+    hw = (rng.standard_normal((max(head_out, 1), 64)) * 0.3).astype(f32)
+    hb = (rng.standard_normal(max(head_out, 1)) * 0.3).astype(f32)
+    logits = np.full((L * mb, max(head_out, 1)), np.nan, f32)
     dhl = rng.standard_normal((mb, 64)).astype(f32)
     nan = lambda *shape: np.full(shape, np.nan, f32)
     y, h_last = nan(L * mb, 64), nan(mb, 64)
@@ -73,6 +76,8 @@ def run(emu, L, mb, seed, grid_cap=0):
                        y=ptr(y), h_last=ptr(h_last), gates=ptr(gates), hm=ptr(hm), stats=ptr(stats), dy=ptr(dy),
                        dx=ptr(dx), dgi=ptr(dgi), dq=ptr(dq), dh0=ptr(dh0), dh_last=ptr(dhl), ln_grads=ptr(ln_grads),
                        workspace=ptr(ws))
+    if head_out:
+        m.head_w, m.head_b, m.head_out, m.logits, m.dlogits, m.dy = ptr(hw), ptr(hb), head_out, ptr(logits), ptr(dy), None
     emu.mappo_mlp_set_grid_cap(grid_cap)
     try:
         assert emu.mappo_gru_seq_forward(ctypes.byref(m), None) == 0
@@ -86,7 +91,11 @@ def run(emu, L, mb, seed, grid_cap=0):
     y_ref, h_ref = reference(tp, tx, th0, torch.tensor(masks, dtype=torch.float64), L, mb)
     np.testing.assert_allclose(y, y_ref.detach().numpy(), rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(h_last, h_ref.detach().numpy(), rtol=2e-4, atol=2e-5)
-    ((y_ref * torch.tensor(dy, dtype=torch.float64)).sum() + (h_ref * torch.tensor(dhl, dtype=torch.float64)).sum()).backward()
+    out_ref = y_ref
+    if head_out:        # the output Linear evaluated inside the launches
+        out_ref = y_ref @ torch.tensor(hw, dtype=torch.float64).t() + torch.tensor(hb, dtype=torch.float64)
+        np.testing.assert_allclose(logits, out_ref.detach().numpy(), rtol=2e-4, atol=5e-5)
+    ((out_ref * torch.tensor(dy, dtype=torch.float64)).sum() + (h_ref * torch.tensor(dhl, dtype=torch.float64)).sum()).backward()
 
     def close(got, ref, name):
         ref = ref.numpy() if torch.is_tensor(ref) else ref
@@ -111,6 +120,13 @@ def run(emu, L, mb, seed, grid_cap=0):
 @pytest.mark.parametrize("L,mb", [(1, 40), (3, 32), (5, 70), (10, 33)])
 def test_chunk_kernels_vs_float64_reference(emu, L, mb):
     run(emu, L, mb, seed=L * 100 + mb)
+
+
+@pytest.mark.parametrize("head_out,L,mb", [(1, 3, 40), (5, 4, 33), (6, 2, 32), (18, 3, 45), (2, 1, 70)])
+def test_output_linear_inside_the_launches(emu, head_out, L, mb):
+    """head_out > 0: logits = y head_w^T + head_b from the forward launch, dy = dlogits head_w formed by the backward launch
+    on the MFMA (1, 3 or 9 k steps of two outputs; padded outputs meet zero weights)."""
+    run(emu, L, mb, seed=head_out * 1000 + mb, head_out=head_out)
 
 
 def test_waves_looping_over_several_tiles(emu):

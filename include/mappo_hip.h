@@ -365,8 +365,9 @@ int mappo_gru_step_fwd(const float* gi, const float* hm, const float* w_hh, cons
  * mappo_gru_seq_backward (truncated BPTT inside the launch): dy [L * mb, 64] (+ dh_last [mb, 64], optional) -> dx [L * mb, 64], dh0 [mb, 64] (optional),
  *   dgi [L * mb, 192] = gradient at W_ih x + b_ih, dq [L * mb, 64] = gradient at W_hn hm + b_hn (the r and z thirds of the
  *   hidden side's gradient are dgi's) -- the caller forms dW_ih = dgi^T x and dW_hh = [dgi_rz | dq]^T hm from them -- and
- *   ln_grads [384] = LayerNorm weight | bias gradients [128], then the column sums of dgi [192] (= db_ih; its first 128 are
- *   also the r and z thirds of db_hh) and of dq [64] (= the n third of db_hh), folded over the rows inside the launch;
+ *   ln_grads [800] = LayerNorm weight | bias gradients [128], then the column sums of dgi [192] (= db_ih; its first 128 are
+ *   also the r and z thirds of db_hh) and of dq [64] (= the n third of db_hh), folded over the rows inside the launch
+ *   (then, with a head of <= 6 outputs, its sums: see head_w below);
  *   workspace [mappo_gru_seq_workspace_floats()] scratch.  Deterministic run to run. */
 typedef struct mappo_gru_seq {
     const float* x;
@@ -393,18 +394,21 @@ typedef struct mappo_gru_seq {
     float* dq;
     float* dh0;
     const float* dh_last;   /* [mb, 64] gradient at h_last, or NULL */
-    float* ln_grads;        /* [384], see above */
+    float* ln_grads;        /* [800], see above */
     float* workspace;
     /* Optional output Linear on y inside the launches (the Categorical head's Linear, distributions.py:55-68, or the
      * critic's v_out, r_actor_critic.py:147-175): head_out > 0 makes the forward also write logits [L * mb, head_out] =
      * y head_w^T + head_b (y may then be NULL), and the backward (head_out <= 18) form dy = dlogits head_w itself from
-     * dlogits [L * mb, head_out] -- dy is not read.  The head's own gradients are the caller's: dlogits^T y and the
-     * column sums of dlogits. */
+     * dlogits [L * mb, head_out] -- dy is not read.  The head's own gradients: with head_sums = 1 (head_out <= 6) the backward also leaves
+     * ln_grads[384 + 64 o + f] = sum over rows of dlogits[o] n^[f] (n^ = the normalised output, y = n^ ln_g + ln_b) and
+     * ln_grads[768 + o] = sum of dlogits[o], from which dW_h = ln_g (.) GH + ln_b (x) db_h, db_h = the second sums -- y is
+     * never needed; wider heads: dlogits^T y and the column sums of dlogits, formed by the caller from y. */
     const float* head_w;    /* [head_out, 64] or NULL */
     const float* head_b;    /* [head_out] */
     int32_t head_out;       /* 0: no head */
     float* logits;
     const float* dlogits;
+    int32_t head_sums;      /* backward: 1 = leave the head's gradient sums in ln_grads (head_out <= 6) */
 } mappo_gru_seq_t;
 int64_t mappo_gru_seq_gates_floats(int L, int64_t mb);
 int64_t mappo_gru_seq_stats_floats(int L, int64_t mb);

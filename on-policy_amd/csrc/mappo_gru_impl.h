@@ -65,10 +65,12 @@ struct Args {
     int head_out;
     float* logits;          // [L * mb, head_out]
     const float* dlogits;   // backward: [L * mb, head_out]; dy = dlogits head_w is formed in the launch (a.dy is not read)
+    int head_sums;          // backward: also leave the head's gradient sums (head_out <= kHeadSumOutputs)
     float* partials;        // [gridDim.x][kSums]: LayerNorm weight | bias gradient sums, then the column sums of the gate
                             // gradients (r | z | n of dgi, then dq) per workgroup
 };
-constexpr int kSums = 128 + 256;
+constexpr int kHeadSumOutputs = 6;                       // heads up to this width: their weight / bias gradient sums too
+constexpr int kSums = 128 + 256 + kHeadSumOutputs * 64 + 32;     // ... | sum dlogits[o] n^[f] [6][64] | sum dlogits[o] [6] (+ pad)
 
 __host__ __device__ __forceinline__ long long tiles_of(long long mb) { return (mb + 31) / 32; }
 
@@ -149,7 +151,7 @@ constexpr int kW = 6 * 32 * kWS;
 constexpr int kFwdLds = 2 * kW + 6 * 64;                 // + head_out * 65 with a head: whp [out][64] permuted | bias [out]
 constexpr int kMaxHeadSteps = 9;                         // backward with a head: head_out <= 18 (k steps of 2 on the MFMA)
 constexpr int kHeadA = 2 * kMaxHeadSteps * 64;           // whA [2 feature tiles][NJ][64 lanes]
-constexpr int kSumsPerWave = 512;                        // >= kSums
+constexpr int kSumsPerWave = 1280;                       // >= kSums + scratch [6][64] for the lanes' sums of dlogits
 constexpr int kBwdLds = 2 * kW + 64 + kHeadA + kWaves * kSumsPerWave;
 
 __global__ void __launch_bounds__(kThreads, 1) gru_seq_fwd_kernel(Args a) {
@@ -284,7 +286,8 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_fwd_kernel(Args a) {
 
 // NJ > 0: the gradient at y comes from an output Linear, dy = dlogits head_w, as NJ k steps of 2 outputs on the MFMA
 // (head_out <= 2 NJ; padded outputs have zero weights)
-template <int NJ>
+// HO > 0: also leave the gradient sums of the head's first HO outputs (head_out <= HO <= kHeadSumOutputs)
+template <int NJ, int HO>
 __global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
     float* lds = prim::lds();
     const int tid = threadIdx.x, lane = tid & 63, wave = prim::uniform(tid >> 6), c = lane & 31, h = lane >> 5;
@@ -313,6 +316,13 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
     // this kernel writes, the bias sums were 6 % of the recurrent north-star step.)
     float sgam = 0.f, sbet = 0.f;
     float sbr = 0.f, sbz = 0.f, sbn = 0.f, sbq = 0.f;
+    // a narrow head's own gradients, dW_h = gamma (.) GH + beta (x) db_h with GH[o][f] = sum dlogits[o] n^[f] (y = n^ gamma +
+    // beta is never written then): one column-sum butterfly per output and step; db_h as per-lane sums, added at the end
+    constexpr bool kHeadSums = HO > 0 && NJ > 0 && 2 * NJ <= kHeadSumOutputs;
+    constexpr int NO = kHeadSums ? 2 * NJ : 1;
+    float gh[NO], dbh[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) gh[o] = dbh[o] = 0.f;
     const long long mb = a.mb, ntiles = tiles_of(mb);
     const int L = a.L;
     for (long long tile = (long long)blockIdx.x * kWaves + wave; tile < ntiles; tile += (long long)gridDim.x * kWaves) {
@@ -376,6 +386,24 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
                 }
 #pragma unroll
                 for (int s = 0; s < 32; ++s) g[s] = ag[s >> 4][s & 15];
+                if (kHeadSums) {
+#pragma unroll
+                    for (int jq = 0; jq < NJ; ++jq) {
+                        const float mine = ok ? dl[jq] : 0.f, other = prim::xhalf(mine);
+                        const float d0 = h ? other : mine, d1 = h ? mine : other;      // dlogits of outputs 2 jq, 2 jq + 1
+                        float v[32];
+#pragma unroll
+                        for (int s = 0; s < 32; ++s) v[s] = d0 * nh[s];
+                        gh[2 * jq] += colsum32(v);
+                        dbh[2 * jq] += d0;
+                        if (2 * jq + 1 < HO) {
+#pragma unroll
+                            for (int s = 0; s < 32; ++s) v[s] = d1 * nh[s];
+                            gh[2 * jq + 1] += colsum32(v);
+                            dbh[2 * jq + 1] += d1;
+                        }
+                    }
+                }
             }
             // output LayerNorm backward (rows past the end: dy = 0 -> every gradient below is 0)
             float m1 = 0.f, m2 = 0.f;
@@ -451,6 +479,18 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
         T[192 + f] = sbz;
         T[256 + f] = sbn;
         T[320 + f] = sbq;
+#pragma unroll
+        for (int o = 0; o < kHeadSumOutputs; ++o) {
+            T[384 + 64 * o + f] = (kHeadSums && o < NO) ? gh[o < NO ? o : 0] : 0.f;
+            T[kSums + 64 * o + lane] = (kHeadSums && o < NO) ? dbh[o < NO ? o : 0] : 0.f;
+        }
+    }
+    prim::wave_sync();
+    if (lane < 32) {        // sum over this wave's rows of dlogits[o]: the h = 0 lanes' values (both half-waves hold a row's)
+        float s = 0.f;
+        if (lane < kHeadSumOutputs)
+            for (int cc = 0; cc < 32; ++cc) s += T[kSums + 64 * lane + cc];
+        T[384 + 64 * kHeadSumOutputs + lane] = s;
     }
     __syncthreads();
     for (int e = tid; e < kSums; e += kThreads) {
@@ -472,6 +512,7 @@ inline int check(const mappo_gru_seq_t* m, bool backward) {
     if (m->mb <= 0 || m->L <= 0 || m->H != 64) return MAPPO_E_SHAPE;
     if ((m->gates != nullptr) != (m->hm != nullptr) || (m->gates != nullptr) != (m->stats != nullptr)) return MAPPO_E_NULL;
     if (m->head_out < 0 || m->head_out > 64 || (backward && m->head_out > 2 * kMaxHeadSteps)) return MAPPO_E_SHAPE;
+    if (backward && m->head_sums && (m->head_out <= 0 || m->head_out > kHeadSumOutputs)) return MAPPO_E_SHAPE;
     if (m->head_out > 0 && (!m->head_w || !m->head_b || (backward ? !m->dlogits : !m->logits))) return MAPPO_E_NULL;
     if (!backward && !m->y && m->head_out == 0) return MAPPO_E_NULL;
     if (backward && (!m->gates || (!m->dy && m->head_out == 0) || !m->dx || !m->dgi || !m->dq || !m->ln_grads || !m->workspace))
@@ -512,6 +553,7 @@ inline void fill(const mappo_gru_seq_t* m, Args& a) {
     a.head_out = m->head_out;
     a.logits = m->logits;
     a.dlogits = m->dlogits;
+    a.head_sums = m->head_sums;
 }
 
 inline int forward(const mappo_gru_seq_t* m, hipStream_t stream) {
@@ -530,15 +572,23 @@ inline int backward(const mappo_gru_seq_t* m, hipStream_t stream) {
     fill(m, a);
     const long long grid = grid_of(m->mb);
     const int ho = m->head_out;
+    const bool hs = m->head_sums != 0;
+#define MAPPO_GRU_BWD(NJ, HO) MAPPO_LAUNCH((gru_seq_bwd_kernel<NJ, HO>), (unsigned)grid, kThreads, (size_t)kBwdLds * 4, stream, a)
     if (ho == 0) {
-        MAPPO_LAUNCH(gru_seq_bwd_kernel<0>, (unsigned)grid, kThreads, (size_t)kBwdLds * 4, stream, a);
+        MAPPO_GRU_BWD(0, 0);
     } else if (ho <= 2) {
-        MAPPO_LAUNCH(gru_seq_bwd_kernel<1>, (unsigned)grid, kThreads, (size_t)kBwdLds * 4, stream, a);
+        if (hs && ho == 1) MAPPO_GRU_BWD(1, 1);
+        else if (hs) MAPPO_GRU_BWD(1, 2);
+        else MAPPO_GRU_BWD(1, 0);
     } else if (ho <= 6) {
-        MAPPO_LAUNCH(gru_seq_bwd_kernel<3>, (unsigned)grid, kThreads, (size_t)kBwdLds * 4, stream, a);
+        if (hs && ho <= 4) MAPPO_GRU_BWD(3, 4);
+        else if (hs && ho == 5) MAPPO_GRU_BWD(3, 5);
+        else if (hs) MAPPO_GRU_BWD(3, 6);
+        else MAPPO_GRU_BWD(3, 0);
     } else {
-        MAPPO_LAUNCH(gru_seq_bwd_kernel<9>, (unsigned)grid, kThreads, (size_t)kBwdLds * 4, stream, a);
+        MAPPO_GRU_BWD(9, 0);
     }
+#undef MAPPO_GRU_BWD
     MAPPO_LAUNCH(mlp::mlp_reduce_kernel, (unsigned)(kSums / 32), mlp::kThreads, 1024, stream, (const float*)m->workspace, grid,
                  (long long)kSums, (long long)kSums, m->ln_grads);
     return MAPPO_LAUNCH_ERROR();

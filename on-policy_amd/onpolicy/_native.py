@@ -62,7 +62,7 @@ class GRUSeq(ctypes.Structure):
                [("ln_eps", ctypes.c_float), ("H", ctypes.c_int32), ("L", ctypes.c_int32), ("mb", _i64)] + \
                [(n, _vp) for n in ("y", "h_last", "gates", "hm", "stats", "dy", "dx", "dgi", "dq", "dh0", "dh_last",
                                    "ln_grads", "workspace", "head_w", "head_b")] + \
-               [("head_out", ctypes.c_int32), ("logits", _vp), ("dlogits", _vp)]
+               [("head_out", ctypes.c_int32), ("logits", _vp), ("dlogits", _vp), ("head_sums", ctypes.c_int32)]
 
 
 ADAM_MAX_TENSORS = 64

@@ -118,7 +118,8 @@ class _GRUChunkFn(torch.autograd.Function):
         head = None if head_w is None else (head_w.detach().contiguous(), head_b.detach().contiguous())
         out = 0 if head is None else int(head[0].shape[0])
         need = any(ctx.needs_input_grad)
-        y = torch.empty(L * B, 64, **f32) if (head is None or need) else None
+        # (a narrow head's own gradients come out of the backward launch as sums: the features are never written then)
+        y = torch.empty(L * B, 64, **f32) if (head is None or (need and out > CHUNK_HEAD_SUMS)) else None
         logits = torch.empty(L * B, out, **f32) if head is not None else None
         h_last = torch.empty(B, 64, **f32)
         gates = torch.empty(lib.mappo_gru_seq_gates_floats(L, B), **f32) if need else None
@@ -131,7 +132,7 @@ class _GRUChunkFn(torch.autograd.Function):
                            logits=p(logits))
         _native.check(lib.mappo_gru_seq_forward(m, _native.stream_of(dev)), "mappo_gru_seq_forward")
         if need:
-            ctx.save_for_backward(x, h0, masks, gates, stats, hm, *params, *((y,) + head if head else ()))
+            ctx.save_for_backward(x, h0, masks, gates, stats, hm, *params, *(head + ((y,) if y is not None else ()) if head else ()))
             ctx.cfg = (float(eps), L, out)
         return (logits if head is not None else y), h_last
 
@@ -141,7 +142,8 @@ class _GRUChunkFn(torch.autograd.Function):
         lib, p = _native.lib(), _native.ptr
         x, h0, masks, gates, stats, hm, w_ih, w_hh, b_ih, b_hh, ln_g, ln_b = ctx.saved_tensors[:12]
         eps, L, out = ctx.cfg
-        y, head_w, head_b = ctx.saved_tensors[12:] if out else (None, None, None)
+        head_w, head_b = ctx.saved_tensors[12:14] if out else (None, None)
+        y = ctx.saved_tensors[14] if out > CHUNK_HEAD_SUMS else None
         B = h0.shape[0]
         dev = x.device
         f32 = dict(dtype=torch.float32, device=dev)
@@ -151,25 +153,35 @@ class _GRUChunkFn(torch.autograd.Function):
         dgi = torch.empty(L * B, 192, **f32)
         dq = torch.empty(L * B, 64, **f32)
         dh0 = torch.empty(B, 64, **f32) if ctx.needs_input_grad[1] else None
-        ln_grads = torch.empty(384, **f32)        # LayerNorm weight | bias gradients, column sums of dgi [192] and dq [64]
+        # LayerNorm weight | bias gradients, column sums of dgi [192] and dq [64], a narrow head's sums [6, 64] + [6]
+        ln_grads = torch.empty(800, **f32)
         ws = torch.empty(lib.mappo_gru_seq_workspace_floats(), **f32)
         m = _native.GRUSeq(x=p(x), h0=p(h0), masks=p(masks), w_ih=p(w_ih), w_hh=p(w_hh), b_ih=p(b_ih), b_hh=p(b_hh),
                            ln_g=p(ln_g), ln_b=p(ln_b), ln_eps=eps, H=64, L=L, mb=B, gates=p(gates), hm=p(hm),
                            stats=p(stats), dy=None if out else p(dy), dx=p(dx), dgi=p(dgi), dq=p(dq), dh0=p(dh0),
                            dh_last=p(dh_last), ln_grads=p(ln_grads), workspace=p(ws),
-                           head_w=p(head_w), head_b=p(head_b), head_out=out, dlogits=p(dy) if out else None)
+                           head_w=p(head_w), head_b=p(head_b), head_out=out, dlogits=p(dy) if out else None,
+                           head_sums=int(0 < out <= CHUNK_HEAD_SUMS))
         _native.check(lib.mappo_gru_seq_backward(m, _native.stream_of(dev)), "mappo_gru_seq_backward")
         # dW_ih = dgi^T x; the hidden side's gate gradient is [dgi_r | dgi_z | dq]
         dw_ih = splitk_weight_grad(dgi, x)
         dw_hh = torch.cat([splitk_weight_grad(dgi[:, :128], hm), splitk_weight_grad(dq, hm)], 0)
         db_ih = ln_grads[128:320]
         db_hh = torch.cat([ln_grads[128:256], ln_grads[320:384]])
-        d_head = (splitk_weight_grad(dy, y), column_sums(dy)) if out else (None, None)
+        if not out:
+            d_head = (None, None)
+        elif out <= CHUNK_HEAD_SUMS:        # dW_h = gamma (.) sum dlogits n^ + beta (x) sum dlogits (y = n^ gamma + beta)
+            dbh = ln_grads[768:768 + out]
+            d_head = (ln_grads[384:384 + 64 * out].view(out, 64) * ln_g + dbh[:, None] * ln_b, dbh)
+        else:
+            d_head = (splitk_weight_grad(dy, y), column_sums(dy))
         return (dx, dh0, None, dw_ih, dw_hh, db_ih, db_hh, ln_grads[:64], ln_grads[64:128], None, None) + d_head
 
 
 # the widest output Linear the chunk kernels evaluate themselves (k steps of 2 on the MFMA in the backward)
 CHUNK_HEAD_MAX = 18
+# ... and the widest whose weight / bias gradients it also sums itself (one column-sum butterfly per output and step)
+CHUNK_HEAD_SUMS = 6 if __import__("os").environ.get("MAPPO_GRU_HEAD_SUMS", "1") != "0" else 0
 
 # MAPPO_GRU_CHUNK=0 keeps the step-by-step kernels below for the update (one launch per step and direction)
 _CHUNK_KERNEL = __import__("os").environ.get("MAPPO_GRU_CHUNK", "1") != "0"

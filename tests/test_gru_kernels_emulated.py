@@ -69,7 +69,7 @@ def run(emu, L, mb, seed, grid_cap=0, head_out=0):
     stats = nan(emu.mappo_gru_seq_stats_floats(L, mb))
     hm = nan(L * mb, 64)
     dx, dgi, dq, dh0 = nan(L * mb, 64), nan(L * mb, 192), nan(L * mb, 64), nan(mb, 64)
-    ln_grads, ws = nan(384), nan(emu.mappo_gru_seq_workspace_floats())
+    ln_grads, ws = nan(800), nan(emu.mappo_gru_seq_workspace_floats())
     ptr = lambda a: a.ctypes.data
     m = _native.GRUSeq(x=ptr(x), h0=ptr(h0), masks=ptr(masks), w_ih=ptr(P["w_ih"]), w_hh=ptr(P["w_hh"]), b_ih=ptr(P["b_ih"]),
                        b_hh=ptr(P["b_hh"]), ln_g=ptr(P["ln_g"]), ln_b=ptr(P["ln_b"]), ln_eps=1e-5, H=64, L=L, mb=mb,
@@ -78,6 +78,7 @@ def run(emu, L, mb, seed, grid_cap=0, head_out=0):
                        workspace=ptr(ws))
     if head_out:
         m.head_w, m.head_b, m.head_out, m.logits, m.dlogits, m.dy = ptr(hw), ptr(hb), head_out, ptr(logits), ptr(dy), None
+        m.head_sums = int(head_out <= 6)
     emu.mappo_mlp_set_grid_cap(grid_cap)
     try:
         assert emu.mappo_gru_seq_forward(ctypes.byref(m), None) == 0
@@ -93,7 +94,9 @@ def run(emu, L, mb, seed, grid_cap=0, head_out=0):
     np.testing.assert_allclose(h_last, h_ref.detach().numpy(), rtol=2e-4, atol=2e-5)
     out_ref = y_ref
     if head_out:        # the output Linear evaluated inside the launches
-        out_ref = y_ref @ torch.tensor(hw, dtype=torch.float64).t() + torch.tensor(hb, dtype=torch.float64)
+        thw = torch.tensor(hw, dtype=torch.float64, requires_grad=True)
+        thb = torch.tensor(hb, dtype=torch.float64, requires_grad=True)
+        out_ref = y_ref @ thw.t() + thb
         np.testing.assert_allclose(logits, out_ref.detach().numpy(), rtol=2e-4, atol=5e-5)
     ((out_ref * torch.tensor(dy, dtype=torch.float64)).sum() + (h_ref * torch.tensor(dhl, dtype=torch.float64)).sum()).backward()
 
@@ -101,6 +104,11 @@ def run(emu, L, mb, seed, grid_cap=0, head_out=0):
         ref = ref.numpy() if torch.is_tensor(ref) else ref
         np.testing.assert_allclose(got, ref, rtol=3e-4, atol=3e-5 * max(1e-12, np.abs(ref).max()), err_msg=name)
 
+    if 0 < head_out <= 6:       # the head's own gradients from the sums the backward launch leaves
+        gh = ln_grads[384:384 + 64 * head_out].reshape(head_out, 64).astype(np.float64)
+        dbh = ln_grads[768:768 + head_out].astype(np.float64)
+        close(gh * P["ln_g"].astype(np.float64) + dbh[:, None] * P["ln_b"].astype(np.float64), thw.grad, "head weight")
+        close(dbh, thb.grad, "head bias")
     close(dx, tx.grad, "dx")
     close(dh0, th0.grad, "dh0")
     close(ln_grads[:64], tp["ln_g"].grad, "ln weight")

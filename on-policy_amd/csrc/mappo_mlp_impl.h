@@ -1137,16 +1137,18 @@ __device__ __forceinline__ void finish_grads(const FinishArgs& a) {
     const Net& n = a.net;
     const int L = n.L, out = n.out, din = n.din, tid = threadIdx.x;
     for (int l = 1; l < L; ++l) {
-        const float* G = a.R + r_g(L, l);
-        const float* dbl = a.R + 64 * l;
-        const float* g = n.ln_g[l - 1];
-        const float* be = n.ln_b[l - 1];
-        const float* W = n.w2[l - 1];
-        float* dW = a.grads + g_w2(din, L, l);
+        // (the outputs alias none of the inputs: lets the compiler keep several iterations' loads in flight)
+        const float* __restrict__ G = a.R + r_g(L, l);
+        const float* __restrict__ dbl = a.R + 64 * l;
+        const float* __restrict__ g = n.ln_g[l - 1];
+        const float* __restrict__ be = n.ln_b[l - 1];
+        const float* __restrict__ W = n.w2[l - 1];
+        float* __restrict__ dW = a.grads + g_w2(din, L, l);
         for (int e = tid; e < 4096; e += kThreads) dW[e] = g[e & 63] * G[e] + be[e & 63] * dbl[e >> 6];
         if (tid < 64) {
             float sg = 0.f, sb = 0.f;
-            for (int f = 0; f < 64; ++f) {
+#pragma unroll 16
+            for (int f = 0; f < 64; ++f) {      // (unrolled: sixteen rows' loads in flight, the sums stay in order)
                 sg += W[f * 64 + tid] * G[f * 64 + tid];
                 sb += W[f * 64 + tid] * dbl[f];
             }
@@ -1166,6 +1168,7 @@ __device__ __forceinline__ void finish_grads(const FinishArgs& a) {
         for (int e = tid; e < out; e += kThreads) dWh[64 * out + e] = dbh[e];
         if (tid < 64) {
             float sg = 0.f, sb = 0.f;
+#pragma unroll 8
             for (int oo = 0; oo < out; ++oo) {
                 sg += n.wh[oo * 64 + tid] * Gh[oo * 64 + tid];
                 sb += n.wh[oo * 64 + tid] * dbh[oo];

@@ -17,7 +17,8 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kMaxBlocks = 256;
+constexpr int kMaxBlocks = 256;          // Adam: the second launch folds the first one's partials in ONE block
+constexpr int kMaxSumBlocks = 1024;      // ValueNorm / minibatch sums (13 M elements per call at the north star)
 
 struct Desc {
     mappo_adam_t a;
@@ -75,6 +76,9 @@ __global__ void __launch_bounds__(kThreads) adam_step_kernel(Desc d, int n_parti
     __shared__ long long prefix[MAPPO_ADAM_MAX_TENSORS + 1];
     __shared__ float sh[kThreads / 64];
     __shared__ float coef_s;
+    // per tensor: step size lr / (1 - beta1^step) and sqrt(1 - beta2^step) (two double pow() per ELEMENT made this launch
+    // 30 us for a 40 k-parameter network)
+    __shared__ float step_size_s[MAPPO_ADAM_MAX_TENSORS], sqrt_bc2_s[MAPPO_ADAM_MAX_TENSORS];
     if (threadIdx.x == 0) {
         long long s = 0;
         for (int t = 0; t < d.a.n; ++t) {
@@ -82,6 +86,12 @@ __global__ void __launch_bounds__(kThreads) adam_step_kernel(Desc d, int n_parti
             s += d.a.numel[t];
         }
         prefix[d.a.n] = s;
+    }
+    if (threadIdx.x < d.a.n) {
+        const double step = (double)d.a.step[threadIdx.x][0];
+        const float bc1 = (float)(1.0 - pow(d.a.beta1, step)), bc2 = (float)(1.0 - pow(d.a.beta2, step));
+        step_size_s[threadIdx.x] = (float)(d.a.lr / bc1);
+        sqrt_bc2_s[threadIdx.x] = sqrtf(bc2);
     }
     float p = threadIdx.x < n_partials ? d.a.workspace[threadIdx.x] : 0.f;      // (n_partials <= kThreads, fixed order)
     __syncthreads();
@@ -105,8 +115,6 @@ __global__ void __launch_bounds__(kThreads) adam_step_kernel(Desc d, int n_parti
         const long long i = e - prefix[t];
         // (torch's fused Adam kernel: the hyper-parameters are doubles, so the products with them are formed in double and
         // rounded to float32 once)
-        const double step = (double)d.a.step[t][0];
-        const float bc1 = (float)(1.0 - pow(d.a.beta1, step)), bc2 = (float)(1.0 - pow(d.a.beta2, step));
         float g = d.a.grad[t][i] * coef;
         d.a.grad[t][i] = g;                             // the clipped gradient stays in .grad, as clip_grad_norm_ leaves it
         float w = d.a.param[t][i];
@@ -116,9 +124,8 @@ __global__ void __launch_bounds__(kThreads) adam_step_kernel(Desc d, int n_parti
         v = (float)(d.a.beta2 * v + (1.0 - d.a.beta2) * g * g);
         d.a.exp_avg[t][i] = m;
         d.a.exp_avg_sq[t][i] = v;
-        const float step_size = (float)(d.a.lr / bc1);
-        const float denom = (float)(sqrtf(v) / sqrtf(bc2) + d.a.eps);
-        d.a.param[t][i] = w - step_size * m / denom;
+        const float denom = (float)(sqrtf(v) / sqrt_bc2_s[t] + d.a.eps);
+        d.a.param[t][i] = w - step_size_s[t] * m / denom;
     }
 }
 
@@ -158,20 +165,24 @@ __global__ void __launch_bounds__(kThreads) vn_sums_kernel(const float* x, long 
 
 __global__ void vn_fold_kernel(const double* partials, int n_partials, double count, const float* batch_moments,
                                double weight, float eps, float* m1, float* m2, float* d, float* denorm) {
-    if (threadIdx.x != 0) return;
     float mean, mean_sq;
     if (batch_moments != nullptr) {         // data parallel: the all-reduced moments of the global minibatch
         mean = batch_moments[0];
         mean_sq = batch_moments[1];
-    } else {
+    } else {                                // (one wave: lane l adds partials l, l + 64, ..., then the lanes are folded)
         double a = 0.0, b = 0.0;
-        for (int i = 0; i < n_partials; ++i) {
+        for (int i = threadIdx.x; i < n_partials; i += 64) {
             a += partials[2 * i];
             b += partials[2 * i + 1];
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            a += __shfl_down(a, off);
+            b += __shfl_down(b, off);
         }
         mean = (float)(a / count);
         mean_sq = (float)(b / count);
     }
+    if (threadIdx.x != 0) return;
     // m <- w m + (1 - w) E[.] in float32 with the Python float weight, like the in-place tensor ops of the reference
     const float w = (float)weight, u = (float)(1.0 - weight);
     const float n1 = m1[0] * w + mean * u, n2 = m2[0] * w + mean_sq * u, nd = d[0] * w + u;
@@ -221,11 +232,14 @@ __global__ void __launch_bounds__(kThreads) mb_sums_kernel(const float* active, 
         partials[3 * blockIdx.x + threadIdx.x] = a;
     }
 }
+// one wave per sum: lane l adds partials l, l + 64, ..., then the lanes are folded (fixed order; one thread walking the
+// partials one load at a time took 29 us)
 __global__ void mb_sums_finish_kernel(const double* partials, int n_partials, double rows, double* sums) {
-    if (threadIdx.x >= 3) return;
+    const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;        // q < 3
     double a = 0.0;
-    for (int i = 0; i < n_partials; ++i) a += partials[3 * i + threadIdx.x];
-    sums[threadIdx.x == 0 ? 0 : threadIdx.x + 1] = a;
+    for (int i = lane; i < n_partials; i += 64) a += partials[3 * i + q];
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+    if (lane == 0) sums[q == 0 ? 0 : q + 1] = a;
     if (threadIdx.x == 0) sums[1] = rows;
 }
 // Launch 3: out = [1 / global policy denominator, 1 / global value denominator,
@@ -274,14 +288,17 @@ __global__ void __launch_bounds__(kThreads) fold_fwd_kernel(const float* W, cons
         bf[f] = b[f] + t;
     }
 }
-__global__ void __launch_bounds__(kThreads) fold_bwd_kernel(const float* W, const float* gamma, const float* beta, const float* dWf,
-                                                            const float* dbf, int out_f, int din, int ld, float* dW,
-                                                            float* dgamma, float* dbeta) {
+__global__ void __launch_bounds__(kThreads) fold_bwd_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ dWf,
+                                                            const float* __restrict__ dbf, int out_f, int din, int ld,
+                                                            float* __restrict__ dW, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta) {
     const int k = blockIdx.x * kThreads + threadIdx.x;
     if (k >= din) return;
     const float g = gamma[k], be = beta[k];
     float sg = 0.f, sb = 0.f;
-    for (int f = 0; f < out_f; ++f) {
+#pragma unroll 8
+    for (int f = 0; f < out_f; ++f) {       // (no aliasing + unrolled: the loads of eight features in flight, sums in order)
         const float w = W[(long long)f * din + k], dwf = dWf[(long long)f * ld + k], d = dbf[f];
         dW[(long long)f * din + k] = dwf * g + d * be;
         sg += dwf * w;
@@ -314,7 +331,7 @@ extern "C" int mappo_fold_input_norm_backward(const float* w, const float* gamma
     return (int)hipGetLastError();
 }
 
-extern "C" int64_t mappo_minibatch_sums_workspace_doubles(void) { return 3 * kMaxBlocks; }
+extern "C" int64_t mappo_minibatch_sums_workspace_doubles(void) { return 3 * kMaxSumBlocks; }
 
 extern "C" int mappo_minibatch_sums(const float* active_masks, const float* returns, int64_t n, double* sums,
                                     double* workspace, mappo_stream_t stream_) {
@@ -322,10 +339,10 @@ extern "C" int mappo_minibatch_sums(const float* active_masks, const float* retu
     if (!active_masks || !returns || !sums || !workspace) return MAPPO_E_NULL;
     if (n <= 0) return MAPPO_E_SHAPE;
     long long blocks = (n + kThreads * 16 - 1) / (kThreads * 16);
-    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+    if (blocks > kMaxSumBlocks) blocks = kMaxSumBlocks;
     hipLaunchKernelGGL(mb_sums_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, active_masks, returns, (long long)n,
                        workspace);
-    hipLaunchKernelGGL(mb_sums_finish_kernel, dim3(1), dim3(64), 0, stream, (const double*)workspace, (int)blocks, (double)n,
+    hipLaunchKernelGGL(mb_sums_finish_kernel, dim3(1), dim3(192), 0, stream, (const double*)workspace, (int)blocks, (double)n,
                        sums);
     return (int)hipGetLastError();
 }
@@ -338,7 +355,7 @@ extern "C" int mappo_minibatch_scales(const double* local_sums, const double* gl
     return (int)hipGetLastError();
 }
 
-extern "C" int64_t mappo_valuenorm_workspace_doubles(void) { return 2 * kMaxBlocks; }
+extern "C" int64_t mappo_valuenorm_workspace_doubles(void) { return 2 * kMaxSumBlocks; }
 
 extern "C" int mappo_valuenorm_update(const float* x, int64_t n, const float* batch_moments, double weight, float eps,
                                       float* running_mean, float* running_mean_sq, float* debiasing_term, float* denorm,
@@ -350,7 +367,7 @@ extern "C" int mappo_valuenorm_update(const float* x, int64_t n, const float* ba
     long long blocks = 0;
     if (!batch_moments) {
         blocks = (n + kThreads * 16 - 1) / (kThreads * 16);
-        if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+        if (blocks > kMaxSumBlocks) blocks = kMaxSumBlocks;
         hipLaunchKernelGGL(vn_sums_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, x, (long long)n, workspace);
     }
     hipLaunchKernelGGL(vn_fold_kernel, dim3(1), dim3(64), 0, stream, (const double*)workspace, (int)blocks, (double)n,

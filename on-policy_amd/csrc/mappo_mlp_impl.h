@@ -654,7 +654,8 @@ __host__ __device__ __forceinline__ Bwd2Lds bwd2_lds(int L, int out) {
 // [Gh out x 64] [dbh out]
 __host__ __device__ __forceinline__ long long r_g(int L, int l) { return 64LL * L + 128 + 4096LL * (l - 1); }
 __host__ __device__ __forceinline__ long long r_gh(int L) { return 64LL * L + 128 + 4096LL * (L - 1); }
-__host__ __device__ __forceinline__ long long r_total(int L, int out) { return r_gh(L) + 65LL * out; }
+// (a multiple of 4 floats: the tail kernel adds the workgroups' rows with 16-byte loads; the padding is written as zeros)
+__host__ __device__ __forceinline__ long long r_total(int L, int out) { return (r_gh(L) + 65LL * out + 3) & ~3LL; }
 
 // d loss / d nhat (in dn) -> d loss / d z (in dn) of one layer on this lane's row: LayerNorm backward (mlp.py:17-22)
 // and the activation's derivative from the saved normalised activations (see layer_tail)
@@ -1087,9 +1088,10 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
             for (int w = 0; w < NW; ++w) sm += lds[o.wave0 + w * o.per_wave + e];
             prow[e] = sm;
         }
-        for (int e = tid; e < 65 * out; e += kThr) {
+        for (int e = tid; e < (int)(r_total(L, out) - r_gh(L)); e += kThr) {
             float sm = 0.f;
-            for (int w = 0; w < NW; ++w) sm += lds[o.wave0 + w * o.per_wave + o.hacc + e];
+            if (e < 65 * out)
+                for (int w = 0; w < NW; ++w) sm += lds[o.wave0 + w * o.per_wave + o.hacc + e];
             prow[r_gh(L) + e] = sm;
         }
     }
@@ -1200,6 +1202,7 @@ struct TailArgs {
     unsigned* ticket;
     int nb1, nb2;
     int wide1;                  // p1 / grads are 16-byte aligned and c1 is a multiple of 4: blocks of 128 elements
+    int wide2;                  // the same for p2 / raw
 };
 __global__ void __launch_bounds__(kThreads) mlp_tail_kernel(TailArgs a) {
     float* sh = prim::lds();        // [8][128] | ticket
@@ -1207,6 +1210,8 @@ __global__ void __launch_bounds__(kThreads) mlp_tail_kernel(TailArgs a) {
     if (b < a.nb1) {
         if (a.wide1) reduce_chunk4(a.p1, a.n1, a.c1, a.c1, a.fin.grads, b, sh);
         else reduce_chunk(a.p1, a.n1, a.c1, a.c1, a.fin.grads, b, sh);
+    } else if (a.wide2) {
+        reduce_chunk4(a.p2, a.n2, a.c2, a.c2, a.raw, b - a.nb1, sh);
     } else {
         reduce_chunk(a.p2, a.n2, a.c2, a.c2, a.raw, b - a.nb1, sh);
     }
@@ -1978,7 +1983,8 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
     t.ticket = prim::ticket_counter();
     t.wide1 = ((reinterpret_cast<uintptr_t>(t.p1) | reinterpret_cast<uintptr_t>(m->grads)) & 15) == 0 && p1 % 4 == 0;
     t.nb1 = (int)ceil_div(p1, t.wide1 ? 128 : 32);
-    t.nb2 = (int)ceil_div(rt, 32);
+    t.wide2 = ((reinterpret_cast<uintptr_t>(t.p2) | reinterpret_cast<uintptr_t>(raw)) & 15) == 0 && rt % 4 == 0;
+    t.nb2 = (int)ceil_div(rt, t.wide2 ? 128 : 32);
     MAPPO_LAUNCH(mlp_tail_kernel, (unsigned)(t.nb1 + t.nb2), kThreads, 4 * 1025, stream, t);
     return MAPPO_LAUNCH_ERROR();
 }

@@ -27,12 +27,11 @@ def test_snapshot_has_no_spills_and_expected_occupancy():
         "mappo_gae.hip", "mappo_copy.hip", "mappo_norm.hip", "mappo_loss.hip", "mappo_rnn.hip", "mappo_mlp.hip",
         "mappo_perm.hip", "mappo_env.hip", "mappo_optim.hip"}
     # no spills, except: the 64-wide time-parallel GAE scan with time limits (a tuning variant, never selected
-    # automatically), the identity-activation forward trunk (<= 32 bytes: loop-invariant addresses reloaded once per tile)
-    # and the GRU chunk backward (<= 128 bytes: its gate arithmetic wants ~480 values in the 256 VALU-addressable
-    # registers at once; the rest of its 512 are accumulator registers)
+    # automatically) and the identity-activation forward trunk (<= 32 bytes: loop-invariant addresses reloaded once per
+    # tile).  (The GRU chunk backward had 100 bytes until its column sums moved from 64 row-layout accumulators to one
+    # running sum per lane and vector.)
     spills = {k: v["scratch_bytes"] for k, v in table.items() if v["scratch_bytes"]}
-    assert all(("gae_scan_kernel<64, true" in k) or ("mlp_fwd_kernel<0," in k and b <= 32) or
-               ("gru_seq_bwd_kernel" in k and b <= 128) for k, b in spills.items()), spills
+    assert all(("gae_scan_kernel<64, true" in k) or ("mlp_fwd_kernel<0," in k and b <= 32) for k, b in spills.items()), spills
     pick = lambda frag: [v for k, v in table.items() if frag in k]      # noqa: E731
     # K9: the forward trunk fits two workgroups of eight waves on a CU (<= 128 registers), the direct-to-LDS weight
     # gradient and the backward chain run one wave per SIMD with their accumulators in the AGPR half of the file
@@ -42,6 +41,8 @@ def test_snapshot_has_no_spills_and_expected_occupancy():
     # no scratch in any of its 15 instances; the GRU chunk kernels likewise one workgroup per CU (104 KB of weights in LDS)
     assert len(pick("mlp_bwd_kernel")) == 15 and all(v["occupancy"] == 1 and v["scratch_bytes"] == 0 for v in pick("mlp_bwd_kernel"))
     assert all(v["occupancy"] == 1 for v in pick("gru_seq_fwd_kernel") + pick("gru_seq_bwd_kernel"))
+    # ... its nine backward instances: no head / head of <= 2, 6, 18 outputs x the head's gradient sums on or off
+    assert len(pick("gru_seq_bwd_kernel")) == 9 and all(v["scratch_bytes"] == 0 for v in pick("gru_seq_bwd_kernel"))
     assert all(v["occupancy"] >= 7 for v in pick("ppo_loss_kernel"))
     assert all(v["occupancy"] >= 6 for v in pick("gru_fwd_kernel")) and all(v["occupancy"] == 8 for v in pick("gru_bwd_kernel"))
     (step,) = pick("gru_step_fwd_kernel")                                # one workgroup per CU by design: W_hh in LDS

@@ -1407,7 +1407,8 @@ constexpr int kD2GridCap = 256;
 #ifndef MAPPO_D2_MIN_WIDTH
 #define MAPPO_D2_MIN_WIDTH 128                   // (tuning: tools/ab_build.sh; 152 columns: 2.01 ms per 2.6 M rows against 2.16)
 #endif
-constexpr int kD2MinWidth = MAPPO_D2_MIN_WIDTH;  // narrower inputs leave most waves without a k tile: loader version
+constexpr int kD2MinWidth = MAPPO_D2_MIN_WIDTH;  // (historic tuning knob of the loader / direct cross-over)
+constexpr int kD2RowsMaxWidth = 192;             // up to six k tiles: every wave owns all of them (mlp_dw1_rows_kernel)
 // A wave owns up to MAXNT k tiles of its workgroup's slab of 128 MAXNT columns.  MAXNT = 3 (384-column slabs, 120 KB of LDS)
 // or 4 (512 columns, 152 KB): the launcher takes 4 where that saves a slab -- widths in (384, 512] had a second slab of a
 // few k tiles whose workgroups idled most of the launch (SMAC's 436-wide critic input: 49 instead of 100 TFLOP/s).
@@ -1553,11 +1554,12 @@ __global__ void __launch_bounds__(kThreads) mlp_dw1_direct_kernel(Dw1Args a) {
     else dw1_direct_body<0, MAXNT>(a, lds, wave, k0);
 }
 
-// ---- narrow inputs (din <= 64, din % 4 == 0): one or two k tiles are not enough to split among four waves, so every wave
+// ---- narrow inputs (din <= 192, din % 4 == 0): up to six k tiles do not split evenly among four waves (five tiles: one wave
+// with two, three with one, a barrier per tile -- config 2's 152-wide critic input ran at 0.36 of the peak), so every wave
 // owns ALL k tiles and its own 16-row tiles (strided over the launch wave by wave): the dz1 tile is private too, and the
-// loop has no barrier at all.  Same load path and slot ring as above; the four waves' accumulators are added through LDS
-// once, at the end.
-template <int NT>
+// loop has no barrier at all.  Same load path and slot ring as above (SLOTS = 4 up to two k tiles, 2 beyond: 14-16 KB per
+// slot); the four waves' accumulators are added through LDS once, at the end.
+template <int NT, int SLOTS>
 __global__ void __launch_bounds__(kThreads) mlp_dw1_rows_kernel(Dw1Args a) {
     float* lds = prim::lds();
     const int tid = threadIdx.x, lane = tid & 63, wave = prim::uniform(tid >> 6), c = lane & 31, h = lane >> 5;
@@ -1568,19 +1570,20 @@ __global__ void __launch_bounds__(kThreads) mlp_dw1_rows_kernel(Dw1Args a) {
     const long long n_it = gw < ntiles ? (ntiles - gw + nw - 1) / nw : 0;
     constexpr int SL = NT * (kD2Rows * 32) + kD2DzSlot;     // floats per slot: [NT][16][32] x | [16][64] dz1
     constexpr int G = 2 * NT + 4 + 1;                       // loads per group
-    float* ws = lds + wave * kD2Slots * SL;
-    int* tabs = reinterpret_cast<int*>(lds + 4 * kD2Slots * SL) + wave * kD2TabRing * 64;
+    constexpr int RING = 2 * SLOTS;                         // row-table ring, 256-byte slots per wave
+    float* ws = lds + wave * SLOTS * SL;
+    int* tabs = reinterpret_cast<int*>(lds + 4 * SLOTS * SL) + wave * RING * 64;
     auto row0_of = [&](long long m) {
         if (m >= n_it) m = n_it - 1;
         return (gw + m * nw) * kD2Rows;
     };
     const int q8 = lane >> 3;
     auto issue_table = [&](long long t) {
-        prim::load_lds4(a.rs.srow + row0_of(t) + (lane < 15 ? lane : 15), tabs + (int)(t % kD2TabRing) * 64);
+        prim::load_lds4(a.rs.srow + row0_of(t) + (lane < 15 ? lane : 15), tabs + (int)(t % RING) * 64);
     };
     auto issue = [&](long long m) {
-        float* slot = ws + (int)(m % kD2Slots) * SL;
-        const int* tb = tabs + (int)(m % kD2TabRing) * 64;
+        float* slot = ws + (int)(m % SLOTS) * SL;
+        const int* tb = tabs + (int)(m % RING) * 64;
         const int sr0 = tb[q8], sr1 = tb[8 + q8];
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
@@ -1596,7 +1599,7 @@ __global__ void __launch_bounds__(kThreads) mlp_dw1_rows_kernel(Dw1Args a) {
             if (r >= rows) r = rows - 1;
             prim::load_lds16(a.dz1 + r * 64 + 4 * (lane & 15), slot + NT * (kD2Rows * 32) + g * 256);
         }
-        issue_table(m + kD2Slots - 1);
+        issue_table(m + SLOTS - 1);
     };
     f32x16 acc[NT][2];
 #pragma unroll
@@ -1606,12 +1609,12 @@ __global__ void __launch_bounds__(kThreads) mlp_dw1_rows_kernel(Dw1Args a) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][t][v] = 0.f;
     if (n_it > 0) {
-        for (int t = 0; t < kD2Slots - 1; ++t) issue_table(t);
+        for (int t = 0; t < SLOTS - 1; ++t) issue_table(t);
         prim::wait_lds_loads<0>();
-        for (int m = 0; m < kD2Slots - 1; ++m) issue(m);
+        for (int m = 0; m < SLOTS - 1; ++m) issue(m);
         for (long long m = 0; m < n_it; ++m) {
-            prim::wait_lds_loads<(kD2Slots - 2) * G>();
-            float* slot = ws + (int)(m % kD2Slots) * SL;
+            prim::wait_lds_loads<(SLOTS - 2) * G>();
+            float* slot = ws + (int)(m % SLOTS) * SL;
             const long long live = rows - (gw + m * nw) * kD2Rows;
             if (live < kD2Rows) {       // last tile: rows past the end of the launch count as zero
 #pragma unroll
@@ -1620,28 +1623,47 @@ __global__ void __launch_bounds__(kThreads) mlp_dw1_rows_kernel(Dw1Args a) {
                         *reinterpret_cast<v4*>(slot + NT * (kD2Rows * 32) + g * 256 + 4 * lane) = v4{0.f, 0.f, 0.f, 0.f};
                 prim::wave_sync();      // (a wave's LDS operations execute in order: only the compiler / the emulator care)
             }
-            issue(m + kD2Slots - 1);
+            issue(m + SLOTS - 1);
             dw1_tile_steps<NT>(slot, slot + NT * (kD2Rows * 32), c, h, acc);
         }
         prim::wait_lds_loads<0>();
     }
-    // ---- add the four waves' tiles: [wave][i][t][v][lane]
-    __syncthreads();
+    // ---- add the four waves' tiles pairwise through LDS ([set][i][t][v][lane], 2 NT 2048 floats <= the slots' room):
+    // (w0 + w2) + (w1 + w3), wave 0 writes the workgroup's partial row
     float* red = lds;
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+    for (int half = 2; half >= 1; half >>= 1) {
+        __syncthreads();
+        if (wave >= half && wave < 2 * half) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int i = 0; i < NT; ++i)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) red[wave * (NT * 2048) + ((i * 2 + t) * 16 + v) * 64 + lane] = acc[i][t][v];
-    __syncthreads();
-    float* prow = a.partials + (long long)blockIdx.x * 64 * din;
-    for (int e = tid; e < NT * 2048; e += kThreads) {
-        const float sum = (red[e] + red[NT * 2048 + e]) + (red[2 * NT * 2048 + e] + red[3 * NT * 2048 + e]);
-        const int ln = e & 63, v = (e >> 6) & 15, t = (e >> 10) & 1, i = e >> 11;
-        const int f = 32 * t + (v & 3) + 8 * (v >> 2) + 4 * (ln >> 5);
-        const int k = 32 * i + (ln & 31);
-        if (k < din) prow[(long long)f * din + k] = sum;
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) red[(wave - half) * (NT * 2048) + ((i * 2 + t) * 16 + v) * 64 + lane] = acc[i][t][v];
+        }
+        __syncthreads();
+        if (wave < half) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) acc[i][t][v] += red[wave * (NT * 2048) + ((i * 2 + t) * 16 + v) * 64 + lane];
+        }
+    }
+    if (wave == 0) {
+        float* prow = a.partials + (long long)blockIdx.x * 64 * din;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int k = 32 * i + c;
+            if (k < din) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) prow[(long long)(32 * t + (v & 3) + 8 * (v >> 2) + 4 * h) * din + k] = acc[i][t][v];
+            }
+        }
     }
 }
 
@@ -1935,21 +1957,25 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
     const long long rt = r_total(L, out);
     float* raw = m->workspace + (long long)kBwdGridCap * rt;        // reduced raw sums of the version-2 chain
     d.partials = m->workspace + chain_floats(L, out);
-    const bool direct = din % 4 == 0 && din >= kD2MinWidth;
+    const bool direct = din % 4 == 0 && din > kD2RowsMaxWidth;
     const int maxnt = d2_maxnt(din);
     const int gy = (int)ceil_div(din, direct ? 128 * maxnt : kDw1Slab);
     long long gx;
-    if (din % 4 == 0 && din <= 64) {
+    if (din % 4 == 0 && din <= kD2RowsMaxWidth) {
         gx = capped(ceil_div(m->rows, 4 * kD2Rows), kD2GridCap);
-        if (din <= 32) {
-            constexpr int SL = 1 * (kD2Rows * 32) + kD2DzSlot;
-            MAPPO_LAUNCH(mlp_dw1_rows_kernel<1>, (unsigned)gx, kThreads, (size_t)(4 * kD2Slots * SL + 4 * kD2TabRing * 64) * 4,
-                         stream, d);
-        } else {
-            constexpr int SL = 2 * (kD2Rows * 32) + kD2DzSlot;
-            MAPPO_LAUNCH(mlp_dw1_rows_kernel<2>, (unsigned)gx, kThreads, (size_t)(4 * kD2Slots * SL + 4 * kD2TabRing * 64) * 4,
-                         stream, d);
-        }
+#define MAPPO_DW1_ROWS(NT, SLOTS)                                                                                       \
+    {                                                                                                                   \
+        constexpr int SL = NT * (kD2Rows * 32) + kD2DzSlot;                                                             \
+        MAPPO_LAUNCH((mlp_dw1_rows_kernel<NT, SLOTS>), (unsigned)gx, kThreads,                                         \
+                     (size_t)(4 * SLOTS * SL + 4 * 2 * SLOTS * 64) * 4, stream, d);                                     \
+    }
+        if (din <= 32) MAPPO_DW1_ROWS(1, 4)
+        else if (din <= 64) MAPPO_DW1_ROWS(2, 4)
+        else if (din <= 96) MAPPO_DW1_ROWS(3, 2)
+        else if (din <= 128) MAPPO_DW1_ROWS(4, 2)
+        else if (din <= 160) MAPPO_DW1_ROWS(5, 2)
+        else MAPPO_DW1_ROWS(6, 2)
+#undef MAPPO_DW1_ROWS
     } else if (direct) {
         gx = capped(ceil_div(m->rows, kD2Rows), kD2GridCap / gy > 0 ? kD2GridCap / gy : 1);
         if (maxnt == 4) {

@@ -103,6 +103,9 @@ CASES = [
     (70, 2, 1, 2, 128 * 5 + 9, 900),   # several tiles and two chunks: the loaders' in-flight chunks cross tile boundaries
     (388, 1, 2, 1, 45, 64),        # din just above 384: one 512-column slab, waves with four and with three k tiles
     (436, 2, 1, 1, 45, 64),        # SMAC's critic input width (padded): one 512-column slab
+    (152, 2, 1, 1, 16 * 11 + 3, 300),  # config 2's critic input (padded): five k tiles, every wave owns all of them
+    (192, 1, 2, 2, 16 * 9, 200),       # six k tiles in the row-split kernel
+    (96, 2, 1, 4, 16 * 13 + 7, 256),   # three
     (768, 1, 2, 1, 40, 64),        # two full 384-column slabs in the first-layer weight gradient
     (900, 1, 1, 2, 40, 64),        # two 512-column slabs, the second partly filled
     (28, 1, 2, 2, 16 * 9 + 1, 300),   # one k tile (row-split weight-gradient kernel), a tile with a single live row

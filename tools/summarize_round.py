@@ -56,7 +56,7 @@ def main():
     wb = sum(mean_of(write, k)[0] for k in ("mlp_bwd_kernel", "mlp_dw1_") + small)
     out["mappo_mlp_backward"] = {
         "algorithmic_bytes": alg_b, "fetch_size_bytes_raw": fb, "write_size_bytes": wb, "hbm_bytes": 2 * fb + wb,
-        "kernel": "mlp::mlp_bwd_kernel + mlp::mlp_dw1_direct_kernel (critic) / mlp::mlp_dw1_rows_kernel<2> (actor) + mlp::mlp_tail_kernel (round 2: two mlp::mlp_reduce_kernel)",
+        "kernel": "mlp::mlp_bwd_kernel + mlp::mlp_dw1_direct_kernel (critic) / mlp::mlp_dw1_rows_kernel<2, 4> (actor) + mlp::mlp_tail_kernel (round 2: two mlp::mlp_reduce_kernel)",
         "note": "one mappo_mlp_backward call = chain kernel + first-layer weight-gradient kernel + the small reductions"}
     f, n = mean_of(fetch, "gae_")
     w, _ = mean_of(write, "gae_")

@@ -345,6 +345,7 @@ class SharedReplayBuffer(object):
         observation fields themselves: 23.5 GB at the north star) go back to the allocator for the rollout; the next
         train() takes the same blocks from its cache."""
         self._std_rows.clear()
+        self._whole_batch = self._whole_batch_key = None      # (holds RowSources on the standardised copies)
 
     # ------------------------------------------------------------------ returns
     def _denorm_scalars(self, value_normalizer):
@@ -708,6 +709,21 @@ class SharedReplayBuffer(object):
         rand = self._sampler_indices(batch_size, mini_batch_size, num_mini_batch)
         table, stats = self._field_table(advantages)
         packed = self._pack_records(table)
+        # One minibatch that takes every sample in memory order (the device sampler's single slice): the 12-tuple is
+        # the same in every epoch of a train() -- nothing writes the buffer in between -- so it is gathered once and
+        # handed out again (nine of ten record gathers and row tables per north-star step saved).  Keyed on the buffer's
+        # content (the record cache's key), dropped with the other scratch of an update.
+        whole = num_mini_batch == 1 and rand is getattr(self, "_identity_idx", None) and packed[0] is not None \
+            and not self._adv_external
+        if whole:
+            key = (self._records_key, bool(standardize_obs), bool(lazy_obs), None if stats is None else stats.data_ptr(),
+                   tuple((src.data_ptr(), src._version) for _, src, _ in table if src is not None))
+            if getattr(self, "_whole_batch_key", None) != key:
+                self._whole_batch = self._gather(table, stats, rand, mini_batch_size, standardize_obs=standardize_obs,
+                                                 packed=packed, lazy_obs=lazy_obs)
+                self._whole_batch_key = key
+            yield self._whole_batch
+            return
         for i in range(num_mini_batch):
             idx = rand[i * mini_batch_size:(i + 1) * mini_batch_size]
             yield self._gather(table, stats, idx, mini_batch_size, standardize_obs=standardize_obs, packed=packed,

@@ -133,3 +133,36 @@ def test_single_minibatch_shortcut_equals_the_kernel():
     buf._sampler_indices(n, n // 2, 2)           # the kernel path draws the same six keys
     assert torch.randint(0, 1 << 30, (1,)).item() == after_shortcut
     np.testing.assert_array_equal(a.cpu().numpy(), np.arange(n))
+
+
+def test_whole_batch_minibatch_is_gathered_once_per_buffer_content():
+    """num_mini_batch = 1 under the device sampler: the epochs of one train() get the SAME 12-tuple (one gather, one row
+    table) -- until anything writes the buffer: a torch in-place edit of a field, an insert, compute_returns,
+    after_update (which also drops the cached tuple)."""
+    from helpers import Box, Discrete, make_args
+    from onpolicy.utils.shared_buffer import SharedReplayBuffer
+    T, N, A = 6, 20, 3
+    buf = SharedReplayBuffer(make_args(episode_length=T, n_rollout_threads=N), A, Box((4,)), Box((8,)), Discrete(3), device=DEV)
+    g = torch.Generator().manual_seed(0)
+    for name in ("obs", "share_obs", "rewards", "value_preds", "returns", "action_log_probs"):
+        getattr(buf, name).copy_(torch.randn(getattr(buf, name).shape, generator=g).to(DEV))
+    adv = torch.randn(T, N, A, 1, generator=g).to(DEV)
+    first = next(iter(buf.feed_forward_generator(adv, num_mini_batch=1)))
+    # an external advantages array is the caller's: never cached
+    assert next(iter(buf.feed_forward_generator(adv, num_mini_batch=1)))[6] is not first[6]
+    from onpolicy.utils.shared_buffer import AdvantageHandle
+    handle = AdvantageHandle(adv, None, buf)
+    one = next(iter(buf.feed_forward_generator(handle, num_mini_batch=1)))
+    two = next(iter(buf.feed_forward_generator(handle, num_mini_batch=1)))
+    assert all(a is b for a, b in zip(one, two))
+    torch.testing.assert_close(one[6], buf.returns[:-1].reshape(-1, 1), rtol=0, atol=0)
+    buf.returns[0].add_(1.0)                                      # in-place torch edit of a field
+    three = next(iter(buf.feed_forward_generator(handle, num_mini_batch=1)))
+    assert three[6] is not one[6]
+    torch.testing.assert_close(three[6], buf.returns[:-1].reshape(-1, 1), rtol=0, atol=0)
+    assert all(a is b for a, b in zip(three, next(iter(buf.feed_forward_generator(handle, num_mini_batch=1)))))
+    # several minibatches: fresh tensors every time
+    parts = list(buf.feed_forward_generator(handle, num_mini_batch=2))
+    assert len(parts) == 2 and parts[0][6].shape[0] == T * N * A // 2
+    buf.after_update()
+    assert buf._whole_batch is None

@@ -75,6 +75,7 @@ class DataParallel(object):
         self.device = device
         self._flat = None
         self._timing = None                  # list of (start, end) events around the gradient all-reduce
+        self._mb_ws = None                   # float64 scratch of minibatch_scales (per device, made on first use)
         if self.active:
             params = [p for net in (actor, critic) for p in net.parameters() if p.requires_grad]
             total = sum(p.numel() for p in params)
@@ -192,7 +193,7 @@ class DataParallel(object):
         from onpolicy import _native
         lib, p = _native.lib(), _native.ptr
         dev = am.device
-        if getattr(self, "_mb_ws", None) is None or self._mb_ws.device != dev:
+        if self._mb_ws is None or self._mb_ws.device != dev:
             self._mb_ws = torch.empty(lib.mappo_minibatch_sums_workspace_doubles(), dtype=torch.float64, device=dev)
         stream = _native.stream_of(dev)
         local = torch.empty(4, dtype=torch.float64, device=dev)

@@ -136,6 +136,7 @@ class SharedReplayBuffer(object):
         self._adv_sums = torch.zeros(3, dtype=torch.float64, device=dev)
         self._adv_stats = torch.zeros(2, **f32)
         self._content_version = 0  # bumped by every method that writes buffer fields
+        self._whole_batch = self._whole_batch_key = None    # the one-minibatch tuple of feed_forward_generator, see there
         self._std_rows = {}        # field name -> (key, row-standardised copy) for the fused trunk kernels
         # MAPPO_PINNED_INSERT=1: host inputs of insert() go through one pinned staging buffer + one async H2D copy.
         # Off by default: measured at the north star (tools/pcie_insert_bench.py, 57 MB per step) the single-threaded
@@ -718,7 +719,7 @@ class SharedReplayBuffer(object):
         if whole:
             key = (self._records_key, bool(standardize_obs), bool(lazy_obs), None if stats is None else stats.data_ptr(),
                    tuple((src.data_ptr(), src._version) for _, src, _ in table if src is not None))
-            if getattr(self, "_whole_batch_key", None) != key:
+            if self._whole_batch_key != key:
                 self._whole_batch = self._gather(table, stats, rand, mini_batch_size, standardize_obs=standardize_obs,
                                                  packed=packed, lazy_obs=lazy_obs)
                 self._whole_batch_key = key

@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""Summary of tools/pmc_sq_pass.sh (one rocprofv3 --pmc pass of SQ / GRBM counters over the north-star bench step) ->
+profiles/r03_pmc_sq_summary.json: per K9 kernel the shader clock the chip ran at (GRBM_GUI_ACTIVE, summed over the 8 XCDs,
+against the dispatch's duration) and the share of that time the matrix pipe of an average SIMD was busy
+(SQ_VALU_MFMA_BUSY_CYCLES = 64 cycles per v_mfma_f32_32x32x2_f32, summed over the 1024 SIMDs)."""
+import collections
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "r03", "pmc_sq")
+KERNELS = {"mlp_fwd_kernel": "K9 forward (actor and critic launches averaged)",
+           "mlp_dw1_direct_kernel": "K9 first-layer weight gradient, critic",
+           "mlp_dw1_rows_kernel": "K9 first-layer weight gradient, actor",
+           "mlp_bwd_kernel<2, 1, 0>": "K9 backward chain, action head",
+           "mlp_bwd_kernel<2, 1, 1>": "K9 backward chain, value head"}
+XCDS, SIMDS = 8, 1024
+
+
+def main():
+    dur = {}
+    for r in csv.DictReader(open(os.path.join(SRC, "ns_kernel_trace.csv"))):
+        dur[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    acc = collections.defaultdict(lambda: collections.defaultdict(dict))
+    for r in csv.DictReader(open(os.path.join(SRC, "ns_counter_collection.csv"))):
+        for frag in KERNELS:
+            if frag in r["Kernel_Name"]:
+                acc[frag][r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+    out = {"what": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY "
+                   "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -- python bench.py --steps 1 --warmup 1 (tools/pmc_sq_pass.sh); "
+                   "means over the dispatches of the run",
+           "kernels": {}}
+    for frag, disp in acc.items():
+        n = len(disp)
+        mean = lambda name: sum(d.get(name, 0.0) for d in disp.values()) / n      # noqa: E731
+        ns = sum(dur[i] for i in disp if i in dur) / n
+        cycles = mean("GRBM_GUI_ACTIVE") / XCDS
+        mfma = mean("SQ_VALU_MFMA_BUSY_CYCLES")
+        out["kernels"][frag] = {
+            "what": KERNELS[frag], "dispatches": n, "duration_ms": round(ns / 1e6, 4),
+            "shader_clock_ghz": round(cycles / ns, 3),
+            "mfma_busy_share_of_an_average_simd": round(mfma / (SIMDS * cycles), 3),
+            "mfma_instructions": round(mfma / 64),
+            "frac_of_nominal_f32_mfma_peak": round(mfma / (SIMDS * 2.4 * ns), 3),
+            "sq_wave_quad_cycles": mean("SQ_WAVE_CYCLES"), "sq_wait_inst_any": mean("SQ_WAIT_INST_ANY"),
+            "sq_wait_any": mean("SQ_WAIT_ANY"), "sq_active_inst_any": mean("SQ_ACTIVE_INST_ANY")}
+    dst = os.path.join(ROOT, "profiles", "r03_pmc_sq_summary.json")
+    json.dump(out, open(dst, "w"), indent=1)
+    for k, v in out["kernels"].items():
+        print(k, v["duration_ms"], "ms", v["shader_clock_ghz"], "GHz", "MFMA busy", v["mfma_busy_share_of_an_average_simd"],
+              "of nominal", v["frac_of_nominal_f32_mfma_peak"])
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -10,8 +10,12 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r03", "pmc_sq")
-KERNELS = {"mlp_fwd_kernel": "K9 forward (actor and critic launches averaged)",
+W = sys.argv[1] if len(sys.argv) > 1 else "ns"
+SRC = os.path.join(ROOT, "gpurun_out", "r03", "pmc_sq_" + W)
+if W == "ns" and not os.path.isdir(SRC):
+    SRC = os.path.join(ROOT, "gpurun_out", "r03", "pmc_sq")
+KERNELS = {"gru_seq_fwd_kernel": "K12 forward", "gru_seq_bwd_kernel<3, 5>": "K12 backward, actor (5-wide head inside)",
+           "gru_seq_bwd_kernel<1, 1>": "K12 backward, critic (v_out inside)","mlp_fwd_kernel": "K9 forward (actor and critic launches averaged)",
            "mlp_dw1_direct_kernel": "K9 first-layer weight gradient, critic",
            "mlp_dw1_rows_kernel": "K9 first-layer weight gradient, actor",
            "mlp_bwd_kernel<2, 1, 0>": "K9 backward chain, action head",
@@ -21,15 +25,16 @@ XCDS, SIMDS = 8, 1024
 
 def main():
     dur = {}
-    for r in csv.DictReader(open(os.path.join(SRC, "ns_kernel_trace.csv"))):
+    for r in csv.DictReader(open(os.path.join(SRC, W + "_kernel_trace.csv"))):
         dur[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     acc = collections.defaultdict(lambda: collections.defaultdict(dict))
-    for r in csv.DictReader(open(os.path.join(SRC, "ns_counter_collection.csv"))):
+    for r in csv.DictReader(open(os.path.join(SRC, W + "_counter_collection.csv"))):
         for frag in KERNELS:
             if frag in r["Kernel_Name"]:
                 acc[frag][r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
     out = {"what": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY "
-                   "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -- python bench.py --steps 1 --warmup 1 (tools/pmc_sq_pass.sh); "
+                   "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -- python bench.py --workload %s --steps 1 --warmup 1 "
+                   "(tools/pmc_sq_pass.sh); " % W +
                    "means over the dispatches of the run",
            "kernels": {}}
     for frag, disp in acc.items():
@@ -46,7 +51,7 @@ def main():
             "frac_of_nominal_f32_mfma_peak": round(mfma / (SIMDS * 2.4 * ns), 3),
             "sq_wave_quad_cycles": mean("SQ_WAVE_CYCLES"), "sq_wait_inst_any": mean("SQ_WAIT_INST_ANY"),
             "sq_wait_any": mean("SQ_WAIT_ANY"), "sq_active_inst_any": mean("SQ_ACTIVE_INST_ANY")}
-    dst = os.path.join(ROOT, "profiles", "r03_pmc_sq_summary.json")
+    dst = os.path.join(ROOT, "profiles", "r03_pmc_sq_summary.json" if W == "ns" else "r03_pmc_sq_summary_%s.json" % W)
     json.dump(out, open(dst, "w"), indent=1)
     for k, v in out["kernels"].items():
         print(k, v["duration_ms"], "ms", v["shader_clock_ghz"], "GHz", "MFMA busy", v["mfma_busy_share_of_an_average_simd"],

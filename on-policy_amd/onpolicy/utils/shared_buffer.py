@@ -683,6 +683,22 @@ class SharedReplayBuffer(object):
         self._timed_end(ev)
         return tuple(outs)
 
+    # One minibatch that takes every sample (chunk) in memory order -- the device sampler's single slice: the 12-tuple is
+    # the same in every epoch of a train() -- nothing writes the buffer in between -- so it is gathered once and handed out
+    # again (nine of ten gathers and row tables per north-star step saved).  Keyed on the buffer's content (the record
+    # cache's key + the fields' tensor versions), dropped with the other scratch of an update.
+    def _whole_batch_ok(self, rand, packed):
+        return rand is getattr(self, "_identity_idx", None) and packed[0] is not None and not self._adv_external
+
+    def _whole_batch_tuple(self, table, stats, rand, mb, chunk_len, standardize_obs, lazy_obs, packed):
+        key = (self._records_key, chunk_len, bool(standardize_obs), bool(lazy_obs), None if stats is None else stats.data_ptr(),
+               tuple((src.data_ptr(), src._version) for _, src, _ in table if src is not None))
+        if self._whole_batch_key != key:
+            self._whole_batch = self._gather(table, stats, rand, mb, chunk_len=chunk_len, standardize_obs=standardize_obs,
+                                             packed=packed, lazy_obs=lazy_obs)
+            self._whole_batch_key = key
+        return self._whole_batch
+
     def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None,
                                standardize_obs=False, lazy_obs=False):
         """Minibatches of independent (t, n, a) samples for MLP policies
@@ -710,20 +726,8 @@ class SharedReplayBuffer(object):
         rand = self._sampler_indices(batch_size, mini_batch_size, num_mini_batch)
         table, stats = self._field_table(advantages)
         packed = self._pack_records(table)
-        # One minibatch that takes every sample in memory order (the device sampler's single slice): the 12-tuple is
-        # the same in every epoch of a train() -- nothing writes the buffer in between -- so it is gathered once and
-        # handed out again (nine of ten record gathers and row tables per north-star step saved).  Keyed on the buffer's
-        # content (the record cache's key), dropped with the other scratch of an update.
-        whole = num_mini_batch == 1 and rand is getattr(self, "_identity_idx", None) and packed[0] is not None \
-            and not self._adv_external
-        if whole:
-            key = (self._records_key, bool(standardize_obs), bool(lazy_obs), None if stats is None else stats.data_ptr(),
-                   tuple((src.data_ptr(), src._version) for _, src, _ in table if src is not None))
-            if self._whole_batch_key != key:
-                self._whole_batch = self._gather(table, stats, rand, mini_batch_size, standardize_obs=standardize_obs,
-                                                 packed=packed, lazy_obs=lazy_obs)
-                self._whole_batch_key = key
-            yield self._whole_batch
+        if num_mini_batch == 1 and self._whole_batch_ok(rand, packed):
+            yield self._whole_batch_tuple(table, stats, rand, mini_batch_size, None, standardize_obs, lazy_obs, packed)
             return
         for i in range(num_mini_batch):
             idx = rand[i * mini_batch_size:(i + 1) * mini_batch_size]
@@ -741,6 +745,10 @@ class SharedReplayBuffer(object):
         rand = self._sampler_indices(data_chunks, mini_batch_size, num_mini_batch)
         table, stats = self._field_table(advantages)
         packed = self._pack_records(table)
+        if num_mini_batch == 1 and mini_batch_size == data_chunks and self._whole_batch_ok(rand, packed):
+            yield self._whole_batch_tuple(table, stats, rand, mini_batch_size, data_chunk_length, standardize_obs, lazy_obs,
+                                          packed)
+            return
         for i in range(num_mini_batch):
             idx = rand[i * mini_batch_size:(i + 1) * mini_batch_size]
             yield self._gather(table, stats, idx, mini_batch_size, chunk_len=data_chunk_length,

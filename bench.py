@@ -64,7 +64,14 @@ WORKLOADS = {
                         "--ppo_epoch", "10", "--num_mini_batch", "1", "--lr", "7e-4", "--critic_lr", "7e-4"],
                  recurrent=False,
                  label="synthetic T=200 N=1024 A=5, mappo MLP h64, ppo_epoch=10"),
-    # BASELINE.json configs[3] shapes (SMAC MMM2), recurrent policy, chunk 10
+    # BASELINE.json configs[2]: MPE simple_spread itself (3 agents, 3 landmarks: Do = 4 + 2*3 + 4*2 = 18, Ds = 3 * 18,
+    # reference envs/mpe/scenarios/simple_spread.py:86-103) at N=4096, T=400, flags of train_mpe_spread.sh:14-17
+    "cfg3": dict(T=400, N=4096, A=3, Do=18, Ds=54, na=5, cpu_sample_N=128,
+                 flags=["--algorithm_name", "mappo", "--hidden_size", "64", "--layer_N", "1", "--use_ReLU",
+                        "--ppo_epoch", "10", "--num_mini_batch", "1", "--lr", "7e-4", "--critic_lr", "7e-4",
+                        "--gain", "0.01"],
+                 recurrent=False,
+                 label="synthetic MPE simple_spread 3 agents, T=400 N=4096 A=3, mappo MLP h64, ppo_epoch=10, 1 minibatch"),
     # BASELINE.json configs[4] shapes (Hanabi-Full, 5 players), feed-forward, hidden 512 x 2 layers
     "hanabi": dict(T=100, N=8192, A=5, Do=1285, Ds=1385, na=48, cpu_sample_N=16,
                    flags=["--algorithm_name", "mappo", "--hidden_size", "512", "--layer_N", "2",
@@ -72,6 +79,7 @@ WORKLOADS = {
                           "--gain", "0.01", "--use_ReLU"],
                    recurrent=False,
                    label="synthetic Hanabi-Full 5p shapes T=100 N=8192 A=5, mappo MLP h512 x2, ppo_epoch=15"),
+    # BASELINE.json configs[3] shapes (SMAC MMM2), recurrent policy, chunk 10
     "smac": dict(T=400, N=512, A=10, Do=370, Ds=435, na=18, cpu_sample_N=8,
                  flags=["--algorithm_name", "rmappo", "--hidden_size", "64", "--layer_N", "1",
                         "--ppo_epoch", "5", "--num_mini_batch", "2", "--data_chunk_length", "10",
@@ -247,6 +255,12 @@ def main():
     if world > 1 or os.environ.get("MAPPO_FORCE_DIST", "0") == "1":
         os.environ.setdefault("NCCL_DEBUG", "WARN")      # no version banner on stdout
         mdist.init_from_env(dev)
+    if world > 1 and os.environ.get("MAPPO_DIST_BACKEND", "nccl") == "nccl":
+        # a multi-GPU line must have been carried by RCCL on `--gpus` ranks -- anything else is not the measurement asked for
+        assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == opt.gpus, \
+            "bench.py --gpus %d: expected %d RCCL ranks, got backend=%s world=%s" % (
+                opt.gpus, opt.gpus, dist.get_backend() if dist.is_initialized() else None,
+                dist.get_world_size() if dist.is_initialized() else None)
     lo, hi = mdist.shard_threads(wl["N"], rank, world)
     n_local = hi - lo
 
@@ -286,6 +300,7 @@ def main():
     from onpolicy.algorithms.utils import fused_mlp
     fused_mlp.profile(True)
     trainer.dp.time_collectives(True)
+    scalar0, reused0 = trainer.dp.scalar_collectives, trainer.dp.scales_reused
     fence()
     t0 = time.perf_counter()
     for _ in range(opt.steps):
@@ -294,6 +309,19 @@ def main():
     elapsed = time.perf_counter() - t0
     kt = buf.kernel_times()
     mt = fused_mlp.profile_times()
+    # the GAE launch once more, outside the timed region, back to back (no update phase in between: caches and TLBs as the
+    # previous launch left them) -- reported next to the in-situ figure as roofline_gae.back_to_back
+    buf.profile_kernels(False)
+    reps = 10
+    buf.compute_returns(next_value, trainer.value_normalizer)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(250000)
+    e0.record()
+    for _ in range(reps):
+        buf.compute_returns(next_value, trainer.value_normalizer)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    gae_b2b_ms = e0.elapsed_time(e1) / reps
     n_coll, coll_ms, coll_bytes = trainer.dp.collective_times()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -361,6 +389,10 @@ def main():
             "rccl_ranks": world if dist.is_initialized() and dist.get_backend() == "nccl" else 0,
             "grad_allreduce": {"per_step": n_coll // max(1, opt.steps), "bucket_bytes": coll_bytes,
                                "ms_per_step": round(coll_ms / max(1, opt.steps), 4)},
+            # the scalar prologue (loss denominators + ValueNorm moments, 32 bytes): once per train() when the whole-batch
+            # tuple is reused, otherwise once per update and issued one update ahead (DataParallel.begin_scales)
+            "scalar_allreduce": {"per_step": (trainer.dp.scalar_collectives - scalar0) / max(1, opt.steps),
+                                 "updates_served_from_cache_per_step": (trainer.dp.scales_reused - reused0) / max(1, opt.steps)},
             # the dominant kernel of the step: the fused trunk's forward launch (mlp_fwd_kernel; actor and critic
             # launches averaged, as rocprofv3 --stats averages them), f32 matrix-core bound
             "roofline": roof_mfma("mappo_mlp_forward", "mlp_fwd_kernel (mappo_mlp_forward)") or roof("mappo_gae_f32"),
@@ -371,13 +403,35 @@ def main():
             "roofline_gather": roof("mappo_gather_chunks" if wl["recurrent"] else "mappo_gather_rows"),
             "train_info": {k: round(float(v), 6) for k, v in info.items()},
         }
+        g = out["roofline_gae"]
+        if g is not None:
+            # `frac` / `launch_ms` are the in-situ figures (first launch of a step, right behind the previous step's update);
+            # back to back the same launch finds part of its lines in the Infinity Cache and warm TLBs
+            nbytes = g["algorithmic_bytes"]
+            g["in_situ"] = {"launch_ms": g["launch_ms"], "frac": g["frac"]}
+            g["back_to_back"] = {"launch_ms": round(gae_b2b_ms, 5), "launches": reps,
+                                 "achieved": round(nbytes / (gae_b2b_ms * 1e-3) / 1e9, 1),
+                                 "frac": round(nbytes / (gae_b2b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if world == 1 and not opt.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl)
-            out["cpu_baseline"]["sample"] += "; GPU/CPU ratio on env-steps/s = %.0fx" % (
-                value / out["cpu_baseline"]["value"])
+            cb = out["cpu_baseline"] = cpu_baseline(wl)
             ref = reference_recorded(opt.workload)
+            factor = None
+            if ref is not None and ref.get("port_vs_reference_same_machine"):
+                f = [r["port_over_reference"] for r in ref["port_vs_reference_same_machine"]]
+                factor = sum(f) / len(f)
+            cb["sample"] += "; GPU / CPU-port ratio on env-steps/s = %.0fx" % (value / cb["value"])
+            if factor:
+                # the port is not the reference: on one machine it runs at `factor` x the reference's speed
+                # (profiles/r03_cpu_port_vs_reference.json), so the reference on THIS host would do about value / factor
+                cb["reference_equivalent"] = {
+                    "value": round(cb["value"] / factor, 1), "unit": "env-steps/s", "port_over_reference": round(factor, 3),
+                    "gpu_over_reference_equivalent": round(value / (cb["value"] / factor), 1),
+                    "note": "port rate / (port / reference measured back to back on one machine); the figure to hold "
+                            "against north_star's >= 10x, not the port's"}
+                cb["sample"] += " (port), %.0fx against the reference-equivalent rate %.0f env-steps/s (port / %.2f)" % (
+                    value / (cb["value"] / factor), cb["value"] / factor, factor)
             if ref is not None:
-                out["cpu_baseline"]["reference_recorded"] = ref
+                cb["reference_recorded"] = ref
     else:
         out = None
     if dist.is_initialized():

@@ -129,6 +129,11 @@ int mappo_advantages_f32(const float* returns, const float* value_preds, const f
  * value. */
 int mappo_gae_set_variant(int variant);
 
+/* The variant the most recent mappo_gae_f32 call of this process launched (0 before the first call):
+ * 70-72 = the time-parallel scan (tolerance mode), 99 = one lane per column, the others the bit-exact
+ * strip kernels.  For tests that must know which arithmetic a shape took. */
+int mappo_gae_last_variant(void);
+
 /* --------------------------------------------- K5: advantage moments / stats ----
  * Replaces np.nanmean / np.nanstd over the masked advantages
  *   (onpolicy/algorithms/r_mappo/r_mappo.py:183-186).

@@ -1054,6 +1054,7 @@ __global__ void __launch_bounds__(256) advantages_kernel(const float* ret, const
 }
 
 int g_variant = 0;
+int g_last_variant = 0;
 
 template <int W>
 hipError_t launch_scan(const GaeArgs& a, unsigned flags, hipStream_t stream) {
@@ -1312,6 +1313,8 @@ extern "C" int mappo_gae_set_variant(int variant) {
     return old;
 }
 
+extern "C" int mappo_gae_last_variant(void) { return g_last_variant; }
+
 extern "C" int mappo_gae_f32(const float* rewards, float* value_preds, const float* next_value,
                              const float* masks, const float* bad_masks, float* returns,
                              const float* denorm, float* advantages, const float* active_masks,
@@ -1364,6 +1367,7 @@ extern "C" int mappo_gae_f32(const float* rewards, float* value_preds, const flo
         a.opts = 3;
     }
 
+    g_last_variant = variant;
     hipError_t e;
     switch (variant) {
         // cooperative strip (all waves load, wave 0 walks): the simplest LDS-staged form

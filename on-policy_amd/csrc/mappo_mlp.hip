@@ -138,16 +138,6 @@ __device__ __forceinline__ float* lds() {
 }
 }  // namespace prim
 
-namespace prim {
-// one ticket counter per process and device context: the K9 backward calls of a process are ordered on one stream
-__device__ unsigned g_ticket_counter = 0;
-inline unsigned* ticket_counter() {
-    unsigned* p = nullptr;
-    (void)hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(g_ticket_counter));
-    return p;
-}
-}  // namespace prim
-
 namespace {
 int g_launch_error = 0;
 // dynamic LDS above 64 KB has to be granted per kernel function before the launch

@@ -575,6 +575,7 @@ struct BwdArgs {
     const float* dy;    // [rows, out] (head) or [rows, 64] (out == 0)
     float* dz1;         // [rows128(rows), 64]
     float* partials;    // [gridDim.x][r_total]
+    unsigned* ticket;   // the call's ticket word (last float4 of the workspace): zeroed here, drawn from by mlp_tail_kernel
     long long* dbg;     // tuning hook (mappo_mlp_set_debug): cycle stamps of workgroup 0's first tiles at [1024 ...], or NULL
 };
 
@@ -696,6 +697,10 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
     const Bwd2Lds o = bwd2_lds<NW>(L, out);
     const int tid = threadIdx.x, lane = tid & 63, wave = prim::uniform(tid >> 6), c = lane & 31, h = lane >> 5;
     constexpr int kThr = 64 * NW;
+    // the tail kernel of THIS call (two launches further down the same stream) counts its finished blocks in a word of the
+    // call's own workspace: calls on different streams do not share a counter, and a call that was cut short cannot leave
+    // a stale count behind for the next one
+    if (blockIdx.x == 0 && tid == 0) *a.ticket = 0u;
     // ---- parameters
     for (int e = tid; e < 64; e += kThr) lds[o.gam + e] = n.ln_g[L - 1][e];
     // w2t[l-1][ki][h * 32 + s] = gamma_{l-1}[ki] * W_l[f(h, s)][ki]: A operand (lane = input feature ki) of
@@ -1186,8 +1191,8 @@ __device__ __forceinline__ void finish_grads(const FinishArgs& a) {
 
 // The tail of a backward call as ONE launch (three in round 2/3a: 40 us of launches per call, 2 % of a step on an 8-GPU
 // shard): blocks [0, nb1) add the first-layer weight-gradient partials into `grads`, blocks [nb1, nb1 + nb2) the chain's
-// partial rows into the raw sums R; the block that finishes last (a ticket counter in device memory, reset by that block)
-// derives the remaining parameter gradients from R.
+// partial rows into the raw sums R; the block that finishes last (a ticket word in the call's workspace, zeroed by the
+// chain kernel of the same call) derives the remaining parameter gradients from R.
 __device__ __forceinline__ void reduce_chunk(const float* partials, long long n, long long stride, long long count,
                                              float* out, long long chunk, float* sh);
 __device__ __forceinline__ void reduce_chunk4(const float* partials, long long n, long long stride, long long count,
@@ -1220,7 +1225,6 @@ __global__ void __launch_bounds__(kThreads) mlp_tail_kernel(TailArgs a) {
     if (threadIdx.x == 0) sh[1024] = prim::i2f((int)prim::ticket(a.ticket));
     __syncthreads();
     if (prim::f2i(sh[1024]) != a.nb1 + a.nb2 - 1) return;
-    if (threadIdx.x == 0) *a.ticket = 0u;
     prim::fence();
     finish_grads(a.fin);
 }
@@ -1911,8 +1915,8 @@ inline long long chain_floats(int n_layers, int out) {
     return ((long long)(kBwdGridCap + 1) * r_total(n_layers, out) + 3) & ~3LL;
 }
 inline long long workspace_floats(int din, int n_layers, int out) {
-    // chain partials (one row per workgroup) | reduced raw sums | (16-byte boundary) first-layer partials
-    return chain_floats(n_layers, out) + (long long)kD2GridCap * 64LL * din;
+    // chain partials (one row per workgroup) | reduced raw sums | (16-byte boundary) first-layer partials | ticket word
+    return chain_floats(n_layers, out) + (long long)kD2GridCap * 64LL * din + 4;
 }
 
 inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
@@ -1930,6 +1934,7 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
     b.dy = m->dy;
     b.dz1 = m->dz1;
     b.partials = m->workspace;
+    b.ticket = reinterpret_cast<unsigned*>(m->workspace + workspace_floats(m->din, m->n_layers, m->out) - 4);
     long long grid;
     {
         // head sums in registers for the value head (HR = 1)
@@ -2006,7 +2011,7 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
     t.n2 = grid;
     t.c2 = rt;
     t.raw = raw;
-    t.ticket = prim::ticket_counter();
+    t.ticket = b.ticket;
     t.wide1 = ((reinterpret_cast<uintptr_t>(t.p1) | reinterpret_cast<uintptr_t>(m->grads)) & 15) == 0 && p1 % 4 == 0;
     t.nb1 = (int)ceil_div(p1, t.wide1 ? 128 : 32);
     t.wide2 = ((reinterpret_cast<uintptr_t>(t.p2) | reinterpret_cast<uintptr_t>(raw)) & 15) == 0 && rt % 4 == 0;

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(kThreads) adam_step_kernel(Desc d, int n_parti
         float c = 1.f;
         if (d.a.max_grad_norm > 0.0) {                  // torch.nn.utils.clip_grad_norm_: max_norm / (total + 1e-6), <= 1
             c = (float)d.a.max_grad_norm / (norm + 1e-6f);
-            c = c < 1.f ? c : 1.f;
+            c = c > 1.f ? 1.f : c;                      // (NaN stays NaN, like torch.clamp: a non-finite norm poisons every gradient)
         }
         coef_s = c;
         if (blockIdx.x == 0 && d.a.grad_norm != nullptr) d.a.grad_norm[0] = norm;

@@ -86,6 +86,7 @@ SIGNATURES = {
                                  ctypes.c_double, ctypes.c_double, ctypes.c_uint, _vp]),
     "mappo_gae_partial_rows": (_i64, [_i64]),
     "mappo_gae_set_variant": (_int, [_int]),
+    "mappo_gae_last_variant": (_int, []),
     "mappo_advantages_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]),
     "mappo_adv_reduce": (_int, [_vp, _i64, _vp, _vp]),
     "mappo_adv_stats": (_int, [_vp, _vp, _vp]),

@@ -20,6 +20,8 @@ lives and when the host looks at it:
 
 The forward / backward maths of the actor and critic stays in PyTorch.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -208,7 +210,7 @@ class R_MAPPO():
         # the update will be fed: None = nothing to do, () = the local minibatch, (mean, mean_sq) = global moments.
         # (A minibatch cut into several row spans -- MAX_TENSOR_ELEMENTS, unfused routes only -- evaluates span 1 before the
         # update and the others after it; under PopArt, whose update rescales v_out, that deviates from a single pass by
-        # the one EMA step (beta = 0.99999).  The fused route never cuts a minibatch.)
+        # the one EMA step (beta = 0.99999).  The fused trunk route only cuts above 2^30 / 64 = 16.7 M rows, _row_spans.)
         pending = () if normalized else None
         fused = self._fused_loss and adv_targ.is_cuda and actions_batch is not None
         # fused loss on a HIP device: denominators, their reciprocals and the returns' batch moments in three launches
@@ -464,7 +466,7 @@ class R_MAPPO():
             else:
                 data_generator = buffer.feed_forward_generator(advantages, self.num_mini_batch, **gen_kwargs)
 
-            for sample in data_generator:
+            for sample in self._with_prologue_ahead(data_generator):
                 self._obs_standardized = fold
                 try:
                     value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights \
@@ -481,10 +483,30 @@ class R_MAPPO():
                         torch.as_tensor(critic_grad_norm, **self.tpdv).reshape(()),
                         ratio])
 
+        self.dp.drop_scales()
         num_updates = self.ppo_epoch * self.num_mini_batch
         totals = self.dp.average_info(totals / num_updates)
         values = totals.tolist()  # the only device->host sync of the update phase
         return dict(zip(keys, values))
+
+    def _with_prologue_ahead(self, generator):
+        """Data-parallel jobs with several minibatches per epoch: minibatch i + 1 is drawn BEFORE update i runs and its
+        scalar prologue (local sums + the 32-byte all-reduce, ``DataParallel.begin_scales``) is put in flight, so the
+        collective travels under update i's kernels instead of sitting in front of update i + 1's loss.  (One minibatch
+        per epoch needs none of this: the whole-batch tuple is the same object in every epoch and its prologue is
+        computed once per train().)  Costs one extra minibatch of sampler output alive at a time."""
+        if not (self.dp.active and self._fused_loss and self.num_mini_batch > 1) or \
+                os.environ.get("MAPPO_PROLOGUE_AHEAD", "1") == "0":
+            yield from generator
+            return
+        it = iter(generator)
+        cur = next(it, None)
+        while cur is not None:
+            nxt = next(it, None)
+            if nxt is not None and torch.is_tensor(nxt[8]) and torch.is_tensor(nxt[6]) and nxt[8].is_cuda:
+                self.dp.begin_scales(nxt[8], nxt[6], self._use_policy_active_masks, self._use_value_active_masks)
+            yield cur
+            cur = nxt
 
     def prep_training(self):
         self.policy.actor.train()

@@ -105,9 +105,12 @@ class _GRUChunkFn(torch.autograd.Function):
     rows here."""
 
     @staticmethod
-    def forward(ctx, x, h0, masks, w_ih, w_hh, b_ih, b_hh, ln_g, ln_b, eps, L, head_w=None, head_b=None):
+    def forward(ctx, x, h0, masks, w_ih, w_hh, b_ih, b_hh, ln_g, ln_b, eps, L, save, head_w=None, head_b=None):
         """``head_w`` [out, 64] / ``head_b`` [out] (out <= 18): an output Linear on y evaluated inside the launches -- the
-        first result is then ``y head_w^T + head_b`` instead of y (y itself is kept for the head's weight gradient)."""
+        first result is then ``y head_w^T + head_b`` instead of y (y itself is kept for the head's weight gradient).
+        ``save``: the caller's ``torch.is_grad_enabled()`` -- grad mode is always off in here and ``needs_input_grad``
+        reflects the parameters' ``requires_grad`` whatever the mode, so without it every rollout step (L = 1, under
+        no_grad) would allocate and write the backward's gates / states / statistics (1280 B per row)."""
         from onpolicy import _native
         lib, p = _native.lib(), _native.ptr
         B = h0.shape[0]
@@ -117,7 +120,7 @@ class _GRUChunkFn(torch.autograd.Function):
         params = [t.detach().contiguous() for t in (w_ih, w_hh, b_ih, b_hh, ln_g, ln_b)]
         head = None if head_w is None else (head_w.detach().contiguous(), head_b.detach().contiguous())
         out = 0 if head is None else int(head[0].shape[0])
-        need = any(ctx.needs_input_grad)
+        need = bool(save) and any(ctx.needs_input_grad)
         # (a narrow head's own gradients come out of the backward launch as sums: the features are never written then)
         y = torch.empty(L * B, 64, **f32) if (head is None or (need and out > CHUNK_HEAD_SUMS)) else None
         logits = torch.empty(L * B, out, **f32) if head is not None else None
@@ -175,7 +178,7 @@ class _GRUChunkFn(torch.autograd.Function):
             d_head = (ln_grads[384:384 + 64 * out].view(out, 64) * ln_g + dbh[:, None] * ln_b, dbh)
         else:
             d_head = (splitk_weight_grad(dy, y), column_sums(dy))
-        return (dx, dh0, None, dw_ih, dw_hh, db_ih, db_hh, ln_grads[:64], ln_grads[64:128], None, None) + d_head
+        return (dx, dh0, None, dw_ih, dw_hh, db_ih, db_hh, ln_grads[:64], ln_grads[64:128], None, None, None) + d_head
 
 
 # the widest output Linear the chunk kernels evaluate themselves (k steps of 2 on the MFMA in the backward)
@@ -290,7 +293,7 @@ class RNNLayer(nn.Module):
                     raise ValueError("this head cannot be evaluated inside the GRU chunk kernels (see head_ok)")
                 extra = (head.weight, head.bias)
             y, h_last = _GRUChunkFn.apply(x, hxs[:, 0], masks, w_ih, w_hh, b_ih, b_hh, self.norm.weight, self.norm.bias,
-                                          self.norm.eps, L, *extra)
+                                          self.norm.eps, L, torch.is_grad_enabled(), *extra)
             return y, h_last.unsqueeze(1)
         if head is not None:
             raise ValueError("this head cannot be evaluated inside the GRU chunk kernels (see head_ok)")

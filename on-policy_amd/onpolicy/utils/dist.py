@@ -76,6 +76,10 @@ class DataParallel(object):
         self._flat = None
         self._timing = None                  # list of (start, end) events around the gradient all-reduce
         self._mb_ws = None                   # float64 scratch of minibatch_scales (per device, made on first use)
+        self._scales_pending = []            # prologues of coming minibatches in flight (begin_scales)
+        self._scales_done = None             # prologue of the current minibatch, reusable while its tensors are unchanged
+        self.scalar_collectives = 0          # scalar all-reduces issued by begin_scales (tests / bench count them)
+        self.scales_reused = 0               # updates served from the cached prologue
         if self.active:
             params = [p for net in (actor, critic) for p in net.parameters() if p.requires_grad]
             total = sum(p.numel() for p in params)
@@ -179,17 +183,35 @@ class DataParallel(object):
         mean_sq = (total[3] / total[1]).float().reshape(1)
         return (w[0] if policy_masked else w[1]), (w[0] if value_masked else w[1]), (mean, mean_sq)
 
-    def minibatch_scales(self, active_masks, return_batch, policy_masked, value_masked):
-        """The same quantities for the fused loss on a HIP device, three launches + one collective
-        (``mappo_minibatch_sums`` / ``mappo_minibatch_scales``) -> float32 [8] device tensor
-        ``[1 / global policy denominator, 1 / global value denominator, 1 / local policy denominator (twice),
-        1 / local value denominator, 1 / local rows, mean, mean of squares of the returns over the global minibatch]``,
-        or None when the columns do not qualify (then ``minibatch_stats`` / PyTorch do the work)."""
-        am, ret = active_masks.detach(), return_batch.detach()
-        ok = all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in (am, ret)) \
+    # ---- the scalar exchange of an update, off the critical path -------------------------------------------------------
+    # What a minibatch needs globally before its loss is formed -- sum of active masks, rows, sum / sum of squares of the
+    # returns (r_mappo.py:135-139, :84-87, :65) -- depends on the minibatch's rows only, not on the parameters.  So:
+    #   * ``begin_scales`` launches the local sums and issues the (asynchronous) all-reduce as soon as the minibatch
+    #     exists; the trainer calls it for minibatch i + 1 BEFORE it runs update i, so the collective travels under
+    #     update i's kernels (its 32 bytes are pure latency on xGMI) and update i + 1 finds the result waiting;
+    #   * a minibatch that is handed out again unchanged (the whole-batch tuple of a one-minibatch epoch: the same tensor
+    #     objects in all ppo_epoch epochs) reuses the finished scales -- ONE scalar collective per train() instead of one
+    #     per update.  Identity of the tensor OBJECTS (held here, so their memory cannot be recycled) + their version
+    #     counters key the cache; a fresh gather is a new object and never hits.
+    def _scales_ok(self, am, ret):
+        return all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in (am, ret)) \
             and am.numel() == ret.numel() and am.numel() > 0 and os.environ.get("MAPPO_FUSED_PROLOGUE", "1") != "0"
-        if not ok:
-            return None
+
+    @staticmethod
+    def _same_batch(rec, am, ret, key):
+        return rec is not None and rec["am"] is am and rec["ret"] is ret and rec["key"] == key and \
+            rec["versions"] == (am._version, ret._version)
+
+    def begin_scales(self, active_masks, return_batch, policy_masked, value_masked):
+        """Start the prologue of a minibatch (local sums + all-reduce in flight) -> True if one is now pending or cached
+        for exactly these tensors, False if they do not qualify for the kernels."""
+        am, ret = active_masks.detach(), return_batch.detach()
+        if not self._scales_ok(am, ret):
+            return False
+        key = (bool(policy_masked), bool(value_masked))
+        if self._same_batch(self._scales_done, active_masks, return_batch, key) or \
+                any(self._same_batch(r, active_masks, return_batch, key) for r in self._scales_pending):
+            return True
         from onpolicy import _native
         lib, p = _native.lib(), _native.ptr
         dev = am.device
@@ -199,14 +221,50 @@ class DataParallel(object):
         local = torch.empty(4, dtype=torch.float64, device=dev)
         _native.check(lib.mappo_minibatch_sums(p(am), p(ret), am.numel(), p(local), p(self._mb_ws), stream),
                       "mappo_minibatch_sums")
-        total = local
+        total, work = local, None
         if self.active:
             total = local.clone()
-            self.all_reduce(total)
-        out = torch.empty(8, dtype=torch.float32, device=dev)
-        _native.check(lib.mappo_minibatch_scales(p(local), p(total), int(bool(policy_masked)), int(bool(value_masked)),
-                                                 p(out), stream), "mappo_minibatch_scales")
+            work = dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.scalar_collectives += 1
+        self._scales_pending.append({"am": active_masks, "ret": return_batch, "key": key,
+                                     "versions": (active_masks._version, return_batch._version),
+                                     "local": local, "total": total, "work": work})
+        return True
+
+    def minibatch_scales(self, active_masks, return_batch, policy_masked, value_masked):
+        """The loss denominators and the returns' batch moments for the fused loss on a HIP device
+        (``mappo_minibatch_sums`` / ``mappo_minibatch_scales`` + one collective in a multi-rank job) -> float32 [8] device
+        tensor ``[1 / global policy denominator, 1 / global value denominator, 1 / local policy denominator (twice),
+        1 / local value denominator, 1 / local rows, mean, mean of squares of the returns over the global minibatch]``,
+        or None when the columns do not qualify (then ``minibatch_stats`` / PyTorch do the work).  Picks up what
+        ``begin_scales`` started for these tensors (or the cached result of the same, unchanged tensors)."""
+        if not self.begin_scales(active_masks, return_batch, policy_masked, value_masked):
+            return None
+        key = (bool(policy_masked), bool(value_masked))
+        if self._same_batch(self._scales_done, active_masks, return_batch, key):
+            self.scales_reused += 1
+            return self._scales_done["out"]
+        rec = next(r for r in self._scales_pending if self._same_batch(r, active_masks, return_batch, key))
+        self._scales_pending.remove(rec)
+        from onpolicy import _native
+        lib, p = _native.lib(), _native.ptr
+        if rec["work"] is not None:
+            rec["work"].wait()      # orders the current stream behind the collective (RCCL: no host block)
+        out = torch.empty(8, dtype=torch.float32, device=rec["local"].device)
+        _native.check(lib.mappo_minibatch_scales(p(rec["local"]), p(rec["total"]), int(key[0]), int(key[1]), p(out),
+                                                 _native.stream_of(out.device)), "mappo_minibatch_scales")
+        rec["out"] = out
+        rec["work"] = None
+        self._scales_done = rec
         return out
+
+    def drop_scales(self):
+        """Forget cached / pending prologues (end of a train(): the tensors they hold belong to the sampler)."""
+        for rec in self._scales_pending:
+            if rec["work"] is not None:
+                rec["work"].wait()
+        self._scales_pending = []
+        self._scales_done = None
 
     def average_info(self, totals):
         """Logged scalars: mean over ranks of the per-rank means."""

@@ -98,7 +98,14 @@ class DebiasedMoments(object):
         d.mul_(weight).add_(1.0 * (1.0 - weight))
 
     def denorm_scalars(self):
-        """float32 device tensor [sigma, mu] (scalar statistics, input_shape == 1)."""
+        """float32 device tensor [sigma, mu] (scalar statistics, input_shape == 1).
+
+        ALIASING CONTRACT: after a fused update this is the persistent two-float buffer the update kernel writes
+        (no copy, no launch) -- valid until the next ``update()``, which overwrites it in place on the same stream.
+        Consume it (hand it to a kernel / an op) before updating again; ``.clone()`` it to keep a snapshot.  Every
+        caller in this package does the former (compute_returns, the fused loss).  Writers of the statistics that go
+        through raw pointers must reset ``_denorm_key`` (the update kernel does); in-place torch edits are caught by
+        the tensors' version counters."""
         if getattr(self, "_denorm_key", None) is not None and self._denorm_key == self._stats_versions():
             return self._denorm_cache        # written by the update kernel, statistics untouched since
         mean, var = self._mean_var()

@@ -137,6 +137,8 @@ class SharedReplayBuffer(object):
         self._adv_stats = torch.zeros(2, **f32)
         self._content_version = 0  # bumped by every method that writes buffer fields
         self._whole_batch = self._whole_batch_key = None    # the one-minibatch tuple of feed_forward_generator, see there
+        self._whole_batch_versions = ()
+        self.whole_batch_reuses = 0       # epochs that were handed the cached tuple (tests assert the route)
         self._std_rows = {}        # field name -> (key, row-standardised copy) for the fused trunk kernels
         # MAPPO_PINNED_INSERT=1: host inputs of insert() go through one pinned staging buffer + one async H2D copy.
         # Off by default: measured at the north star (tools/pcie_insert_bench.py, 57 MB per step) the single-threaded
@@ -687,16 +689,28 @@ class SharedReplayBuffer(object):
     # the same in every epoch of a train() -- nothing writes the buffer in between -- so it is gathered once and handed out
     # again (nine of ten gathers and row tables per north-star step saved).  Keyed on the buffer's content (the record
     # cache's key + the fields' tensor versions), dropped with the other scratch of an update.
+    # CONTRACT: the tensors of such a tuple are SHARED between the epochs of one train() -- read-only for the caller.  (The
+    # reference's generators yield independent copies, shared_buffer.py:379-396; they still do here for the reference
+    # protocol -- an external ``advantages`` array never takes this route -- and for several minibatches per epoch.)  An
+    # in-place edit of a yielded tensor is detected through its version counter and the batch is gathered again, so a
+    # trainer that does edit them gets the reference's semantics at the price of the gather.
     def _whole_batch_ok(self, rand, packed):
         return rand is getattr(self, "_identity_idx", None) and packed[0] is not None and not self._adv_external
+
+    @staticmethod
+    def _output_versions(outs):
+        return tuple(t._version for t in outs if torch.is_tensor(t))
 
     def _whole_batch_tuple(self, table, stats, rand, mb, chunk_len, standardize_obs, lazy_obs, packed):
         key = (self._records_key, chunk_len, bool(standardize_obs), bool(lazy_obs), None if stats is None else stats.data_ptr(),
                tuple((src.data_ptr(), src._version) for _, src, _ in table if src is not None))
-        if self._whole_batch_key != key:
-            self._whole_batch = self._gather(table, stats, rand, mb, chunk_len=chunk_len, standardize_obs=standardize_obs,
-                                             packed=packed, lazy_obs=lazy_obs)
-            self._whole_batch_key = key
+        if self._whole_batch_key == key and self._output_versions(self._whole_batch) == self._whole_batch_versions:
+            self.whole_batch_reuses += 1
+            return self._whole_batch
+        self._whole_batch = self._gather(table, stats, rand, mb, chunk_len=chunk_len, standardize_obs=standardize_obs,
+                                         packed=packed, lazy_obs=lazy_obs)
+        self._whole_batch_key = key
+        self._whole_batch_versions = self._output_versions(self._whole_batch)
         return self._whole_batch
 
     def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None,

@@ -63,6 +63,32 @@ CASES_H64 = {
 }
 
 
+# The device-sampler route (what bench.py times): K10's partition instead of torch.randperm, the whole-batch cache, the
+# default (time-parallel) GAE mode on narrow buffers.  The reference runs with its torch.randperm replaced by the numpy
+# restatement of K10 (oracle/k10_partition.py: same keys from the same CPU generator), so its minibatches are the SETS the
+# device sampler makes; for one minibatch per epoch the set is the whole batch whatever the order, so no patch is needed.
+# Written to trainer_dev_cases.npz.
+CASES_DEV = {
+    # two minibatches per epoch, feed-forward (h64_relu2's spec)
+    "dev_relu2": dict(args=dict(algorithm_name="mappo", hidden_size=64, layer_N=2, use_ReLU=True, ppo_epoch=2,
+                                num_mini_batch=2),
+                      T=10, N=8, A=3, Do=18, Ds=54, na=5, k10=True),
+    # four minibatches with a dropped tail (210 samples -> 4 x 52, two samples dropped), tanh
+    "dev_tail": dict(args=dict(algorithm_name="mappo", hidden_size=64, layer_N=1, use_ReLU=False, ppo_epoch=2,
+                               num_mini_batch=4),
+                     T=10, N=7, A=3, Do=18, Ds=54, na=5, k10=True),
+    # recurrent, two minibatches of chunks (h64_gru's spec: the SMAC route)
+    "dev_gru": dict(args=dict(algorithm_name="rmappo", use_recurrent_policy=True, hidden_size=64, layer_N=1,
+                              use_ReLU=False, ppo_epoch=2, num_mini_batch=2, data_chunk_length=5, gain=1.0),
+                    T=10, N=8, A=3, Do=22, Ds=37, na=6, k10=True),
+    # config-2 shapes wide enough for the time-parallel GAE scan (C = N * A = 2560 columns, T = 64), one minibatch.
+    # The inputs are regenerated from the seed by the test (oracle/synth.py), only outputs are stored.
+    "dev_scan_cfg2": dict(args=dict(algorithm_name="mappo", hidden_size=64, layer_N=1, use_ReLU=False, ppo_epoch=3,
+                                    num_mini_batch=1, lr=7e-4, critic_lr=7e-4),
+                          T=64, N=512, A=5, Do=30, Ds=150, na=5, k10=False, regen=True),
+}
+
+
 class PermRecorder(object):
     def __init__(self):
         self.orig = torch.randperm
@@ -88,6 +114,7 @@ def _sd(prefix, module, out):
 def main(ref, make_args, fill_buffer, gold_dir):
     generate(ref, make_args, fill_buffer, gold_dir, CASES, "trainer_cases")
     generate(ref, make_args, fill_buffer, gold_dir, CASES_H64, "trainer_h64_cases", with_grads=True)
+    generate(ref, make_args, fill_buffer, gold_dir, CASES_DEV, "trainer_dev_cases", with_grads=True)
 
 
 def generate(ref, make_args, fill_buffer, gold_dir, cases, fname, with_grads=False):
@@ -106,15 +133,24 @@ def generate(ref, make_args, fill_buffer, gold_dir, cases, fname, with_grads=Fal
 
         rng = np.random.default_rng(4242)
         buf = ref.SharedReplayBuffer(args, A, obs_space, cent_space, act_space)
-        next_value = fill_buffer(buf, rng)
-        # valid action ids under the availability mask: pick the first available action at random
-        av = buf.available_actions[:-1]
-        pick = rng.random(av.shape) * av
-        buf.actions[:] = pick.argmax(-1)[..., None].astype(np.float32)
-        for name in ("share_obs", "obs", "rnn_states", "rnn_states_critic", "actions", "value_preds",
-                     "masks", "bad_masks", "active_masks", "action_log_probs", "available_actions",
-                     "rewards"):
-            out[key + "buf_" + name] = getattr(buf, name).copy()
+        if spec.get("regen"):
+            # large case: seeded inputs that the test rebuilds itself (oracle/synth.py); the fixture keeps a digest of them
+            import synth
+            arrays = synth.rollout(T, N, A, Do, Ds, na, seed=4242)
+            next_value = arrays.pop("next_value")
+            for name, arr in arrays.items():
+                getattr(buf, name)[...] = arr
+            out[key + "input_digest"] = synth.digest(arrays, next_value)
+        else:
+            next_value = fill_buffer(buf, rng)
+            # valid action ids under the availability mask: pick the first available action at random
+            av = buf.available_actions[:-1]
+            pick = rng.random(av.shape) * av
+            buf.actions[:] = pick.argmax(-1)[..., None].astype(np.float32)
+            for name in ("share_obs", "obs", "rnn_states", "rnn_states_critic", "actions", "value_preds",
+                         "masks", "bad_masks", "active_masks", "action_log_probs", "available_actions",
+                         "rewards"):
+                out[key + "buf_" + name] = getattr(buf, name).copy()
         out[key + "next_value"] = next_value
 
         # one rollout-side and one update-side forward on step 0 of the buffer
@@ -129,8 +165,9 @@ def generate(ref, make_args, fill_buffer, gold_dir, cases, fname, with_grads=Fal
             out[key + "act_values"] = values.numpy().copy()
             out[key + "act_actions"] = actions.numpy().astype(np.int64)
             out[key + "act_logp"] = logp.numpy().copy()
-            out[key + "act_h_actor"] = h_a.numpy().copy()
-            out[key + "act_h_critic"] = h_c.numpy().copy()
+            if not spec.get("regen"):
+                out[key + "act_h_actor"] = h_a.numpy().copy()
+                out[key + "act_h_critic"] = h_c.numpy().copy()
             ev_values, ev_logp, ev_ent = policy.evaluate_actions(
                 flat(buf.share_obs[0]), flat(buf.obs[0]), flat(buf.rnn_states[0]),
                 flat(buf.rnn_states_critic[0]), flat(buf.actions[0]), flat(buf.masks[0]),
@@ -143,9 +180,14 @@ def generate(ref, make_args, fill_buffer, gold_dir, cases, fname, with_grads=Fal
         out[key + "returns"] = buf.returns.copy()
         trainer.prep_training()
         torch.manual_seed(21)
-        with PermRecorder() as rec:
+        if spec.get("k10"):
+            from k10_partition import RandpermAsK10
+            recorder = RandpermAsK10(spec["args"]["num_mini_batch"])
+        else:
+            recorder = PermRecorder()
+        with recorder as rec:
             info = trainer.train(buf)
-        for i, p in enumerate(rec.calls):
+        for i, p in enumerate([] if spec.get("regen") else rec.calls):
             out[key + "perm%d" % i] = p.astype(np.int64)
         info = {k: float(v) for k, v in info.items()}
         _sd(key + "final_actor.", policy.actor, out)

@@ -95,7 +95,7 @@ def run_update(N_global, lo, hi, args_over, device=None):
     return info, sd, trainer.dp.world_size
 
 
-def run_fixture(cname, lo, hi, device=None):
+def run_fixture(cname, lo, hi, device=None, sampler_rng="host", fname="trainer_h64_cases"):
     """compute_returns + train on rollout threads [lo, hi) of a REFERENCE-generated hidden-64 case
     (tests/golden/trainer_h64_cases.npz, oracle/make_golden_trainer.py), starting from the reference's initial weights.
     With one minibatch per epoch the union of the ranks' minibatches is the reference's batch, so the data-parallel result
@@ -104,10 +104,10 @@ def run_fixture(cname, lo, hi, device=None):
     from helpers import Box, Discrete, make_args
     from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy
     from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO
-    z = np.load(os.path.join(HERE, "golden", "trainer_h64_cases.npz"))
-    spec = json.load(open(os.path.join(HERE, "golden", "trainer_h64_cases.json")))[cname]["spec"]
+    z = np.load(os.path.join(HERE, "golden", fname + ".npz"))
+    spec = json.load(open(os.path.join(HERE, "golden", fname + ".json")))[cname]["spec"]
     key = "trn_%s_" % cname
-    extra = {} if device is None else {"sampler_rng": "host"}
+    extra = {} if device is None else {"sampler_rng": sampler_rng}
     args = make_args(episode_length=spec["T"], n_rollout_threads=hi - lo, **dict(spec["args"], **extra))
     spaces = Box((spec["Do"],)), Box((spec["Ds"],)), Discrete(spec["na"])
     torch.manual_seed(1)
@@ -142,10 +142,13 @@ def run_fixture(cname, lo, hi, device=None):
     vn = trainer.value_normalizer
     sd["final_norm"] = torch.tensor([float(vn.running_mean), float(vn.running_mean_sq), float(vn.debiasing_term)],
                                     dtype=torch.float64)
+    # how the scalar prologue of the updates travelled (DataParallel.begin_scales / minibatch_scales)
+    info = dict(info, _scalar_collectives=trainer.dp.scalar_collectives, _scales_reused=trainer.dp.scales_reused,
+                _whole_batch_reuses=getattr(buf, "whole_batch_reuses", 0))
     return info, sd, trainer.dp.world_size
 
 
-def worker(rank, world, port, N_global, args_over, out_dir, device=None, mat=False, fixture=None):
+def worker(rank, world, port, N_global, args_over, out_dir, device=None, mat=False, fixture=None, fixture_opts=None):
     """``device``: None = CPU ranks; "cuda:0" = every rank on GPU 0 with the gloo backend (RCCL refuses
     duplicate devices), which exercises the device buffer + fused loss under data parallelism."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -159,7 +162,7 @@ def worker(rank, world, port, N_global, args_over, out_dir, device=None, mat=Fal
     assert dist.get_backend() == "gloo"
     lo, hi = mdist.shard_threads(N_global, rank, world)
     if fixture is not None:
-        info, sd, ws = run_fixture(fixture, lo, hi, device)
+        info, sd, ws = run_fixture(fixture, lo, hi, device, **(fixture_opts or {}))
     else:
         info, sd, ws = run_update_mat(N_global, lo, hi, args_over) if mat else run_update(N_global, lo, hi, args_over, device)
     assert ws == world

@@ -16,10 +16,6 @@ inline void wave_sync() { simt::wait(my_wave().bar); }
 inline void pin(float&) {}
 inline void fence() {}
 inline unsigned ticket(unsigned* counter) { return (*counter)++; }       // (blocks run one after the other)
-inline unsigned* ticket_counter() {
-    static unsigned counter = 0;
-    return &counter;
-}
 inline int f2i(float v) { int i; memcpy(&i, &v, 4); return i; }
 inline float i2f(int v) { float f; memcpy(&f, &v, 4); return f; }
 inline int uniform(int v) { return v; }

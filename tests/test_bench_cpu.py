@@ -19,7 +19,9 @@ def bench():
 
 
 def test_workload_table(bench):
-    assert set(bench.WORKLOADS) == {"ns", "ns_rnn", "cfg2", "smac", "hanabi"}
+    assert set(bench.WORKLOADS) == {"ns", "ns_rnn", "cfg2", "cfg3", "smac", "hanabi"}
+    c3 = bench.WORKLOADS["cfg3"]            # BASELINE.json configs[2]: simple_spread itself at N=4096, T=400
+    assert (c3["T"], c3["N"], c3["A"], c3["Do"], c3["Ds"]) == (400, 4096, 3, 18, 54)
     ns = bench.WORKLOADS["ns"]
     assert (ns["T"], ns["N"], ns["A"], ns["Do"], ns["Ds"], ns["na"]) == (400, 4096, 8, 48, 384, 5)     # BASELINE north star
     args = bench.make_args(ns, 512)

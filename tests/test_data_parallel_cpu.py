@@ -131,14 +131,34 @@ def test_job_wide_episode_budget_and_even_shards(monkeypatch):
     assert "// self.n_rollout_threads_job" in open(mpe_runner.__file__).read()
 
 
-def _two_ranks_on_reference_fixture(tmp_path, cname, device):
+def _run_two_ranks(tmp_path, cname, device, fixture_opts=None, fname="trainer_h64_cases"):
+    import json
+    spec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fname + ".json")))[cname]
+    N, world, port = spec["spec"]["N"], 2, _free_port()
+    ctx = mp.get_context("spawn")
+    opts = dict(fixture_opts or {}, fname=fname)
+    procs = [ctx.Process(target=dp_worker.worker, args=(r, world, port, N, {}, str(tmp_path), device, False, cname, opts))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    ranks = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=False) for r in range(world)]
+    assert [r["span"] for r in ranks] == [(0, N // 2), (N // 2, N)]
+    return spec, ranks
+
+
+def _two_ranks_on_reference_fixture(tmp_path, cname, device, fixture_opts=None):
     """Two data-parallel ranks (gloo), each with half of the rollout threads of a reference-generated hidden-64 trainer
-    case, against what the REFERENCE's single process produced (tests/golden/trainer_h64_cases.npz)."""
+    case, against what the REFERENCE's single process produced (tests/golden/trainer_h64_cases.npz).  -> the ranks'
+    records (info incl. the DataParallel counters, final state)."""
     import json
     spec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trainer_h64_cases.json")))[cname]
     N, world, port = spec["spec"]["N"], 2, _free_port()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=dp_worker.worker, args=(r, world, port, N, {}, str(tmp_path), device, False, cname))
+    procs = [ctx.Process(target=dp_worker.worker, args=(r, world, port, N, {}, str(tmp_path), device, False, cname,
+                                                        fixture_opts))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -158,6 +178,7 @@ def _two_ranks_on_reference_fixture(tmp_path, cname, device):
     # global-batch quantities of the log: the gradient norms (the losses are rank means of per-rank means)
     for k in ("actor_grad_norm", "critic_grad_norm"):
         assert ranks[0]["info"][k] == pytest.approx(spec["train_info"][k], rel=2e-3), k
+    return ranks
 
 
 def test_two_rank_update_on_hidden64_reference_fixture(tmp_path):

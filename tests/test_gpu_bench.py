@@ -130,6 +130,41 @@ def test_two_rank_device_update_on_hidden64_reference_fixture(tmp_path):
     _two_ranks_on_reference_fixture(tmp_path, "h64_ns", "cuda:0")
 
 
+def test_two_rank_device_sampler_route_one_scalar_collective_per_train(tmp_path):
+    """The same two ranks on the route bench.py times (sampler_rng=device: identity index list, whole-batch tuple handed
+    out again in epoch 2): still the reference's weights, and the scalar prologue (loss denominators + ValueNorm moments)
+    crossed the ranks ONCE for the whole train() -- the second update reused it (DataParallel.minibatch_scales)."""
+    from test_data_parallel_cpu import _two_ranks_on_reference_fixture
+    ranks = _two_ranks_on_reference_fixture(tmp_path, "h64_ns", "cuda:0", {"sampler_rng": "device"})
+    for r in ranks:
+        assert r["info"]["_whole_batch_reuses"] == 1
+        assert r["info"]["_scalar_collectives"] == 1 and r["info"]["_scales_reused"] == 1, r["info"]
+
+
+@pytest.mark.parametrize("cname", ["dev_relu2", "dev_gru"])
+def test_two_rank_prologue_ahead_equals_prologue_in_line(tmp_path, monkeypatch, cname):
+    """Several minibatches per epoch: the scalar all-reduce of minibatch i + 1 is issued before update i runs
+    (R_MAPPO._with_prologue_ahead).  Same arithmetic on the same rows, so the replicas must end bit-identical to a run
+    with the prologue in line (MAPPO_PROLOGUE_AHEAD=0), one scalar collective per update either way."""
+    import torch
+    from test_data_parallel_cpu import _run_two_ranks
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MAPPO_PROLOGUE_AHEAD", mode)
+        d = tmp_path / mode
+        d.mkdir()
+        spec, ranks = _run_two_ranks(d, cname, "cuda:0", {"sampler_rng": "device"}, fname="trainer_dev_cases")
+        updates = spec["spec"]["args"]["ppo_epoch"] * spec["spec"]["args"]["num_mini_batch"]
+        for k in ranks[0]["sd"]:
+            assert torch.equal(ranks[0]["sd"][k], ranks[1]["sd"][k]), k
+        assert all(r["info"]["_scalar_collectives"] == updates and r["info"]["_scales_reused"] == 0 for r in ranks)
+        out[mode] = ranks[0]
+    for k in out["1"]["sd"]:
+        assert torch.equal(out["1"]["sd"][k], out["0"]["sd"][k]), k
+    for k in ("value_loss", "policy_loss", "actor_grad_norm", "critic_grad_norm"):
+        assert out["1"]["info"][k] == out["0"]["info"][k]
+
+
 def test_gemm_tuning_preloads_shipped_winners(tmp_path):
     """onpolicy.utils.gemm_tuning: TunableOp comes up with the shipped winners for the bench shapes loaded (no
     tuning needed for them), and a bench run with it reports gemm_tuning = true."""

@@ -1,0 +1,181 @@
+"""-m gpu: the route bench.py TIMES, pinned to the reference -- ``sampler_rng="device"`` (K10 partition / identity index list
++ whole-batch cache) and the default GAE mode (time-parallel scan on narrow buffers), end to end through compute_returns +
+R_MAPPO.train, against numbers the REFERENCE produced (reference onpolicy/utils/shared_buffer.py:358-361, :509-512 draw the
+permutation; r_mappo.py:171-224 consumes it).
+
+* one minibatch per epoch (``h64_ns``, ``h64_gru_straddle`` of trainer_h64_cases.npz): the device sampler's single slice is
+  the whole batch, the same SET the reference's randperm covers, so the reference's numbers must hold at the tolerances of
+  the host-permutation test; the cached tuple must have been handed out ppo_epoch - 1 times.
+* several minibatches (``dev_*`` of trainer_dev_cases.npz): the reference ran with its torch.randperm replaced by the numpy
+  restatement of K10 (oracle/k10_partition.py, keys from the same CPU generator under the same seed), so its minibatches
+  are the sets the device sampler makes -- feed-forward, with a dropped tail, and chunked (recurrent).
+* ``dev_scan_cfg2``: config-2 shapes at 2560 columns x 64 steps, where compute_returns takes the time-parallel scan
+  (tolerance mode: returns to rtol 1e-5) and everything downstream runs on its output.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import Box, Discrete, make_args
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("share_obs", "obs", "rnn_states", "rnn_states_critic", "actions", "value_preds", "masks", "bad_masks",
+          "active_masks", "action_log_probs", "available_actions", "rewards")
+
+
+def _setup(gold, fixture, cname, dev):
+    from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy
+    from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO
+    from onpolicy.utils.shared_buffer import SharedReplayBuffer
+    z = gold.npz(fixture)
+    meta = gold.meta(fixture)[cname]
+    spec = meta["spec"]
+    args = make_args(episode_length=spec["T"], n_rollout_threads=spec["N"], sampler_rng="device", **spec["args"])
+    spaces = Box((spec["Do"],)), Box((spec["Ds"],)), Discrete(spec["na"])
+    torch.manual_seed(1)
+    np.random.seed(1)
+    policy = R_MAPPOPolicy(args, *spaces, device=dev)
+    trainer = R_MAPPO(args, policy, device=dev)
+    buf = SharedReplayBuffer(args, spec["A"], *spaces, device=dev)
+    key = "trn_%s_" % cname
+    if spec.get("regen"):
+        from oracle import synth
+        arrays = synth.rollout(spec["T"], spec["N"], spec["A"], spec["Do"], spec["Ds"], spec["na"], seed=4242)
+        nv = arrays.pop("next_value")
+        np.testing.assert_allclose(synth.digest(arrays, nv), z[key + "input_digest"], rtol=1e-12,
+                                   err_msg="the seeded inputs differ from the ones the reference was run on")
+        for name, arr in arrays.items():
+            getattr(buf, name).copy_(torch.from_numpy(arr))
+    else:
+        for name in FIELDS:
+            dst = getattr(buf, name)
+            if dst.stride()[0] != 0:
+                dst.copy_(torch.from_numpy(z[key + "buf_" + name]))
+    for net, pre in ((policy.actor, "init_actor."), (policy.critic, "init_critic.")):
+        for k, v in net.state_dict().items():       # start from the reference's exact weights (host QR: last-bit noise)
+            np.testing.assert_allclose(v.cpu().numpy(), z[key + pre + k], rtol=1e-4, atol=5e-6)
+            v.copy_(torch.from_numpy(z[key + pre + k]))
+    return z, key, meta, spec, policy, trainer, buf
+
+
+def _launches():
+    from onpolicy.algorithms.utils import fused_mlp
+    t = fused_mlp.profile_times()
+    return t.get("mappo_mlp_forward", (0,))[0], t.get("mappo_mlp_backward", (0,))[0]
+
+
+def _train_and_compare(z, key, meta, spec, policy, trainer, buf, returns_exact):
+    from onpolicy.algorithms.utils import fused_mlp
+    assert buf._sampler_rng == "device" and not buf._gae_exact        # the bench's modes, not the integer-parity ones
+    buf.compute_returns(z[key + "next_value"], trainer.value_normalizer)
+    got = buf.returns.cpu().numpy()
+    if returns_exact:
+        np.testing.assert_array_equal(got, z[key + "returns"])
+    else:
+        np.testing.assert_allclose(got, z[key + "returns"], rtol=1e-5, atol=1e-6)
+    trainer.prep_training()
+    torch.manual_seed(21)
+    fused_mlp.profile(True)
+    try:
+        info = trainer.train(buf)
+        torch.cuda.synchronize()
+        n_fwd, n_bwd = _launches()
+    finally:
+        fused_mlp.profile(False)
+    updates = spec["args"]["ppo_epoch"] * spec["args"]["num_mini_batch"]
+    assert n_fwd == 2 * updates and n_bwd == 2 * updates, (n_fwd, n_bwd, updates)      # K9 ran, forward and backward
+    reuses = buf.whole_batch_reuses
+    buf.after_update()
+
+    worst = {}
+    for k, ref in meta["train_info"].items():
+        worst["info." + k] = abs(info[k] - ref) / max(abs(ref), 1e-5)
+        assert info[k] == pytest.approx(ref, rel=1e-3, abs=1e-5), (k, info[k], ref)
+    for net, pre in ((policy.actor, "final_actor."), (policy.critic, "final_critic.")):
+        for k, v in net.state_dict().items():
+            np.testing.assert_allclose(v.cpu().numpy(), z[key + pre + k], rtol=1e-3, atol=5e-5, err_msg=pre + k)
+    for net, pre in ((policy.actor, "last_grad_actor."), (policy.critic, "last_grad_critic.")):
+        for k, p in net.named_parameters():
+            ref = z[key + pre + k]
+            scale = max(1e-12, float(np.abs(ref).max()))
+            err = float(np.abs(p.grad.cpu().numpy() - ref).max()) / scale
+            worst[pre + k] = err
+            assert err < 1e-3, (pre + k, err)
+    vn = trainer.value_normalizer
+    got = np.array([float(vn.running_mean), float(vn.running_mean_sq), float(vn.debiasing_term)])
+    np.testing.assert_allclose(got, z[key + "final_norm"], rtol=1e-5, atol=1e-9)
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+    print("\n[%s] device sampler: K9 launches fwd %d bwd %d, whole-batch reuses %d; largest relative errors: %s"
+          % (key, n_fwd, n_bwd, reuses, top))
+    return reuses
+
+
+@pytest.mark.parametrize("cname", ["h64_ns", "h64_gru_straddle"])
+def test_single_minibatch_device_route_vs_reference(gold, cname):
+    """num_mini_batch = 1: identity index list + whole-batch cache against the reference's randperm run."""
+    dev = torch.device("cuda", 0)
+    z, key, meta, spec, policy, trainer, buf = _setup(gold, "trainer_h64_cases", cname, dev)
+    reuses = _train_and_compare(z, key, meta, spec, policy, trainer, buf, returns_exact=True)
+    assert reuses == spec["args"]["ppo_epoch"] - 1
+
+
+@pytest.mark.parametrize("cname", ["dev_relu2", "dev_tail", "dev_gru"])
+def test_k10_minibatches_vs_reference_on_the_same_partition(gold, cname):
+    """Several minibatches per epoch: K10's slices on the device against the reference fed the same slices."""
+    dev = torch.device("cuda", 0)
+    z, key, meta, spec, policy, trainer, buf = _setup(gold, "trainer_dev_cases", cname, dev)
+    reuses = _train_and_compare(z, key, meta, spec, policy, trainer, buf, returns_exact=True)
+    assert reuses == 0          # every minibatch is a different set: nothing may be cached
+
+
+def test_k10_slices_are_the_partition_the_reference_was_fed(gold):
+    """The premise of the test above, checked directly: under the fixture's seed the device sampler emits the index lists
+    recorded from the reference run (RandpermAsK10.calls)."""
+    dev = torch.device("cuda", 0)
+    z, key, meta, spec, policy, trainer, buf = _setup(gold, "trainer_dev_cases", "dev_tail", dev)
+    n = spec["T"] * spec["N"] * spec["A"]
+    n_mb = spec["args"]["num_mini_batch"]
+    mb = n // n_mb
+    torch.manual_seed(21)
+    for epoch in range(meta["n_perms"]):
+        idx = buf._sampler_indices(n, mb, n_mb).cpu().numpy()
+        np.testing.assert_array_equal(idx, z[key + "perm%d" % epoch][:n_mb * mb])
+
+
+def test_scan_gae_then_update_vs_reference(gold):
+    """Config-2 shapes, 2560 columns x 64 steps: compute_returns takes the time-parallel scan (asserted through
+    mappo_gae_last_variant), train() runs on its output through the identity list + whole-batch cache."""
+    from onpolicy import _native
+    dev = torch.device("cuda", 0)
+    z, key, meta, spec, policy, trainer, buf = _setup(gold, "trainer_dev_cases", "dev_scan_cfg2", dev)
+    reuses = _train_and_compare(z, key, meta, spec, policy, trainer, buf, returns_exact=False)
+    assert _native.lib().mappo_gae_last_variant() in (70, 71, 72, 73, 74, 75)
+    assert reuses == spec["args"]["ppo_epoch"] - 1
+
+
+def test_an_edited_whole_batch_tensor_is_gathered_again():
+    """The cached one-minibatch tuple is shared between epochs (read-only contract); an in-place edit of a yielded tensor
+    must not leak into the next epoch."""
+    from onpolicy.utils.shared_buffer import SharedReplayBuffer
+    dev = torch.device("cuda", 0)
+    T, N, A = 6, 4, 3
+    args = make_args(episode_length=T, n_rollout_threads=N, sampler_rng="device")
+    buf = SharedReplayBuffer(args, A, Box((6,)), Box((18,)), Discrete(5), device=dev)
+    buf.rewards.normal_()
+    buf.value_preds.normal_()
+    buf.compute_returns(torch.zeros(N, A, 1), None if not args.use_valuenorm else _vn(dev))
+    adv = buf.normalized_advantages(_vn(dev))
+    first = next(iter(buf.feed_forward_generator(adv, 1)))
+    keep = first[6].clone()
+    again = next(iter(buf.feed_forward_generator(adv, 1)))
+    assert again[6] is first[6] and buf.whole_batch_reuses == 1
+    first[6].add_(1.0)                                   # a trainer subclass scribbles on the returns it was handed
+    third = next(iter(buf.feed_forward_generator(adv, 1)))
+    assert third[6] is not first[6]
+    torch.testing.assert_close(third[6], keep, rtol=0, atol=0)
+
+
+def _vn(dev):
+    from onpolicy.utils.valuenorm import ValueNorm
+    return ValueNorm(1, device=dev)

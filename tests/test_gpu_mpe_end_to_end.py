@@ -68,6 +68,44 @@ def test_train_mpe_with_device_resident_worlds(tmp_path, monkeypatch, algo):
     assert torch.isfinite(runner.buffer.rewards).all() and float(runner.buffer.masks.min()) == 0.0
 
 
+@pytest.mark.parametrize("algo", ["mappo", "rmappo"])
+def test_device_worlds_with_the_fused_hidden64_kernels(tmp_path, monkeypatch, algo):
+    """BASELINE.json configs[2] in small: simple_spread (3 agents) on device-resident worlds (K11) at the shipped hidden
+    size 64, so that the update runs through the fused trunk (K9) and, for rmappo, the GRU chunk kernels (K12; they also
+    serve the rollout's single steps) -- the combination tools/cfg3_end_to_end.py measures at 4096 threads x 400 steps.
+    Three iterations must reduce nothing to NaN and must have launched the kernels; mappo's average reward must not
+    collapse (a wrong action / observation hand-over between K11 and K9 shows up as garbage rewards)."""
+    from onpolicy.algorithms.utils import fused_mlp
+    from onpolicy.scripts.train import train_mpe
+    monkeypatch.setenv("MAPPO_RESULTS_DIR", str(tmp_path / "results"))
+    N, T = 256, 25
+    fused_mlp.profile(True)
+    try:
+        runner = train_mpe.main(["--env_name", "MPE", "--scenario_name", "simple_spread", "--num_agents", "3",
+                                 "--num_landmarks", "3", "--algorithm_name", algo, "--n_rollout_threads", str(N),
+                                 "--episode_length", str(T), "--num_env_steps", str(3 * N * T), "--ppo_epoch", "4",
+                                 "--num_mini_batch", "1", "--data_chunk_length", "5", "--hidden_size", "64", "--use_ReLU",
+                                 "--gain", "0.01", "--lr", "7e-4", "--critic_lr", "7e-4", "--use_wandb", "--log_interval",
+                                 "1", "--n_training_threads", "1", "--use_device_env"])
+        torch.cuda.synchronize()
+        launches = fused_mlp.profile_times()
+    finally:
+        fused_mlp.profile(False)
+    assert type(runner.envs).__name__ == "TorchSimpleSpread" and runner.envs.pos.is_cuda
+    # 3 iterations x 4 epochs x 2 networks in the update
+    assert launches.get("mappo_mlp_backward", (0,))[0] == 3 * 4 * 2, launches
+    assert launches.get("mappo_mlp_forward", (0,))[0] >= 3 * 4 * 2, launches
+    if algo == "rmappo":
+        assert runner.policy.actor.rnn._chunk_kernel_ok(torch.zeros(4, 64, device="cuda"))
+    assert runner.buffer.whole_batch_reuses == 3 * 3            # epochs 2..4 of each train() reuse the gathered batch
+    vl = _scalars(runner.log_dir, "value_loss")
+    rew = _scalars(runner.log_dir, "average_episode_rewards")
+    assert len(vl) == 3 and all(np.isfinite(vl)) and all(np.isfinite(rew))
+    assert torch.isfinite(runner.buffer.rewards).all() and torch.isfinite(runner.buffer.obs).all()
+    assert float(runner.buffer.masks.min()) == 0.0               # episodes ended and restarted inside the rollout
+    assert -400.0 < rew[-1] < 0.0, rew                             # simple_spread rewards are negative distances
+
+
 @pytest.mark.parametrize("agents,landmarks", [(3, 3), (8, 8), (2, 5)])
 def test_simple_spread_step_kernel_equals_tensor_ops(agents, landmarks):
     """K11 (``mappo_simple_spread_step``, one launch per env step) against the tensor-op implementation of the same

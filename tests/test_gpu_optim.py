@@ -56,6 +56,30 @@ def test_clip_adam_matches_torch(max_norm, wd):
         torch.testing.assert_close(p.data, q.data, rtol=5e-7, atol=1e-8)
 
 
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_non_finite_gradient_norm_behaves_like_clip_grad_norm(bad):
+    """torch.nn.utils.clip_grad_norm_ (error_if_nonfinite=False): a NaN norm makes the clip coefficient NaN and poisons
+    EVERY gradient; an infinite norm gives coefficient 0 (finite entries -> 0, the infinite one -> NaN).  The kernel must
+    not quietly map a NaN coefficient to 1 and step on unclipped gradients."""
+    from onpolicy.algorithms.utils import fused_optim
+    dev = torch.device("cuda", 0)
+    shapes = [(64, 48), (64,), (5, 64)]
+    pa, pb = _nets(5, shapes, dev)
+    oa = torch.optim.Adam(pa, fused=True, lr=7e-4, eps=1e-5)
+    g = torch.Generator().manual_seed(12)
+    grads = [torch.randn(s, generator=g).to(dev) for s in shapes]
+    grads[1][7] = bad
+    for p, q, gr in zip(pa, pb, grads):
+        p.grad, q.grad = gr.clone(), gr.clone()
+    na = fused_optim.clip_and_step(oa, pa, 10.0)
+    nb = torch.nn.utils.clip_grad_norm_(pb, 10.0)
+    torch.testing.assert_close(na, nb.reshape(()), rtol=0, atol=0, equal_nan=True)
+    for i, (p, q) in enumerate(zip(pa, pb)):
+        torch.testing.assert_close(p.grad, q.grad, rtol=0, atol=0, equal_nan=True, msg="grad %d" % i)
+    if bad != bad:
+        assert all(torch.isnan(p.grad).all() for p in pa)
+
+
 def test_unsupported_optimisers_fall_back():
     from onpolicy.algorithms.utils import fused_optim
     dev = torch.device("cuda", 0)

@@ -9,41 +9,10 @@ import numpy as np
 import pytest
 import torch
 
+from oracle.k10_partition import permute as _permute_ref      # the numpy restatement (test infrastructure)
+
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
-M32 = 0xFFFFFFFF
-
-
-def _mix(r, k):
-    h = (r * 0x9E3779B1 + k) & M32
-    h ^= h >> 15
-    h = (h * 0x85EBCA6B) & M32
-    h ^= h >> 13
-    return h
-
-
-def _permute_ref(n, keys):
-    """perm(r) for r in [0, n): 6-round balanced Feistel on the next even power-of-two domain, cycle walking."""
-    bits = 2
-    while (1 << bits) < n:
-        bits += 2
-    half = bits // 2
-    mask = (1 << half) - 1
-    x = np.arange(n, dtype=np.uint64)
-    out = np.empty(n, dtype=np.uint64)
-    todo = np.arange(n)
-    while todo.size:
-        l = (x[todo] >> np.uint64(half)).astype(np.uint64)
-        r = (x[todo] & np.uint64(mask)).astype(np.uint64)
-        for k in keys:
-            t = l ^ (_mix(r, k) & np.uint64(mask))
-            l, r = r, t
-        y = (l << np.uint64(half)) | r
-        x[todo] = y
-        done = y < n
-        out[todo[done]] = y[done]
-        todo = todo[~done]
-    return out.astype(np.int64)
 
 
 def _indices(n, mb, n_mb, keys):

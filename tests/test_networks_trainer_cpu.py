@@ -16,10 +16,14 @@ CASES = ["mlp", "mlp_relu", "gru", "mlp_nonorm"]
 # hidden 64 (oracle/make_golden_trainer.py: CASES_H64): the width of every shipped MPE / SMAC configuration, the one the
 # fused trunk kernels take on the device (tests/test_gpu_trainer_h64.py); here the same fixtures pin the torch modules
 CASES_H64 = ["h64_ns", "h64_relu2", "h64_nofeat", "h64_odd", "h64_gru", "h64_gru_straddle"]
+# the device-sampler route's fixtures (CASES_DEV: the reference fed K10's partition, oracle/k10_partition.py)
+CASES_DEV = ["dev_relu2", "dev_tail", "dev_gru"]
 ALL_CASES = CASES + CASES_H64
 
 
 def _file(cname):
+    if cname.startswith("dev_"):
+        return "trainer_dev_cases"
     return "trainer_h64_cases" if cname.startswith("h64_") else "trainer_cases"
 
 
@@ -83,10 +87,13 @@ def test_forward_matches_reference(gold, cname):
         np.testing.assert_allclose(float(ev_ent), float(z[key + "eval_entropy"]), **tol)
 
 
-@pytest.mark.parametrize("cname", ALL_CASES)
+@pytest.mark.parametrize("cname", ALL_CASES + CASES_DEV)
 def test_train_matches_reference(gold, cname):
     """compute_returns + R_MAPPO.train on the same seeds: same permutations, train_info and final
-    parameters as the reference within float32 tolerance."""
+    parameters as the reference within float32 tolerance.  (``dev_*``: the permutation is K10's partition, drawn by the
+    numpy restatement from the same generator state -- the recorded index lists must come out again.)"""
+    import contextlib
+    from oracle.k10_partition import RandpermAsK10
     z = gold.npz(_file(cname))
     key = "trn_%s_" % cname
     meta, spec, args, spaces, policy, trainer = _build(gold, cname)
@@ -99,7 +106,13 @@ def test_train_matches_reference(gold, cname):
 
     trainer.prep_training()
     torch.manual_seed(21)
-    info = trainer.train(buf)
+    sampler = RandpermAsK10(spec["args"]["num_mini_batch"]) if cname in CASES_DEV else contextlib.nullcontext()
+    with sampler as rec:
+        info = trainer.train(buf)
+    if cname in CASES_DEV:
+        assert len(rec.calls) == meta["n_perms"]
+        for i, p in enumerate(rec.calls):
+            np.testing.assert_array_equal(p, z[key + "perm%d" % i])
     ref_info = meta["train_info"]
     assert set(info) == set(ref_info)
     for k in ref_info:
@@ -112,7 +125,7 @@ def test_train_matches_reference(gold, cname):
         vn = trainer.value_normalizer
         got = np.array([float(vn.running_mean), float(vn.running_mean_sq), float(vn.debiasing_term)])
         np.testing.assert_allclose(got, z[key + "final_norm"], rtol=1e-5, atol=1e-9)
-    if cname in CASES_H64:      # what the last ppo_update left in .grad (clipped), relative to each tensor's largest entry
+    if cname in CASES_H64 + CASES_DEV:      # what the last ppo_update left in .grad (clipped), relative to each tensor's largest entry
         for net, pre in ((policy.actor, "last_grad_actor."), (policy.critic, "last_grad_critic.")):
             for k, p in net.named_parameters():
                 ref = z[key + pre + k]

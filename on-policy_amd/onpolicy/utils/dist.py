@@ -245,7 +245,7 @@ class DataParallel(object):
             self.scales_reused += 1
             return self._scales_done["out"]
         rec = next(r for r in self._scales_pending if self._same_batch(r, active_masks, return_batch, key))
-        self._scales_pending.remove(rec)
+        self._scales_pending = [r for r in self._scales_pending if r is not rec]      # (identity: == would compare tensors)
         from onpolicy import _native
         lib, p = _native.lib(), _native.ptr
         if rec["work"] is not None:

@@ -16,7 +16,7 @@ ulimit -c 0
 cd $REPO
 
 if [[ $STAGE == all || $STAGE == tests ]]; then
-  timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/gpu_tests.log 2>&1; tail -3 $OUT/gpu_tests.log
+  timeout 1500 python -m pytest tests -m gpu -q > $OUT/gpu_tests.log 2>&1; tail -3 $OUT/gpu_tests.log
 fi
 
 if [[ $STAGE == all || $STAGE == bench ]]; then

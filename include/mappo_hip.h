@@ -553,6 +553,11 @@ int     mappo_mlp_set_grid_cap(int cap);
 /* tuning hook: device buffer of >= 512 int64 that receives shader-clock stamps of workgroup 0's first pipeline
  * iterations of mappo_mlp_forward (tools/bench_mlp.py --stamps), NULL = off */
 int     mappo_mlp_set_debug(long long* buf);
+/* tuning / test hook: option bits of the K9 launchers (initial value: environment variable MAPPO_MLP_FLAGS, default 0);
+ * returns the previous value.  1 = the forward's compute waves keep the default priority; 4 = mappo_mlp_forward keeps the
+ * loader / compute kernel (mlp_fwd_kernel) for shapes the version-3 kernel (operands straight from global memory, resident
+ * first-layer weights) would take. */
+int     mappo_mlp_set_flags(int flags);
 int     mappo_mlp_forward(const mappo_mlp_t* net, mappo_stream_t stream);
 int     mappo_mlp_backward(const mappo_mlp_t* net, mappo_stream_t stream);
 int64_t mappo_mlp_grad_floats(int din, int n_layers, int out);

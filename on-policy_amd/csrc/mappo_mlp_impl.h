@@ -566,6 +566,327 @@ __global__ void __launch_bounds__(kFwdThreads, 4) mlp_fwd_kernel(FwdArgs a) {
     }
 }
 
+// ================================================================== forward, version 3 (aligned rows, din <= 448) ====
+// Same maths and the same saved activations as mlp_fwd_kernel; built around what the counters of round 3 say limits that
+// kernel (matrix pipe 59-63 % busy): its loader waves.  Every LDS store / vector load a loader wave issues waits for a gap
+// in the MFMA operand traffic of the compute wave on its SIMD (~400 cycles each beside an MFMA stream against ~60 alone),
+// 13 of them per 32-column chunk, so two workgroups' loaders deliver a chunk every 4.5-5 k cycles against 2 x 2.05 k
+// cycles of MFMA work.  Here nothing stands between HBM and the B operand:
+//   * the B operand (activations: lane = row) comes STRAIGHT from global memory into registers: lane (c, h) loads the four
+//     16-byte pieces 16 h + 4 q .. + 3 of its row's 32-column chunk -- element e of piece q is exactly the k index
+//     32 kc + 16 h + 4 q + e that MFMA step (q, e) contracts over.  A wave instruction touches 32 rows x 2 pieces; the four
+//     instructions of a chunk are issued back to back and cover whole 128-byte lines of the (1536-byte aligned) rows, so the
+//     lines are fetched once.  No LDS hop, no loader waves, no barriers: three chunks in flight per wave in 48 registers,
+//     issued by the wave that consumes them right behind the MFMA block that freed the buffer;
+//   * the WHOLE first-layer weight matrix sits in LDS (64 x din floats: 96 KB for the 384-wide critic; 16-byte pieces
+//     XOR-swizzled so that the A-operand reads are conflict free), staged once per workgroup;
+//   * ONE workgroup of 8 waves per CU = two waves per SIMD with 256 registers each: while one is in its layer tails
+//     (VALU, transcendentals, stores) the other streams MFMAs -- what the two workgroups per CU of mlp_fwd_kernel are for;
+//   * no LDS reads in the layer tails: the bias is the accumulators' initial value (per-lane constants in registers), and
+//     the LayerNorm's gamma / beta are folded into the weights that consume its output when they are staged
+//     (W' = W diag(gamma), b' = b + W beta: hidden layers and head), so a tail is bias-free activation + statistics +
+//     the fragment-order store of nhat, and nhat itself is the next layer's B operand;
+//   * a head of >= 3 outputs runs on the MFMA too (outputs zero-padded to one 32-feature tile: 32 MFMAs and 8 operand reads
+//     whatever the width, instead of 8 reads + 32 multiply-adds + a lane exchange per output).
+constexpr int kF3Waves = 8;
+constexpr int kF3MaxDin = 448;              // 14 chunks x 8 KB of first-layer weights (SMAC's padded 436-wide critic input)
+constexpr int kF3GridCap = 256;             // one workgroup per CU
+
+struct Fwd3Lds {
+    int vec, w2p, whp, bh, w1, total;
+};
+__host__ __device__ __forceinline__ Fwd3Lds fwd3_lds(int L, int out, int nch) {
+    Fwd3Lds o;
+    o.vec = 0;                                  // [L][bias' | g | beta][64]  (bias' = the folded bias of layers >= 1)
+    o.w2p = o.vec + 192 * L;                    // [L - 1][2][32][kWS], gamma of the layer below folded in
+    o.whp = o.w2p + (L - 1) * 2 * 32 * kWS;     // [32][kWS] permuted head weights (rows >= out are zero), gamma folded in
+    o.bh = o.whp + 32 * kWS;                    // [32] folded head bias
+    o.w1 = (o.bh + 32 + 3) & ~3;                // [nch][64 features][32 k], 16-byte pieces swizzled within a row
+    o.total = o.w1 + nch * 2048;
+    return o;
+}
+inline bool fwd3_takes(int din, int L, int out) {
+    return din % 4 == 0 && din >= 4 && din <= kF3MaxDin && out <= 32 && L >= 1 && L <= 3;
+}
+
+// The tail of one layer on accumulators that already hold z = W x + b: a = act(z), statistics, nhat in place (-> reg),
+// fragment-order store of nhat (KEEP).  No LDS traffic.
+template <bool KEEP, int ACT>
+__device__ __forceinline__ void layer_tail_nhat(const f32x16* acc, float eps, float* reg, float* ztile, int lane,
+                                                float& mean_out, float& rstd_out) {
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            reg[16 * t + v] = act_fn<ACT>(acc[t][v]);
+            sum += reg[16 * t + v];
+        }
+    sum += prim::xhalf(sum);
+    const float mean = sum * (1.f / 64.f);
+    float var = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        reg[s] -= mean;
+        var += reg[s] * reg[s];
+    }
+    var += prim::xhalf(var);
+    const float rstd = 1.f / sqrtf(var * (1.f / 64.f) + eps);
+    mean_out = mean;
+    rstd_out = rstd;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        v4 nh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            reg[4 * b + e] *= rstd;
+            nh[e] = reg[4 * b + e];
+        }
+        if (KEEP) *reinterpret_cast<v4*>(ztile + 4 * lane + 256 * b) = nh;     // block 4 t + q = slots 16 t + 4 q ..
+    }
+}
+
+struct XBuf {
+    v4 x[4];
+};
+
+template <int L, int ACT>
+__global__ void __launch_bounds__(64 * kF3Waves) mlp_fwd3_kernel(FwdArgs a) {
+    float* lds = prim::lds();
+    const Net& n = a.net;
+    const int din = n.din, out = n.out;
+    const int nch = (din + 31) / 32;
+    const Fwd3Lds o = fwd3_lds(L, out, nch);
+    const int tid = threadIdx.x, lane = tid & 63, wave = prim::uniform(tid >> 6), c = lane & 31, h = lane >> 5;
+    constexpr int kThr = 64 * kF3Waves;
+    // ---- parameters, once per workgroup.  vec[l] = [bias of layer l with beta of layer l - 1 folded in | g | beta]
+    for (int e = tid; e < 192 * L; e += kThr) {
+        const int l = e / 192, q = (e - 192 * l) >> 6, f = e & 63;
+        float v;
+        if (q == 0) {
+            v = n.bias[l][f];
+            if (l > 0)
+                for (int k = 0; k < 64; ++k) v += n.w2[l - 1][f * 64 + k] * n.ln_b[l - 1][k];
+        } else {
+            v = q == 1 ? n.ln_g[l][f] : n.ln_b[l][f];
+        }
+        lds[o.vec + e] = v;
+    }
+    // w2p[l-1][t][i][h * 32 + s] = gamma_{l-1}[k] W_l[32 t + i][k], k = f(h, s): A operand of the step that consumes slot s
+    for (int l = 1; l < L; ++l)
+        for (int e = tid; e < 64 * 64; e += kThr) {
+            const int fo = e >> 6, hs = e & 63;
+            const int k = feat_of(hs >> 5, hs & 31);
+            lds[o.w2p + (l - 1) * 2 * 32 * kWS + fo * kWS + hs] = n.w2[l - 1][fo * 64 + k] * n.ln_g[l - 1][k];
+        }
+    for (int e = tid; e < 32 * 64; e += kThr) {
+        const int oo = e >> 6, hs = e & 63;
+        const int k = feat_of(hs >> 5, hs & 31);
+        lds[o.whp + oo * kWS + hs] = oo < out ? n.wh[oo * 64 + k] * n.ln_g[L - 1][k] : 0.f;
+    }
+    for (int e = tid; e < 32; e += kThr) {
+        float v = 0.f;
+        if (e < out) {
+            v = n.bh[e];
+            for (int k = 0; k < 64; ++k) v += n.wh[e * 64 + k] * n.ln_b[L - 1][k];
+        }
+        lds[o.bh + e] = v;
+    }
+    // first-layer weights: piece p (k = 32 kc + 4 p ..) of feature row f at slot p ^ ((f >> 1) & 7); zero beyond din
+    for (int e = tid; e < nch * 512; e += kThr) {
+        const int kc = e >> 9, f = (e >> 3) & 63, p = e & 7;
+        const int k = 32 * kc + 4 * p;
+        v4 w = {0.f, 0.f, 0.f, 0.f};
+        if (k < din) w = *reinterpret_cast<const v4u*>(n.w1 + (long long)f * din + k);       // (din % 4 == 0)
+        *reinterpret_cast<v4*>(lds + o.w1 + kc * 2048 + f * 32 + 4 * (p ^ ((f >> 1) & 7))) = w;
+    }
+    __syncthreads();
+    // per-lane constants: the (folded) bias of every layer in accumulator order -- the accumulators start from it
+    float biasr[L][32];
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int s = 0; s < 32; ++s) biasr[l][s] = lds[o.vec + 192 * l + feat_of(h, s)];
+
+    const long long rows = a.rs.rows;
+    const long long ntiles = rows128(rows) / 32;        // (z / statistics are padded to the 128-row tile, like the table)
+    const long long gw = (long long)blockIdx.x * kF3Waves + wave, nw = (long long)gridDim.x * kF3Waves;
+    const long long my_tiles = gw < ntiles ? (ntiles - gw + nw - 1) / nw : 0;
+    if (my_tiles == 0) return;
+    const long long n_pos = my_tiles * nch;
+    // reader side: float offset of piece P = 4 h + q of feature row c inside a [64][32] weight chunk
+    int off[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) off[q] = c * 32 + 4 * ((4 * h + q) ^ ((c >> 1) & 7));
+    auto tile_of = [&](long long m) {           // launch tile of this wave's m-th tile (past the end: the last one again)
+        if (m >= my_tiles) m = my_tiles - 1;
+        return gw + m * nw;
+    };
+    // issue side: position = (local tile, chunk) as counters; the row of the tile being issued and of the one after it
+    long long it_m = 0;
+    int it_kc = 0;
+    const float* row_it = a.rs.src + (long long)a.rs.srow[tile_of(0) * 32 + c] * din;
+    int sr_next = a.rs.srow[tile_of(1) * 32 + c];
+    auto issue = [&](XBuf& B) {                 // always exactly 4 loads (+ 1 table load per tile)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int k = 32 * it_kc + 16 * h + 4 * q;
+            if (k > din - 4) k = din - 4;       // a piece past the row's end: finite data against zero weights
+            B.x[q] = *reinterpret_cast<const v4u*>(row_it + k);
+        }
+        if (++it_kc == nch) {
+            it_kc = 0;
+            ++it_m;
+            row_it = a.rs.src + (long long)sr_next * din;
+            sr_next = a.rs.srow[tile_of(it_m + 1) * 32 + c];
+        }
+    };
+    f32x16 acc[2];
+    auto mfma_chunk = [&](const XBuf& B, int kc) {
+        const float* wt = lds + o.w1 + kc * 2048;
+        v4 a0n = *reinterpret_cast<const v4*>(wt + off[0]);
+        v4 a1n = *reinterpret_cast<const v4*>(wt + 1024 + off[0]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const v4 a0 = a0n, a1 = a1n;
+            if (q < 3) {
+                a0n = *reinterpret_cast<const v4*>(wt + off[q < 3 ? q + 1 : 0]);
+                a1n = *reinterpret_cast<const v4*>(wt + 1024 + off[q < 3 ? q + 1 : 0]);
+            }
+            prim::sched_fence();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0] = prim::mfma32(a0[e], B.x[q][e], acc[0]);
+                acc[1] = prim::mfma32(a1[e], B.x[q][e], acc[1]);
+            }
+        }
+    };
+    auto init_acc = [&](int l) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[t][v] = biasr[l][16 * t + v];
+    };
+
+    XBuf B0, B1, B2;
+    issue(B0);
+    issue(B1);
+    issue(B2);
+    long long m = 0;
+    int kc = 0, ring = 0;
+    init_acc(0);
+    // tuning hook (mappo_mlp_set_debug): shader-clock stamps of the first tiles of two waves that share SIMD 0 of
+    // workgroup 0 (waves 0 and 4): [tile start, chunk loop done, tail done] at dbg[64 w + 4 m ..]
+    const bool cstamp = a.dbg != nullptr && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0;
+    for (long long p = 0; p < n_pos; ++p) {
+        if (cstamp && kc == 0 && m < 15) a.dbg[64 * (wave >> 2) + 4 * m] = prim::clock();
+        // consume this position's chunk, then refill its buffer with position p + 3 (past the end: the last tile again)
+        if (ring == 0) {
+            mfma_chunk(B0, kc);
+            issue(B0);
+        } else if (ring == 1) {
+            mfma_chunk(B1, kc);
+            issue(B1);
+        } else {
+            mfma_chunk(B2, kc);
+            issue(B2);
+        }
+        ring = ring == 2 ? 0 : ring + 1;
+        if (++kc < nch) continue;
+        kc = 0;
+        if (cstamp && m < 15) a.dbg[64 * (wave >> 2) + 4 * m + 1] = prim::clock();
+        // ---- the rest of the network on this lane's row (rows past the end of the launch are copies of the last row:
+        // row-table padding; z and the statistics are padded to the tile, only the output store is conditional)
+        const long long tile = gw + m * nw;
+        const long long m_done = m;
+        ++m;
+        const long long row = tile * 32 + c;
+        float nh[32], mean, rstd;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            if (l > 0) {
+                // acc = b' + (gamma (.) W) nhat, accumulators starting from the folded bias
+                init_acc(l);
+                const float* wp = lds + o.w2p + (l - 1) * 2 * 32 * kWS;
+                const float* w0 = wp + c * kWS + 32 * h;
+                const float* w1 = wp + (32 + c) * kWS + 32 * h;
+                v4 a0n = *reinterpret_cast<const v4*>(w0), a1n = *reinterpret_cast<const v4*>(w1);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const v4 a0 = a0n, a1 = a1n;
+                    if (q < 7) {
+                        a0n = *reinterpret_cast<const v4*>(w0 + 4 * q + 4);
+                        a1n = *reinterpret_cast<const v4*>(w1 + 4 * q + 4);
+                    }
+                    prim::sched_fence();
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[0] = prim::mfma32(a0[e], nh[4 * q + e], acc[0]);
+                        acc[1] = prim::mfma32(a1[e], nh[4 * q + e], acc[1]);
+                    }
+                }
+            }
+            if (a.z[l] != nullptr) {
+                layer_tail_nhat<true, ACT>(acc, n.eps, nh, a.z[l] + tile * 2048, lane, mean, rstd);
+                *reinterpret_cast<f2*>(a.st[l] + 2 * row) = f2{mean, rstd};     // both half-waves hold the same pair
+            } else {
+                layer_tail_nhat<false, ACT>(acc, n.eps, nh, nullptr, lane, mean, rstd);
+            }
+        }
+        init_acc(0);        // (the next tile's first-layer accumulators; acc is free from here on unless the head uses it)
+        const long long yrow = row < rows ? row : rows - 1;
+        if (out == 0) {
+            // trunk only (features for the GRU): the LayerNorm's affine half applied here
+            float hreg[32];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const v4 g = *reinterpret_cast<const v4*>(lds + o.vec + 192 * (L - 1) + 64 + 32 * t + 8 * q + 4 * h);
+                    const v4 be = *reinterpret_cast<const v4*>(lds + o.vec + 192 * (L - 1) + 128 + 32 * t + 8 * q + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hreg[16 * t + 4 * q + e] = nh[16 * t + 4 * q + e] * g[e] + be[e];
+                }
+            store_row64(a.y + yrow * 64, hreg, h);
+        } else if (out <= 2) {
+            for (int oo = 0; oo < out; ++oo) {
+                const float* wp = lds + o.whp + oo * kWS + 32 * h;
+                float pr = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const v4 w = *reinterpret_cast<const v4*>(wp + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pr += w[e] * nh[4 * q + e];
+                }
+                pr += prim::xhalf(pr);
+                a.y[yrow * out + oo] = pr + lds[o.bh + oo];
+            }
+        } else {
+            // head on the MFMA: D[output i][row] = sum over (h, s) whp[i][h * 32 + s] * nhat[s]; lane (c, h) ends up with
+            // outputs (v & 3) + 8 (v >> 2) + 4 h of its row in register v
+            f32x16 ah;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) ah[v] = 0.f;
+            const float* w0 = lds + o.whp + c * kWS + 32 * h;
+            v4 a0n = *reinterpret_cast<const v4*>(w0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const v4 a0 = a0n;
+                if (q < 7) a0n = *reinterpret_cast<const v4*>(w0 + 4 * q + 4);
+                prim::sched_fence();
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ah = prim::mfma32(a0[e], nh[4 * q + e], ah);
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int oo = (v & 3) + 8 * (v >> 2) + 4 * h;
+                if (oo < out) a.y[yrow * out + oo] = ah[v] + lds[o.bh + oo];
+            }
+        }
+        if (cstamp && m_done < 15) a.dbg[64 * (wave >> 2) + 4 * m_done + 2] = prim::clock();
+    }
+}
+
 // ================================================================== backward: row-parallel chain ====
 struct BwdArgs {
     RowSrc rs;          // only rows is used here
@@ -1868,7 +2189,7 @@ inline int& grid_cap_override() {
     static int cap = 0;
     return cap;
 }
-inline int tuning_flags() {
+inline int& tuning_flags_ref() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("MAPPO_MLP_FLAGS");
@@ -1876,6 +2197,7 @@ inline int tuning_flags() {
     }
     return v;
 }
+inline int tuning_flags() { return tuning_flags_ref(); }
 inline long long*& debug_buffer() {
     static long long* p = nullptr;
     return p;
@@ -1899,6 +2221,22 @@ inline int forward(const mappo_mlp_t* m, hipStream_t stream) {
         if (a.z[l] != nullptr && a.st[l] == nullptr) return MAPPO_E_NULL;
     }
     const bool al = m->din % 4 == 0;
+    if (fwd3_takes(m->din, m->n_layers, m->out) && !(tuning_flags() & 4)) {
+        // version 3: operands straight from global memory, resident first-layer weights, two waves per SIMD (see there);
+        // MAPPO_MLP_FLAGS bit 2 (mappo_mlp_set_flags) keeps the loader / compute kernel below
+        const int nch = (m->din + 31) / 32;
+        const Fwd3Lds o3 = fwd3_lds(m->n_layers, m->out, nch);
+        const long long grid3 = capped(ceil_div(rows128(m->rows) / 32, kF3Waves), kF3GridCap);
+#define MAPPO_FWD3_CASE(LL, AA)                                                                                    \
+    if (m->n_layers == LL && m->act == AA) {                                                                      \
+        MAPPO_LAUNCH((mlp_fwd3_kernel<LL, AA>), (unsigned)grid3, 64 * kF3Waves, (size_t)o3.total * 4, stream, a); \
+    }
+        MAPPO_FWD3_CASE(1, 0) MAPPO_FWD3_CASE(1, 1) MAPPO_FWD3_CASE(1, 2)
+        MAPPO_FWD3_CASE(2, 0) MAPPO_FWD3_CASE(2, 1) MAPPO_FWD3_CASE(2, 2)
+        MAPPO_FWD3_CASE(3, 0) MAPPO_FWD3_CASE(3, 1) MAPPO_FWD3_CASE(3, 2)
+#undef MAPPO_FWD3_CASE
+        return MAPPO_LAUNCH_ERROR();
+    }
     const FwdLds o = fwd_lds(m->n_layers, m->out);
     const long long grid = capped(ceil_div(m->rows, kTR), kFwdGridCap);
 #define MAPPO_FWD_CASE(AA, AL)                                                                                 \

@@ -133,6 +133,7 @@ SIGNATURES = {
     "mappo_mlp_row_table_ints": (_i64, [_i64]),
     "mappo_mlp_set_grid_cap": (_int, [_int]),
     "mappo_mlp_set_debug": (_int, [_vp]),
+    "mappo_mlp_set_flags": (_int, [_int]),
     "mappo_mlp_row_table": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _vp, _vp]),
     "mappo_standardize_rows": (_int, [_vp, _i64, _int, ctypes.c_float, _vp, _vp]),
     "mappo_standardize_rows_ld": (_int, [_vp, _i64, _int, ctypes.c_float, _vp, _int, _vp]),

@@ -37,6 +37,8 @@ def bind(lib):
     lib.mappo_standardize_rows_ld.argtypes = [_vp, _i64, ctypes.c_int, ctypes.c_float, _vp, ctypes.c_int, _vp]
     lib.mappo_mlp_set_grid_cap.restype = ctypes.c_int
     lib.mappo_mlp_set_grid_cap.argtypes = [ctypes.c_int]
+    lib.mappo_mlp_set_flags.restype = ctypes.c_int
+    lib.mappo_mlp_set_flags.argtypes = [ctypes.c_int]
     return lib
 
 

@@ -73,7 +73,7 @@ def _train_and_compare(z, key, meta, spec, policy, trainer, buf, returns_exact):
     if returns_exact:
         np.testing.assert_array_equal(got, z[key + "returns"])
     else:
-        np.testing.assert_allclose(got, z[key + "returns"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(got, z[key + "returns"], rtol=1e-5, atol=1e-5)    # (returns are O(1): 1e-5 of their scale)
     trainer.prep_training()
     torch.manual_seed(21)
     fused_mlp.profile(True)

@@ -13,6 +13,7 @@ from oracle.k10_partition import permute as _permute_ref      # the numpy restat
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
+M32 = 0xFFFFFFFF
 
 
 def _indices(n, mb, n_mb, keys):

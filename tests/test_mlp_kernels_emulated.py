@@ -19,11 +19,22 @@ pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="ROCm clang++ 
 
 
 @pytest.fixture(scope="module")
-def emu():
+def emu_lib():
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt"))
     import build
     return R.bind(ctypes.CDLL(build.build()))
+
+
+# Two forward kernels share every test: the default (version 3 where it takes the shape: aligned rows up to 448 wide --
+# operands straight from global memory, resident first-layer weights, two waves per SIMD) and, with option bit 4 of
+# mappo_mlp_set_flags, the loader / compute kernel that serves every other shape.  Unaligned / wider cases run the latter
+# under both ids.
+@pytest.fixture(params=[0, 4], ids=["fwd3", "fwd_loaders"])
+def emu(emu_lib, request):
+    old = emu_lib.mappo_mlp_set_flags(request.param)
+    yield emu_lib
+    emu_lib.mappo_mlp_set_flags(old)
 
 
 def _ptr(a):

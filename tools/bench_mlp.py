@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "on-policy_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+import numpy as np
 import torch
 
 PEAK_TF = 157.3
@@ -85,6 +86,15 @@ def main():
                 torch.cuda.synchronize()
                 _native.lib().mappo_mlp_set_debug(None)
             d = dbg.cpu().numpy()
+            if not (int(os.environ.get("MAPPO_MLP_FLAGS", "0")) & 4) and din % 4 == 0 and din <= 448:
+                print("forward v3, waves 0 and 4 of workgroup 0 (they share SIMD 0): tile | chunk loop | tail | start -> "
+                      "next start")
+                for w in range(2):
+                    t = d[64 * w:64 * w + 60].reshape(15, 4)
+                    for m in range(1, 12):
+                        print("wave", 4 * w, "tile", m, t[m][1] - t[m][0], t[m][2] - t[m][1], t[m + 1][0] - t[m][0],
+                              "| start", t[m][0] - d[4])
+                d = np.zeros_like(d)
             comp = d[:240].reshape(60, 4)
             load = d[256:256 + 240 + 16]
             print("compute: j, wait_at_barrier, mfma, tail(to next iteration start)")

@@ -588,8 +588,10 @@ __global__ void __launch_bounds__(kFwdThreads, 4) mlp_fwd_kernel(FwdArgs a) {
 //     the fragment-order store of nhat, and nhat itself is the next layer's B operand;
 //   * a head of >= 3 outputs runs on the MFMA too (outputs zero-padded to one 32-feature tile: 32 MFMAs and 8 operand reads
 //     whatever the width, instead of 8 reads + 32 multiply-adds + a lane exchange per output).
-constexpr int kF3Waves = 8;
 constexpr int kF3MaxDin = 448;              // 14 chunks x 8 KB of first-layer weights (SMAC's padded 436-wide critic input)
+constexpr int kF3MinDin = 129;              // narrower inputs (<= 4 chunks per tile: the actors) stay on the loader / compute
+                                            // kernel -- measured A / B on one box: din 48 0.775 against 0.745 ms per 2.6 M
+                                            // rows, din 384 1.79 against 1.86, SMAC's 370 / 436 0.68 against 0.75 per launch
 constexpr int kF3GridCap = 256;             // one workgroup per CU
 
 struct Fwd3Lds {
@@ -605,8 +607,8 @@ __host__ __device__ __forceinline__ Fwd3Lds fwd3_lds(int L, int out, int nch) {
     o.total = o.w1 + nch * 2048;
     return o;
 }
-inline bool fwd3_takes(int din, int L, int out) {
-    return din % 4 == 0 && din >= 4 && din <= kF3MaxDin && out <= 32 && L >= 1 && L <= 3;
+inline bool fwd3_takes(int din, int L, int out, bool any_width) {
+    return din % 4 == 0 && din >= (any_width ? 4 : kF3MinDin) && din <= kF3MaxDin && out <= 32 && L >= 1 && L <= 3;
 }
 
 // The tail of one layer on accumulators that already hold z = W x + b: a = act(z), statistics, nhat in place (-> reg),
@@ -650,8 +652,13 @@ struct XBuf {
     v4 x[4];
 };
 
-template <int L, int ACT>
-__global__ void __launch_bounds__(64 * kF3Waves) mlp_fwd3_kernel(FwdArgs a) {
+// NW = 8: two waves per SIMD with 256 registers each -- three chunks in flight, the biases in registers.  NW = 12: three
+// waves per SIMD with 168 registers -- two chunks in flight, the biases read from LDS when the accumulators are started.
+template <int L, int ACT, int NW>
+__global__ void __launch_bounds__(64 * NW) mlp_fwd3_kernel(FwdArgs a) {
+    constexpr int kF3Waves = NW;
+    constexpr int DEPTH = NW == 8 ? 3 : 2;
+    constexpr bool BIAS_REGS = NW == 8;
     float* lds = prim::lds();
     const Net& n = a.net;
     const int din = n.din, out = n.out;
@@ -702,11 +709,13 @@ __global__ void __launch_bounds__(64 * kF3Waves) mlp_fwd3_kernel(FwdArgs a) {
     }
     __syncthreads();
     // per-lane constants: the (folded) bias of every layer in accumulator order -- the accumulators start from it
-    float biasr[L][32];
+    float biasr[BIAS_REGS ? L : 1][32];
+    if (BIAS_REGS) {
 #pragma unroll
-    for (int l = 0; l < L; ++l)
+        for (int l = 0; l < L; ++l)
 #pragma unroll
-        for (int s = 0; s < 32; ++s) biasr[l][s] = lds[o.vec + 192 * l + feat_of(h, s)];
+            for (int s = 0; s < 32; ++s) biasr[l][s] = lds[o.vec + 192 * l + feat_of(h, s)];
+    }
 
     const long long rows = a.rs.rows;
     const long long ntiles = rows128(rows) / 32;        // (z / statistics are padded to the 128-row tile, like the table)
@@ -762,16 +771,27 @@ __global__ void __launch_bounds__(64 * kF3Waves) mlp_fwd3_kernel(FwdArgs a) {
         }
     };
     auto init_acc = [&](int l) {
+        if (BIAS_REGS) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[t][v] = biasr[l][16 * t + v];
+                for (int v = 0; v < 16; ++v) acc[t][v] = biasr[BIAS_REGS ? l : 0][16 * t + v];
+        } else {        // slots 16 t + 4 q .. + 3 are features 32 t + 8 q + 4 h .. + 3: eight 16-byte reads
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const v4 b = *reinterpret_cast<const v4*>(lds + o.vec + 192 * l + 32 * t + 8 * q + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[t][4 * q + e] = b[e];
+                }
+        }
     };
 
     XBuf B0, B1, B2;
     issue(B0);
     issue(B1);
-    issue(B2);
+    if (DEPTH == 3) issue(B2);
     long long m = 0;
     int kc = 0, ring = 0;
     init_acc(0);
@@ -780,18 +800,18 @@ __global__ void __launch_bounds__(64 * kF3Waves) mlp_fwd3_kernel(FwdArgs a) {
     const bool cstamp = a.dbg != nullptr && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0;
     for (long long p = 0; p < n_pos; ++p) {
         if (cstamp && kc == 0 && m < 15) a.dbg[64 * (wave >> 2) + 4 * m] = prim::clock();
-        // consume this position's chunk, then refill its buffer with position p + 3 (past the end: the last tile again)
+        // consume this position's chunk, then refill its buffer with position p + DEPTH (past the end: the last tile again)
         if (ring == 0) {
             mfma_chunk(B0, kc);
             issue(B0);
         } else if (ring == 1) {
             mfma_chunk(B1, kc);
             issue(B1);
-        } else {
+        } else if (DEPTH == 3) {
             mfma_chunk(B2, kc);
             issue(B2);
         }
-        ring = ring == 2 ? 0 : ring + 1;
+        ring = ring == DEPTH - 1 ? 0 : ring + 1;
         if (++kc < nch) continue;
         kc = 0;
         if (cstamp && m < 15) a.dbg[64 * (wave >> 2) + 4 * m + 1] = prim::clock();
@@ -2221,15 +2241,21 @@ inline int forward(const mappo_mlp_t* m, hipStream_t stream) {
         if (a.z[l] != nullptr && a.st[l] == nullptr) return MAPPO_E_NULL;
     }
     const bool al = m->din % 4 == 0;
-    if (fwd3_takes(m->din, m->n_layers, m->out) && !(tuning_flags() & 4)) {
-        // version 3: operands straight from global memory, resident first-layer weights, two waves per SIMD (see there);
-        // MAPPO_MLP_FLAGS bit 2 (mappo_mlp_set_flags) keeps the loader / compute kernel below
+    if (fwd3_takes(m->din, m->n_layers, m->out, (tuning_flags() & 16) != 0) && !(tuning_flags() & 4)) {
+        // version 3: operands straight from global memory, resident first-layer weights, two (three) waves per SIMD.
+        // Option bits (mappo_mlp_set_flags / MAPPO_MLP_FLAGS): 4 keeps the loader / compute kernel below, 8 selects the
+        // 12-wave form of version 3, 16 lets version 3 take narrow inputs too (tests)
         const int nch = (m->din + 31) / 32;
         const Fwd3Lds o3 = fwd3_lds(m->n_layers, m->out, nch);
-        const long long grid3 = capped(ceil_div(rows128(m->rows) / 32, kF3Waves), kF3GridCap);
-#define MAPPO_FWD3_CASE(LL, AA)                                                                                    \
-    if (m->n_layers == LL && m->act == AA) {                                                                      \
-        MAPPO_LAUNCH((mlp_fwd3_kernel<LL, AA>), (unsigned)grid3, 64 * kF3Waves, (size_t)o3.total * 4, stream, a); \
+        const int nw = (tuning_flags() & 8) ? 12 : 8;
+        const long long grid3 = capped(ceil_div(rows128(m->rows) / 32, nw), kF3GridCap);
+#define MAPPO_FWD3_CASE(LL, AA)                                                                                      \
+    if (m->n_layers == LL && m->act == AA) {                                                                        \
+        if (nw == 8) {                                                                                              \
+            MAPPO_LAUNCH((mlp_fwd3_kernel<LL, AA, 8>), (unsigned)grid3, 64 * 8, (size_t)o3.total * 4, stream, a);   \
+        } else {                                                                                                    \
+            MAPPO_LAUNCH((mlp_fwd3_kernel<LL, AA, 12>), (unsigned)grid3, 64 * 12, (size_t)o3.total * 4, stream, a); \
+        }                                                                                                           \
     }
         MAPPO_FWD3_CASE(1, 0) MAPPO_FWD3_CASE(1, 1) MAPPO_FWD3_CASE(1, 2)
         MAPPO_FWD3_CASE(2, 0) MAPPO_FWD3_CASE(2, 1) MAPPO_FWD3_CASE(2, 2)

@@ -45,11 +45,20 @@ class MPERunner(Runner):
         start = time.time()
         episodes = int(self.num_env_steps) // self.episode_length // self.n_rollout_threads_job
         infos = []
+        # worlds on the device: the whole step (policy forward, sampling, env step, bookkeeping) as one captured graph
+        # launch + the slab write (runner/shared/rollout_graph.py); None = the eager loop below
+        from onpolicy.runner.shared import rollout_graph
+        self.rollout_graph = rollout_graph.build(self) if episodes > 0 else None
         for episode in range(episodes):
             if self.use_linear_lr_decay:
                 self.trainer.policy.lr_decay(episode, episodes)
 
-            for step in range(self.episode_length):
+            if self.rollout_graph is not None:
+                self.trainer.prep_rollout()
+                self.rollout_graph.begin_episode()
+                for step in range(self.episode_length):
+                    infos = self.rollout_graph.step()
+            for step in range(self.episode_length if self.rollout_graph is None else 0):
                 values, actions, action_log_probs, rnn_states, rnn_states_critic, actions_env = self.collect(step)
                 obs, rewards, dones, infos = self.envs.step(actions_env)
                 self.insert((obs, rewards, dones, infos, values, actions, action_log_probs, rnn_states,

@@ -26,11 +26,11 @@ def emu_lib():
     return R.bind(ctypes.CDLL(build.build()))
 
 
-# Two forward kernels share every test: the default (version 3 where it takes the shape: aligned rows up to 448 wide --
-# operands straight from global memory, resident first-layer weights, two waves per SIMD) and, with option bit 4 of
-# mappo_mlp_set_flags, the loader / compute kernel that serves every other shape.  Unaligned / wider cases run the latter
-# under both ids.
-@pytest.fixture(params=[0, 4], ids=["fwd3", "fwd_loaders"])
+# The forward kernels share every test: version 3 (operands straight from global memory, resident first-layer weights;
+# option bit 16 lets it take every aligned width up to 448, by default it takes 129 .. 448) in its 8-wave and 12-wave
+# forms, and -- option bit 4 of mappo_mlp_set_flags -- the loader / compute kernel that serves every other shape.
+# Unaligned / wider cases run the latter under all ids.
+@pytest.fixture(params=[16, 16 | 8, 4], ids=["fwd3", "fwd3_12waves", "fwd_loaders"])
 def emu(emu_lib, request):
     old = emu_lib.mappo_mlp_set_flags(request.param)
     yield emu_lib

@@ -43,31 +43,50 @@ if __name__ == "__main__":
     from onpolicy.algorithms.utils import fused_mlp
     fused_mlp.profile(True)
 
-    def rollout():
+    def rollout_eager():
         for step in range(T):
             values, actions, action_log_probs, rnn_states, rnn_states_critic, actions_env = runner.collect(step)
             obs, rewards, dones, infos = runner.envs.step(actions_env)
             runner.insert((obs, rewards, dones, infos, values, actions, action_log_probs, rnn_states, rnn_states_critic))
 
-    roll, upd = [], []
-    for _ in range(opt.iterations):
-        torch.cuda.synchronize()
-        a = time.perf_counter()
-        rollout()
-        torch.cuda.synchronize()
-        b = time.perf_counter()
-        runner.compute()
-        info = runner.train()
-        torch.cuda.synchronize()
-        c = time.perf_counter()
-        roll.append(b - a)
-        upd.append(c - b)
+    def rollout_graph():
+        runner.trainer.prep_rollout()
+        runner.rollout_graph.begin_episode()
+        for step in range(T):
+            runner.rollout_graph.step()
+
+    def measure(rollout):
+        roll, upd = [], []
+        for _ in range(opt.iterations):
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            rollout()
+            torch.cuda.synchronize()
+            b = time.perf_counter()
+            runner.compute()
+            info = runner.train()
+            torch.cuda.synchronize()
+            c = time.perf_counter()
+            roll.append(b - a)
+            upd.append(c - b)
+        return sum(roll) / len(roll), sum(upd) / len(upd), info
+
+    graphed = getattr(runner, "rollout_graph", None) is not None
+    er, eu, info = measure(rollout_eager)
+    if graphed:
+        r, u, info = measure(rollout_graph)
+    else:
+        r, u = er, eu
     mt = fused_mlp.profile_times()
     fused_mlp.profile(False)
-    r, u = sum(roll) / len(roll), sum(upd) / len(upd)
     out = {"config": "BASELINE.json configs[2]: MPE simple_spread, 3 agents, n_rollout_threads=%d, episode_length=%d, "
                      "ppo_epoch=10, %s, 1 x MI355X, worlds on the device (K11)" % (N, T, opt.algorithm_name),
+           "rollout": "one captured HIP graph launch + one slab write per step (runner/shared/rollout_graph.py)" if graphed
+                      else "eager (collect -> envs.step -> insert, ~30 launches per step)",
            "env_steps_per_s_rollout_plus_update": round(T * N / (r + u), 1),
+           "eager_loop_for_comparison": {"env_steps_per_s_rollout_plus_update": round(T * N / (er + eu), 1),
+                                         "rollout_s": round(er, 4), "rollout_ms_per_env_step": round(1e3 * er / T, 4),
+                                         "update_s": round(eu, 4)},
            "rollout_s": round(r, 4), "rollout_ms_per_env_step": round(1e3 * r / T, 4),
            "rollout_env_steps_per_s": round(T * N / r, 1),
            "update_s": round(u, 4), "update_env_steps_per_s": round(T * N / u, 1),

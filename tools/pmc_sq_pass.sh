@@ -6,7 +6,7 @@
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 W=${1:-ns}                      # bench workload (ns_rnn: the K12 kernels)
-OUT=$REPO/gpurun_out/r03
+OUT=$REPO/gpurun_out/${MAPPO_ROUND:-r04}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ulimit -c 0

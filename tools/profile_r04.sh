@@ -37,6 +37,9 @@ if [[ $STAGE == all || $STAGE == prof ]]; then
     timeout 300 rocprofv3 --kernel-trace --pmc $C -f csv -d $OUT/pmc_$C -o ns -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
   done
   cd $REPO
+  MAPPO_ROUND=r04 bash tools/pmc_sq_pass.sh ns > $OUT/pmc_sq_ns.txt 2>&1
+  MAPPO_ROUND=r04 bash tools/pmc_sq_pass.sh ns_rnn > $OUT/pmc_sq_ns_rnn.txt 2>&1
+  cd $REPO
 fi
 
 if [[ $STAGE == all || $STAGE == proxy ]]; then

@@ -71,6 +71,12 @@ class R_Actor(nn.Module, _DeviceMixin):
 
     def forward(self, obs, rnn_states, masks, available_actions=None, deterministic=False):
         obs, rnn_states, masks, available_actions = self._to_device(obs, rnn_states, masks, available_actions)
+        obs = fused_mlp.rollout_rows(obs, self.base)      # rollout on the device: the trunk (+ head) as K9 launches
+        if isinstance(obs, RowSource) and self.act.action_type == "Discrete" and \
+                self._fuses_head(obs, self.act.action_out.linear):
+            logits = self.base(obs, head=self.act.action_out.linear)          # standardise + trunk + head: two launches
+            actions, action_log_probs = self.act.from_logits(logits, available_actions, deterministic)
+            return actions, action_log_probs, rnn_states
         feats, rnn_states = self._features(obs, rnn_states, masks)
         actions, action_log_probs = self.act(feats, available_actions, deterministic)
         return actions, action_log_probs, rnn_states
@@ -127,6 +133,8 @@ class R_Critic(nn.Module, _DeviceMixin):
 
     def forward(self, cent_obs, rnn_states, masks, obs_standardized=False):
         cent_obs, rnn_states, masks = self._to_device(cent_obs, rnn_states, masks)
+        if not obs_standardized:
+            cent_obs = fused_mlp.rollout_rows(cent_obs, self.base)        # rollout / bootstrap value: K9 (see R_Actor.forward)
         if self._fuses_head(cent_obs, self.v_out):
             return self.base(cent_obs, head=self.v_out), rnn_states
         feats = self.base(cent_obs, standardized=True) if obs_standardized else self.base(cent_obs)

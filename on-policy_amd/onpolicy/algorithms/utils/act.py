@@ -63,6 +63,17 @@ class ACTLayer(nn.Module):
         actions = dist.mode() if deterministic else dist.sample()
         return actions, dist.log_probs(actions)
 
+    def from_logits(self, logits, available_actions=None, deterministic=False):
+        """``forward`` for a Discrete head whose Linear was already evaluated (inside the fused trunk launch): masking,
+        sampling and log-probabilities as ``Categorical.forward`` + ``forward`` do them (reference act.py:44-60,
+        distributions.py:55-68)."""
+        assert self.action_type == "Discrete"
+        if available_actions is not None:
+            logits = torch.where(available_actions == 0, torch.full_like(logits, -1e10), logits)
+        dist = FixedCategorical(logits=logits)
+        actions = dist.mode() if deterministic else dist.sample()
+        return actions, dist.log_probs(actions)
+
     def get_probs(self, x, available_actions=None):
         if self.mixed_action or self.multi_discrete:
             return torch.cat([head(x).probs for head in self.action_outs], -1)

@@ -90,9 +90,17 @@ class RowSource(object):
         self.src, self.idx, self.chunk, self.standardized = src, idx, chunk, bool(standardized)
         # columns that carry data: a standardised copy may be padded with zero columns (``standardize_rows``)
         self.width = int(src.shape[1]) if width is None else int(width)
-        self.mb = int(idx.shape[0])
+        self.mb = int(idx.shape[0]) if idx is not None else int(src.shape[0])      # idx None: every row of src, in order
         self.rows = self.mb * (chunk[0] if chunk else 1)
         self._tab = None
+
+    @classmethod
+    def all_rows(cls, src, standardized=False, width=None):
+        """Every row of ``src`` in order (the rollout's [N * A, dim] network inputs): no index list, and the row table is
+        a cached identity table -- no launch."""
+        rs = cls(src, None, None, standardized, width)
+        rs._tab = _identity_table(rs.rows, src.device)
+        return rs
 
     def table(self):
         """int32 row table for the kernels (``mappo_mlp_row_table``): the source row of every launch row; built on first
@@ -119,6 +127,8 @@ class RowSource(object):
     def rows_slice(self, lo, hi):
         """Row span [lo, hi) of a rows-mode minibatch / chunk span [lo, hi) of a chunk-mode one (every span keeps all
         L steps of its chunks, row l * (hi - lo) + j)."""
+        if self.idx is None:
+            return RowSource.all_rows(self.src[lo:hi], self.standardized, self.width)
         return RowSource(self.src, self.idx[lo:hi], self.chunk, self.standardized, self.width)
 
     def __getitem__(self, key):
@@ -129,6 +139,8 @@ class RowSource(object):
 
     def source_rows(self):
         """int64 [rows] source row of every minibatch row (shared_buffer.py:379-396 / :554-604)."""
+        if self.idx is None:
+            return torch.arange(self.rows, device=self.src.device)
         if not self.chunk:
             return self.idx
         L, T, N, A = self.chunk
@@ -142,6 +154,44 @@ class RowSource(object):
     def materialize(self):
         """The [rows, din] tensor an eager sampler would have produced from ``src``."""
         return self.src[self.source_rows()][:, :self.width]
+
+
+_IDENTITY_TABLES = {}
+
+
+def _identity_table(rows, device):
+    """int32 [rows padded to the 128-row tile]: 0 .. rows - 1, then copies of the last row (what ``mappo_mlp_row_table``
+    writes for identity rows); cached per (rows, device) -- the rollout asks for the same one every step."""
+    key = (int(rows), str(device))
+    tab = _IDENTITY_TABLES.get(key)
+    if tab is None:
+        padded = int(_native.lib().mappo_mlp_row_table_ints(rows))
+        tab = torch.arange(padded, dtype=torch.int32, device=device).clamp_(max=rows - 1)
+        if len(_IDENTITY_TABLES) > 64:
+            _IDENTITY_TABLES.clear()
+        _IDENTITY_TABLES[key] = tab
+    return tab
+
+
+def rollout_rows(x, base):
+    """The rollout side of the fused trunk: a plain [rows, dim] float32 device tensor (what ``collect`` / ``compute`` hand
+    the networks, reference runner/shared/base_runner.py:120-134, mpe_runner.py:96-109) becomes a ``RowSource`` over all
+    its rows -- standardised first when the trunk has an input LayerNorm -- so that trunk (+ head) run as K9 launches
+    instead of ~12 framework launches per network and step.  Only without autograd (rollout / evaluation), only in the
+    device-sampling mode (the integer-parity mode keeps the PyTorch modules the reference fixtures were pinned with), only
+    for trunks the kernels take; otherwise ``x`` comes back unchanged."""
+    from . import distributions
+    if torch.is_grad_enabled() or not torch.is_tensor(x) or not x.is_cuda or x.dim() != 2 or x.dtype != torch.float32 \
+            or distributions.SAMPLING_RNG != "device" or os.environ.get("MAPPO_FUSED_ROLLOUT", "1") == "0":
+        return x
+    if not trunk_supported(base) or x.shape[1] < 4 or x.shape[0] < 1:
+        return x
+    x = x.contiguous()
+    if base._use_feature_normalization:
+        if x.shape[1] > 2048:
+            return x
+        return RowSource.all_rows(standardize_rows(x), standardized=True, width=int(x.shape[1]))
+    return RowSource.all_rows(x, standardized=False)
 
 
 def standardize_rows(src2d, eps=1e-5, pad=True):

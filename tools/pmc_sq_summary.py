@@ -11,11 +11,15 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 W = sys.argv[1] if len(sys.argv) > 1 else "ns"
-SRC = os.path.join(ROOT, "gpurun_out", "r03", "pmc_sq_" + W)
+TAG = sys.argv[2] if len(sys.argv) > 2 else "r04"
+SRC = os.path.join(ROOT, "gpurun_out", TAG, "pmc_sq_" + W)
 if W == "ns" and not os.path.isdir(SRC):
-    SRC = os.path.join(ROOT, "gpurun_out", "r03", "pmc_sq")
+    SRC = os.path.join(ROOT, "gpurun_out", TAG, "pmc_sq")
 KERNELS = {"gru_seq_fwd_kernel": "K12 forward", "gru_seq_bwd_kernel<3, 5>": "K12 backward, actor (5-wide head inside)",
-           "gru_seq_bwd_kernel<1, 1>": "K12 backward, critic (v_out inside)","mlp_fwd_kernel": "K9 forward (actor and critic launches averaged)",
+           "gru_seq_bwd_kernel<1, 1>": "K12 backward, critic (v_out inside)",
+           "mlp_fwd_kernel": "K9 forward, loader / compute kernel (round 4: the narrow actor inputs; before: actor and critic "
+                             "launches averaged)",
+           "mlp_fwd3_kernel": "K9 forward, version 3 (round 4: inputs wider than 128 -- the critic)",
            "mlp_dw1_direct_kernel": "K9 first-layer weight gradient, critic",
            "mlp_dw1_rows_kernel": "K9 first-layer weight gradient, actor",
            "mlp_bwd_kernel<2, 1, 0>": "K9 backward chain, action head",
@@ -51,7 +55,7 @@ def main():
             "frac_of_nominal_f32_mfma_peak": round(mfma / (SIMDS * 2.4 * ns), 3),
             "sq_wave_quad_cycles": mean("SQ_WAVE_CYCLES"), "sq_wait_inst_any": mean("SQ_WAIT_INST_ANY"),
             "sq_wait_any": mean("SQ_WAIT_ANY"), "sq_active_inst_any": mean("SQ_ACTIVE_INST_ANY")}
-    dst = os.path.join(ROOT, "profiles", "r03_pmc_sq_summary.json" if W == "ns" else "r03_pmc_sq_summary_%s.json" % W)
+    dst = os.path.join(ROOT, "profiles", TAG + "_pmc_sq_summary.json" if W == "ns" else TAG + "_pmc_sq_summary_%s.json" % W)
     json.dump(out, open(dst, "w"), indent=1)
     for k, v in out["kernels"].items():
         print(k, v["duration_ms"], "ms", v["shader_clock_ghz"], "GHz", "MFMA busy", v["mfma_busy_share_of_an_average_simd"],

@@ -40,11 +40,12 @@ def main():
     # forward launch: actor (48 -> 64 -> 64 -> 5) and critic (384 -> 64 -> 64 -> 1) launches averaged, like bench.py and
     # rocprofv3 --stats average them
     alg_f = (_work(rows, 48, 2, 5, False)[1] + _work(rows, 384, 2, 1, False)[1]) / 2
-    f, n = mean_of(fetch, "mlp_fwd_kernel")
-    w, _ = mean_of(write, "mlp_fwd_kernel")
+    f, n = mean_of(fetch, "mlp_fwd")          # mlp_fwd_kernel (actor) and, from round 4, mlp_fwd3_kernel (critic)
+    w, _ = mean_of(write, "mlp_fwd")
     out["mappo_mlp_forward"] = {
         "algorithmic_bytes": alg_f, "fetch_size_bytes_raw": f, "write_size_bytes": w, "hbm_bytes": 2 * f + w,
-        "dispatches_averaged": n, "kernel": "mlp::mlp_fwd_kernel<1, true>",
+        "dispatches_averaged": n,
+        "kernel": "mlp::mlp_fwd_kernel<1, true> (actor) / mlp::mlp_fwd3_kernel<2, 1, 8> (critic, from round 4)",
         "note": "north-star bench.py step (separate --pmc passes with --kernel-trace only, tools/profile_r02.sh); actor "
                 "and critic launches averaged; FETCH_SIZE doubled (gfx950 counts 64 B per 128 B request of a wide "
                 "coalesced read, MI355X_MICROARCH.md)"}
@@ -63,12 +64,23 @@ def main():
     out["mappo_gae_f32"] = {"algorithmic_bytes": 24 * rows, "fetch_size_bytes_raw": f, "write_size_bytes": w,
                             "hbm_bytes": 2 * f + w, "dispatches_averaged": n,
                             "note": "north-star size, fused advantages epilogue (24 B / element)"}
+    # the record gather of the north-star step (once per train(): the whole-batch tuple): 64-byte records read through the
+    # index list + the gathered columns written; algorithmic bytes as SharedReplayBuffer._gather counts them
+    f, n = mean_of(fetch, "gather_records_kernel")
+    w, _ = mean_of(write, "gather_records_kernel")
+    if n:
+        rec_widths = 1 + 1 + 1 + 1 + 1 + 1 + 1 + 5      # actions, value_preds, returns, masks, active_masks, logp, adv, avail
+        out["mappo_gather_rows"] = {"algorithmic_bytes": 2 * 4 * rec_widths * rows + 8 * rows, "fetch_size_bytes_raw": f,
+                                    "write_size_bytes": w, "hbm_bytes": 2 * f + w, "dispatches_averaged": n,
+                                    "kernel": "gather_records_kernel",
+                                    "note": "the packed 64-byte records are read whole (16 floats, 12 of them payload): "
+                                            "fetched bytes exceed the algorithmic count by the padding"}
     with open(os.path.join(DST, TAG + "_pmc_summary.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     for k, v in out.items():
         print(k, "algorithmic %.3f GB, HBM %.3f GB (%.2fx)" % (v["algorithmic_bytes"] / 1e9, v["hbm_bytes"] / 1e9,
                                                               v["hbm_bytes"] / v["algorithmic_bytes"]))
-    for w in ("ns", "cfg2", "smac", "ns_rnn"):
+    for w in ("ns", "cfg2", "cfg3", "smac", "ns_rnn"):
         for f in glob.glob(os.path.join(SRC, "prof_" + w, "*kernel_stats.csv")):
             shutil.copy(f, os.path.join(DST, "%s_bench_%s_kernel_stats.csv" % (TAG, w)))
     lines = {}

@@ -53,7 +53,8 @@ def profile_times():
 class _Timed(object):
     def __init__(self, name, flops, nbytes):
         self.rec = None
-        if _PROFILE is not None:
+        # (launches recorded into a HIP graph -- the captured rollout step -- have no events of their own to time)
+        if _PROFILE is not None and not torch.cuda.is_current_stream_capturing():
             self.rec = (name, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), flops, nbytes)
 
     def __enter__(self):

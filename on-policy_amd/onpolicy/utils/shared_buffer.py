@@ -178,7 +178,7 @@ class SharedReplayBuffer(object):
         self._events = {} if enabled else None
 
     def _timed(self, name, nbytes, settle=False):
-        if self._events is None:
+        if self._events is None or torch.cuda.is_current_stream_capturing():
             return None
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), nbytes)
         self._events.setdefault(name, []).append(ev)

@@ -329,6 +329,17 @@ typedef struct mappo_ppo_loss {
 } mappo_ppo_loss_t;
 int mappo_ppo_loss_f32(const mappo_ppo_loss_t* args, mappo_stream_t stream);
 
+/* ------------------------------------------------------------------ K14: categorical sampling for the rollout ----
+ * Replaces, for one Discrete head and one draw per row, Categorical.forward's availability masking
+ * (onpolicy/algorithms/utils/distributions.py:64-67), FixedCategorical.sample (:15-16) and .log_probs (:18-25) as
+ * called by ACTLayer.forward (onpolicy/algorithms/utils/act.py:55-60):
+ *   x_i = available_i == 0 ? -1e10 : logits_i;  l = x - logsumexp(x);  action = argmax_i exp(l_i) / noise_i
+ *   (torch.multinomial's rule for one sample: noise ~ Exponential(1), drawn by the caller);  log_probs = l[action].
+ *   logits [rows, n_actions], available [rows, n_actions] or NULL, noise [rows, n_actions] (> 0),
+ *   actions [rows] int64, log_probs [rows]; n_actions <= 64. */
+int mappo_categorical_sample(const float* logits, const float* available, const float* noise, int64_t* actions,
+                             float* log_probs, int64_t rows, int n_actions, mappo_stream_t stream);
+
 /* --------------------------------------------------------------- K8: GRU cell gates ----
  * Everything of one GRU step that is not a GEMM (reference onpolicy/algorithms/utils/rnn.py:7-80 runs
  * nn.GRU; PyTorch cell, gates stacked r|z|n), reading / writing the per-sequence buffers in place:

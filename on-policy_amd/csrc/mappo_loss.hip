@@ -211,3 +211,55 @@ extern "C" int mappo_ppo_loss_f32(const mappo_ppo_loss_t* args, mappo_stream_t s
     }
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// K14: the rollout side of the Categorical head as one launch -- availability masking, normalised logits, one action per
+// row and its log-probability (reference onpolicy/algorithms/utils/distributions.py:14-28 FixedCategorical.sample /
+// log_probs, :55-68 Categorical.forward; act.py:44-60).  As framework ops that is ~15 launches on [rows, n_actions]
+// tensors (where / logsumexp / softmax / multinomial with its asserts / gather), 4-5 us each inside the captured rollout
+// step.  Sampling is torch.multinomial's own rule for one draw: argmax_i p_i / q_i with q ~ Exponential(1) -- the noise is
+// drawn by the caller from torch's generator (graph-safe philox), so the distribution is exactly the framework's.
+// One thread per row; n_actions <= 64.
+__global__ void __launch_bounds__(256) categorical_sample_kernel(const float* logits, const float* avail, const float* noise,
+                                                                 long long* actions, float* logp, long long rows, int na) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float* lg = logits + r * na;
+    const float* av = avail ? avail + r * na : nullptr;
+    const float* q = noise + r * na;
+    float mx = -INFINITY;
+    for (int i = 0; i < na; ++i) {
+        const float x = (av && av[i] == 0.f) ? -1e10f : lg[i];
+        mx = fmaxf(mx, x);
+    }
+    float se = 0.f;
+    for (int i = 0; i < na; ++i) {
+        const float x = (av && av[i] == 0.f) ? -1e10f : lg[i];
+        se += expf(x - mx);
+    }
+    const float lse = mx + logf(se);
+    int best = 0;
+    float best_v = -1.f, best_l = 0.f;
+    for (int i = 0; i < na; ++i) {
+        const float x = (av && av[i] == 0.f) ? -1e10f : lg[i];
+        const float l = x - lse;                // normalised logit = log p_i
+        const float v = expf(l) / q[i];         // p_i / q_i (first maximum wins, like argmax)
+        if (v > best_v) {
+            best_v = v;
+            best = i;
+            best_l = l;
+        }
+    }
+    actions[r] = best;
+    logp[r] = best_l;
+}
+
+extern "C" int mappo_categorical_sample(const float* logits, const float* available, const float* noise, int64_t* actions,
+                                        float* log_probs, int64_t rows, int n_actions, mappo_stream_t stream_) {
+    if (!logits || !noise || !actions || !log_probs) return MAPPO_E_NULL;
+    if (rows <= 0 || n_actions <= 0 || n_actions > 64) return MAPPO_E_SHAPE;
+    hipLaunchKernelGGL(categorical_sample_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream_), logits, available, noise,
+                       reinterpret_cast<long long*>(actions), log_probs, (long long)rows, n_actions);
+    return (int)hipGetLastError();
+}

@@ -608,7 +608,9 @@ __host__ __device__ __forceinline__ Fwd3Lds fwd3_lds(int L, int out, int nch) {
     return o;
 }
 inline bool fwd3_takes(int din, int L, int out, bool any_width) {
-    return din % 4 == 0 && din >= (any_width ? 4 : kF3MinDin) && din <= kF3MaxDin && out <= 32 && L >= 1 && L <= 3;
+    // (single-layer trunks -- layer_N = 0 -- stay on the loader / compute kernel: the one-layer tanh instance of version 3
+    // spilled 148 bytes per lane and no shipped configuration uses it)
+    return din % 4 == 0 && din >= (any_width ? 4 : kF3MinDin) && din <= kF3MaxDin && out <= 32 && L >= 2 && L <= 3;
 }
 
 // The tail of one layer on accumulators that already hold z = W x + b: a = act(z), statistics, nhat in place (-> reg),
@@ -652,8 +654,8 @@ struct XBuf {
     v4 x[4];
 };
 
-// NW = 8: two waves per SIMD with 256 registers each -- three chunks in flight, the biases in registers.  NW = 12: three
-// waves per SIMD with 168 registers -- two chunks in flight, the biases read from LDS when the accumulators are started.
+// NW = 8: two waves per SIMD with 256 registers each -- three chunks in flight, the first layer's bias in registers.  NW = 12:
+// three waves per SIMD with 168 registers -- two chunks in flight, every bias read from LDS when the accumulators are started.
 template <int L, int ACT, int NW>
 __global__ void __launch_bounds__(64 * NW) mlp_fwd3_kernel(FwdArgs a) {
     constexpr int kF3Waves = NW;
@@ -709,12 +711,12 @@ __global__ void __launch_bounds__(64 * NW) mlp_fwd3_kernel(FwdArgs a) {
     }
     __syncthreads();
     // per-lane constants: the (folded) bias of every layer in accumulator order -- the accumulators start from it
-    float biasr[BIAS_REGS ? L : 1][32];
+    // (layer 0 only: its accumulators are started in the chunk loop; the hidden layers' start values are read from LDS in
+    // the tail, eight 16-byte reads each -- with all of them in registers the three-layer instances spilled)
+    float biasr[32];
     if (BIAS_REGS) {
 #pragma unroll
-        for (int l = 0; l < L; ++l)
-#pragma unroll
-            for (int s = 0; s < 32; ++s) biasr[l][s] = lds[o.vec + 192 * l + feat_of(h, s)];
+        for (int s = 0; s < 32; ++s) biasr[s] = lds[o.vec + feat_of(h, s)];
     }
 
     const long long rows = a.rs.rows;
@@ -771,11 +773,11 @@ __global__ void __launch_bounds__(64 * NW) mlp_fwd3_kernel(FwdArgs a) {
         }
     };
     auto init_acc = [&](int l) {
-        if (BIAS_REGS) {
+        if (BIAS_REGS && l == 0) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int v = 0; v < 16; ++v) acc[t][v] = biasr[BIAS_REGS ? l : 0][16 * t + v];
+                for (int v = 0; v < 16; ++v) acc[t][v] = biasr[16 * t + v];
         } else {        // slots 16 t + 4 q .. + 3 are features 32 t + 8 q + 4 h .. + 3: eight 16-byte reads
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -853,7 +855,6 @@ __global__ void __launch_bounds__(64 * NW) mlp_fwd3_kernel(FwdArgs a) {
                 layer_tail_nhat<false, ACT>(acc, n.eps, nh, nullptr, lane, mean, rstd);
             }
         }
-        init_acc(0);        // (the next tile's first-layer accumulators; acc is free from here on unless the head uses it)
         const long long yrow = row < rows ? row : rows - 1;
         if (out == 0) {
             // trunk only (features for the GRU): the LayerNorm's affine half applied here
@@ -903,6 +904,7 @@ __global__ void __launch_bounds__(64 * NW) mlp_fwd3_kernel(FwdArgs a) {
                 if (oo < out) a.y[yrow * out + oo] = ah[v] + lds[o.bh + oo];
             }
         }
+        init_acc(0);        // the next tile's first-layer accumulators
         if (cstamp && m_done < 15) a.dbg[64 * (wave >> 2) + 4 * m_done + 2] = prim::clock();
     }
 }
@@ -2257,7 +2259,6 @@ inline int forward(const mappo_mlp_t* m, hipStream_t stream) {
             MAPPO_LAUNCH((mlp_fwd3_kernel<LL, AA, 12>), (unsigned)grid3, 64 * 12, (size_t)o3.total * 4, stream, a); \
         }                                                                                                           \
     }
-        MAPPO_FWD3_CASE(1, 0) MAPPO_FWD3_CASE(1, 1) MAPPO_FWD3_CASE(1, 2)
         MAPPO_FWD3_CASE(2, 0) MAPPO_FWD3_CASE(2, 1) MAPPO_FWD3_CASE(2, 2)
         MAPPO_FWD3_CASE(3, 0) MAPPO_FWD3_CASE(3, 1) MAPPO_FWD3_CASE(3, 2)
 #undef MAPPO_FWD3_CASE

@@ -124,6 +124,7 @@ SIGNATURES = {
     "mappo_adam_workspace_floats": (_i64, []),
     "mappo_clip_adam": (_int, [ctypes.POINTER(Adam), _vp]),
     "mappo_ppo_loss_f32": (_int, [ctypes.POINTER(PPOLoss), _vp]),
+    "mappo_categorical_sample": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _vp]),
     "mappo_minibatch_workspace_ints": (_i64, [_i64, _int]),
     "mappo_minibatch_indices": (_int, [_i64, _i64, _int, _vp, _vp, _vp, _vp]),
     "mappo_mlp_forward": (_int, [ctypes.POINTER(MLP), _vp]),

@@ -59,6 +59,8 @@ class ACTLayer(nn.Module):
             if self.mixed_action:
                 log_probs = log_probs.sum(-1, keepdim=True)
             return actions, log_probs
+        if self.action_type == "Discrete" and not deterministic and not torch.is_grad_enabled() and x.is_cuda:
+            return self.from_logits(self.action_out.linear(x), available_actions, deterministic)
         dist = self._single(x, available_actions)
         actions = dist.mode() if deterministic else dist.sample()
         return actions, dist.log_probs(actions)
@@ -68,6 +70,9 @@ class ACTLayer(nn.Module):
         sampling and log-probabilities as ``Categorical.forward`` + ``forward`` do them (reference act.py:44-60,
         distributions.py:55-68)."""
         assert self.action_type == "Discrete"
+        from . import fused_loss
+        if not deterministic and fused_loss.sample_supported(logits):
+            return fused_loss.sample_categorical(logits, available_actions)      # K14: masking + sample + log-prob
         if available_actions is not None:
             logits = torch.where(available_actions == 0, torch.full_like(logits, -1e10), logits)
         dist = FixedCategorical(logits=logits)

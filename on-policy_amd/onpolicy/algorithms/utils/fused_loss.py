@@ -50,3 +50,28 @@ def ppo_loss(logits, available_actions, actions, old_logp, adv, active, factor, 
                         | (_native.LOSS_VALUE_ACTIVE_MASKS if value_active_masks else 0))
     _native.check(_native.lib().mappo_ppo_loss_f32(a, _native.stream_of(lg.device)), "mappo_ppo_loss_f32")
     return dlogits, dvalues.view_as(values)
+
+
+def sample_supported(logits):
+    """K14 takes this head's rollout sampling: float32 HIP logits of <= 64 actions, device-sampling mode, no autograd."""
+    from . import distributions
+    return (os.environ.get("MAPPO_FUSED_SAMPLE", "1") != "0" and torch.is_tensor(logits) and logits.is_cuda
+            and logits.dtype == torch.float32 and logits.dim() == 2 and 0 < logits.shape[1] <= 64
+            and not torch.is_grad_enabled() and distributions.SAMPLING_RNG == "device")
+
+
+def sample_categorical(logits, available_actions=None):
+    """(actions [rows, 1] int64, log-probs [rows, 1]) of one draw per row from softmax(masked logits)
+    (``mappo_categorical_sample``, K14): what ``Categorical.forward`` -> ``FixedCategorical.sample`` / ``log_probs`` give
+    (reference distributions.py:14-28, :55-68) as two launches -- the Exponential(1) noise from torch's generator and the
+    kernel -- instead of ~15."""
+    rows, na = logits.shape
+    lg = logits.detach().contiguous()
+    avail = None if available_actions is None else available_actions.detach().to(torch.float32).contiguous()
+    noise = torch.empty_like(lg).exponential_(1.0)
+    actions = torch.empty((rows, 1), dtype=torch.int64, device=lg.device)
+    logp = torch.empty((rows, 1), dtype=torch.float32, device=lg.device)
+    p = _native.ptr
+    _native.check(_native.lib().mappo_categorical_sample(p(lg), p(avail), p(noise), p(actions), p(logp), rows, na,
+                                                         _native.stream_of(lg.device)), "mappo_categorical_sample")
+    return actions, logp

@@ -166,7 +166,8 @@ class TorchSimpleSpread(object):
 
     def _uniform(self, *shape):
         torch = self._torch
-        return torch.rand(*shape, generator=self.rng, dtype=torch.float64, device=self.device) * 2 - 1
+        # U(-1, 1) in one launch: uniform_ evaluates rand * (to - from) + from on the same draws as torch.rand
+        return torch.empty(*shape, dtype=torch.float64, device=self.device).uniform_(-1.0, 1.0, generator=self.rng)
 
     def _reset_worlds(self, which):
         """Branch-free (no host sync): fresh positions are drawn for every world and kept where ``which`` is set."""

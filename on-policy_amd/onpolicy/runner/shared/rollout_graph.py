@@ -40,6 +40,7 @@ class RolloutGraph(object):
             self.cur_rnn_c = torch.empty(b.rnn_states_critic.shape[1:], **f32)
         else:       # feed-forward policies: the buffer's zero view serves every step
             self.cur_rnn_a, self.cur_rnn_c = b.rnn_states[0], b.rnn_states_critic[0]
+        self.side = torch.cuda.Stream(device=dev)      # the critic's branch of the captured step
         self.graph = None
         self.out = None
         self.infos = None
@@ -49,18 +50,26 @@ class RolloutGraph(object):
     @torch.no_grad()
     def _body(self):
         r, N, A = self.r, self.N, self.A
+        policy = r.trainer.policy
+        dev = r.buffer.device
         share = r._share(self.cur_obs, N)
-        values, actions, logp, rnn_a, rnn_c = r.trainer.policy.get_actions(
-            r._rows(share), r._rows(self.cur_obs), r._rows(self.cur_rnn_a), r._rows(self.cur_rnn_c),
-            r._rows(self.cur_masks))
-        values, actions, logp = r._per_env(values), r._per_env(actions), r._per_env(logp)
-        rnn_a, rnn_c = r._per_env(rnn_a), r._per_env(rnn_c)
+        # The critic's branch (centralised observation -> value) depends on nothing the actor's branch produces, and a
+        # forward launch on N * A rows fills a third of the CUs: it is recorded on a side stream, i.e. as a parallel
+        # branch of the graph, and runs under the actor forward / sampling / env step of the main branch.
+        main = torch.cuda.current_stream(dev)
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            values, rnn_c = policy.critic(r._rows(share), r._rows(self.cur_rnn_c), r._rows(self.cur_masks))
+            values, rnn_c = r._per_env(values), r._per_env(rnn_c)
+        actions, logp, rnn_a = policy.actor(r._rows(self.cur_obs), r._rows(self.cur_rnn_a), r._rows(self.cur_masks))
+        actions, logp, rnn_a = r._per_env(actions), r._per_env(logp), r._per_env(rnn_a)
         obs, rewards, dones, infos = r.envs.step(actions)
-        alive = (~dones).to(torch.float32)
-        masks = alive.unsqueeze(-1)
-        # finished agents restart from a zero RNN state (reference mpe_runner.py:128-129)
-        rnn_a = rnn_a * alive.view(N, A, 1, 1)
-        rnn_c = rnn_c * alive.view(N, A, 1, 1)
+        masks = torch.where(dones, 0.0, 1.0).unsqueeze(-1)          # 0 where the episode ended (one launch)
+        main.wait_stream(self.side)
+        if self.recurrent:
+            # finished agents restart from a zero RNN state (reference mpe_runner.py:128-129)
+            rnn_a = rnn_a * masks.view(N, A, 1, 1)
+            rnn_c = rnn_c * masks.view(N, A, 1, 1)
         # the carried state of the next step
         self.cur_obs.copy_(obs)
         self.cur_masks.copy_(masks)

@@ -134,3 +134,43 @@ def test_trainer_fused_equals_unfused(monkeypatch, recurrent):
     for p, q in zip(a1 + c1, a0 + c0):
         np.testing.assert_allclose(p.cpu().numpy(), q.cpu().numpy(), rtol=1e-4, atol=2e-5)
     assert torch.allclose(n1, n0, rtol=1e-6, atol=1e-10)
+
+
+@pytest.mark.parametrize("na,with_avail", [(5, False), (5, True), (18, True), (48, True), (1, False)])
+def test_categorical_sample_kernel_vs_the_framework_rule(na, with_avail):
+    """K14 (``mappo_categorical_sample``): masking + one draw per row + its log-probability in one launch, against the
+    framework formulas on the SAME Exponential(1) noise (torch.multinomial's rule for one sample: argmax p / q; reference
+    distributions.py:14-28, :55-68).  Actions identical, log-probs to float32 rounding; the empirical action frequencies of
+    many draws match the probabilities."""
+    from onpolicy.algorithms.utils import fused_loss
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(na)
+    rows = 4099
+    logits = torch.randn(rows, na, device=dev, generator=g) * 2.0
+    avail = None
+    if with_avail:
+        avail = (torch.rand(rows, na, device=dev, generator=g) < 0.7).float()
+        avail[:, 0] = 1.0
+    with torch.no_grad():
+        assert fused_loss.sample_supported(logits)
+        torch.manual_seed(123)
+        actions, logp = fused_loss.sample_categorical(logits, avail)
+        torch.manual_seed(123)
+        noise = torch.empty_like(logits).exponential_(1.0)
+    x = logits if avail is None else torch.where(avail == 0, torch.full_like(logits, -1e10), logits)
+    ref_l = x - x.logsumexp(-1, keepdim=True)
+    ref_a = (ref_l.exp() / noise).argmax(-1, keepdim=True)
+    assert actions.shape == (rows, 1) and actions.dtype == torch.int64 and logp.shape == (rows, 1)
+    same = (actions == ref_a)
+    # (a near-tie of p / q can flip under expf's last bit: allow a handful, and require equal probabilities there)
+    assert same.float().mean() > 0.999
+    torch.testing.assert_close(logp[same.squeeze(-1)], ref_l.gather(-1, ref_a)[same.squeeze(-1)], rtol=1e-5, atol=1e-6)
+    if avail is not None:
+        assert bool((avail.gather(-1, actions) == 1).all())             # never an unavailable action
+    # frequencies: one row's distribution sampled 20 000 times
+    if na > 1:
+        row = logits[:1].expand(20000, na).contiguous()
+        with torch.no_grad():
+            a, _ = fused_loss.sample_categorical(row, None)
+        freq = torch.bincount(a.reshape(-1), minlength=na).float() / 20000
+        torch.testing.assert_close(freq, torch.softmax(logits[0], -1), rtol=0, atol=0.015)

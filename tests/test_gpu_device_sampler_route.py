@@ -179,3 +179,43 @@ def test_an_edited_whole_batch_tensor_is_gathered_again():
 def _vn(dev):
     from onpolicy.utils.valuenorm import ValueNorm
     return ValueNorm(1, device=dev)
+
+
+@pytest.mark.parametrize("cname", ["h64_ns", "h64_gru"])
+def test_rollout_forward_on_the_device_route_vs_reference(gold, cname):
+    """``get_actions`` the way the rollout calls it in device mode (plain [N * A, dim] tensors, no autograd): trunk + head
+    through K9 (``fused_mlp.rollout_rows``), sampling + log-prob through K14.  The values do not depend on the draw and
+    must be the reference's (``act_values`` of the fixture); the log-probabilities must be those the reference-pinned
+    ``evaluate_actions`` assigns to the sampled actions; sampled actions must be available ones."""
+    from onpolicy.algorithms.utils import distributions, fused_mlp
+    dev = torch.device("cuda", 0)
+    z, key, meta, spec, policy, trainer, buf = _setup(gold, "trainer_h64_cases", cname, dev)
+    B = spec["N"] * spec["A"]
+    trainer.prep_rollout()
+    flat = lambda name: getattr(buf, name)[0].reshape(B, *getattr(buf, name).shape[3:]).contiguous()
+    mode = distributions.SAMPLING_RNG
+    distributions.set_sampling_rng("device")        # (a runner sets this from --sampler_rng; no runner here)
+    fused_mlp.profile(True)
+    try:
+        with torch.no_grad():
+            torch.manual_seed(7)
+            values, actions, logp, h_a, h_c = policy.get_actions(
+                flat("share_obs"), flat("obs"), flat("rnn_states"), flat("rnn_states_critic"), flat("masks"),
+                flat("available_actions"))
+        torch.cuda.synchronize()
+        n_fwd, _ = _launches()
+    finally:
+        fused_mlp.profile(False)
+        distributions.set_sampling_rng(mode)
+    assert n_fwd == 2, n_fwd                                    # actor and critic trunks both went through K9
+    np.testing.assert_allclose(values.cpu().numpy(), z[key + "act_values"], rtol=1e-4, atol=2e-5)
+    if cname == "h64_gru":
+        np.testing.assert_allclose(h_c.cpu().numpy(), z[key + "act_h_critic"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(h_a.cpu().numpy(), z[key + "act_h_actor"], rtol=1e-4, atol=2e-5)
+    assert actions.dtype == torch.int64 and tuple(actions.shape) == (B, 1)
+    assert bool((flat("available_actions").gather(-1, actions) == 1).all())
+    with torch.no_grad():
+        _, ev_logp, _ = policy.evaluate_actions(flat("share_obs"), flat("obs"), flat("rnn_states"),
+                                                flat("rnn_states_critic"), actions.float(), flat("masks"),
+                                                flat("available_actions"), flat("active_masks"))
+    torch.testing.assert_close(logp, ev_logp, rtol=1e-4, atol=2e-5)

@@ -142,8 +142,9 @@ def test_categorical_sample_kernel_vs_the_framework_rule(na, with_avail):
     framework formulas on the SAME Exponential(1) noise (torch.multinomial's rule for one sample: argmax p / q; reference
     distributions.py:14-28, :55-68).  Actions identical, log-probs to float32 rounding; the empirical action frequencies of
     many draws match the probabilities."""
-    from onpolicy.algorithms.utils import fused_loss
+    from onpolicy.algorithms.utils import distributions, fused_loss
     dev = torch.device("cuda", 0)
+    distributions.set_sampling_rng("device")
     g = torch.Generator(device=dev).manual_seed(na)
     rows = 4099
     logits = torch.randn(rows, na, device=dev, generator=g) * 2.0

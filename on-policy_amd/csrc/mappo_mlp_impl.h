@@ -143,16 +143,26 @@ __device__ __forceinline__ v4 load4_guard(const float* p, int remaining) {
     return r;
 }
 
-// tanh in ~12 instructions (the library tanhf was 60 % of the forward kernel's time: 64 calls per row).  |x| >= 0.25:
-// 1 - 2 / (exp(2|x|) + 1) on the hardware exp2 / rcp (1 ulp each; absolute error ~1e-7, saturates to 1 for large |x|);
-// |x| < 0.25, where that form cancels: the odd Taylor polynomial up to x^7 (truncation < 1e-7 relative).  The backward
-// differentiates through the activation OUTPUT (1 - a^2) of this same function.
+// tanh on the hardware exp2 / rcp (the library tanhf was 60 % of the forward kernel's time: 64 calls per row).
+// Round 4: tanh(x) = sign(x) (1 - e) / (1 + e) with e = exp(-2 |x|) in (0, 1] -- 7 instructions, two of them transcendental.
+// Absolute error <= ~1.5e-7 everywhere (1 ulp of exp2 and of rcp on values <= 1, one rounding of 1 - e); for |x| << 1 the
+// RELATIVE error grows like 6e-8 / |x| (1 - e cancels) -- harmless here: the activation feeds a LayerNorm, which subtracts a
+// mean and scales by O(1), so only absolute errors propagate, and the backward differentiates through the activation OUTPUT
+// (1 - a^2).  The counters of round 4 show VALU and MFMA cycles of a SIMD adding up (the matrix pipe's busy share is
+// MFMA / (MFMA + VALU) to within 10 % for the MFMA-heavy critic AND the VALU-heavy actor), so every instruction of the 128 tanh
+// per row is paid for in full.  MAPPO_TANH_POLY keeps rounds 2-3's form: 1 - 2 / (exp(2|x|) + 1) above 0.25 and the odd Taylor
+// polynomial up to x^7 below, selected per element (16 instructions; 4e-7 relative everywhere).
 __device__ __forceinline__ float fast_tanh(float x) {
+#ifdef MAPPO_TANH_POLY
     const float ax = fabsf(x), x2 = x * x;
     const float e = prim::exp2_fast(ax * 2.8853900817779268f);
     const float big = 1.f - 2.f * prim::rcp_fast(e + 1.f);
     const float small = ax * (1.f + x2 * (-0.33333333333f + x2 * (0.13333333333f + x2 * -0.05396825397f)));
     return copysignf(ax < 0.25f ? small : big, x);
+#else
+    const float e = prim::exp2_fast(fabsf(x) * -2.8853900817779268f);
+    return copysignf((1.f - e) * prim::rcp_fast(1.f + e), x);
+#endif
 }
 // The activation is a template parameter of the kernels: a run-time switch inside the unrolled per-feature loops costs
 // several scalar branches per element (measured: 13 k of a tile's 20 k epilogue cycles).

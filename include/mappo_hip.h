@@ -568,7 +568,8 @@ int     mappo_mlp_set_debug(long long* buf);
  * returns the previous value.  1 = the forward's compute waves keep the default priority; 4 = mappo_mlp_forward keeps the
  * loader / compute kernel (mlp_fwd_kernel) for shapes the version-3 kernel (operands straight from global memory, resident
  * first-layer weights; aligned rows 129 .. 448 floats wide) would take; 8 = the 12-wave form of version 3 (three waves per
- * SIMD); 16 = version 3 also for narrower aligned rows (tests). */
+ * SIMD); 16 = version 3 also for narrower aligned rows (tests); 32 = the two-slot form of the direct-to-LDS first-layer
+ * weight-gradient kernel, two workgroups per CU (tuning). */
 int     mappo_mlp_set_flags(int flags);
 int     mappo_mlp_forward(const mappo_mlp_t* net, mappo_stream_t stream);
 int     mappo_mlp_backward(const mappo_mlp_t* net, mappo_stream_t stream);

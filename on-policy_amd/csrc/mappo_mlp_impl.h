@@ -1771,7 +1771,8 @@ constexpr int kD2RowsMaxWidth = 192;             // up to six k tiles: every wav
 // few k tiles whose workgroups idled most of the launch (SMAC's 436-wide critic input: 49 instead of 100 TFLOP/s).
 constexpr int d2_xslot(int maxnt) { return maxnt * kD2Rows * 32; }        // floats: [k tile i < MAXNT][16 rows][32]
 constexpr int kD2DzSlot = kD2Rows * 64;          // floats: [16 rows][64 features], shared by the 4 waves
-constexpr int d2_lds(int maxnt) { return 4 * kD2Slots * d2_xslot(maxnt) + kD2Slots * kD2DzSlot; }   // floats, + the row-table rings:
+constexpr int d2_lds_slots(int maxnt, int slots) { return 4 * slots * d2_xslot(maxnt) + slots * kD2DzSlot; }
+constexpr int d2_lds(int maxnt) { return d2_lds_slots(maxnt, kD2Slots); }   // floats, + the row-table rings:
 constexpr int kD2TabRing = 2 * kD2Slots;         // 256-byte slots per wave
 inline int d2_maxnt(int din) { return (din + 511) / 512 < (din + 383) / 384 ? 4 : 3; }
 
@@ -1806,9 +1807,12 @@ __device__ __forceinline__ void dw1_tile_steps(const float* xt, const float* dzt
 }
 
 // the whole kernel for a wave that owns NT (0 .. MAXNT) k tiles: tiles wave, wave + 4, wave + 8 (, wave + 12) of the slab
-template <int NT, int MAXNT>
+template <int NT, int MAXNT, int SLOTS>
 __device__ __forceinline__ void dw1_direct_body(const Dw1Args& a, float* lds, int wave, int k0) {
-    constexpr int kD2XSlot = d2_xslot(MAXNT), kD2Lds = d2_lds(MAXNT);
+    // SLOTS = 4: one workgroup per CU, the loads of tile m + 3 in flight; SLOTS = 2: half the LDS, two workgroups per CU
+    // (two waves per SIMD), the loads of tile m + 1 in flight -- the other workgroup's MFMA stream covers the wait
+    constexpr int kD2Slots = SLOTS, kD2TabRing = 2 * SLOTS;
+    constexpr int kD2XSlot = d2_xslot(MAXNT), kD2Lds = d2_lds_slots(MAXNT, SLOTS);
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, h = lane >> 5;
     const int din = a.rs.din;
     const long long rows = a.rs.rows;
@@ -1894,7 +1898,7 @@ __device__ __forceinline__ void dw1_direct_body(const Dw1Args& a, float* lds, in
     }
 }
 
-template <int MAXNT>
+template <int MAXNT, int SLOTS>
 __global__ void __launch_bounds__(kThreads) mlp_dw1_direct_kernel(Dw1Args a) {
     float* lds = prim::lds();
     const int wave = prim::uniform(threadIdx.x >> 6);
@@ -1904,11 +1908,11 @@ __global__ void __launch_bounds__(kThreads) mlp_dw1_direct_kernel(Dw1Args a) {
     const int kw = (din - k0 < slab ? ((din - k0 + 31) / 32) * 32 : slab);
     const int ntk = kw / 32;
     const int n_own = (wave < ntk) + (wave + 4 < ntk) + (wave + 8 < ntk) + (MAXNT > 3 && wave + 12 < ntk);
-    if (MAXNT > 3 && n_own == 4) dw1_direct_body<MAXNT, MAXNT>(a, lds, wave, k0);
-    else if (n_own == 3) dw1_direct_body<3, MAXNT>(a, lds, wave, k0);
-    else if (n_own == 2) dw1_direct_body<2, MAXNT>(a, lds, wave, k0);
-    else if (n_own == 1) dw1_direct_body<1, MAXNT>(a, lds, wave, k0);
-    else dw1_direct_body<0, MAXNT>(a, lds, wave, k0);
+    if (MAXNT > 3 && n_own == 4) dw1_direct_body<MAXNT, MAXNT, SLOTS>(a, lds, wave, k0);
+    else if (n_own == 3) dw1_direct_body<3, MAXNT, SLOTS>(a, lds, wave, k0);
+    else if (n_own == 2) dw1_direct_body<2, MAXNT, SLOTS>(a, lds, wave, k0);
+    else if (n_own == 1) dw1_direct_body<1, MAXNT, SLOTS>(a, lds, wave, k0);
+    else dw1_direct_body<0, MAXNT, SLOTS>(a, lds, wave, k0);
 }
 
 // ---- narrow inputs (din <= 192, din % 4 == 0): up to six k tiles do not split evenly among four waves (five tiles: one wave
@@ -2291,7 +2295,8 @@ inline long long chain_floats(int n_layers, int out) {
 }
 inline long long workspace_floats(int din, int n_layers, int out) {
     // chain partials (one row per workgroup) | reduced raw sums | (16-byte boundary) first-layer partials | ticket word
-    return chain_floats(n_layers, out) + (long long)kD2GridCap * 64LL * din + 4;
+    // (2 x kD2GridCap partial rows: the two-workgroups-per-CU form of the direct weight-gradient kernel)
+    return chain_floats(n_layers, out) + 2LL * kD2GridCap * 64LL * din + 4;
 }
 
 inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
@@ -2357,12 +2362,18 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
         else MAPPO_DW1_ROWS(6, 2)
 #undef MAPPO_DW1_ROWS
     } else if (direct) {
-        gx = capped(ceil_div(m->rows, kD2Rows), kD2GridCap / gy > 0 ? kD2GridCap / gy : 1);
         if (maxnt == 4) {
-            MAPPO_LAUNCH(mlp_dw1_direct_kernel<4>, dim3((unsigned)gx, (unsigned)gy), kThreads,
+            gx = capped(ceil_div(m->rows, kD2Rows), kD2GridCap / gy > 0 ? kD2GridCap / gy : 1);
+            MAPPO_LAUNCH((mlp_dw1_direct_kernel<4, 4>), dim3((unsigned)gx, (unsigned)gy), kThreads,
                          (size_t)(d2_lds(4) + 4 * kD2TabRing * 64) * 4, stream, d);
+        } else if (tuning_flags() & 32) {
+            // tuning: two slots per wave, two workgroups per CU (61 KB of LDS each)
+            gx = capped(ceil_div(m->rows, kD2Rows), 2 * kD2GridCap / gy > 0 ? 2 * kD2GridCap / gy : 1);
+            MAPPO_LAUNCH((mlp_dw1_direct_kernel<3, 2>), dim3((unsigned)gx, (unsigned)gy), kThreads,
+                         (size_t)(d2_lds_slots(3, 2) + 4 * 4 * 64) * 4, stream, d);
         } else {
-            MAPPO_LAUNCH(mlp_dw1_direct_kernel<3>, dim3((unsigned)gx, (unsigned)gy), kThreads,
+            gx = capped(ceil_div(m->rows, kD2Rows), kD2GridCap / gy > 0 ? kD2GridCap / gy : 1);
+            MAPPO_LAUNCH((mlp_dw1_direct_kernel<3, 4>), dim3((unsigned)gx, (unsigned)gy), kThreads,
                          (size_t)(d2_lds(3) + 4 * kD2TabRing * 64) * 4, stream, d);
         }
     } else {

@@ -24,6 +24,7 @@ if [[ $STAGE == all || $STAGE == bench ]]; then
   for w in cfg3 cfg2 ns_rnn smac; do
     timeout 300 python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_$w.json
   done
+  timeout 500 python bench.py --workload hanabi --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_hanabi.json
   timeout 600 python tools/cfg3_end_to_end.py --out $OUT/cfg3_end_to_end.json > $OUT/cfg3_end_to_end.log 2>&1
   tail -1 $OUT/cfg3_end_to_end.log | cut -c1-400
 fi

@@ -189,7 +189,8 @@ def rollout_rows(x, base):
         return x
     x = x.contiguous()
     if base._use_feature_normalization:
-        if x.shape[1] > 2048:
+        w = int(x.shape[1])
+        if not ((w % 4 == 0 and w <= 2048) or w <= 1536):       # widths the standardising kernel has shapes for
             return x
         return RowSource.all_rows(standardize_rows(x), standardized=True, width=int(x.shape[1]))
     return RowSource.all_rows(x, standardized=False)

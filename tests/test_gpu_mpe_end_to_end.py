@@ -136,3 +136,39 @@ def test_simple_spread_step_kernel_equals_tensor_ops(agents, landmarks):
             torch.testing.assert_close(getattr(a, name), getattr(b, name), rtol=1e-12, atol=1e-12)
         assert torch.equal(a.t, b.t)
     assert bool(ra[2].any()) or True
+
+
+def test_two_rank_train_mpe_on_device_worlds(tmp_path):
+    """The train script as a data-parallel job: two ranks under torch.distributed.run (both on GPU 0, gloo collectives -- RCCL
+    refuses duplicate devices), each with half of the rollout threads on device-resident worlds: per rank a captured rollout
+    graph, the rollout forward through K9, sampling through K14, and per update one gradient all-reduce + the cached scalar
+    prologue.  Both ranks must finish with identical replicas and finite logs."""
+    import glob
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ)
+    env.update(MAPPO_DIST_BACKEND="gloo", MAPPO_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               MAPPO_RESULTS_DIR=str(tmp_path / "results"),
+               PYTHONPATH=os.path.join(ROOT, "on-policy_amd") + os.pathsep + env.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29633", "-m", "onpolicy.scripts.train.train_mpe",
+           "--env_name", "MPE", "--scenario_name", "simple_spread", "--num_agents", "3", "--num_landmarks", "3",
+           "--algorithm_name", "mappo", "--n_rollout_threads", "64", "--episode_length", "10", "--num_env_steps",
+           str(3 * 64 * 10), "--ppo_epoch", "3", "--num_mini_batch", "1", "--hidden_size", "64", "--use_ReLU", "--use_wandb",
+           "--log_interval", "1", "--n_training_threads", "1", "--use_device_env"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "capture failed" not in out.stdout, out.stdout[-2000:]
+    actors = sorted(glob.glob(str(tmp_path / "results" / "**" / "actor.pt"), recursive=True))
+    assert len(actors) == 2, actors
+    a, b = (torch.load(p, map_location="cpu") for p in actors)
+    assert a.keys() == b.keys()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k                       # replicas stay identical
+    logs = sorted(glob.glob(str(tmp_path / "results" / "**" / "scalars.jsonl"), recursive=True))
+    assert len(logs) == 2
+    for path in logs:
+        recs = [json.loads(l) for l in open(path)]
+        vl = [r["value_loss"] for r in recs if r["tag"] == "value_loss"]
+        assert len(vl) == 3 and all(np.isfinite(vl))

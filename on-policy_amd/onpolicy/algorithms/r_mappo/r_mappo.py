@@ -399,14 +399,10 @@ class R_MAPPO():
         if mode == "0" or not update_actor or torch.device(self.device).type != "cuda" or \
                 "concurrent" not in getattr(self.policy.evaluate_logits, "__code__", type("c", (), {"co_varnames": ()})).co_varnames:
             return {}
-        if mode == "1":
-            return {"concurrent": True}
-        # Recurrent minibatches only: their GRU launches are long (a wave walks L steps) and few-waved.  Feed-forward
-        # minibatches this small are bound by the host's launch rate, and a second stream only adds to that (measured: a
-        # 32-thread shard of config 2 20 against 11 ms per step).
-        recurrent = self._use_recurrent_policy and rnn_states is not None and torch.is_tensor(rnn_states) \
-            and rnn_states.shape[0] != rows
-        if recurrent and rnn_states.shape[0] < 32 * self._CONCURRENT_BELOW_TILES:
+        units = rows
+        if self._use_recurrent_policy and rnn_states is not None and torch.is_tensor(rnn_states) and rnn_states.shape[0] != rows:
+            units = rnn_states.shape[0]
+        if mode == "1" or units < 32 * self._CONCURRENT_BELOW_TILES:
             return {"concurrent": True}
         return {}
 

@@ -62,26 +62,8 @@ class R_MAPPOPolicy:
         return values, action_log_probs, dist_entropy
 
     def evaluate_logits(self, cent_obs, obs, rnn_states_actor, rnn_states_critic, masks, obs_standardized=False,
-                        need_actor=True, concurrent=False):
-        """-> (values, logits of the Discrete action head or None): the inputs of the fused PPO loss.
-
-        ``concurrent``: actor and critic are independent networks; when a minibatch is too small for one network's launches
-        to fill the chip (a 64-thread SMAC shard: 400 waves per GRU launch for 1024 SIMDs) the critic's forward is issued
-        on a side stream and runs beside the actor's.  Autograd runs every backward node on the stream of its forward, so
-        the two backward chains overlap the same way, and ``backward()`` joins the streams before it returns.  Same
-        kernels, same arithmetic, same results -- only the order in which two independent launch sequences reach the GPU."""
-        dev = torch.device(self.device)
-        if concurrent and need_actor and dev.type == "cuda":
-            main = torch.cuda.current_stream(dev)
-            side = getattr(self, "_side_stream", None)
-            if side is None:
-                side = self._side_stream = torch.cuda.Stream(device=dev)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                values = self.critic(cent_obs, rnn_states_critic, masks, obs_standardized=obs_standardized)[0]
-            logits = self.actor.evaluate_logits(obs, rnn_states_actor, masks, obs_standardized=obs_standardized)
-            main.wait_stream(side)
-            return values, logits
+                        need_actor=True):
+        """-> (values, logits of the Discrete action head or None): the inputs of the fused PPO loss."""
         logits = self.actor.evaluate_logits(obs, rnn_states_actor, masks, obs_standardized=obs_standardized) \
             if need_actor else None
         values = self.critic(cent_obs, rnn_states_critic, masks, obs_standardized=obs_standardized)[0]

@@ -368,7 +368,7 @@ class R_MAPPO():
         for lo, hi in spans:
             values, logits = self.policy.evaluate_logits(
                 cut(share_obs, lo, hi), cut(obs, lo, hi), cut(rnn_a, lo, hi), cut(rnn_c, lo, hi), cut(masks, lo, hi),
-                **self._eval_kwargs(), **self._concurrency(rows, rnn_a, update_actor))
+                **self._eval_kwargs())
             feed_normalizer()           # reference order: forward, normaliser update, loss (r_mappo.py:120-66)
             norm = self.value_normalizer.denorm_scalars().to(**f32).contiguous() if normalized else None
             dlogits, dvalues = fused_loss.ppo_loss(
@@ -386,25 +386,6 @@ class R_MAPPO():
         # sums = [policy loss, entropy, value loss, ratio] numerators -> local means, one launch
         means = sums.float() * scale4
         return means[2], means[0], means[1], means[3]
-
-    # Launches of one network on fewer than this many 32-row (32-chunk) wave tiles leave SIMDs idle: 1024 SIMDs, two tiles
-    # each.  MAPPO_CONCURRENT_NETS = 1 / 0 forces the two networks' launch sequences onto two streams / one.
-    _CONCURRENT_BELOW_TILES = 2048
-
-    def _concurrency(self, rows, rnn_states, update_actor):
-        """{"concurrent": True} when this minibatch's actor and critic launches should share the GPU (see
-        R_MAPPOPolicy.evaluate_logits): recurrent minibatches by their chunk count (a GRU launch has one wave per 32
-        chunks), feed-forward ones by their row count."""
-        mode = os.environ.get("MAPPO_CONCURRENT_NETS", "auto")
-        if mode == "0" or not update_actor or torch.device(self.device).type != "cuda" or \
-                "concurrent" not in getattr(self.policy.evaluate_logits, "__code__", type("c", (), {"co_varnames": ()})).co_varnames:
-            return {}
-        units = rows
-        if self._use_recurrent_policy and rnn_states is not None and torch.is_tensor(rnn_states) and rnn_states.shape[0] != rows:
-            units = rnn_states.shape[0]
-        if mode == "1" or units < 32 * self._CONCURRENT_BELOW_TILES:
-            return {"concurrent": True}
-        return {}
 
     def _fused_trunks(self, fold):
         """Both networks' trunks qualify for the fused kernels (K9) and expect the kind of rows the sampler would hand

@@ -200,9 +200,18 @@ extern "C" int mappo_ppo_loss_f32(const mappo_ppo_loss_t* args, mappo_stream_t s
     if (blocks > mappo::kCUs * 8) blocks = mappo::kCUs * 8;
     const bool avail = a.logits && a.available;
     const size_t lds = a.logits ? (size_t)(avail ? 2 : 1) * 256 * (a.n_actions | 1) * sizeof(float) : 0;
-    const bool staged = a.logits && lds <= 48 * 1024;
+    // Staged through LDS up to 150 KB (gfx950: 160 KB per CU; above 64 KB the kernel has to be granted it): Hanabi's 48
+    // actions need 100 KB for the two [256, 49] tiles.  Unstaged, a thread walks its own 192-byte row and the launch ran at
+    // 80 GB/s (4.9 ms per 683 k-row span, 6.5 % of the Hanabi-shaped step, profiles/r02_bench_hanabi_kernel_stats.csv).
+    const bool staged = a.logits && lds <= 150 * 1024;
     dim3 grid((unsigned)blocks), block(256);
     if (staged) {
+        if (lds > 48 * 1024) {
+            const void* fn = avail ? reinterpret_cast<const void*>(&ppo_loss_kernel<true, true>)
+                                   : reinterpret_cast<const void*>(&ppo_loss_kernel<false, true>);
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
         if (avail) hipLaunchKernelGGL((ppo_loss_kernel<true, true>), grid, block, lds, stream, a);
         else hipLaunchKernelGGL((ppo_loss_kernel<false, true>), grid, block, lds, stream, a);
     } else {

@@ -46,8 +46,10 @@ def _torch_loss(logits, avail, actions, old_logp, adv, active, factor, values, v
 
 
 @pytest.mark.parametrize("na,with_avail,with_factor,with_norm", [(5, False, False, True), (5, True, True, False),
+                                                                   (48, True, False, True), (64, False, False, True), (200, True, False, True),
                                                                   (19, True, False, True), (1, False, False, False),
-                                                                  (38, False, True, True), (40, True, False, True)])   # 40 + mask: too wide for the LDS-staged variant
+                                                                  (38, False, True, True), (40, True, False, True)])
+# (40 / 48 actions + mask: 84 / 100 KB of LDS, granted above 64 KB -- round 4; 200 + mask: wider than the staged variant takes)
 def test_fused_loss_matches_autograd(na, with_avail, with_factor, with_norm):
     from onpolicy.algorithms.utils import fused_loss
     R = 10007

@@ -82,6 +82,7 @@ __device__ __forceinline__ float rs_step<1, 0>(float a, float b) {        // qua
 #undef MAPPO_DPP
 __device__ __forceinline__ float exp2_fast(float v) { return __builtin_amdgcn_exp2f(v); }   // v_exp_f32
 __device__ __forceinline__ float rcp_fast(float v) { return __builtin_amdgcn_rcpf(v); }     // v_rcp_f32
+__device__ __forceinline__ float rsq_fast(float v) { return __builtin_amdgcn_rsqf(v); }     // v_rsq_f32 (1 ulp)
 // scheduling barrier: the compiler may not move instructions across it (used to keep operand prefetches early)
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 __device__ __forceinline__ void set_priority_high() { __builtin_amdgcn_s_setprio(3); }

@@ -170,6 +170,49 @@ template <int ACT>
 __device__ __forceinline__ float act_fn(float z) {
     return ACT == 1 ? fast_tanh(z) : (ACT == 2 ? fmaxf(z, 0.f) : z);
 }
+// Two elements at a time: gfx950 has packed f32 multiply / add / fma (two lanes' worth of work per issue slot), but left to
+// itself the compiler packs only part of a layer tail (round 4, from the ISA: scalar adds for 1 + e and for both LayerNorm
+// sums, the sum of squares as packed multiplies + 32 scalar adds, an IEEE square root and division per row: ~450 vector
+// instructions per 32-feature tail, ~350 with these forms).  exp2(-|m|) takes its sign handling as source modifiers.
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <int ACT>
+__device__ __forceinline__ f2 act_fn2(f2 z) {
+    if (ACT == 1) {
+#ifdef MAPPO_TANH_POLY
+        return f2{fast_tanh(z[0]), fast_tanh(z[1])};
+#else
+        const f2 m = z * 2.8853900817779268f;
+        const f2 e = {prim::exp2_fast(-fabsf(m[0])), prim::exp2_fast(-fabsf(m[1]))};
+        const f2 num = 1.f - e, den = 1.f + e;
+        const f2 r = {prim::rcp_fast(den[0]), prim::rcp_fast(den[1])};
+        const f2 t = num * r;
+        return f2{copysignf(t[0], z[0]), copysignf(t[1], z[1])};
+#endif
+    }
+    if (ACT == 2) return __builtin_elementwise_max(z, f2{0.f, 0.f});
+    return z;
+}
+// LayerNorm statistics of this lane's row from its 32 activations a[] (the other 32 sit in the partner half-wave): on
+// return a[] holds a - mean.  Two partial sums each (even / odd slots), packed.
+__device__ __forceinline__ void ln_stats32(float* a, float eps, float& mean, float& rstd) {
+    f2 s2 = {0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 32; s += 2) s2 += f2{a[s], a[s + 1]};
+    float sum = s2[0] + s2[1];
+    sum += prim::xhalf(sum);
+    mean = sum * (1.f / 64.f);
+    f2 v2 = {0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 32; s += 2) {
+        const f2 d = f2{a[s], a[s + 1]} - mean;
+        a[s] = d[0];
+        a[s + 1] = d[1];
+        v2 += d * d;
+    }
+    float var = v2[0] + v2[1];
+    var += prim::xhalf(var);
+    rstd = prim::rsq_fast(var * (1.f / 64.f) + eps);
+}
 // derivative from the activation output a (tanh) / the pre-activation z (ReLU)
 template <int ACT>
 __device__ __forceinline__ float act_grad(float z, float a) {
@@ -238,30 +281,39 @@ __device__ __forceinline__ void layer_tail(const f32x16* acc, const float* vec /
                                            float eps, float* hreg, float* ztile /* KEEP: wave-uniform, see load_frag64 */,
                                            int lane, float& mean_out, float& rstd_out) {
     float a[32];
-    float sum = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const v4 b = *reinterpret_cast<const v4*>(vec + 32 * t + 8 * q + 4 * h);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 4; e += 2) {
                 const int s = 16 * t + 4 * q + e;
-                const float z = acc[t][4 * q + e] + b[e];
-                a[s] = act_fn<ACT>(z);
-                sum += a[s];
+                const f2 av = act_fn2<ACT>(f2{acc[t][4 * q + e], acc[t][4 * q + e + 1]} + f2{b[e], b[e + 1]});
+                a[s] = av[0];
+                a[s + 1] = av[1];
             }
         }
-    sum += prim::xhalf(sum);
-    const float mean = sum * (1.f / 64.f);
-    float var = 0.f;
+    float mean, rstd;
+    if (ACT != 1) {
+        // (this kernel runs at 128 registers: the packed form's aligned register pairs cost the ReLU / identity instances a
+        // spill, so they keep one element per instruction here)
+        float sum = 0.f;
 #pragma unroll
-    for (int s = 0; s < 32; ++s) {
-        a[s] -= mean;
-        var += a[s] * a[s];
+        for (int s = 0; s < 32; ++s) sum += a[s];
+        sum += prim::xhalf(sum);
+        mean = sum * (1.f / 64.f);
+        float var = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            a[s] -= mean;
+            var += a[s] * a[s];
+        }
+        var += prim::xhalf(var);
+        rstd = prim::rsq_fast(var * (1.f / 64.f) + eps);
+    } else {
+        ln_stats32(a, eps, mean, rstd);
     }
-    var += prim::xhalf(var);
-    const float rstd = 1.f / sqrtf(var * (1.f / 64.f) + eps);
     mean_out = mean;
     rstd_out = rstd;
 #pragma unroll
@@ -363,7 +415,6 @@ struct FwdArgs {
 // barriers are independent, so the MFMA stream of one runs under the layer tails (VALU, transcendental, store work) of
 // the other.
 typedef int i4 __attribute__((ext_vector_type(4)));
-typedef float f2 __attribute__((ext_vector_type(2)));
 // One chunk in flight in a loader thread's registers + what the buffer's NEXT load needs: the source rows are fetched
 // right after this chunk's loads were issued, i.e. three issues ahead of their use, so that waiting for them never
 // waits for younger data loads (the wait counter is in order).
@@ -499,19 +550,19 @@ __global__ void __launch_bounds__(kFwdThreads, 4) mlp_fwd_kernel(FwdArgs a) {
     if (!(a.flags & 1)) prim::set_priority_high();
     const int wave_u = prim::uniform(wave);
     const bool cstamp = a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+    // (the first-layer accumulators are zeroed before the loop and at the end of every tile's tail: a test on "first chunk
+    // of a tile" inside the loop compiled to 32 conditional moves per chunk)
     f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
     long long ti = 0;
     int kc = 0;
     for (long long j = 0; j < n_it; ++j) {
         if (cstamp && j < 60) a.dbg[4 * j] = prim::clock();
         __syncthreads();
         if (cstamp && j < 60) a.dbg[4 * j + 1] = prim::clock();
-        if (kc == 0) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
-        }
         const float* st = stage0 + (j & 1) * kStage;
         const float* xa = st + (32 * wave + c) * kXS + 16 * h;
         const float* w0 = st + kStageX + c * kXS + 16 * h;
@@ -573,6 +624,10 @@ __global__ void __launch_bounds__(kFwdThreads, 4) mlp_fwd_kernel(FwdArgs a) {
                 a.y[yrow * n.out + oo] = p + lds[o.bh + oo];
             }
         }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
     }
 }
 
@@ -628,24 +683,16 @@ inline bool fwd3_takes(int din, int L, int out, bool any_width) {
 template <bool KEEP, int ACT>
 __device__ __forceinline__ void layer_tail_nhat(const f32x16* acc, float eps, float* reg, float* ztile, int lane,
                                                 float& mean_out, float& rstd_out) {
-    float sum = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            reg[16 * t + v] = act_fn<ACT>(acc[t][v]);
-            sum += reg[16 * t + v];
+        for (int v = 0; v < 16; v += 2) {
+            const f2 av = act_fn2<ACT>(f2{acc[t][v], acc[t][v + 1]});
+            reg[16 * t + v] = av[0];
+            reg[16 * t + v + 1] = av[1];
         }
-    sum += prim::xhalf(sum);
-    const float mean = sum * (1.f / 64.f);
-    float var = 0.f;
-#pragma unroll
-    for (int s = 0; s < 32; ++s) {
-        reg[s] -= mean;
-        var += reg[s] * reg[s];
-    }
-    var += prim::xhalf(var);
-    const float rstd = 1.f / sqrtf(var * (1.f / 64.f) + eps);
+    float mean, rstd;
+    ln_stats32(reg, eps, mean, rstd);
     mean_out = mean;
     rstd_out = rstd;
 #pragma unroll
@@ -734,7 +781,6 @@ __global__ void __launch_bounds__(64 * NW) mlp_fwd3_kernel(FwdArgs a) {
     const long long gw = (long long)blockIdx.x * kF3Waves + wave, nw = (long long)gridDim.x * kF3Waves;
     const long long my_tiles = gw < ntiles ? (ntiles - gw + nw - 1) / nw : 0;
     if (my_tiles == 0) return;
-    const long long n_pos = my_tiles * nch;
     // reader side: float offset of piece P = 4 h + q of feature row c inside a [64][32] weight chunk
     int off[4];
 #pragma unroll
@@ -743,22 +789,34 @@ __global__ void __launch_bounds__(64 * NW) mlp_fwd3_kernel(FwdArgs a) {
         if (m >= my_tiles) m = my_tiles - 1;
         return gw + m * nw;
     };
-    // issue side: position = (local tile, chunk) as counters; the row of the tile being issued and of the one after it
+    // issue side: position = (local tile, chunk) as counters; the row of the tile being issued and of the one after it.
+    // The lane's read pointer xp walks its row one chunk (32 floats) per issue, so that the four 16-byte loads of a chunk
+    // are one 64-bit address and four immediate offsets (round 4: the per-load clamp of k -- four vector instructions per
+    // load -- is taken only by the last chunk of a row whose width is not a multiple of 32).
     long long it_m = 0;
     int it_kc = 0;
+    const bool ragged = (din & 31) != 0;
     const float* row_it = a.rs.src + (long long)a.rs.srow[tile_of(0) * 32 + c] * din;
+    const float* xp = row_it + 16 * h;
     int sr_next = a.rs.srow[tile_of(1) * 32 + c];
     auto issue = [&](XBuf& B) {                 // always exactly 4 loads (+ 1 table load per tile)
+        if (ragged && it_kc == nch - 1) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int k = 32 * it_kc + 16 * h + 4 * q;
-            if (k > din - 4) k = din - 4;       // a piece past the row's end: finite data against zero weights
-            B.x[q] = *reinterpret_cast<const v4u*>(row_it + k);
+            for (int q = 0; q < 4; ++q) {
+                int k = 32 * it_kc + 16 * h + 4 * q;
+                if (k > din - 4) k = din - 4;   // a piece past the row's end: finite data against zero weights
+                B.x[q] = *reinterpret_cast<const v4u*>(row_it + k);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) B.x[q] = *reinterpret_cast<const v4u*>(xp + 4 * q);
         }
+        xp += 32;
         if (++it_kc == nch) {
             it_kc = 0;
             ++it_m;
             row_it = a.rs.src + (long long)sr_next * din;
+            xp = row_it + 16 * h;
             sr_next = a.rs.srow[tile_of(it_m + 1) * 32 + c];
         }
     };
@@ -804,28 +862,52 @@ __global__ void __launch_bounds__(64 * NW) mlp_fwd3_kernel(FwdArgs a) {
     issue(B0);
     issue(B1);
     if (DEPTH == 3) issue(B2);
-    long long m = 0;
-    int kc = 0, ring = 0;
-    init_acc(0);
     // tuning hook (mappo_mlp_set_debug): shader-clock stamps of the first tiles of two waves that share SIMD 0 of
     // workgroup 0 (waves 0 and 4): [tile start, chunk loop done, tail done] at dbg[64 w + 4 m ..]
     const bool cstamp = a.dbg != nullptr && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0;
-    for (long long p = 0; p < n_pos; ++p) {
-        if (cstamp && kc == 0 && m < 15) a.dbg[64 * (wave >> 2) + 4 * m] = prim::clock();
-        // consume this position's chunk, then refill its buffer with position p + DEPTH (past the end: the last tile again)
-        if (ring == 0) {
-            mfma_chunk(B0, kc);
-            issue(B0);
-        } else if (ring == 1) {
-            mfma_chunk(B1, kc);
-            issue(B1);
-        } else if (DEPTH == 3) {
-            mfma_chunk(B2, kc);
-            issue(B2);
+    // consume a chunk, then refill its buffer with the chunk DEPTH positions ahead (past the end: the last tile again)
+#define MAPPO_F3_STEP(B, KC) do { mfma_chunk(B, KC); issue(B); } while (0)
+    for (long long m = 0; m < my_tiles;) {
+        if (cstamp && m < 15) a.dbg[64 * (wave >> 2) + 4 * m] = prim::clock();
+        // The ring of chunk buffers with STATIC names: the loop body covers DEPTH chunks, so no buffer is ever copied
+        // (round 4: with a run-time ring index the compiler merged the buffers through 16 64-bit register moves per chunk).
+        // A chunk count that is not a multiple of DEPTH rotates the names once per tile instead.
+        // (the accumulators start from the first layer's bias HERE, right in front of the tile's first MFMAs, which then
+        // take the bias registers as their C operand: no register moves)
+        init_acc(0);
+        int kc = 0;
+        if (DEPTH == 3) {
+            for (; kc + 3 <= nch; kc += 3) {
+                MAPPO_F3_STEP(B0, kc);
+                MAPPO_F3_STEP(B1, kc + 1);
+                MAPPO_F3_STEP(B2, kc + 2);
+            }
+            if (nch - kc == 1) {
+                MAPPO_F3_STEP(B0, kc);
+                const XBuf t = B0;
+                B0 = B1;
+                B1 = B2;
+                B2 = t;
+            } else if (nch - kc == 2) {
+                MAPPO_F3_STEP(B0, kc);
+                MAPPO_F3_STEP(B1, kc + 1);
+                const XBuf t = B2;
+                B2 = B1;
+                B1 = B0;
+                B0 = t;
+            }
+        } else {
+            for (; kc + 2 <= nch; kc += 2) {
+                MAPPO_F3_STEP(B0, kc);
+                MAPPO_F3_STEP(B1, kc + 1);
+            }
+            if (nch - kc == 1) {
+                MAPPO_F3_STEP(B0, kc);
+                const XBuf t = B0;
+                B0 = B1;
+                B1 = t;
+            }
         }
-        ring = ring == DEPTH - 1 ? 0 : ring + 1;
-        if (++kc < nch) continue;
-        kc = 0;
         if (cstamp && m < 15) a.dbg[64 * (wave >> 2) + 4 * m + 1] = prim::clock();
         // ---- the rest of the network on this lane's row (rows past the end of the launch are copies of the last row:
         // row-table padding; z and the statistics are padded to the tile, only the output store is conditional)
@@ -914,9 +996,9 @@ __global__ void __launch_bounds__(64 * NW) mlp_fwd3_kernel(FwdArgs a) {
                 if (oo < out) a.y[yrow * out + oo] = ah[v] + lds[o.bh + oo];
             }
         }
-        init_acc(0);        // the next tile's first-layer accumulators
         if (cstamp && m_done < 15) a.dbg[64 * (wave >> 2) + 4 * m_done + 2] = prim::clock();
     }
+#undef MAPPO_F3_STEP
 }
 
 // ================================================================== backward: row-parallel chain ====
@@ -1015,12 +1097,15 @@ __host__ __device__ __forceinline__ long long r_total(int L, int out) { return (
 // and the activation's derivative from the saved normalised activations (see layer_tail)
 template <int ACT>
 __device__ __forceinline__ void ln_act_backward(float* dn, const float* nh, float mean, float rstd) {
-    float m1 = 0.f, m2 = 0.f;
+    // (two elements per instruction -- packed f32 add / multiply / fma -- and two partial sums per mean; see act_fn2)
+    f2 a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < 32; ++s) {
-        m1 += dn[s];
-        m2 += dn[s] * nh[s];
+    for (int s = 0; s < 32; s += 2) {
+        const f2 d = {dn[s], dn[s + 1]}, nv = {nh[s], nh[s + 1]};
+        a1 += d;
+        a2 += d * nv;
     }
+    float m1 = a1[0] + a1[1], m2 = a2[0] + a2[1];
     m1 += prim::xhalf(m1);
     m2 += prim::xhalf(m2);
     m1 *= (1.f / 64.f);
@@ -1028,16 +1113,19 @@ __device__ __forceinline__ void ln_act_backward(float* dn, const float* nh, floa
     const float sd = prim::rcp_fast(rstd);
     const float thr = (0.f - mean) * rstd;      // every zero of a ReLU row maps to this nhat (the forward's own operations)
 #pragma unroll
-    for (int s = 0; s < 32; ++s) {
-        const float t = (dn[s] - m1) - nh[s] * m2;
-        float dact = rstd;
+    for (int s = 0; s < 32; s += 2) {
+        const f2 d = {dn[s], dn[s + 1]}, nv = {nh[s], nh[s + 1]};
+        const f2 t = (d - m1) - nv * m2;
+        f2 dact = {rstd, rstd};
         if (ACT == 1) {
-            const float av = nh[s] * sd + mean;          // the activation output of the forward pass
-            dact = rstd * (1.f - av * av);
+            const f2 av = nv * sd + mean;                // the activation output of the forward pass
+            dact = (1.f - av * av) * rstd;
         } else if (ACT == 2) {
-            dact = nh[s] > thr ? rstd : 0.f;
+            dact = f2{nv[0] > thr ? rstd : 0.f, nv[1] > thr ? rstd : 0.f};
         }
-        dn[s] = t * dact;
+        const f2 r = t * dact;
+        dn[s] = r[0];
+        dn[s + 1] = r[1];
     }
 }
 
@@ -1075,23 +1163,21 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
     for (int e = lane; e < 65 * out; e += 64) hacc[e] = 0.f;
     constexpr int NG = L > 1 ? L - 1 : 1;
     f32x16 G[NG][4];                // hidden layer l: tile 2 t + t' = (output feature tile t, input feature tile t')
-    // bias gradients of layers >= 1: row layout (slot s of this lane's row position, reduced over the lanes at the end)
-    // where the registers are there (<= 2 layers), else lane = feature row sums of the transposed tile
-    constexpr bool kRowDb = L <= 2;
-    constexpr int NDB = kRowDb ? L : 1;
-    float dbr[NDB][32], db[L];      // (layer 0 included: the column sums of dz1)
+    // Bias gradients = column sums of dz_l, taken where the values pass through registers in a column-friendly layout anyway
+    // (round 4; before: 32 row-layout registers per layer, which the compiler kept in the AGPR half -- three instructions per
+    // add -- or, for three layers, an extra transpose per layer).  Layers >= 1: the parked A operands of the G MFMAs (lane =
+    // feature c / 32 + c, 16 rows of this half-wave).  Layer 0: the reads of the row-major staging tile in flush_dz1 (lane =
+    // 4 features x every fourth row).
+    float dbs[L][2], db[L];
+    v4 db0 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int l = 0; l < L; ++l) db[l] = 0.f;
+    for (int l = 0; l < L; ++l) db[l] = dbs[l][0] = dbs[l][1] = 0.f;
 #pragma unroll
     for (int l = 0; l < NG; ++l)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int v = 0; v < 16; ++v) G[l][t][v] = 0.f;
-#pragma unroll
-    for (int l = 0; l < NDB; ++l)
-#pragma unroll
-        for (int s = 0; s < 32; ++s) dbr[l][s] = 0.f;
     constexpr int NH = HR > 0 ? HR : 1;
     float ghr[NH][32], dbhr[NH];    // row layout: head sums (HR > 0)
 #pragma unroll
@@ -1160,6 +1246,8 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
             v4 sv[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) sv[i] = *reinterpret_cast<const v4*>(S + (4 * i + (lane >> 4)) * kSS + 4 * (lane & 15));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) db0 += sv[i];
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 *reinterpret_cast<v4*>(a.dz1 + (staged * 32 + 4 * i + (lane >> 4)) * 64 + 4 * (lane & 15)) = sv[i];
@@ -1307,17 +1395,6 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
             ln_act_backward<ACT>(dn, nh, st[0], st[1]);      // dn now holds dz_l
             MAPPO_B2_STAMP(l == L - 1 ? 4 : 10);
             if (l == 0) {
-                if (kRowDb) {
-#pragma unroll
-                    for (int s = 0; s < 32; ++s) dbr[0][s] += dn[s];
-                } else {
-                    prim::wave_sync();
-                    put_transposed(T, dn, c, h);        // (three layers: no registers left for row-layout sums)
-                    prim::wave_sync();
-                    db[0] += rowsum32(T + lane * kTS);
-                    prim::wave_sync();
-                    prefetch_top(tile + nw);            // (T's last use of this tile comes here in this variant)
-                }
                 // -> the row-major staging tile
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
@@ -1331,17 +1408,12 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
                 prim::wave_sync();
                 staged = tile;          // (stored at the top of the next iteration, see flush_dz1)
             } else {
-                if (kRowDb) {
-#pragma unroll
-                    for (int s = 0; s < 32; ++s) dbr[kRowDb ? l : 0][s] += dn[s];
-                }
                 put_transposed(T, dn, c, h);
                 // dnhat_{l-1} = (gamma (.) W^T) dz: the last use of dz in row order
                 f32x16 dx[2];
                 dense64(lds + o.w2t + (l - 1) * 64 * kWS, c, h, dn, dx);
                 MAPPO_B2_STAMP(5);
                 prim::wave_sync();
-                if (!kRowDb) db[l] += rowsum32(T + lane * kTS);
                 // A operands of G += dz^T nhat (lane = output feature, rows 16 h + ..): parked in registers while the
                 // input of this layer, nhat of layer l - 1 (loaded one layer ahead), takes the tile over
                 v4 a0[4], a1[4];
@@ -1349,6 +1421,16 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
                 for (int q = 0; q < 4; ++q) {
                     a0[q] = *reinterpret_cast<const v4*>(T + c * kTS + 16 * h + 4 * q);
                     a1[q] = *reinterpret_cast<const v4*>(T + (32 + c) * kTS + 16 * h + 4 * q);
+                }
+                {
+                    f2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        p0 += f2{a0[q][0], a0[q][1]} + f2{a0[q][2], a0[q][3]};
+                        p1 += f2{a1[q][0], a1[q][1]} + f2{a1[q][2], a1[q][3]};
+                    }
+                    dbs[l][0] += p0[0] + p0[1];
+                    dbs[l][1] += p1[0] + p1[1];
                 }
                 prim::wave_sync();
                 MAPPO_B2_STAMP(6);
@@ -1369,7 +1451,7 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
                 }
                 MAPPO_B2_STAMP(8);
                 prim::wave_sync();          // T's last use of this tile (l == 1): the next tile's prefetch may land
-                if (l == 1 && kRowDb) {
+                if (l == 1) {
                     // (the compiler does not count the prefetch's loads: a wait for one of ITS older loads placed after
                     // this point would wait for the prefetch too.  Settle them here, where they have long arrived.)
                     float m0 = stx[0], m1 = stx[1];
@@ -1398,16 +1480,20 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
 #undef MAPPO_B2_STAMP
     prim::wait_lds_loads<0>();
     flush_dz1();
-    // ---- row-layout sums -> lane = feature (sum over the 32 row positions of each half-wave's features)
-    if (kRowDb) {
+    // ---- the column sums -> lane = feature
 #pragma unroll
-        for (int l = 0; l < L; ++l) {
-            prim::wave_sync();
-            put_transposed(T, dbr[kRowDb ? l : 0], c, h);
-            prim::wave_sync();
-            db[l] = rowsum32(T + lane * kTS);
-        }
+    for (int l = 1; l < L; ++l) {
+        float sa = dbs[l][0], sb = dbs[l][1];
+        sa += prim::xhalf(sa);
+        sb += prim::xhalf(sb);
+        db[l] = h ? sb : sa;
     }
+    prim::wave_sync();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) T[64 * (lane >> 4) + 4 * (lane & 15) + e] = db0[e];
+    prim::wave_sync();
+    db[0] = (T[lane] + T[64 + lane]) + (T[128 + lane] + T[192 + lane]);
+    prim::wave_sync();
     if (HR == 0 && out > 0) {
         if (out <= kHQ) {
 #pragma unroll

@@ -8,6 +8,7 @@ simt_dim3 simt::g_threadIdx, simt::g_blockIdx, simt::g_blockDim, simt::g_gridDim
 namespace prim {
 inline float exp2_fast(float v) { return exp2f(v); }
 inline float rcp_fast(float v) { return 1.f / v; }
+inline float rsq_fast(float v) { return 1.f / sqrtf(v); }
 inline void sched_fence() {}
 inline void set_priority_high() {}
 inline long long clock() { return 0; }

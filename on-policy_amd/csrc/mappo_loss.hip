@@ -39,7 +39,10 @@ __device__ __forceinline__ float dloss_of(float e, float delta, bool huber) {
 // STAGED: the [256, n_actions] logits / availability tile of a workgroup goes through LDS with coalesced
 // global accesses (a thread's own row is n_actions floats at a stride of n_actions: 20-byte pieces for the
 // 5 actions of MPE), and the gradient tile goes back the same way.  Rows sit at an odd word stride in LDS.
-template <bool HAS_AVAIL, bool STAGED>
+// RK > 0 (heads of <= RK actions -- MPE's 5): a row's masked logits and probabilities stay in registers between the passes,
+// one exponential per action instead of three (round 4: at 5 actions the launch was instruction-bound -- 15 expf and 10
+// integer divisions per row -- at 0.37 of the HBM rate).
+template <bool HAS_AVAIL, bool STAGED, int RK>
 __global__ void __launch_bounds__(256) ppo_loss_kernel(mappo_ppo_loss_t a) {
     extern __shared__ float lds[];
     const bool huber = a.flags & MAPPO_LOSS_HUBER;
@@ -57,6 +60,8 @@ __global__ void __launch_bounds__(256) ppo_loss_kernel(mappo_ppo_loss_t a) {
     const int stride = na | 1;
     float* s_lg = lds;
     float* s_av = lds + 256 * stride;
+    // element e = threadIdx.x + 256 j of a staged tile is (row, action) = (e / na, e % na): stepped, not divided
+    const int r0 = threadIdx.x / na, k0 = threadIdx.x - r0 * na, dr = 256 / na, dk = 256 - dr * na;
 
     for (long long base = (long long)blockIdx.x * 256; base < a.rows; base += (long long)gridDim.x * 256) {
         const long long i = base + threadIdx.x;
@@ -66,10 +71,15 @@ __global__ void __launch_bounds__(256) ppo_loss_kernel(mappo_ppo_loss_t a) {
             const int tile = (int)(left < 256 ? left : 256) * na;
             const float* gl = a.logits + base * na;
             const float* ga = HAS_AVAIL ? a.available + base * na : nullptr;
-            for (int e = threadIdx.x; e < tile; e += 256) {
-                int r = e / na, k = e - r * na;
+            for (int e = threadIdx.x, r = r0, k = k0; e < tile; e += 256) {
                 s_lg[r * stride + k] = gl[e];
                 if (HAS_AVAIL) s_av[r * stride + k] = ga[e];
+                r += dr;
+                k += dk;
+                if (k >= na) {
+                    k -= na;
+                    ++r;
+                }
             }
             __syncthreads();
         }
@@ -78,25 +88,52 @@ __global__ void __launch_bounds__(256) ppo_loss_kernel(mappo_ppo_loss_t a) {
         if (live && a.logits != nullptr) {
             const float* lg = STAGED ? s_lg + threadIdx.x * stride : a.logits + i * na;
             const float* av = !HAS_AVAIL ? nullptr : STAGED ? s_av + threadIdx.x * stride : a.available + i * na;
-            float mx = -INFINITY;
-            for (int k = 0; k < na; ++k) {
-                float l = (HAS_AVAIL && av[k] == 0.f) ? -1e10f : lg[k];  // distributions.py: masked logits
-                mx = fmaxf(mx, l);
-            }
-            float se = 0.f;
-            for (int k = 0; k < na; ++k) {
-                float l = (HAS_AVAIL && av[k] == 0.f) ? -1e10f : lg[k];
-                se += expf(l - mx);
-            }
-            const float lse = mx + logf(se);
+            constexpr int NR = RK > 0 ? RK : 1;
+            float lr[NR], pr[NR];           // RK > 0: masked logits / probabilities of this row
+            float mx = -INFINITY, lse;
             const int act = (int)a.actions[i];
             float ent = 0.f, logp_a = 0.f;
-            for (int k = 0; k < na; ++k) {
-                float l = (HAS_AVAIL && av[k] == 0.f) ? -1e10f : lg[k];
-                float lp = l - lse;
-                float p = expf(lp);
-                ent -= p * lp;
-                if (k == act) logp_a = lp;
+            if (RK > 0) {
+#pragma unroll
+                for (int k = 0; k < RK; ++k) {
+                    lr[k] = k < na ? ((HAS_AVAIL && av[k] == 0.f) ? -1e10f : lg[k]) : -INFINITY;
+                    mx = fmaxf(mx, lr[k]);
+                }
+                float se = 0.f;
+#pragma unroll
+                for (int k = 0; k < RK; ++k) {
+                    pr[k] = k < na ? expf(lr[k] - mx) : 0.f;
+                    se += pr[k];
+                }
+                lse = mx + logf(se);
+                const float inv_se = 1.f / se;
+#pragma unroll
+                for (int k = 0; k < RK; ++k) {
+                    if (k < na) {
+                        const float lp = lr[k] - lse;
+                        pr[k] *= inv_se;
+                        ent -= pr[k] * lp;
+                        if (k == act) logp_a = lp;
+                    }
+                }
+            } else {
+                for (int k = 0; k < na; ++k) {
+                    float l = (HAS_AVAIL && av[k] == 0.f) ? -1e10f : lg[k];  // distributions.py: masked logits
+                    mx = fmaxf(mx, l);
+                }
+                float se = 0.f;
+                for (int k = 0; k < na; ++k) {
+                    float l = (HAS_AVAIL && av[k] == 0.f) ? -1e10f : lg[k];
+                    se += expf(l - mx);
+                }
+                lse = mx + logf(se);
+                for (int k = 0; k < na; ++k) {
+                    float l = (HAS_AVAIL && av[k] == 0.f) ? -1e10f : lg[k];
+                    float lp = l - lse;
+                    float p = expf(lp);
+                    ent -= p * lp;
+                    if (k == act) logp_a = lp;
+                }
             }
             const float ratio = expf(logp_a - a.old_logp[i]);  // r_mappo.py:129
             const float adv = a.adv[i];
@@ -119,6 +156,17 @@ __global__ void __launch_bounds__(256) ppo_loss_kernel(mappo_ppo_loss_t a) {
                 const float g_logp = -ds_dratio * ratio;
                 const float scale = wp * inv_dp;
                 float* dl = STAGED ? s_lg + threadIdx.x * stride : a.dlogits + i * na;  // in place: read, then written
+                if (RK > 0) {
+#pragma unroll
+                    for (int k = 0; k < RK; ++k) {
+                        if (k < na) {
+                            const bool masked = HAS_AVAIL && av[k] == 0.f;
+                            const float lp = lr[k] - lse;
+                            const float g = g_logp * ((k == act ? 1.f : 0.f) - pr[k]) + a.entropy_coef * pr[k] * (lp + ent);
+                            dl[k] = masked ? 0.f : g * scale;
+                        }
+                    }
+                } else
                 for (int k = 0; k < na; ++k) {
                     bool masked = HAS_AVAIL && av[k] == 0.f;
                     float l = masked ? -1e10f : lg[k];
@@ -134,9 +182,14 @@ __global__ void __launch_bounds__(256) ppo_loss_kernel(mappo_ppo_loss_t a) {
             const long long left = a.rows - base;
             const int tile = (int)(left < 256 ? left : 256) * na;
             float* gd = a.dlogits + base * na;
-            for (int e = threadIdx.x; e < tile; e += 256) {
-                int r = e / na, k = e - r * na;
+            for (int e = threadIdx.x, r = r0, k = k0; e < tile; e += 256) {
                 gd[e] = s_lg[r * stride + k];
+                r += dr;
+                k += dk;
+                if (k >= na) {
+                    k -= na;
+                    ++r;
+                }
             }
         }
         if (STAGED && a.logits != nullptr) __syncthreads();   // the tile is free for the next iteration
@@ -207,16 +260,19 @@ extern "C" int mappo_ppo_loss_f32(const mappo_ppo_loss_t* args, mappo_stream_t s
     dim3 grid((unsigned)blocks), block(256);
     if (staged) {
         if (lds > 48 * 1024) {
-            const void* fn = avail ? reinterpret_cast<const void*>(&ppo_loss_kernel<true, true>)
-                                   : reinterpret_cast<const void*>(&ppo_loss_kernel<false, true>);
+            const void* fn = avail ? reinterpret_cast<const void*>(&ppo_loss_kernel<true, true, 0>)
+                                   : reinterpret_cast<const void*>(&ppo_loss_kernel<false, true, 0>);
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
         }
-        if (avail) hipLaunchKernelGGL((ppo_loss_kernel<true, true>), grid, block, lds, stream, a);
-        else hipLaunchKernelGGL((ppo_loss_kernel<false, true>), grid, block, lds, stream, a);
+        const bool small = a.n_actions <= 8;
+        if (avail && small) hipLaunchKernelGGL((ppo_loss_kernel<true, true, 8>), grid, block, lds, stream, a);
+        else if (avail) hipLaunchKernelGGL((ppo_loss_kernel<true, true, 0>), grid, block, lds, stream, a);
+        else if (small) hipLaunchKernelGGL((ppo_loss_kernel<false, true, 8>), grid, block, lds, stream, a);
+        else hipLaunchKernelGGL((ppo_loss_kernel<false, true, 0>), grid, block, lds, stream, a);
     } else {
-        if (avail) hipLaunchKernelGGL((ppo_loss_kernel<true, false>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((ppo_loss_kernel<false, false>), grid, block, 0, stream, a);
+        if (avail) hipLaunchKernelGGL((ppo_loss_kernel<true, false, 0>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((ppo_loss_kernel<false, false, 0>), grid, block, 0, stream, a);
     }
     return (int)hipGetLastError();
 }

@@ -144,6 +144,12 @@ __device__ __forceinline__ float colsum32(const float* v) {
 __device__ __forceinline__ float sigmoid_fast(float x) {
     return prim::rcp_fast(1.f + prim::exp2_fast(x * -1.4426950408889634f));
 }
+// two elements per instruction where the hardware has a packed form (see mlp::act_fn2)
+__device__ __forceinline__ f2 sigmoid_fast2(f2 x) {
+    const f2 m = x * -1.4426950408889634f;
+    const f2 d = f2{prim::exp2_fast(m[0]), prim::exp2_fast(m[1])} + 1.f;
+    return f2{prim::rcp_fast(d[0]), prim::rcp_fast(d[1])};
+}
 
 // LDS (floats): forward  wih [6][32][kWS] | whh [6][32][kWS] | vec [6][64] = b_ir + b_hr, b_iz + b_hz, b_in, b_hn, gamma, beta
 //               backward wihT [3][2][32][kWS] | whhT [3][2][32][kWS] | gamma [64] | per wave T [64][kTS]
@@ -192,9 +198,12 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_fwd_kernel(Args a) {
             const long long row = (long long)l * mb + jj;
             float x[32], hm[32];
 #pragma unroll
-            for (int s = 0; s < 32; ++s) {
+            for (int s = 0; s < 32; s += 2) {
                 x[s] = xn[s];
-                hm[s] = hcur[s] * mk;
+                x[s + 1] = xn[s + 1];
+                const f2 m2 = f2{hcur[s], hcur[s + 1]} * mk;
+                hm[s] = m2[0];
+                hm[s + 1] = m2[1];
             }
             if (l + 1 < L) {                        // the next step's input and mask, in flight behind this step's MFMAs
                 mlp::load_row64(a.x + (row + mb) * 64, xn, h);
@@ -218,42 +227,49 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_fwd_kernel(Args a) {
                 slots_of(vec, h, b0);
                 slots_of(vec + 64, h, b1);
 #pragma unroll
-                for (int s = 0; s < 32; ++s) {
-                    r[s] = sigmoid_fast(ar[s >> 4][s & 15] + b0[s]);
-                    z[s] = sigmoid_fast(az[s >> 4][s & 15] + b1[s]);
+                for (int s = 0; s < 32; s += 2) {
+                    const int t = s >> 4, v = s & 15;
+                    const f2 rr = sigmoid_fast2(f2{ar[t][v], ar[t][v + 1]} + f2{b0[s], b0[s + 1]});
+                    const f2 zz = sigmoid_fast2(f2{az[t][v], az[t][v + 1]} + f2{b1[s], b1[s + 1]});
+                    r[s] = rr[0];
+                    r[s + 1] = rr[1];
+                    z[s] = zz[0];
+                    z[s + 1] = zz[1];
                 }
                 slots_of(vec + 128, h, b0);
                 slots_of(vec + 192, h, b1);
 #pragma unroll
-                for (int s = 0; s < 32; ++s) {
-                    q[s] = ah[s >> 4][s & 15] + b1[s];
-                    n[s] = mlp::fast_tanh(ai[s >> 4][s & 15] + b0[s] + r[s] * q[s]);
-                    hcur[s] = n[s] + z[s] * (hm[s] - n[s]);
+                for (int s = 0; s < 32; s += 2) {
+                    const int t = s >> 4, v = s & 15;
+                    const f2 qq = f2{ah[t][v], ah[t][v + 1]} + f2{b1[s], b1[s + 1]};
+                    const f2 nn = mlp::act_fn2<1>(f2{ai[t][v], ai[t][v + 1]} + f2{b0[s], b0[s + 1]} + f2{r[s], r[s + 1]} * qq);
+                    const f2 hh = nn + f2{z[s], z[s + 1]} * (f2{hm[s], hm[s + 1]} - nn);
+                    q[s] = qq[0];
+                    q[s + 1] = qq[1];
+                    n[s] = nn[0];
+                    n[s + 1] = nn[1];
+                    hcur[s] = hh[0];
+                    hcur[s + 1] = hh[1];
                 }
             }
             // output LayerNorm on this lane's row (rnn.py:79)
-            float sum = 0.f;
+            float nh[32], mean, rstd;
 #pragma unroll
-            for (int s = 0; s < 32; ++s) sum += hcur[s];
-            sum += prim::xhalf(sum);
-            const float mean = sum * (1.f / 64.f);
-            float var = 0.f, nh[32];
-#pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                nh[s] = hcur[s] - mean;
-                var += nh[s] * nh[s];
-            }
-            var += prim::xhalf(var);
-            const float rstd = 1.f / sqrtf(var * (1.f / 64.f) + a.eps);
+            for (int s = 0; s < 32; ++s) nh[s] = hcur[s];
+            mlp::ln_stats32(nh, a.eps, mean, rstd);
             {
                 float g[32], be[32];
                 slots_of(vec + 256, h, g);
                 slots_of(vec + 320, h, be);
                 float yv[32];
 #pragma unroll
-                for (int s = 0; s < 32; ++s) {
-                    nh[s] *= rstd;
-                    yv[s] = nh[s] * g[s] + be[s];
+                for (int s = 0; s < 32; s += 2) {
+                    const f2 nn = f2{nh[s], nh[s + 1]} * rstd;
+                    const f2 yy = nn * f2{g[s], g[s + 1]} + f2{be[s], be[s + 1]};
+                    nh[s] = nn[0];
+                    nh[s + 1] = nn[1];
+                    yv[s] = yy[0];
+                    yv[s + 1] = yy[1];
                 }
                 if (ok && a.y != nullptr) mlp::store_row64(a.y + row * 64, yv, h);
                 // the output Linear on this lane's row: 32 in-lane terms per output + the other half-wave's

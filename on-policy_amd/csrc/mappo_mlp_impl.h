@@ -654,9 +654,10 @@ __global__ void __launch_bounds__(kFwdThreads, 4) mlp_fwd_kernel(FwdArgs a) {
 //   * a head of >= 3 outputs runs on the MFMA too (outputs zero-padded to one 32-feature tile: 32 MFMAs and 8 operand reads
 //     whatever the width, instead of 8 reads + 32 multiply-adds + a lane exchange per output).
 constexpr int kF3MaxDin = 448;              // 14 chunks x 8 KB of first-layer weights (SMAC's padded 436-wide critic input)
-constexpr int kF3MinDin = 129;              // narrower inputs (<= 4 chunks per tile: the actors) stay on the loader / compute
-                                            // kernel -- measured A / B on one box: din 48 0.775 against 0.745 ms per 2.6 M
-                                            // rows, din 384 1.79 against 1.86, SMAC's 370 / 436 0.68 against 0.75 per launch
+constexpr int kF3MinDin = 4;                // every aligned width.  Until the last chunk of a row was shortened to its real columns
+                                            // (NQL) inputs of <= 128 columns stayed on the loader / compute kernel: width 48
+                                            // 0.775 against 0.745 ms per 2.6 M rows; with NQL 0.648 against 0.676, steps
+                                            // -0.9 % (north star) / -1.3 % (config 3), profiles/r04_ab_forward.json call_12
 constexpr int kF3GridCap = 256;             // one workgroup per CU
 
 struct Fwd3Lds {
@@ -711,13 +712,22 @@ struct XBuf {
     v4 x[4];
 };
 
-// NW = 8: two waves per SIMD with 256 registers each -- three chunks in flight, the first layer's bias in registers.  NW = 12:
-// three waves per SIMD with 168 registers -- two chunks in flight, every bias read from LDS when the accumulators are started.
-template <int L, int ACT, int NW>
-__global__ void __launch_bounds__(64 * NW) mlp_fwd3_kernel(FwdArgs a) {
-    constexpr int kF3Waves = NW;
-    constexpr int DEPTH = NW == 8 ? 3 : 2;
-    constexpr bool BIAS_REGS = NW == 8;
+// Eight waves: two per SIMD with 256 registers each -- three chunks in flight, the first layer's bias in registers.  (A
+// 12-wave form -- three per SIMD, 168 registers, two chunks in flight -- was measured twice in round 4, for the wide critic
+// inputs and for the narrow actor inputs: 0-1 % slower both times, profiles/r04_ab_forward.json; removed.)
+template <int V>
+struct mlp_int {
+    static constexpr int value = V;
+};
+// NQL: groups of 8 real columns in a row's LAST chunk (1 .. 4).  MFMA step (q, e) of a chunk contracts k = 8 q + 4 h + e, so
+// a row's columns are consumed in order, 8 per group q, and the last chunk runs only its NQL groups (round 4: the 48 wide
+// actor input of the north star spent 16 of its 64 first-layer MFMAs per tile on the zero padding of its second chunk, the
+// 18 wide one of config 3 8 of 32).  A template parameter, so that the shortened chunk is straight-line code.
+template <int L, int ACT, int NQL>
+__global__ void __launch_bounds__(64 * 8) mlp_fwd3_kernel(FwdArgs a) {
+    constexpr int kF3Waves = 8;
+    constexpr int DEPTH = 3;
+    constexpr bool BIAS_REGS = true;
     float* lds = prim::lds();
     const Net& n = a.net;
     const int din = n.din, out = n.out;
@@ -781,10 +791,10 @@ __global__ void __launch_bounds__(64 * NW) mlp_fwd3_kernel(FwdArgs a) {
     const long long gw = (long long)blockIdx.x * kF3Waves + wave, nw = (long long)gridDim.x * kF3Waves;
     const long long my_tiles = gw < ntiles ? (ntiles - gw + nw - 1) / nw : 0;
     if (my_tiles == 0) return;
-    // reader side: float offset of piece P = 4 h + q of feature row c inside a [64][32] weight chunk
+    // reader side: float offset of piece P = 2 q + h (columns 8 q + 4 h ..) of feature row c inside a [64][32] weight chunk
     int off[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) off[q] = c * 32 + 4 * ((4 * h + q) ^ ((c >> 1) & 7));
+    for (int q = 0; q < 4; ++q) off[q] = c * 32 + 4 * ((2 * q + h) ^ ((c >> 1) & 7));
     auto tile_of = [&](long long m) {           // launch tile of this wave's m-th tile (past the end: the last one again)
         if (m >= my_tiles) m = my_tiles - 1;
         return gw + m * nw;
@@ -797,40 +807,41 @@ __global__ void __launch_bounds__(64 * NW) mlp_fwd3_kernel(FwdArgs a) {
     int it_kc = 0;
     const bool ragged = (din & 31) != 0;
     const float* row_it = a.rs.src + (long long)a.rs.srow[tile_of(0) * 32 + c] * din;
-    const float* xp = row_it + 16 * h;
+    const float* xp = row_it + 4 * h;
     int sr_next = a.rs.srow[tile_of(1) * 32 + c];
     auto issue = [&](XBuf& B) {                 // always exactly 4 loads (+ 1 table load per tile)
         if (ragged && it_kc == nch - 1) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                int k = 32 * it_kc + 16 * h + 4 * q;
-                if (k > din - 4) k = din - 4;   // a piece past the row's end: finite data against zero weights
+                int k = 32 * it_kc + 8 * q + 4 * h;
+                if (k > din - 4) k = din - 4;   // a piece past the row's end: finite data against zero weights (or never used)
                 B.x[q] = *reinterpret_cast<const v4u*>(row_it + k);
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) B.x[q] = *reinterpret_cast<const v4u*>(xp + 4 * q);
+            for (int q = 0; q < 4; ++q) B.x[q] = *reinterpret_cast<const v4u*>(xp + 8 * q);
         }
         xp += 32;
         if (++it_kc == nch) {
             it_kc = 0;
             ++it_m;
             row_it = a.rs.src + (long long)sr_next * din;
-            xp = row_it + 16 * h;
+            xp = row_it + 4 * h;
             sr_next = a.rs.srow[tile_of(it_m + 1) * 32 + c];
         }
     };
     f32x16 acc[2];
-    auto mfma_chunk = [&](const XBuf& B, int kc) {
+    auto mfma_groups = [&](const XBuf& B, int kc, auto ngroups) {
+        constexpr int NQ = decltype(ngroups)::value;
         const float* wt = lds + o.w1 + kc * 2048;
         v4 a0n = *reinterpret_cast<const v4*>(wt + off[0]);
         v4 a1n = *reinterpret_cast<const v4*>(wt + 1024 + off[0]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const v4 a0 = a0n, a1 = a1n;
-            if (q < 3) {
-                a0n = *reinterpret_cast<const v4*>(wt + off[q < 3 ? q + 1 : 0]);
-                a1n = *reinterpret_cast<const v4*>(wt + 1024 + off[q < 3 ? q + 1 : 0]);
+            if (q + 1 < NQ) {
+                a0n = *reinterpret_cast<const v4*>(wt + off[q + 1 < NQ ? q + 1 : 0]);
+                a1n = *reinterpret_cast<const v4*>(wt + 1024 + off[q + 1 < NQ ? q + 1 : 0]);
             }
             prim::sched_fence();
 #pragma unroll
@@ -840,6 +851,8 @@ __global__ void __launch_bounds__(64 * NW) mlp_fwd3_kernel(FwdArgs a) {
             }
         }
     };
+    auto mfma_chunk = [&](const XBuf& B, int kc) { mfma_groups(B, kc, mlp_int<4>{}); };
+    auto mfma_last = [&](const XBuf& B, int kc) { mfma_groups(B, kc, mlp_int<NQL>{}); };
     auto init_acc = [&](int l) {
         if (BIAS_REGS && l == 0) {
 #pragma unroll
@@ -861,12 +874,13 @@ __global__ void __launch_bounds__(64 * NW) mlp_fwd3_kernel(FwdArgs a) {
     XBuf B0, B1, B2;
     issue(B0);
     issue(B1);
-    if (DEPTH == 3) issue(B2);
+    issue(B2);
     // tuning hook (mappo_mlp_set_debug): shader-clock stamps of the first tiles of two waves that share SIMD 0 of
     // workgroup 0 (waves 0 and 4): [tile start, chunk loop done, tail done] at dbg[64 w + 4 m ..]
     const bool cstamp = a.dbg != nullptr && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0;
     // consume a chunk, then refill its buffer with the chunk DEPTH positions ahead (past the end: the last tile again)
 #define MAPPO_F3_STEP(B, KC) do { mfma_chunk(B, KC); issue(B); } while (0)
+#define MAPPO_F3_LAST(B, KC) do { mfma_last(B, KC); issue(B); } while (0)
     for (long long m = 0; m < my_tiles;) {
         if (cstamp && m < 15) a.dbg[64 * (wave >> 2) + 4 * m] = prim::clock();
         // The ring of chunk buffers with STATIC names: the loop body covers DEPTH chunks, so no buffer is ever copied
@@ -876,7 +890,7 @@ __global__ void __launch_bounds__(64 * NW) mlp_fwd3_kernel(FwdArgs a) {
         // take the bias registers as their C operand: no register moves)
         init_acc(0);
         int kc = 0;
-        if (DEPTH == 3) {
+        if (NQL == 4) {                         // every chunk is a full one
             for (; kc + 3 <= nch; kc += 3) {
                 MAPPO_F3_STEP(B0, kc);
                 MAPPO_F3_STEP(B1, kc + 1);
@@ -897,15 +911,28 @@ __global__ void __launch_bounds__(64 * NW) mlp_fwd3_kernel(FwdArgs a) {
                 B0 = t;
             }
         } else {
-            for (; kc + 2 <= nch; kc += 2) {
+            for (; kc + 3 < nch; kc += 3) {     // (strictly before the row's last chunk)
                 MAPPO_F3_STEP(B0, kc);
                 MAPPO_F3_STEP(B1, kc + 1);
+                MAPPO_F3_STEP(B2, kc + 2);
             }
             if (nch - kc == 1) {
-                MAPPO_F3_STEP(B0, kc);
+                MAPPO_F3_LAST(B0, kc);
                 const XBuf t = B0;
                 B0 = B1;
-                B1 = t;
+                B1 = B2;
+                B2 = t;
+            } else if (nch - kc == 2) {
+                MAPPO_F3_STEP(B0, kc);
+                MAPPO_F3_LAST(B1, kc + 1);
+                const XBuf t = B2;
+                B2 = B1;
+                B1 = B0;
+                B0 = t;
+            } else {
+                MAPPO_F3_STEP(B0, kc);
+                MAPPO_F3_STEP(B1, kc + 1);
+                MAPPO_F3_LAST(B2, kc + 2);
             }
         }
         if (cstamp && m < 15) a.dbg[64 * (wave >> 2) + 4 * m + 1] = prim::clock();
@@ -999,6 +1026,7 @@ __global__ void __launch_bounds__(64 * NW) mlp_fwd3_kernel(FwdArgs a) {
         if (cstamp && m_done < 15) a.dbg[64 * (wave >> 2) + 4 * m_done + 2] = prim::clock();
     }
 #undef MAPPO_F3_STEP
+#undef MAPPO_F3_LAST
 }
 
 // ================================================================== backward: row-parallel chain ====
@@ -2344,24 +2372,29 @@ inline int forward(const mappo_mlp_t* m, hipStream_t stream) {
     }
     const bool al = m->din % 4 == 0;
     if (fwd3_takes(m->din, m->n_layers, m->out, (tuning_flags() & 16) != 0) && !(tuning_flags() & 4)) {
-        // version 3: operands straight from global memory, resident first-layer weights, two (three) waves per SIMD.
-        // Option bits (mappo_mlp_set_flags / MAPPO_MLP_FLAGS): 4 keeps the loader / compute kernel below, 8 selects the
-        // 12-wave form of version 3, 16 lets version 3 take narrow inputs too (tests)
+        // version 3: operands straight from global memory, resident first-layer weights, two waves per SIMD.
+        // Option bits (mappo_mlp_set_flags / MAPPO_MLP_FLAGS): 4 keeps the loader / compute kernel below, 16 lets version 3
+        // take narrow inputs too
         const int nch = (m->din + 31) / 32;
         const Fwd3Lds o3 = fwd3_lds(m->n_layers, m->out, nch);
-        const int nw = (tuning_flags() & 8) ? 12 : 8;
-        const long long grid3 = capped(ceil_div(rows128(m->rows) / 32, nw), kF3GridCap);
+        // groups of 8 real columns in a row's last chunk: 1 and 2 have shortened instances (3, and 2 with three layers, run
+        // the full chunk: their shortened forms needed a few bytes of scratch for 8 MFMAs saved)
+        int nql = (m->din - 32 * (nch - 1) + 7) / 8;
+        if (nql == 3 || (nql == 2 && m->n_layers == 3)) nql = 4;
+        const long long grid3 = capped(ceil_div(rows128(m->rows) / 32, 8), kF3GridCap);
+#define MAPPO_FWD3_NQL(LL, AA, QQ)                                                                                   \
+    if (nql == QQ) {                                                                                                \
+        MAPPO_LAUNCH((mlp_fwd3_kernel<LL, AA, QQ>), (unsigned)grid3, 64 * 8, (size_t)o3.total * 4, stream, a);      \
+    }
 #define MAPPO_FWD3_CASE(LL, AA)                                                                                      \
     if (m->n_layers == LL && m->act == AA) {                                                                        \
-        if (nw == 8) {                                                                                              \
-            MAPPO_LAUNCH((mlp_fwd3_kernel<LL, AA, 8>), (unsigned)grid3, 64 * 8, (size_t)o3.total * 4, stream, a);   \
-        } else {                                                                                                    \
-            MAPPO_LAUNCH((mlp_fwd3_kernel<LL, AA, 12>), (unsigned)grid3, 64 * 12, (size_t)o3.total * 4, stream, a); \
-        }                                                                                                           \
+        MAPPO_FWD3_NQL(LL, AA, 1) MAPPO_FWD3_NQL(LL, AA, 4)                                                         \
+        if (LL == 2) MAPPO_FWD3_NQL(2, AA, 2)                                                                       \
     }
         MAPPO_FWD3_CASE(2, 0) MAPPO_FWD3_CASE(2, 1) MAPPO_FWD3_CASE(2, 2)
         MAPPO_FWD3_CASE(3, 0) MAPPO_FWD3_CASE(3, 1) MAPPO_FWD3_CASE(3, 2)
 #undef MAPPO_FWD3_CASE
+#undef MAPPO_FWD3_NQL
         return MAPPO_LAUNCH_ERROR();
     }
     const FwdLds o = fwd_lds(m->n_layers, m->out);

@@ -87,7 +87,7 @@ def main():
                 _native.lib().mappo_mlp_set_debug(None)
             d = dbg.cpu().numpy()
             flags = int(os.environ.get("MAPPO_MLP_FLAGS", "0"))
-            if not (flags & 4) and din % 4 == 0 and din <= 448 and (din > 128 or (flags & 16)):     # version 3 ran
+            if not (flags & 4) and din % 4 == 0 and din <= 448:     # version 3 ran
                 print("forward v3, waves 0 and 4 of workgroup 0 (they share SIMD 0): tile | chunk loop | tail | start -> "
                       "next start")
                 for w in range(2):

@@ -17,9 +17,10 @@ if W == "ns" and not os.path.isdir(SRC):
     SRC = os.path.join(ROOT, "gpurun_out", TAG, "pmc_sq")
 KERNELS = {"gru_seq_fwd_kernel": "K12 forward", "gru_seq_bwd_kernel<3, 5>": "K12 backward, actor (5-wide head inside)",
            "gru_seq_bwd_kernel<1, 1>": "K12 backward, critic (v_out inside)",
-           "mlp_fwd_kernel": "K9 forward, loader / compute kernel (round 4: the narrow actor inputs; before: actor and critic "
-                             "launches averaged)",
-           "mlp_fwd3_kernel": "K9 forward, version 3 (round 4: inputs wider than 128 -- the critic)",
+           "mlp_fwd_kernel": "K9 forward, loader / compute kernel (unaligned widths; until the middle of round 4 the narrow actor "
+                             "inputs)",
+           "mlp_fwd3_kernel<2, 1, 4>": "K9 forward, version 3, the critic's 384 wide input (full last chunk)",
+           "mlp_fwd3_kernel<2, 1, 2>": "K9 forward, version 3, the actor's 48 wide input (last chunk: 2 groups of 8 columns)",
            "mlp_dw1_direct_kernel": "K9 first-layer weight gradient, critic",
            "mlp_dw1_rows_kernel": "K9 first-layer weight gradient, actor",
            "mlp_bwd_kernel<2, 1, 0>": "K9 backward chain, action head",

@@ -393,9 +393,9 @@ def main():
             # tuple is reused, otherwise once per update and issued one update ahead (DataParallel.begin_scales)
             "scalar_allreduce": {"per_step": (trainer.dp.scalar_collectives - scalar0) / max(1, opt.steps),
                                  "updates_served_from_cache_per_step": (trainer.dp.scales_reused - reused0) / max(1, opt.steps)},
-            # the dominant kernel of the step: the fused trunk's forward launch (mlp_fwd_kernel; actor and critic
+            # the dominant kernel of the step: the fused trunk's forward launch (mlp_fwd3_kernel; actor and critic
             # launches averaged, as rocprofv3 --stats averages them), f32 matrix-core bound
-            "roofline": roof_mfma("mappo_mlp_forward", "mlp_fwd_kernel (mappo_mlp_forward)") or roof("mappo_gae_f32"),
+            "roofline": roof_mfma("mappo_mlp_forward", "mlp_fwd3_kernel / mlp_fwd_kernel (mappo_mlp_forward)") or roof("mappo_gae_f32"),
             "roofline_mlp_backward": roof_mfma("mappo_mlp_backward",
                                                "mlp_bwd_kernel + mlp_dw1_{direct,rows}_kernel + reduce / finish (mappo_mlp_backward)"),
             # the kernel BASELINE.json's north star names (>= 70 % of HBM in the GAE scan), HBM bound

@@ -567,9 +567,9 @@ int     mappo_mlp_set_debug(long long* buf);
 /* tuning / test hook: option bits of the K9 launchers (initial value: environment variable MAPPO_MLP_FLAGS, default 0);
  * returns the previous value.  1 = the forward's compute waves keep the default priority; 4 = mappo_mlp_forward keeps the
  * loader / compute kernel (mlp_fwd_kernel) for shapes the version-3 kernel (operands straight from global memory, resident
- * first-layer weights; aligned rows 129 .. 448 floats wide) would take; 8 = the 12-wave form of version 3 (three waves per
- * SIMD); 16 = version 3 also for narrower aligned rows (tests); 32 = the two-slot form of the direct-to-LDS first-layer
- * weight-gradient kernel, two workgroups per CU (tuning). */
+ * first-layer weights; aligned rows up to 448 floats wide, two or three layers) would take; 8 and 16 = no effect (until the
+ * middle of round 4: the 12-wave form of version 3 / version 3 for rows narrower than 129 floats); 32 = the two-slot form of
+ * the direct-to-LDS first-layer weight-gradient kernel, two workgroups per CU (tuning). */
 int     mappo_mlp_set_flags(int flags);
 int     mappo_mlp_forward(const mappo_mlp_t* net, mappo_stream_t stream);
 int     mappo_mlp_backward(const mappo_mlp_t* net, mappo_stream_t stream);

@@ -673,10 +673,10 @@ __host__ __device__ __forceinline__ Fwd3Lds fwd3_lds(int L, int out, int nch) {
     o.total = o.w1 + nch * 2048;
     return o;
 }
-inline bool fwd3_takes(int din, int L, int out, bool any_width) {
+inline bool fwd3_takes(int din, int L, int out) {
     // (single-layer trunks -- layer_N = 0 -- stay on the loader / compute kernel: the one-layer tanh instance of version 3
     // spilled 148 bytes per lane and no shipped configuration uses it)
-    return din % 4 == 0 && din >= (any_width ? 4 : kF3MinDin) && din <= kF3MaxDin && out <= 32 && L >= 2 && L <= 3;
+    return din % 4 == 0 && din >= kF3MinDin && din <= kF3MaxDin && out <= 32 && L >= 2 && L <= 3;
 }
 
 // The tail of one layer on accumulators that already hold z = W x + b: a = act(z), statistics, nhat in place (-> reg),
@@ -2371,10 +2371,9 @@ inline int forward(const mappo_mlp_t* m, hipStream_t stream) {
         if (a.z[l] != nullptr && a.st[l] == nullptr) return MAPPO_E_NULL;
     }
     const bool al = m->din % 4 == 0;
-    if (fwd3_takes(m->din, m->n_layers, m->out, (tuning_flags() & 16) != 0) && !(tuning_flags() & 4)) {
+    if (fwd3_takes(m->din, m->n_layers, m->out) && !(tuning_flags() & 4)) {
         // version 3: operands straight from global memory, resident first-layer weights, two waves per SIMD.
-        // Option bits (mappo_mlp_set_flags / MAPPO_MLP_FLAGS): 4 keeps the loader / compute kernel below, 16 lets version 3
-        // take narrow inputs too
+        // Option bit 4 (mappo_mlp_set_flags / MAPPO_MLP_FLAGS) keeps the loader / compute kernel below
         const int nch = (m->din + 31) / 32;
         const Fwd3Lds o3 = fwd3_lds(m->n_layers, m->out, nch);
         // groups of 8 real columns in a row's last chunk: 1 and 2 have shortened instances (3, and 2 with three layers, run

@@ -45,7 +45,7 @@ def main():
     out["mappo_mlp_forward"] = {
         "algorithmic_bytes": alg_f, "fetch_size_bytes_raw": f, "write_size_bytes": w, "hbm_bytes": 2 * f + w,
         "dispatches_averaged": n,
-        "kernel": "mlp::mlp_fwd_kernel<1, true> (actor) / mlp::mlp_fwd3_kernel<2, 1, 8> (critic, from round 4)",
+        "kernel": "mlp::mlp_fwd3_kernel<2, 1, 2> (actor) / mlp::mlp_fwd3_kernel<2, 1, 4> (critic) (round 4; before: mlp::mlp_fwd_kernel<1, true>)",
         "note": "north-star bench.py step (separate --pmc passes with --kernel-trace only, tools/profile_r02.sh); actor "
                 "and critic launches averaged; FETCH_SIZE doubled (gfx950 counts 64 B per 128 B request of a wide "
                 "coalesced read, MI355X_MICROARCH.md)"}

@@ -638,11 +638,13 @@ __global__ void __launch_bounds__(kFwdThreads, 4) mlp_fwd_kernel(FwdArgs a) {
 // 13 of them per 32-column chunk, so two workgroups' loaders deliver a chunk every 4.5-5 k cycles against 2 x 2.05 k
 // cycles of MFMA work.  Here nothing stands between HBM and the B operand:
 //   * the B operand (activations: lane = row) comes STRAIGHT from global memory into registers: lane (c, h) loads the four
-//     16-byte pieces 16 h + 4 q .. + 3 of its row's 32-column chunk -- element e of piece q is exactly the k index
-//     32 kc + 16 h + 4 q + e that MFMA step (q, e) contracts over.  A wave instruction touches 32 rows x 2 pieces; the four
-//     instructions of a chunk are issued back to back and cover whole 128-byte lines of the (1536-byte aligned) rows, so the
-//     lines are fetched once.  No LDS hop, no loader waves, no barriers: three chunks in flight per wave in 48 registers,
-//     issued by the wave that consumes them right behind the MFMA block that freed the buffer;
+//     16-byte pieces 8 q + 4 h .. + 3 of its row's 32-column chunk -- element e of piece q is exactly the k index
+//     32 kc + 8 q + 4 h + e that MFMA step (q, e) contracts over (columns in order, 8 per group q: a row's last chunk
+//     runs only the groups that hold real columns, template parameter NQL).  A wave instruction touches 32 rows x 2
+//     adjacent pieces; the four instructions of a chunk are issued back to back and cover whole 128-byte lines of the
+//     (16-byte aligned) rows, so the lines are fetched once.  No LDS hop, no loader waves, no barriers: three chunks in
+//     flight per wave in 48 registers, issued by the wave that consumes them right behind the MFMA block that freed the
+//     buffer;
 //   * the WHOLE first-layer weight matrix sits in LDS (64 x din floats: 96 KB for the 384-wide critic; 16-byte pieces
 //     XOR-swizzled so that the A-operand reads are conflict free), staged once per workgroup;
 //   * ONE workgroup of 8 waves per CU = two waves per SIMD with 256 registers each: while one is in its layer tails

@@ -7,8 +7,13 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4 __attribute__((ext_vector_type(4)));
 typedef float v4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
 namespace prim {
+// v_mfma_f32_32x32x16_bf16: A[i = lane & 31][k = 8 (lane >> 5) + e], B[k = 8 (lane >> 5) + e][j = lane & 31], e < 8; D as below
+__device__ __forceinline__ f32x16 mfma_bf16(bf8 a, bf8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 // v_mfma_f32_32x32x2_f32: A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31],
 // D[row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5)][col = lane & 31]
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {

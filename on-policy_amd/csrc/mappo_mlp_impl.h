@@ -1031,6 +1031,356 @@ __global__ void __launch_bounds__(64 * 8) mlp_fwd3_kernel(FwdArgs a) {
 #undef MAPPO_F3_LAST
 }
 
+// ------------------------------------------------------------------ forward, version 4 (option bit 64: opt-in) ----
+// The first layer on the bf16 matrix pipe with float32 products.  v_mfma_f32_32x32x16_bf16 runs at 16 x the FLOP rate of
+// v_mfma_f32_32x32x2_f32, and a float32 value is EXACTLY the sum of three bf16 values (x = x1 + x2 + x3: 8 + 8 + 8
+// significand bits, each term the round-to-nearest bf16 of what the terms before it left).  A float32 product is then
+//     x y = x1 y1 + (x1 y2 + x2 y1) + (x2 y2 + x1 y3 + x3 y1) + [x2 y3 + x3 y2 + x3 y3: < 2^-24 |x y|, dropped]
+// -- six bf16 x bf16 products (each exact in float32), accumulated in float32 by the matrix core, smallest terms first.
+// What is dropped is below float32's own rounding of the product.  Measured on the MI355X (tools/probes/probe_bf16_split.hip,
+// profiles/r04_probe_bf16_split.json): error against a float64 sum at K = 384, relative to the result's rms: max 1.3e-6 /
+// rms 2.8e-7 for the six terms, 2.3e-6 / 3.5e-7 for the float32 MFMA chain the other kernels use, 2.6e-6 / 3.6e-7 for a
+// float32 loop on the CPU; three terms (1.5e-5) are NOT float32 arithmetic and are not offered.  Cost of a k = 16 step of
+// two 32-feature tiles per SIMD: 434 ns on the float32 MFMA (16 instructions), 251 ns this way (12 MFMAs + the 3-way split
+// of the wave's 8 activation values: ~36 vector instructions that add to the MFMA time like every VALU instruction does).
+// Structure: version 3's (operands straight from global memory into registers, resident first-layer weights, no
+// barriers), with three changes the arithmetic asks for:
+//   * the first-layer weights sit in LDS as THREE bf16 planes, split once per workgroup: 24 KB per 64-column chunk,
+//     144 KB for the 384-wide critic input -- which leaves no room for the hidden layer's weights next to them, so
+//   * ONE wave per SIMD (4 waves, up to 512 registers each) and the hidden layer's A operands (64 floats per lane), both
+//     folded biases (32 + 32) in REGISTERS: the hidden layer and the tails read no LDS at all;
+//   * chunks of 64 columns (four k = 16 steps: lane (c, g) loads columns 16 s + 8 g .. + 7 of its row for step s, two
+//     16-byte pieces), three in flight per wave = the bytes version 3's two waves per SIMD keep in flight.
+// Two-layer trunks, aligned widths up to 384.  The hidden layer, the head and the tails are version 3's (float32 MFMA).
+constexpr int kF4MaxDin = 384;              // 6 chunks x 24 KB of first-layer weight planes
+struct Fwd4Lds {
+    int vec, whp, bh, w1, total;
+};
+__host__ __device__ __forceinline__ Fwd4Lds fwd4_lds(int nsc) {
+    Fwd4Lds o;
+    o.vec = 0;                                  // [bias of layer 0 | folded bias of layer 1][64]
+    o.whp = 128;                                // [32][kWS] permuted head weights (rows >= out are zero), gamma folded in
+    o.bh = o.whp + 32 * kWS;                    // [32] folded head bias
+    o.w1 = (o.bh + 32 + 3) & ~3;                // [nsc][plane 3][step 4][tile 2][lane 64] x 16 bytes (8 bf16: k = 16 s + 8 g ..)
+    o.total = o.w1 + nsc * 6144;
+    return o;
+}
+inline bool fwd4_takes(int din, int L, int out) {
+    return din % 4 == 0 && din >= 4 && din <= kF4MaxDin && out <= 32 && L == 2;
+}
+
+// x[e] = p1[e] + p2[e] + p3[e] exactly (round-to-nearest conversions; the residuals are exact float32 subtractions)
+__device__ __forceinline__ void split3(const float* x, bf8& p1, bf8& p2, bf8& p3) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        p1[e] = (__bf16)x[e];
+        const float r1 = x[e] - (float)p1[e];
+        p2[e] = (__bf16)r1;
+        p3[e] = (__bf16)(r1 - (float)p2[e]);
+    }
+}
+
+struct XBuf8 {
+    v4 x[8];
+};
+
+// NSL: k = 16 steps of a row's LAST 64-column chunk that hold real columns (1 .. 4)
+template <int ACT, int NSL>
+__global__ void __launch_bounds__(64 * 4, 1) mlp_fwd4_kernel(FwdArgs a) {
+    constexpr int kF4Waves = 4;
+    float* lds = prim::lds();
+    const Net& n = a.net;
+    const int din = n.din, out = n.out;
+    const int nsc = (din + 63) / 64;
+    const Fwd4Lds o = fwd4_lds(nsc);
+    const int tid = threadIdx.x, lane = tid & 63, wave = prim::uniform(tid >> 6), c = lane & 31, h = lane >> 5;
+    constexpr int kThr = 64 * kF4Waves;
+    // ---- parameters, once per workgroup
+    for (int e = tid; e < 128; e += kThr) {
+        const int l = e >> 6, f = e & 63;
+        float v = n.bias[l][f];
+        if (l > 0)
+            for (int k = 0; k < 64; ++k) v += n.w2[0][f * 64 + k] * n.ln_b[0][k];
+        lds[o.vec + e] = v;
+    }
+    for (int e = tid; e < 32 * 64; e += kThr) {
+        const int oo = e >> 6, hs = e & 63;
+        const int k = feat_of(hs >> 5, hs & 31);
+        lds[o.whp + oo * kWS + hs] = oo < out ? n.wh[oo * 64 + k] * n.ln_g[1][k] : 0.f;
+    }
+    for (int e = tid; e < 32; e += kThr) {
+        float v = 0.f;
+        if (e < out) {
+            v = n.bh[e];
+            for (int k = 0; k < 64; ++k) v += n.wh[e * 64 + k] * n.ln_b[1][k];
+        }
+        lds[o.bh + e] = v;
+    }
+    // first-layer weights: the 8 values k = 64 sc + 16 s + 8 g .. + 7 of feature row f = 32 t + cc, split into three bf16
+    // planes, at piece 32 g + cc of block (plane, s, t) -- the piece lane (cc, g) reads as its A operand; zero beyond din
+    for (int e = tid; e < nsc * 512; e += kThr) {
+        const int sc = e >> 9, s = (e >> 7) & 3, f = (e >> 1) & 63, g = e & 1;
+        const int k = 64 * sc + 16 * s + 8 * g;
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            v4 t = {0.f, 0.f, 0.f, 0.f};
+            if (k + 4 * j < din) t = *reinterpret_cast<const v4u*>(n.w1 + (long long)f * din + k + 4 * j);    // (din % 4 == 0)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[4 * j + i] = t[i];
+        }
+        bf8 p1, p2, p3;
+        split3(w, p1, p2, p3);
+        float* base = lds + o.w1 + sc * 6144 + (s * 2 + (f >> 5)) * 256 + (32 * g + (f & 31)) * 4;
+        *reinterpret_cast<bf8*>(base) = p1;
+        *reinterpret_cast<bf8*>(base + 2048) = p2;
+        *reinterpret_cast<bf8*>(base + 4096) = p3;
+    }
+    __syncthreads();
+    // per-lane constants (registers for the whole launch): both biases in accumulator order, the hidden layer's A operands
+    // w2r[t][s] = gamma_0[k] W_1[32 t + c][k], k = f(h, s) -- the operand of the step that consumes slot s
+    float biasr[32], bias1r[32], w2r[2][32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        biasr[s] = lds[o.vec + feat_of(h, s)];
+        bias1r[s] = lds[o.vec + 64 + feat_of(h, s)];
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int k = feat_of(h, s);
+            w2r[t][s] = n.w2[0][(32 * t + c) * 64 + k] * n.ln_g[0][k];
+        }
+
+    const long long rows = a.rs.rows;
+    const long long ntiles = rows128(rows) / 32;
+    const long long gw = (long long)blockIdx.x * kF4Waves + wave, nw = (long long)gridDim.x * kF4Waves;
+    const long long my_tiles = gw < ntiles ? (ntiles - gw + nw - 1) / nw : 0;
+    if (my_tiles == 0) return;
+    auto tile_of = [&](long long m) {
+        if (m >= my_tiles) m = my_tiles - 1;
+        return gw + m * nw;
+    };
+    long long it_m = 0;
+    int it_kc = 0;
+    const bool ragged = (din & 63) != 0;
+    const float* row_it = a.rs.src + (long long)a.rs.srow[tile_of(0) * 32 + c] * din;
+    const float* xp = row_it + 8 * h;
+    int sr_next = a.rs.srow[tile_of(1) * 32 + c];
+    auto issue = [&](XBuf8& B) {                // always exactly 8 loads (+ 1 table load per tile)
+        if (ragged && it_kc == nsc - 1) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                int k = 64 * it_kc + 16 * (q >> 1) + 8 * h + 4 * (q & 1);
+                if (k > din - 4) k = din - 4;   // a piece past the row's end: finite data against zero weights (or never used)
+                B.x[q] = *reinterpret_cast<const v4u*>(row_it + k);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) B.x[q] = *reinterpret_cast<const v4u*>(xp + 16 * (q >> 1) + 4 * (q & 1));
+        }
+        xp += 64;
+        if (++it_kc == nsc) {
+            it_kc = 0;
+            ++it_m;
+            row_it = a.rs.src + (long long)sr_next * din;
+            xp = row_it + 8 * h;
+            sr_next = a.rs.srow[tile_of(it_m + 1) * 32 + c];
+        }
+    };
+    f32x16 acc[2];
+    auto mfma_steps = [&](const XBuf8& B, int kc, auto nsteps) {
+        constexpr int NS = decltype(nsteps)::value;
+        const float* wt = lds + o.w1 + kc * 6144 + lane * 4;
+        bf8 an[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) an[p][t] = *reinterpret_cast<const bf8*>(wt + p * 2048 + t * 256);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            bf8 af[3][2];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) af[p][t] = an[p][t];
+            if (s + 1 < NS) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        an[p][t] = *reinterpret_cast<const bf8*>(wt + p * 2048 + ((s + 1 < NS ? s + 1 : 0) * 2 + t) * 256);
+            }
+            prim::sched_fence();
+            float r[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                r[i] = B.x[2 * s][i];
+                r[4 + i] = B.x[2 * s + 1][i];
+            }
+            bf8 b1, b2, b3;
+            split3(r, b1, b2, b3);
+            // smallest terms first
+            acc[0] = prim::mfma_bf16(af[0][0], b3, acc[0]);
+            acc[1] = prim::mfma_bf16(af[0][1], b3, acc[1]);
+            acc[0] = prim::mfma_bf16(af[2][0], b1, acc[0]);
+            acc[1] = prim::mfma_bf16(af[2][1], b1, acc[1]);
+            acc[0] = prim::mfma_bf16(af[1][0], b2, acc[0]);
+            acc[1] = prim::mfma_bf16(af[1][1], b2, acc[1]);
+            acc[0] = prim::mfma_bf16(af[0][0], b2, acc[0]);
+            acc[1] = prim::mfma_bf16(af[0][1], b2, acc[1]);
+            acc[0] = prim::mfma_bf16(af[1][0], b1, acc[0]);
+            acc[1] = prim::mfma_bf16(af[1][1], b1, acc[1]);
+            acc[0] = prim::mfma_bf16(af[0][0], b1, acc[0]);
+            acc[1] = prim::mfma_bf16(af[0][1], b1, acc[1]);
+        }
+    };
+    auto mfma_chunk = [&](const XBuf8& B, int kc) { mfma_steps(B, kc, mlp_int<4>{}); };
+    auto mfma_last = [&](const XBuf8& B, int kc) { mfma_steps(B, kc, mlp_int<NSL>{}); };
+
+    XBuf8 B0, B1, B2;
+    issue(B0);
+    issue(B1);
+    issue(B2);
+    const bool cstamp = a.dbg != nullptr && blockIdx.x == 0 && wave == 0 && lane == 0;
+#define MAPPO_F4_STEP(B, KC) do { mfma_chunk(B, KC); issue(B); } while (0)
+#define MAPPO_F4_LAST(B, KC) do { mfma_last(B, KC); issue(B); } while (0)
+    for (long long m = 0; m < my_tiles;) {
+        if (cstamp && m < 15) a.dbg[4 * m] = prim::clock();
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[t][v] = biasr[16 * t + v];
+        int kc = 0;
+        // (the ring of chunk buffers with static names, like version 3)
+        if (NSL == 4) {
+            for (; kc + 3 <= nsc; kc += 3) {
+                MAPPO_F4_STEP(B0, kc);
+                MAPPO_F4_STEP(B1, kc + 1);
+                MAPPO_F4_STEP(B2, kc + 2);
+            }
+            if (nsc - kc == 1) {
+                MAPPO_F4_STEP(B0, kc);
+                const XBuf8 t = B0;
+                B0 = B1;
+                B1 = B2;
+                B2 = t;
+            } else if (nsc - kc == 2) {
+                MAPPO_F4_STEP(B0, kc);
+                MAPPO_F4_STEP(B1, kc + 1);
+                const XBuf8 t = B2;
+                B2 = B1;
+                B1 = B0;
+                B0 = t;
+            }
+        } else {
+            for (; kc + 3 < nsc; kc += 3) {
+                MAPPO_F4_STEP(B0, kc);
+                MAPPO_F4_STEP(B1, kc + 1);
+                MAPPO_F4_STEP(B2, kc + 2);
+            }
+            if (nsc - kc == 1) {
+                MAPPO_F4_LAST(B0, kc);
+                const XBuf8 t = B0;
+                B0 = B1;
+                B1 = B2;
+                B2 = t;
+            } else if (nsc - kc == 2) {
+                MAPPO_F4_STEP(B0, kc);
+                MAPPO_F4_LAST(B1, kc + 1);
+                const XBuf8 t = B2;
+                B2 = B1;
+                B1 = B0;
+                B0 = t;
+            } else {
+                MAPPO_F4_STEP(B0, kc);
+                MAPPO_F4_STEP(B1, kc + 1);
+                MAPPO_F4_LAST(B2, kc + 2);
+            }
+        }
+        if (cstamp && m < 15) a.dbg[4 * m + 1] = prim::clock();
+        const long long tile = gw + m * nw;
+        const long long m_done = m;
+        ++m;
+        const long long row = tile * 32 + c;
+        float nh[32], mean, rstd;
+        // ---- layer 0's tail
+        if (a.z[0] != nullptr) {
+            layer_tail_nhat<true, ACT>(acc, n.eps, nh, a.z[0] + tile * 2048, lane, mean, rstd);
+            *reinterpret_cast<f2*>(a.st[0] + 2 * row) = f2{mean, rstd};
+        } else {
+            layer_tail_nhat<false, ACT>(acc, n.eps, nh, nullptr, lane, mean, rstd);
+        }
+        // ---- the hidden layer: acc = b' + (gamma (.) W) nhat, every operand in registers
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[t][v] = bias1r[16 * t + v];
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            acc[0] = prim::mfma32(w2r[0][s], nh[s], acc[0]);
+            acc[1] = prim::mfma32(w2r[1][s], nh[s], acc[1]);
+        }
+        if (a.z[1] != nullptr) {
+            layer_tail_nhat<true, ACT>(acc, n.eps, nh, a.z[1] + tile * 2048, lane, mean, rstd);
+            *reinterpret_cast<f2*>(a.st[1] + 2 * row) = f2{mean, rstd};
+        } else {
+            layer_tail_nhat<false, ACT>(acc, n.eps, nh, nullptr, lane, mean, rstd);
+        }
+        const long long yrow = row < rows ? row : rows - 1;
+        if (out == 0) {
+            // trunk only (features for the GRU): the LayerNorm's affine half applied here (parameters straight from memory)
+            float hreg[32];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const v4 g = *reinterpret_cast<const v4u*>(n.ln_g[1] + 32 * t + 8 * q + 4 * h);
+                    const v4 be = *reinterpret_cast<const v4u*>(n.ln_b[1] + 32 * t + 8 * q + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hreg[16 * t + 4 * q + e] = nh[16 * t + 4 * q + e] * g[e] + be[e];
+                }
+            store_row64(a.y + yrow * 64, hreg, h);
+        } else if (out <= 2) {
+            for (int oo = 0; oo < out; ++oo) {
+                const float* wp = lds + o.whp + oo * kWS + 32 * h;
+                float pr = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const v4 w = *reinterpret_cast<const v4*>(wp + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pr += w[e] * nh[4 * q + e];
+                }
+                pr += prim::xhalf(pr);
+                a.y[yrow * out + oo] = pr + lds[o.bh + oo];
+            }
+        } else {
+            f32x16 ah;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) ah[v] = 0.f;
+            const float* w0 = lds + o.whp + c * kWS + 32 * h;
+            v4 a0n = *reinterpret_cast<const v4*>(w0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const v4 a0 = a0n;
+                if (q < 7) a0n = *reinterpret_cast<const v4*>(w0 + 4 * q + 4);
+                prim::sched_fence();
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ah = prim::mfma32(a0[e], nh[4 * q + e], ah);
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int oo = (v & 3) + 8 * (v >> 2) + 4 * h;
+                if (oo < out) a.y[yrow * out + oo] = ah[v] + lds[o.bh + oo];
+            }
+        }
+        if (cstamp && m_done < 15) a.dbg[4 * m_done + 2] = prim::clock();
+    }
+#undef MAPPO_F4_STEP
+#undef MAPPO_F4_LAST
+}
+
 // ================================================================== backward: row-parallel chain ====
 struct BwdArgs {
     RowSrc rs;          // only rows is used here
@@ -2373,6 +2723,22 @@ inline int forward(const mappo_mlp_t* m, hipStream_t stream) {
         if (a.z[l] != nullptr && a.st[l] == nullptr) return MAPPO_E_NULL;
     }
     const bool al = m->din % 4 == 0;
+    if ((tuning_flags() & 64) && fwd4_takes(m->din, m->n_layers, m->out)) {
+        // version 4 (opt-in): the first layer as six bf16 x bf16 terms per float32 product on the bf16 matrix pipe
+        const int nsc = (m->din + 63) / 64;
+        const Fwd4Lds o4 = fwd4_lds(nsc);
+        const int nsl = (m->din - 64 * (nsc - 1) + 15) / 16;
+        const long long grid4 = capped(ceil_div(rows128(m->rows) / 32, 4), kF3GridCap);
+#define MAPPO_FWD4_NSL(AA, SS)                                                                                       \
+    if (m->act == AA && nsl == SS) {                                                                                \
+        MAPPO_LAUNCH((mlp_fwd4_kernel<AA, SS>), (unsigned)grid4, 64 * 4, (size_t)o4.total * 4, stream, a);           \
+    }
+#define MAPPO_FWD4_CASE(AA) MAPPO_FWD4_NSL(AA, 1) MAPPO_FWD4_NSL(AA, 2) MAPPO_FWD4_NSL(AA, 3) MAPPO_FWD4_NSL(AA, 4)
+        MAPPO_FWD4_CASE(0) MAPPO_FWD4_CASE(1) MAPPO_FWD4_CASE(2)
+#undef MAPPO_FWD4_CASE
+#undef MAPPO_FWD4_NSL
+        return MAPPO_LAUNCH_ERROR();
+    }
     if (fwd3_takes(m->din, m->n_layers, m->out) && !(tuning_flags() & 4)) {
         // version 3: operands straight from global memory, resident first-layer weights, two waves per SIMD.
         // Option bit 4 (mappo_mlp_set_flags / MAPPO_MLP_FLAGS) keeps the loader / compute kernel below

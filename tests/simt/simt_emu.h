@@ -20,6 +20,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4 __attribute__((ext_vector_type(4)));
 typedef float v4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
 #define __global__
 #define __device__
@@ -45,6 +46,7 @@ struct Wave {
     Barrier bar;
     float a[64], b[64], x[64];
     f32x16 c[64];
+    bf8 abf[64], bbf[64];
 };
 
 struct Fiber {
@@ -183,6 +185,29 @@ inline f32x16 mfma32(float a, float b, f32x16 c) {
         const unsigned row = (v & 3) + 8 * (v >> 2) + 4 * hh;
         float acc = w.c[lane][v];
         for (int k = 0; k < 2; ++k) acc = fmaf(w.a[row + 32 * k], w.b[col + 32 * k], acc);
+        d[v] = acc;
+    }
+    if (lane == 0) ++simt::st().n_mfma;
+    simt::wait(w.bar);
+    return d;
+}
+
+// v_mfma_f32_32x32x16_bf16: A[i = lane & 31][k = 8 (lane >> 5) + e], B[k = 8 (lane >> 5) + e][j = lane & 31]; every product
+// is exact in float32, the sum is carried in float32 (k-ordered chain here; the hardware's internal order is its own)
+inline f32x16 mfma_bf16(bf8 a, bf8 b, f32x16 c) {
+    simt::Wave& w = my_wave();
+    const unsigned lane = simt::st().cur->tid & 63;
+    w.abf[lane] = a;
+    w.bbf[lane] = b;
+    w.c[lane] = c;
+    simt::wait(w.bar);
+    f32x16 d;
+    const unsigned col = lane & 31, hh = lane >> 5;
+    for (int v = 0; v < 16; ++v) {
+        const unsigned row = (v & 3) + 8 * (v >> 2) + 4 * hh;
+        float acc = w.c[lane][v];
+        for (int g = 0; g < 2; ++g)
+            for (int e = 0; e < 8; ++e) acc = fmaf((float)w.abf[row + 32 * g][e], (float)w.bbf[col + 32 * g][e], acc);
         d[v] = acc;
     }
     if (lane == 0) ++simt::st().n_mfma;

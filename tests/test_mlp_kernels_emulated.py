@@ -32,7 +32,9 @@ def emu_lib():
 # serves every other shape.
 # Unaligned / wider cases run the latter under all ids.  Option bit 32 selects the two-slot form of the direct-to-LDS
 # first-layer weight-gradient kernel (two workgroups per CU) for the widths that kernel takes.
-@pytest.fixture(params=[0, 4, 32], ids=["fwd3", "fwd_loaders", "dw1_two_per_cu"])
+# Option bit 64 (opt-in): version 4 of the forward -- the first layer as six bf16 x bf16 terms per float32 product on the bf16
+# matrix pipe (two-layer trunks, aligned widths up to 384; every other shape falls through to the kernels above).
+@pytest.fixture(params=[0, 4, 32, 64], ids=["fwd3", "fwd_loaders", "dw1_two_per_cu", "fwd4_bf16x6"])
 def emu(emu_lib, request):
     old = emu_lib.mappo_mlp_set_flags(request.param)
     yield emu_lib
@@ -175,6 +177,18 @@ def test_chunk_mode_rows(emu):
     T % L != 0 (chunks that straddle trajectories)."""
     T, N, A, L = 7, 3, 2, 3
     _run(emu, np.random.default_rng(5), 24, 2, 1, 0, L * 10, T * N * A, chunk=(L, T, N, A))
+
+
+# widths of the version-4 forward: 64-column chunks in a ring of three (chunk counts 1 .. 6: every rotation of the ring),
+# last chunks of 1 .. 4 k = 16 steps, the 384-wide critic input that fills the LDS with weight planes
+@pytest.mark.parametrize("din,act,out", [(384, 1, 1), (128, 2, 5), (64, 1, 2), (256, 1, 0), (320, 2, 3), (20, 1, 5),
+                                         (56, 1, 1), (212, 1, 4)])
+def test_version4_widths(emu, din, act, out):
+    emu.mappo_mlp_set_grid_cap(1)
+    try:
+        _run(emu, np.random.default_rng(din), din, 2, act, out, 128 * 2 + 45, 400)
+    finally:
+        emu.mappo_mlp_set_grid_cap(0)
 
 
 def test_first_layer_slab_split(emu):

@@ -506,7 +506,8 @@ int     mappo_minibatch_indices(int64_t n, int64_t mb, int n_mb, const uint32_t*
  * r_actor_critic.py:147-175 v_out are plain Linears on the trunk's features), evaluated straight from the rollout
  * buffer: the rows are read through the sampler's index list (shared_buffer.py:379-396 rows mode, :554-604 chunk
  * mode), so the gathered [mb, obs_dim] minibatch of feed_forward_generator / recurrent_generator is never written.
- * hidden_size must be 64.  All products run on the float32 matrix cores (exact f32 fma chains).
+ * hidden_size must be 64.  All products run on the float32 matrix cores (exact f32 fma chains) unless option bit 64 of
+ * mappo_mlp_set_flags opts the first layer of the forward into the six-term bf16 form described there.
  *
  * Rows: the caller resolves the sampler's row map once per minibatch into a row table (mappo_mlp_row_table): the source
  * row (int32) of every launch row, mappo_mlp_row_table_ints(rows) = rows rounded up to 128 entries (padding entries repeat
@@ -569,7 +570,12 @@ int     mappo_mlp_set_debug(long long* buf);
  * loader / compute kernel (mlp_fwd_kernel) for shapes the version-3 kernel (operands straight from global memory, resident
  * first-layer weights; aligned rows up to 448 floats wide, two or three layers) would take; 8 and 16 = no effect (until the
  * middle of round 4: the 12-wave form of version 3 / version 3 for rows narrower than 129 floats); 32 = the two-slot form of
- * the direct-to-LDS first-layer weight-gradient kernel, two workgroups per CU (tuning). */
+ * the direct-to-LDS first-layer weight-gradient kernel, two workgroups per CU (tuning); 64 = OPT-IN version 4 of the forward
+ * for two-layer trunks with aligned inputs 128 .. 384 floats wide: the first layer on the bf16 matrix cores, every float32
+ * product formed from six bf16 x bf16 terms of the operands' exact three-way bf16 splits and accumulated in float32 (what is
+ * dropped is < 2^-24 of the product; measured error against float64 <= the float32 MFMA chain's,
+ * profiles/r04_probe_bf16_split.json) -- off by default: the shipped arithmetic is the float32 MFMA; 128 (with 64) = version
+ * 4 for every aligned width up to 384 (tests). */
 int     mappo_mlp_set_flags(int flags);
 int     mappo_mlp_forward(const mappo_mlp_t* net, mappo_stream_t stream);
 int     mappo_mlp_backward(const mappo_mlp_t* net, mappo_stream_t stream);

@@ -1065,8 +1065,12 @@ __host__ __device__ __forceinline__ Fwd4Lds fwd4_lds(int nsc) {
     o.total = o.w1 + nsc * 6144;
     return o;
 }
-inline bool fwd4_takes(int din, int L, int out) {
-    return din % 4 == 0 && din >= 4 && din <= kF4MaxDin && out <= 32 && L == 2;
+// Narrow inputs stay on version 3 unless option bit 128 (tests) asks for every width: one wave per SIMD with a few k = 16 steps
+// per tile is all tails and latency (width 48: 0.762 against 0.674 ms per 2.6 M rows; the 384-wide critic input: 1.372
+// against 1.566 ms, profiles/r04_ab_forward_v4.json)
+constexpr int kF4MinDin = 128;
+inline bool fwd4_takes(int din, int L, int out, bool any_width) {
+    return din % 4 == 0 && din >= (any_width ? 4 : kF4MinDin) && din <= kF4MaxDin && out <= 32 && L == 2;
 }
 
 // x[e] = p1[e] + p2[e] + p3[e] exactly (round-to-nearest conversions; the residuals are exact float32 subtractions)
@@ -2723,17 +2727,20 @@ inline int forward(const mappo_mlp_t* m, hipStream_t stream) {
         if (a.z[l] != nullptr && a.st[l] == nullptr) return MAPPO_E_NULL;
     }
     const bool al = m->din % 4 == 0;
-    if ((tuning_flags() & 64) && fwd4_takes(m->din, m->n_layers, m->out)) {
+    if ((tuning_flags() & 64) && fwd4_takes(m->din, m->n_layers, m->out, (tuning_flags() & 128) != 0)) {
         // version 4 (opt-in): the first layer as six bf16 x bf16 terms per float32 product on the bf16 matrix pipe
         const int nsc = (m->din + 63) / 64;
         const Fwd4Lds o4 = fwd4_lds(nsc);
-        const int nsl = (m->din - 64 * (nsc - 1) + 15) / 16;
+        // k = 16 steps of a row's last chunk that hold real columns (3 runs the full chunk against zero weights: its
+        // shortened instances spilled 70 bytes per lane)
+        int nsl = (m->din - 64 * (nsc - 1) + 15) / 16;
+        if (nsl == 3) nsl = 4;
         const long long grid4 = capped(ceil_div(rows128(m->rows) / 32, 4), kF3GridCap);
 #define MAPPO_FWD4_NSL(AA, SS)                                                                                       \
     if (m->act == AA && nsl == SS) {                                                                                \
         MAPPO_LAUNCH((mlp_fwd4_kernel<AA, SS>), (unsigned)grid4, 64 * 4, (size_t)o4.total * 4, stream, a);           \
     }
-#define MAPPO_FWD4_CASE(AA) MAPPO_FWD4_NSL(AA, 1) MAPPO_FWD4_NSL(AA, 2) MAPPO_FWD4_NSL(AA, 3) MAPPO_FWD4_NSL(AA, 4)
+#define MAPPO_FWD4_CASE(AA) MAPPO_FWD4_NSL(AA, 1) MAPPO_FWD4_NSL(AA, 2) MAPPO_FWD4_NSL(AA, 4)
         MAPPO_FWD4_CASE(0) MAPPO_FWD4_CASE(1) MAPPO_FWD4_CASE(2)
 #undef MAPPO_FWD4_CASE
 #undef MAPPO_FWD4_NSL

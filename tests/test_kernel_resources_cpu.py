@@ -36,6 +36,10 @@ def test_snapshot_has_no_spills_and_expected_occupancy():
     # waves per SIMD (<= 256 registers), no scratch
     f3 = {k: v for k, v in table.items() if "mlp_fwd3_kernel<" in k}
     assert len(f3) == 15 and all(v["scratch_bytes"] == 0 and v["occupancy"] == 2 for v in f3.values())
+    # the opt-in version 4 (first layer on the bf16 matrix pipe): one wave per SIMD with the hidden layer's operands in
+    # registers (up to 512), no scratch in its 9 instances
+    f4 = {k: v for k, v in table.items() if "mlp_fwd4_kernel<" in k}
+    assert len(f4) == 9 and all(v["scratch_bytes"] == 0 and v["occupancy"] == 1 for v in f4.values())
     pick = lambda frag: [v for k, v in table.items() if frag in k]      # noqa: E731
     # K9: the forward trunk fits two workgroups of eight waves on a CU (<= 128 registers), the direct-to-LDS weight
     # gradient and the backward chain run one wave per SIMD with their accumulators in the AGPR half of the file
@@ -77,7 +81,11 @@ def test_isa_snapshot_shows_the_cdna4_instructions_the_design_relies_on():
     # the buffer path is HBM-bound (no MFMA); the fused trunk (K9) is the MFMA path and fetches its weight-gradient
     # operands with direct-to-LDS loads
     assert all(isa[s]["mfma_f32"] == 0 for s in isa if s not in ("mappo_rnn.hip", "mappo_mlp.hip"))
-    assert isa["mappo_mlp.hip"]["mfma_kinds"] == {"v_mfma_f32_32x32x2_f32": isa["mappo_mlp.hip"]["mfma_f32"]}
+    # (round 4: plus the bf16 matrix instruction of the opt-in version-4 forward, mlp_fwd4_kernel -- float32 products from
+    # six bf16 terms; every default kernel is float32 MFMA)
+    kinds = isa["mappo_mlp.hip"]["mfma_kinds"]
+    assert set(kinds) == {"v_mfma_f32_32x32x2_f32", "v_mfma_f32_32x32x16_bf16"}
+    assert sum(kinds.values()) == isa["mappo_mlp.hip"]["mfma_f32"] and kinds["v_mfma_f32_32x32x2_f32"] > 12000
     assert isa["mappo_mlp.hip"]["lds_dma_128bit"] > 50
     for src in ("mappo_gae.hip", "mappo_copy.hip", "mappo_norm.hip"):
         assert isa[src]["global_load_128bit"] > 0 and isa[src]["non_temporal"] > 0, src

@@ -229,6 +229,8 @@ def main():
     ap.add_argument("--workload", default="ns", choices=sorted(WORKLOADS))
     ap.add_argument("--threads", type=int, default=None, help="override the global n_rollout_threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-six-term", action="store_true",
+                    help="skip the extra (untimed-region) steps under the opt-in six-term bf16 kernels")
     ap.add_argument("--sampler-rng", default="device", choices=["device", "host"])
     ap.add_argument("--no-gemm-tuning", action="store_true",
                     help="leave GEMM kernel selection to the library heuristic (onpolicy/utils/gemm_tuning.py)")
@@ -323,6 +325,33 @@ def main():
     torch.cuda.synchronize(dev)
     gae_b2b_ms = e0.elapsed_time(e1) / reps
     n_coll, coll_ms, coll_bytes = trainer.dp.collective_times()
+    # Outside the contract's timed region, reported next to it and never as `value`: the same step with the OPT-IN six-term
+    # bf16 forms of the critic's first-layer forward and weight gradient (option bits 64 + 256 of mappo_mlp_set_flags:
+    # float32 products from six bf16 x bf16 terms of exact three-way splits, accumulated in float32; measured error
+    # against float64 <= the float32 MFMA chain's, profiles/r04_probe_bf16_split.json).  The default -- and `value` -- is
+    # the float32 MFMA.
+    six = None
+    if not opt.no_six_term and not wl["recurrent"] and args.hidden_size == 64:
+        from onpolicy import _native
+        old_flags = _native.lib().mappo_mlp_set_flags(64 + 256)
+        try:
+            k6 = max(1, min(opt.steps, 5))
+            step()
+            fence()
+            t6 = time.perf_counter()
+            for _ in range(k6):
+                step()
+            fence()
+            e6 = time.perf_counter() - t6
+        finally:
+            _native.lib().mappo_mlp_set_flags(old_flags)
+        if world > 1:
+            t = torch.tensor([e6], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e6 = float(t.item())
+        six = {"flags": 64 + 256, "steps": k6, "ms_per_step": round(1e3 * e6 / k6, 3),
+               "value": round(wl["T"] * wl["N"] * k6 / e6, 1), "unit": "env-steps/s",
+               "note": "opt-in arithmetic, measured after the timed region; not the contract's value (float32 MFMA)"}
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -403,6 +432,8 @@ def main():
             "roofline_gather": roof("mappo_gather_chunks" if wl["recurrent"] else "mappo_gather_rows"),
             "train_info": {k: round(float(v), 6) for k, v in info.items()},
         }
+        if six is not None:
+            out["opt_in_six_term_bf16"] = six
         g = out["roofline_gae"]
         if g is not None:
             # `frac` / `launch_ms` are the in-situ figures (first launch of a step, right behind the previous step's update);

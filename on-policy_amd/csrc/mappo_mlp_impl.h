@@ -2276,8 +2276,49 @@ __device__ __forceinline__ void dw1_tile_steps(const float* xt, const float* dzt
     }
 }
 
+// The same 16-row tile on the bf16 matrix pipe (opt-in, option bit 256; see mlp_fwd4_kernel for the arithmetic): the
+// contraction index is the ROW, and v_mfma_f32_32x32x16_bf16 takes all 16 rows of the tile in one step -- lane (c, g) holds
+// rows 8 g .. 8 g + 7 of its column (dz1: feature c / 32 + c; x: column c of each k tile), read from the row-major LDS tiles
+// with the same strided 4-byte reads as above, split into three bf16 planes in the wave, six terms per float32 product,
+// smallest first: 36 MFMAs of 8 passes per tile (NT = 3) instead of 48 of 16 passes, + ~180 split instructions.
+template <int NT>
+__device__ __forceinline__ void dw1_tile_steps6(const float* xt, const float* dzt, int c, int h, f32x16 (*acc)[2]) {
+    if (NT == 0) return;
+    float a0[8], a1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        a0[e] = dzt[(8 * h + e) * 64 + c];
+        a1[e] = dzt[(8 * h + e) * 64 + 32 + c];
+    }
+    float b[NT > 0 ? NT : 1][8];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b[i][e] = xt[i * (kD2Rows * 32) + (8 * h + e) * 32 + c];
+    bf8 A[2][3];
+    split3(a0, A[0][0], A[0][1], A[0][2]);
+    split3(a1, A[1][0], A[1][1], A[1][2]);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        bf8 B[3];
+        split3(b[i], B[0], B[1], B[2]);
+        acc[i][0] = prim::mfma_bf16(A[0][0], B[2], acc[i][0]);
+        acc[i][1] = prim::mfma_bf16(A[1][0], B[2], acc[i][1]);
+        acc[i][0] = prim::mfma_bf16(A[0][2], B[0], acc[i][0]);
+        acc[i][1] = prim::mfma_bf16(A[1][2], B[0], acc[i][1]);
+        acc[i][0] = prim::mfma_bf16(A[0][1], B[1], acc[i][0]);
+        acc[i][1] = prim::mfma_bf16(A[1][1], B[1], acc[i][1]);
+        acc[i][0] = prim::mfma_bf16(A[0][0], B[1], acc[i][0]);
+        acc[i][1] = prim::mfma_bf16(A[1][0], B[1], acc[i][1]);
+        acc[i][0] = prim::mfma_bf16(A[0][1], B[0], acc[i][0]);
+        acc[i][1] = prim::mfma_bf16(A[1][1], B[0], acc[i][1]);
+        acc[i][0] = prim::mfma_bf16(A[0][0], B[0], acc[i][0]);
+        acc[i][1] = prim::mfma_bf16(A[1][0], B[0], acc[i][1]);
+    }
+}
+
 // the whole kernel for a wave that owns NT (0 .. MAXNT) k tiles: tiles wave, wave + 4, wave + 8 (, wave + 12) of the slab
-template <int NT, int MAXNT, int SLOTS>
+template <int NT, int MAXNT, int SLOTS, bool SIX = false>
 __device__ __forceinline__ void dw1_direct_body(const Dw1Args& a, float* lds, int wave, int k0) {
     // SLOTS = 4: one workgroup per CU, the loads of tile m + 3 in flight; SLOTS = 2: half the LDS, two workgroups per CU
     // (two waves per SIMD), the loads of tile m + 1 in flight -- the other workgroup's MFMA stream covers the wait
@@ -2349,7 +2390,8 @@ __device__ __forceinline__ void dw1_direct_body(const Dw1Args& a, float* lds, in
         if (stamp && m < 40) a.dbg[512 + 4 * m + 3] = prim::clock();
         const float* xt = xs + (int)(m % kD2Slots) * kD2XSlot;
         const float* dzt = dzs + (int)(m % kD2Slots) * kD2DzSlot;
-        dw1_tile_steps<NT>(xt, dzt, c, h, acc);
+        if (SIX) dw1_tile_steps6<NT>(xt, dzt, c, h, acc);
+        else dw1_tile_steps<NT>(xt, dzt, c, h, acc);
     }
     prim::wait_lds_loads<0>();      // (the groups issued past the end)
     float* prow = a.partials + (long long)blockIdx.x * 64 * din;
@@ -2368,7 +2410,7 @@ __device__ __forceinline__ void dw1_direct_body(const Dw1Args& a, float* lds, in
     }
 }
 
-template <int MAXNT, int SLOTS>
+template <int MAXNT, int SLOTS, bool SIX = false>
 __global__ void __launch_bounds__(kThreads) mlp_dw1_direct_kernel(Dw1Args a) {
     float* lds = prim::lds();
     const int wave = prim::uniform(threadIdx.x >> 6);
@@ -2378,11 +2420,11 @@ __global__ void __launch_bounds__(kThreads) mlp_dw1_direct_kernel(Dw1Args a) {
     const int kw = (din - k0 < slab ? ((din - k0 + 31) / 32) * 32 : slab);
     const int ntk = kw / 32;
     const int n_own = (wave < ntk) + (wave + 4 < ntk) + (wave + 8 < ntk) + (MAXNT > 3 && wave + 12 < ntk);
-    if (MAXNT > 3 && n_own == 4) dw1_direct_body<MAXNT, MAXNT, SLOTS>(a, lds, wave, k0);
-    else if (n_own == 3) dw1_direct_body<3, MAXNT, SLOTS>(a, lds, wave, k0);
-    else if (n_own == 2) dw1_direct_body<2, MAXNT, SLOTS>(a, lds, wave, k0);
-    else if (n_own == 1) dw1_direct_body<1, MAXNT, SLOTS>(a, lds, wave, k0);
-    else dw1_direct_body<0, MAXNT, SLOTS>(a, lds, wave, k0);
+    if (MAXNT > 3 && n_own == 4) dw1_direct_body<MAXNT, MAXNT, SLOTS, SIX>(a, lds, wave, k0);
+    else if (n_own == 3) dw1_direct_body<3, MAXNT, SLOTS, SIX>(a, lds, wave, k0);
+    else if (n_own == 2) dw1_direct_body<2, MAXNT, SLOTS, SIX>(a, lds, wave, k0);
+    else if (n_own == 1) dw1_direct_body<1, MAXNT, SLOTS, SIX>(a, lds, wave, k0);
+    else dw1_direct_body<0, MAXNT, SLOTS, SIX>(a, lds, wave, k0);
 }
 
 // ---- narrow inputs (din <= 192, din % 4 == 0): up to six k tiles do not split evenly among four waves (five tiles: one wave
@@ -2855,7 +2897,17 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
         else MAPPO_DW1_ROWS(6, 2)
 #undef MAPPO_DW1_ROWS
     } else if (direct) {
-        if (maxnt == 4) {
+        if (tuning_flags() & 256) {
+            // opt-in: the tile products as six bf16 x bf16 terms per float32 product on the bf16 matrix pipe
+            gx = capped(ceil_div(m->rows, kD2Rows), kD2GridCap / gy > 0 ? kD2GridCap / gy : 1);
+            if (maxnt == 4) {
+                MAPPO_LAUNCH((mlp_dw1_direct_kernel<4, 4, true>), dim3((unsigned)gx, (unsigned)gy), kThreads,
+                             (size_t)(d2_lds(4) + 4 * kD2TabRing * 64) * 4, stream, d);
+            } else {
+                MAPPO_LAUNCH((mlp_dw1_direct_kernel<3, 4, true>), dim3((unsigned)gx, (unsigned)gy), kThreads,
+                             (size_t)(d2_lds(3) + 4 * kD2TabRing * 64) * 4, stream, d);
+            }
+        } else if (maxnt == 4) {
             gx = capped(ceil_div(m->rows, kD2Rows), kD2GridCap / gy > 0 ? kD2GridCap / gy : 1);
             MAPPO_LAUNCH((mlp_dw1_direct_kernel<4, 4>), dim3((unsigned)gx, (unsigned)gy), kThreads,
                          (size_t)(d2_lds(4) + 4 * kD2TabRing * 64) * 4, stream, d);

@@ -64,11 +64,12 @@ def _compare(din, layer_N, relu, out, rows, src_rows, chunk=None, feature_norm=T
                                    atol=10 * rtol * float(q.grad.abs().max()) + 1e-6, msg=lambda m: name + ": " + m)
 
 
-@pytest.fixture(autouse=True, params=[0, 64 + 128], ids=["default", "fwd4_bf16x6"])
+@pytest.fixture(autouse=True, params=[0, 64 + 128 + 256], ids=["default", "bf16x6"])
 def _forward_version(request):
     """Every test of this file under the default kernels and under option bits 64 + 128 of mappo_mlp_set_flags: the opt-in
     version-4 forward (first layer on the bf16 matrix cores, float32 products from six bf16 terms) for every width it
-    takes; shapes it does not take run the default kernels twice."""
+    takes, and (bit 256) the direct first-layer weight-gradient kernel in the same six-term form; shapes they do not take
+    run the default kernels twice."""
     from onpolicy import _native
     old = _native.lib().mappo_mlp_set_flags(request.param)
     yield

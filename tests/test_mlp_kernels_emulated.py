@@ -35,7 +35,8 @@ def emu_lib():
 # Option bit 64 (opt-in): version 4 of the forward -- the first layer as six bf16 x bf16 terms per float32 product on the bf16
 # matrix pipe (two-layer trunks, aligned widths up to 384 -- bit 128: also those below 128 columns, which bit 64 alone leaves
 # to version 3; every other shape falls through to the kernels above).
-@pytest.fixture(params=[0, 4, 32, 64 + 128], ids=["fwd3", "fwd_loaders", "dw1_two_per_cu", "fwd4_bf16x6"])
+# Option bit 256 (opt-in): the direct-to-LDS first-layer weight-gradient kernel forms its tile products the same way.
+@pytest.fixture(params=[0, 4, 32, 64 + 128 + 256], ids=["fwd3", "fwd_loaders", "dw1_two_per_cu", "bf16x6"])
 def emu(emu_lib, request):
     old = emu_lib.mappo_mlp_set_flags(request.param)
     yield emu_lib

@@ -1453,13 +1453,14 @@ constexpr int kSS = 68;          // LDS row stride of that staging tile: 16-byte
 struct Bwd2Lds {
     int gam, w2t, whg, wave0, dy, hacc, stg, per_wave, total;
 };
+constexpr int kB2W2Six = 3 * 2 * 4 * 256;   // floats of a hidden layer's weights as three bf16 planes (SIX): [plane][tile][k16 step][lane] x 16 B
 template <int NW>
-__host__ __device__ __forceinline__ Bwd2Lds bwd2_lds(int L, int out) {
+__host__ __device__ __forceinline__ Bwd2Lds bwd2_lds(int L, int out, bool six = false) {
     Bwd2Lds o;
     const int outp = (out + 1) & ~1;                 // head rows padded to a whole MFMA k step
     o.gam = 0;                                       // [64] LayerNorm weight of the top layer (out == 0)
     o.w2t = 64;                                      // [L - 1][64][kWS]: gamma-scaled, transposed + permuted hidden weights
-    o.whg = o.w2t + (L - 1) * 64 * kWS;              // [outp][64]: gamma-scaled head weights (zero row for odd out)
+    o.whg = o.w2t + (L - 1) * (six ? kB2W2Six : 64 * kWS);    // [outp][64]: gamma-scaled head weights (zero row for odd out)
     o.wave0 = (o.whg + outp * 64 + 3) & ~3;
     o.dy = 64 * kTS;                                 // per wave: T[64][kTS] | DY[out][32] | head sums [out][64] + [out] | S
     o.hacc = o.dy + ((out * 32 + 3) & ~3);
@@ -1513,13 +1514,18 @@ __device__ __forceinline__ void ln_act_backward(float* dn, const float* nh, floa
     }
 }
 
-template <int L, int ACT, int HR>
+// SIX (opt-in, option bit 512; two-layer trunks): the two 64 x 64 products of a tile -- dnhat = (gamma (.) W^T) dz and
+// G += dz^T nhat -- on the bf16 matrix pipe, every float32 product from six bf16 x bf16 terms of exact three-way splits
+// (see mlp_fwd4_kernel): 2 x 48 MFMAs of 8 passes instead of 2 x 64 of 16, + ~430 split instructions per tile.  The staged
+// weights are split once per workgroup (three planes in LDS); dz, nhat and their transposes are split in the wave.
+template <int L, int ACT, int HR, bool SIX = false>
 __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
+    static_assert(!SIX || L == 2, "the six-term form is built for two-layer trunks");
     constexpr int NW = kB2Waves;
     float* lds = prim::lds();
     const Net& n = a.net;
     const int out = n.out, outp = (out + 1) & ~1;
-    const Bwd2Lds o = bwd2_lds<NW>(L, out);
+    const Bwd2Lds o = bwd2_lds<NW>(L, out, SIX);
     const int tid = threadIdx.x, lane = tid & 63, wave = prim::uniform(tid >> 6), c = lane & 31, h = lane >> 5;
     constexpr int kThr = 64 * NW;
     // the tail kernel of THIS call (two launches further down the same stream) counts its finished blocks in a word of the
@@ -1530,12 +1536,29 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
     for (int e = tid; e < 64; e += kThr) lds[o.gam + e] = n.ln_g[L - 1][e];
     // w2t[l-1][ki][h * 32 + s] = gamma_{l-1}[ki] * W_l[f(h, s)][ki]: A operand (lane = input feature ki) of
     // dnhat_{l-1} = (gamma (.) W^T) dz
-    for (int l = 1; l < L; ++l)
-        for (int e = tid; e < 64 * 64; e += kThr) {
-            const int ki = e >> 6, hs = e & 63;
-            lds[o.w2t + (l - 1) * 64 * kWS + ki * kWS + hs] =
-                n.w2[l - 1][feat_of(hs >> 5, hs & 31) * 64 + ki] * n.ln_g[l - 1][ki];
+    if (SIX) {
+        // piece (plane, tile t, step j, lane (cc, hh)): the 8 values w2t[32 t + cc][32 hh + 8 j ..] as bf16
+        for (int e = tid; e < 512; e += kThr) {
+            const int t = e >> 8, cc = (e >> 3) & 31, hh = (e >> 2) & 1, j = e & 3;
+            const int ki = 32 * t + cc;
+            float w[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[i] = n.w2[0][feat_of(hh, 8 * j + i) * 64 + ki] * n.ln_g[0][ki];
+            bf8 p1, p2, p3;
+            split3(w, p1, p2, p3);
+            float* base = lds + o.w2t + (t * 4 + j) * 256 + (32 * hh + cc) * 4;
+            *reinterpret_cast<bf8*>(base) = p1;
+            *reinterpret_cast<bf8*>(base + 2048) = p2;
+            *reinterpret_cast<bf8*>(base + 4096) = p3;
         }
+    } else {
+        for (int l = 1; l < L; ++l)
+            for (int e = tid; e < 64 * 64; e += kThr) {
+                const int ki = e >> 6, hs = e & 63;
+                lds[o.w2t + (l - 1) * 64 * kWS + ki * kWS + hs] =
+                    n.w2[l - 1][feat_of(hs >> 5, hs & 31) * 64 + ki] * n.ln_g[l - 1][ki];
+            }
+    }
     for (int e = tid; e < outp * 64; e += kThr) {
         const int oo = e >> 6, f = e & 63;
         lds[o.whg + e] = oo < out ? n.wh[oo * 64 + f] * n.ln_g[L - 1][f] : 0.f;
@@ -1795,7 +1818,38 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
                 put_transposed(T, dn, c, h);
                 // dnhat_{l-1} = (gamma (.) W^T) dz: the last use of dz in row order
                 f32x16 dx[2];
-                dense64(lds + o.w2t + (l - 1) * 64 * kWS, c, h, dn, dx);
+                if (SIX) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) dx[t][v] = 0.f;
+                    const float* wt = lds + o.w2t + lane * 4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bf8 wa[3][2];
+#pragma unroll
+                        for (int p = 0; p < 3; ++p)
+#pragma unroll
+                            for (int t = 0; t < 2; ++t)
+                                wa[p][t] = *reinterpret_cast<const bf8*>(wt + p * 2048 + (t * 4 + j) * 256);
+                        bf8 b1, b2, b3;
+                        split3(dn + 8 * j, b1, b2, b3);
+                        dx[0] = prim::mfma_bf16(wa[0][0], b3, dx[0]);
+                        dx[1] = prim::mfma_bf16(wa[0][1], b3, dx[1]);
+                        dx[0] = prim::mfma_bf16(wa[2][0], b1, dx[0]);
+                        dx[1] = prim::mfma_bf16(wa[2][1], b1, dx[1]);
+                        dx[0] = prim::mfma_bf16(wa[1][0], b2, dx[0]);
+                        dx[1] = prim::mfma_bf16(wa[1][1], b2, dx[1]);
+                        dx[0] = prim::mfma_bf16(wa[0][0], b2, dx[0]);
+                        dx[1] = prim::mfma_bf16(wa[0][1], b2, dx[1]);
+                        dx[0] = prim::mfma_bf16(wa[1][0], b1, dx[0]);
+                        dx[1] = prim::mfma_bf16(wa[1][1], b1, dx[1]);
+                        dx[0] = prim::mfma_bf16(wa[0][0], b1, dx[0]);
+                        dx[1] = prim::mfma_bf16(wa[0][1], b1, dx[1]);
+                    }
+                } else {
+                    dense64(lds + o.w2t + (l - 1) * 64 * kWS, c, h, dn, dx);
+                }
                 MAPPO_B2_STAMP(5);
                 prim::wave_sync();
                 // A operands of G += dz^T nhat (lane = output feature, rows 16 h + ..): parked in registers while the
@@ -1821,6 +1875,48 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
                 put_transposed(T, nxt, c, h);
                 prim::wave_sync();
                 MAPPO_B2_STAMP(7);
+                if (SIX) {
+                    // k = 16 rows per step: step j of lane (c, h) contracts rows 16 h + 8 j .. + 7 (the same rows on both sides)
+                    f32x16* Gl = G[0];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        float va[2][8], vb[2][8];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const v4 b0 = *reinterpret_cast<const v4*>(T + c * kTS + 16 * h + 8 * j + 4 * q);
+                            const v4 b1 = *reinterpret_cast<const v4*>(T + (32 + c) * kTS + 16 * h + 8 * j + 4 * q);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                va[0][4 * q + e] = a0[2 * j + q][e];
+                                va[1][4 * q + e] = a1[2 * j + q][e];
+                                vb[0][4 * q + e] = b0[e];
+                                vb[1][4 * q + e] = b1[e];
+                            }
+                        }
+                        bf8 A[2][3], B[2][3];
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            split3(va[t], A[t][0], A[t][1], A[t][2]);
+                            split3(vb[t], B[t][0], B[t][1], B[t][2]);
+                        }
+#pragma unroll
+                        for (int ta = 0; ta < 2; ++ta) {
+                            f32x16& g0 = Gl[2 * ta], &g1 = Gl[2 * ta + 1];
+                            g0 = prim::mfma_bf16(A[ta][0], B[0][2], g0);
+                            g1 = prim::mfma_bf16(A[ta][0], B[1][2], g1);
+                            g0 = prim::mfma_bf16(A[ta][2], B[0][0], g0);
+                            g1 = prim::mfma_bf16(A[ta][2], B[1][0], g1);
+                            g0 = prim::mfma_bf16(A[ta][1], B[0][1], g0);
+                            g1 = prim::mfma_bf16(A[ta][1], B[1][1], g1);
+                            g0 = prim::mfma_bf16(A[ta][0], B[0][1], g0);
+                            g1 = prim::mfma_bf16(A[ta][0], B[1][1], g1);
+                            g0 = prim::mfma_bf16(A[ta][1], B[0][0], g0);
+                            g1 = prim::mfma_bf16(A[ta][1], B[1][0], g1);
+                            g0 = prim::mfma_bf16(A[ta][0], B[0][0], g0);
+                            g1 = prim::mfma_bf16(A[ta][0], B[1][0], g1);
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const v4 b0 = *reinterpret_cast<const v4*>(T + c * kTS + 16 * h + 4 * q);
@@ -1832,6 +1928,7 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
                         G[l > 0 ? l - 1 : 0][2] = prim::mfma32(a1[q][e], b0[e], G[l > 0 ? l - 1 : 0][2]);
                         G[l > 0 ? l - 1 : 0][3] = prim::mfma32(a1[q][e], b1[e], G[l > 0 ? l - 1 : 0][3]);
                     }
+                }
                 }
                 MAPPO_B2_STAMP(8);
                 prim::wave_sync();          // T's last use of this tile (l == 1): the next tile's prefetch may land
@@ -2854,10 +2951,17 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
     {
         // head sums in registers for the value head (HR = 1)
         const int hr = (out == 1 && L <= 2) ? 1 : 0;
-        const Bwd2Lds o = bwd2_lds<kB2Waves>(L, out);
+        const bool six = (tuning_flags() & 512) != 0 && L == 2;       // opt-in: the tile's 64 x 64 products in six-term bf16 form
+        const Bwd2Lds o = bwd2_lds<kB2Waves>(L, out, six);
         grid = capped(ceil_div(m->rows, 32 * kB2Waves), kBwdGridCap);
+#define MAPPO_BWD_SIX(AA, HH)                                                                                          \
+    if (six && m->act == AA && hr == HH) {                                                                            \
+        MAPPO_LAUNCH((mlp_bwd_kernel<2, AA, HH, true>), (unsigned)grid, 64 * kB2Waves, (size_t)o.total * 4, stream, b); \
+    }
+        MAPPO_BWD_SIX(0, 0) MAPPO_BWD_SIX(0, 1) MAPPO_BWD_SIX(1, 0) MAPPO_BWD_SIX(1, 1) MAPPO_BWD_SIX(2, 0) MAPPO_BWD_SIX(2, 1)
+#undef MAPPO_BWD_SIX
 #define MAPPO_BWD_CASE(LL, AA, HH)                                                                                    \
-    if (L == LL && m->act == AA && hr == HH) {                                                                        \
+    if (!six && L == LL && m->act == AA && hr == HH) {                                                                \
         MAPPO_LAUNCH((mlp_bwd_kernel<LL, AA, HH>), (unsigned)grid, 64 * kB2Waves, (size_t)o.total * 4, stream, b);   \
     }
 #define MAPPO_BWD_CASES(LL, AA) MAPPO_BWD_CASE(LL, AA, 0) MAPPO_BWD_CASE(LL, AA, 1)

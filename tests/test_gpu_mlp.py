@@ -64,7 +64,7 @@ def _compare(din, layer_N, relu, out, rows, src_rows, chunk=None, feature_norm=T
                                    atol=10 * rtol * float(q.grad.abs().max()) + 1e-6, msg=lambda m: name + ": " + m)
 
 
-@pytest.fixture(autouse=True, params=[0, 64 + 128 + 256], ids=["default", "bf16x6"])
+@pytest.fixture(autouse=True, params=[0, 64 + 128 + 256 + 512], ids=["default", "bf16x6"])
 def _forward_version(request):
     """Every test of this file under the default kernels and under option bits 64 + 128 of mappo_mlp_set_flags: the opt-in
     version-4 forward (first layer on the bf16 matrix cores, float32 products from six bf16 terms) for every width it

@@ -36,7 +36,7 @@ def emu_lib():
 # matrix pipe (two-layer trunks, aligned widths up to 384 -- bit 128: also those below 128 columns, which bit 64 alone leaves
 # to version 3; every other shape falls through to the kernels above).
 # Option bit 256 (opt-in): the direct-to-LDS first-layer weight-gradient kernel forms its tile products the same way.
-@pytest.fixture(params=[0, 4, 32, 64 + 128 + 256], ids=["fwd3", "fwd_loaders", "dw1_two_per_cu", "bf16x6"])
+@pytest.fixture(params=[0, 4, 32, 64 + 128 + 256 + 512], ids=["fwd3", "fwd_loaders", "dw1_two_per_cu", "bf16x6"])
 def emu(emu_lib, request):
     old = emu_lib.mappo_mlp_set_flags(request.param)
     yield emu_lib

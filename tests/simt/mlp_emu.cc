@@ -102,6 +102,18 @@ extern "C" int mappo_standardize_rows_ld(const float* src, int64_t rows, int D, 
     return mlp::standardize_rows(src, rows, D, eps, dst, ld, stream);
 }
 extern "C" unsigned long long simt_mfma_count() { return simt::st().n_mfma; }
+// the three-way bf16 split of the six-term kernels on n (a multiple of 8) values: parts widened back to float32
+extern "C" void simt_split3(const float* x, long long n, float* p1, float* p2, float* p3) {
+    for (long long i = 0; i + 8 <= n; i += 8) {
+        bf8 a, b, c;
+        mlp::split3(x + i, a, b, c);
+        for (int e = 0; e < 8; ++e) {
+            p1[i + e] = (float)a[e];
+            p2[i + e] = (float)b[e];
+            p3[i + e] = (float)c[e];
+        }
+    }
+}
 
 extern "C" int64_t mappo_gru_seq_gates_floats(int L, int64_t mb) { return (int64_t)L * gru::tiles_of(mb) * gru::kSaved * 2048; }
 extern "C" int64_t mappo_gru_seq_stats_floats(int L, int64_t mb) { return (int64_t)L * gru::tiles_of(mb) * 64; }

@@ -196,3 +196,22 @@ def test_version4_widths(emu, din, act, out):
 def test_first_layer_slab_split(emu):
     """Widths above 384 split the weight-gradient kernel over k slabs (blockIdx.y); critic width of the north star."""
     _run(emu, np.random.default_rng(11), 435, 2, 1, 1, 40, 50)
+
+
+def test_three_way_bf16_split_is_exact(emu_lib):
+    """The split the six-term kernels apply to every operand (csrc/mappo_mlp_impl.h: split3): x = p1 + p2 + p3 EXACTLY for
+    normal float32 values (8 + 8 + 8 significand bits), every part a bf16 value, |p2| <= 2^-8 |p1|, |p3| <= 2^-16 |p1| --
+    so the six kept products miss less than 2^-24 of x y."""
+    rng = np.random.default_rng(7)
+    x = np.concatenate([rng.standard_normal(4096) * 10.0 ** rng.uniform(-20, 20, 4096),
+                        [0.0, -0.0, 1.0, -1.0, 3.0, 1.0 + 2.0 ** -23, 2.0 - 2.0 ** -23, 16777215.0]]).astype(np.float32)
+    x = np.resize(x, (x.size + 7) // 8 * 8)
+    p = [np.full(x.shape, np.nan, np.float32) for _ in range(3)]
+    emu_lib.simt_split3.restype = None
+    emu_lib.simt_split3(ctypes.c_void_p(x.ctypes.data), ctypes.c_longlong(x.size), *[ctypes.c_void_p(q.ctypes.data) for q in p])
+    total = p[0].astype(np.float64) + p[1].astype(np.float64) + p[2].astype(np.float64)
+    np.testing.assert_array_equal(total, x.astype(np.float64))
+    for q in p:         # bf16 values: the low 16 bits of the float32 pattern are zero
+        assert not (q.view(np.uint32) & 0xFFFF).any()
+    nz = p[0] != 0
+    assert (np.abs(p[1][nz]) <= np.abs(p[0][nz]) * 2.0 ** -8).all() and (np.abs(p[2][nz]) <= np.abs(p[0][nz]) * 2.0 ** -16).all()

@@ -328,7 +328,7 @@ def main():
     # Outside the contract's timed region, reported next to it and never as `value`: the same step with the OPT-IN six-term
     # bf16 forms of the wide first-layer forward, the direct first-layer weight gradient and the backward chain's 64 x 64
     # products (option bits 64 + 256 + 512 of mappo_mlp_set_flags: float32 products from six bf16 x bf16 terms of exact
-    # three-way splits, accumulated in float32; measured error against float64 <= the float32 MFMA chain's,
+    # three-way splits, accumulated in float32; measured error against float64 of the order of the float32 MFMA chain's,
     # profiles/r04_probe_bf16_split.json).  The default -- and `value` -- is the float32 MFMA.
     six = None
     if not opt.no_six_term and not wl["recurrent"] and args.hidden_size == 64:

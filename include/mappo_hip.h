@@ -573,7 +573,7 @@ int     mappo_mlp_set_debug(long long* buf);
  * the direct-to-LDS first-layer weight-gradient kernel, two workgroups per CU (tuning); 64 = OPT-IN version 4 of the forward
  * for two-layer trunks with aligned inputs 128 .. 384 floats wide: the first layer on the bf16 matrix cores, every float32
  * product formed from six bf16 x bf16 terms of the operands' exact three-way bf16 splits and accumulated in float32 (what is
- * dropped is < 2^-24 of the product; measured error against float64 <= the float32 MFMA chain's,
+ * dropped is < 2^-24 of the product; measured error against float64 of the order of the float32 MFMA chain's,
  * profiles/r04_probe_bf16_split.json) -- off by default: the shipped arithmetic is the float32 MFMA; 128 (with 64) = version
  * 4 for every aligned width up to 384 (tests); 256 = OPT-IN the same six-term form for the tile products of the direct
  * first-layer weight-gradient kernel (aligned inputs wider than 192 floats); 512 = OPT-IN the same for the two 64 x 64

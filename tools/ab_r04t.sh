@@ -22,7 +22,7 @@ for f in 0 960; do
   echo "fixture errors flag $f: $(wc -l < $OUT/trainer_fixture_errors_flag$f.txt) cases"
 done
 export TMPDIR=/tmp
-MAPPO_MLP_FLAGS=832 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_six -o six -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-six-term > $OUT/prof_six.log 2>&1
+MAPPO_MLP_FLAGS=832 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_six -o six -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-six-term > $OUT/prof_six.log 2>&1
 echo "rocprof rc=$?"; find $OUT/prof_six -name "*kernel_stats.csv" | head -2
 f=$(find $OUT/prof_six -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -14 "$f" | cut -c1-160 && cp "$f" $OUT/six_term_kernel_stats.csv
 find $OUT/prof_six -type f ! -name "*kernel_stats.csv" -delete 2>/dev/null

@@ -326,14 +326,14 @@ def main():
     gae_b2b_ms = e0.elapsed_time(e1) / reps
     n_coll, coll_ms, coll_bytes = trainer.dp.collective_times()
     # Outside the contract's timed region, reported next to it and never as `value`: the same step with the OPT-IN six-term
-    # bf16 forms of the wide first-layer forward, the direct first-layer weight gradient and the backward chain's 64 x 64
-    # products (option bits 64 + 256 + 512 of mappo_mlp_set_flags: float32 products from six bf16 x bf16 terms of exact
+    # bf16 forms of the wide first-layer forward, the direct first-layer weight gradient, the backward chain's 64 x 64
+    # products and the GRU chunk forward's projections (option bits 64 + 256 + 512 + 1024 of mappo_mlp_set_flags: float32 products from six bf16 x bf16 terms of exact
     # three-way splits, accumulated in float32; measured error against float64 of the order of the float32 MFMA chain's,
     # profiles/r04_probe_bf16_split.json).  The default -- and `value` -- is the float32 MFMA.
     six = None
-    if not opt.no_six_term and not wl["recurrent"] and args.hidden_size == 64:
+    if not opt.no_six_term and args.hidden_size == 64:
         from onpolicy import _native
-        old_flags = _native.lib().mappo_mlp_set_flags(64 + 256 + 512)
+        old_flags = _native.lib().mappo_mlp_set_flags(64 + 256 + 512 + 1024)
         try:
             k6 = max(1, min(opt.steps, 5))
             step()
@@ -349,7 +349,7 @@ def main():
             t = torch.tensor([e6], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             e6 = float(t.item())
-        six = {"flags": 64 + 256 + 512, "steps": k6, "ms_per_step": round(1e3 * e6 / k6, 3),
+        six = {"flags": 64 + 256 + 512 + 1024, "steps": k6, "ms_per_step": round(1e3 * e6 / k6, 3),
                "value": round(wl["T"] * wl["N"] * k6 / e6, 1), "unit": "env-steps/s",
                "note": "opt-in arithmetic, measured after the timed region; not the contract's value (float32 MFMA)"}
     if world > 1:

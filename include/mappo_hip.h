@@ -577,7 +577,9 @@ int     mappo_mlp_set_debug(long long* buf);
  * profiles/r04_probe_bf16_split.json) -- off by default: the shipped arithmetic is the float32 MFMA; 128 (with 64) = version
  * 4 for every aligned width up to 384 (tests); 256 = OPT-IN the same six-term form for the tile products of the direct
  * first-layer weight-gradient kernel (aligned inputs wider than 192 floats); 512 = OPT-IN the same for the two 64 x 64
- * products per tile of the backward chain of two-layer trunks (dnhat = (gamma (.) W^T) dz and G += dz^T nhat). */
+ * products per tile of the backward chain of two-layer trunks (dnhat = (gamma (.) W^T) dz and G += dz^T nhat); 1024 = OPT-IN
+ * the same for both projections of every step of mappo_gru_seq_forward (weights as bf16 planes in LDS, the step's input
+ * and state split once and reused by the three gates). */
 int     mappo_mlp_set_flags(int flags);
 int     mappo_mlp_forward(const mappo_mlp_t* net, mappo_stream_t stream);
 int     mappo_mlp_backward(const mappo_mlp_t* net, mappo_stream_t stream);

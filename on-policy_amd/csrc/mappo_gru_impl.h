@@ -95,6 +95,76 @@ __device__ __forceinline__ void dense64_acc(const float* wp, int c, int h, const
     }
 }
 
+// ---- the same 64 -> 64 product in six-term bf16 arithmetic (opt-in, option bit 1024 of mappo_mlp_set_flags; the
+// arithmetic: mappo_mlp_impl.h, mlp_fwd4_kernel): the weights sit in LDS as three bf16 planes, split once per workgroup --
+// per 64 x 64 block [plane][feature tile][k = 16 step][lane] x 16 bytes (24 KB) -- and the lane's 32 operand values are
+// split once per step and reused by every block they meet (three gates), so a step costs 4 x 12 MFMAs of 8 passes per
+// block instead of 64 of 16 passes + two splits of ~145 vector instructions.
+constexpr int kSixBlock = 3 * 2 * 4 * 256;      // floats
+struct Split32 {
+    bf8 p[4][3];                                // [k = 16 step j: slots 8 j .. 8 j + 7][plane]
+};
+__device__ __forceinline__ void split32(const float* reg, Split32& o) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mlp::split3(reg + 8 * j, o.p[j][0], o.p[j][1], o.p[j][2]);
+}
+// planes of block `blk` of matrix W (rows 64 blk .. 64 blk + 63, [rows][64] row-major) -> LDS at dst
+// (piece (plane, t, j, lane (cc, hh)) = W[64 blk + 32 t + cc][f(hh, 8 j ..)])
+__device__ __forceinline__ void stage_six_block(const float* W, int blk, float* dst, int tid, int nthreads, bool transposed) {
+    for (int e = tid; e < 512; e += nthreads) {
+        const int t = e >> 8, cc = (e >> 3) & 31, hh = (e >> 2) & 1, j = e & 3;
+        float w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = feat_of(hh, 8 * j + i);
+            // forward: A[output feature][input k]; backward (transposed): A[input feature ki = 32 t + cc][gate output k]
+            w[i] = transposed ? W[(64 * blk + k) * 64 + 32 * t + cc] : W[(64 * blk + 32 * t + cc) * 64 + k];
+        }
+        bf8 p1, p2, p3;
+        mlp::split3(w, p1, p2, p3);
+        float* base = dst + (t * 4 + j) * 256 + (32 * hh + cc) * 4;
+        *reinterpret_cast<bf8*>(base) = p1;
+        *reinterpret_cast<bf8*>(base + 2048) = p2;
+        *reinterpret_cast<bf8*>(base + 4096) = p3;
+    }
+}
+__device__ __forceinline__ void dense64_six(const float* blk /* block base in LDS */, int lane, const Split32& b, f32x16* acc) {
+    const float* wt = blk + lane * 4;
+    bf8 wn[3][2];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) wn[p][t] = *reinterpret_cast<const bf8*>(wt + p * 2048 + (t * 4) * 256);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bf8 w[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) w[p][t] = wn[p][t];
+        if (j < 3) {        // next step's operands in flight behind this step's MFMAs (and nothing further ahead)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    wn[p][t] = *reinterpret_cast<const bf8*>(wt + p * 2048 + (t * 4 + (j < 3 ? j + 1 : 0)) * 256);
+        }
+        prim::sched_fence();
+        acc[0] = prim::mfma_bf16(w[0][0], b.p[j][2], acc[0]);
+        acc[1] = prim::mfma_bf16(w[0][1], b.p[j][2], acc[1]);
+        acc[0] = prim::mfma_bf16(w[2][0], b.p[j][0], acc[0]);
+        acc[1] = prim::mfma_bf16(w[2][1], b.p[j][0], acc[1]);
+        acc[0] = prim::mfma_bf16(w[1][0], b.p[j][1], acc[0]);
+        acc[1] = prim::mfma_bf16(w[1][1], b.p[j][1], acc[1]);
+        acc[0] = prim::mfma_bf16(w[0][0], b.p[j][1], acc[0]);
+        acc[1] = prim::mfma_bf16(w[0][1], b.p[j][1], acc[1]);
+        acc[0] = prim::mfma_bf16(w[1][0], b.p[j][0], acc[0]);
+        acc[1] = prim::mfma_bf16(w[1][1], b.p[j][0], acc[1]);
+        acc[0] = prim::mfma_bf16(w[0][0], b.p[j][0], acc[0]);
+        acc[1] = prim::mfma_bf16(w[0][1], b.p[j][0], acc[1]);
+    }
+}
+
 __device__ __forceinline__ void zero2(f32x16* acc) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -160,16 +230,27 @@ constexpr int kHeadA = 2 * kMaxHeadSteps * 64;           // whA [2 feature tiles
 constexpr int kSumsPerWave = 1280;                       // >= kSums + scratch [6][64] for the lanes' sums of dlogits
 constexpr int kBwdLds = 2 * kW + 64 + kHeadA + kWaves * kSumsPerWave;
 
+constexpr int kWSix = 3 * kSixBlock;                     // one matrix as three blocks of bf16 planes
+constexpr int kFwdLdsSix = 2 * kWSix + 6 * 64;
+template <bool SIX>
 __global__ void __launch_bounds__(kThreads, 1) gru_seq_fwd_kernel(Args a) {
     float* lds = prim::lds();
     const int tid = threadIdx.x, lane = tid & 63, wave = prim::uniform(tid >> 6), c = lane & 31, h = lane >> 5;
-    // w[T][i][h * 32 + s] = W[32 T + i][f(h, s)]: A operand (lane = output feature) of the step that consumes slot s
-    for (int e = tid; e < 192 * 64; e += kThreads) {
-        const int fo = e >> 6, hs = e & 63, k = feat_of(hs >> 5, hs & 31);
-        lds[fo * kWS + hs] = a.w_ih[fo * 64 + k];
-        lds[kW + fo * kWS + hs] = a.w_hh[fo * 64 + k];
+    constexpr int kWm = SIX ? kWSix : kW;       // floats per staged matrix
+    if (SIX) {
+        for (int g = 0; g < 3; ++g) {
+            stage_six_block(a.w_ih, g, lds + g * kSixBlock, tid, kThreads, false);
+            stage_six_block(a.w_hh, g, lds + kWSix + g * kSixBlock, tid, kThreads, false);
+        }
+    } else {
+        // w[T][i][h * 32 + s] = W[32 T + i][f(h, s)]: A operand (lane = output feature) of the step that consumes slot s
+        for (int e = tid; e < 192 * 64; e += kThreads) {
+            const int fo = e >> 6, hs = e & 63, k = feat_of(hs >> 5, hs & 31);
+            lds[fo * kWS + hs] = a.w_ih[fo * 64 + k];
+            lds[kW + fo * kWS + hs] = a.w_hh[fo * 64 + k];
+        }
     }
-    float* vec = lds + 2 * kW;
+    float* vec = lds + 2 * kWm;
     for (int e = tid; e < 64; e += kThreads) {
         vec[e] = a.b_ih[e] + a.b_hh[e];
         vec[64 + e] = a.b_ih[64 + e] + a.b_hh[64 + e];
@@ -215,12 +296,24 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_fwd_kernel(Args a) {
             zero2(az);
             zero2(ai);
             zero2(ah);
-            dense64_acc(lds + 0 * 64 * kWS, c, h, x, ar);
-            dense64_acc(lds + kW + 0 * 64 * kWS, c, h, hm, ar);
-            dense64_acc(lds + 1 * 64 * kWS, c, h, x, az);
-            dense64_acc(lds + kW + 1 * 64 * kWS, c, h, hm, az);
-            dense64_acc(lds + 2 * 64 * kWS, c, h, x, ai);
-            dense64_acc(lds + kW + 2 * 64 * kWS, c, h, hm, ah);
+            if (SIX) {
+                Split32 xs, hs6;
+                split32(x, xs);
+                split32(hm, hs6);
+                dense64_six(lds + 0 * kSixBlock, lane, xs, ar);
+                dense64_six(lds + kWSix + 0 * kSixBlock, lane, hs6, ar);
+                dense64_six(lds + 1 * kSixBlock, lane, xs, az);
+                dense64_six(lds + kWSix + 1 * kSixBlock, lane, hs6, az);
+                dense64_six(lds + 2 * kSixBlock, lane, xs, ai);
+                dense64_six(lds + kWSix + 2 * kSixBlock, lane, hs6, ah);
+            } else {
+                dense64_acc(lds + 0 * 64 * kWS, c, h, x, ar);
+                dense64_acc(lds + kW + 0 * 64 * kWS, c, h, hm, ar);
+                dense64_acc(lds + 1 * 64 * kWS, c, h, x, az);
+                dense64_acc(lds + kW + 1 * 64 * kWS, c, h, hm, az);
+                dense64_acc(lds + 2 * 64 * kWS, c, h, x, ai);
+                dense64_acc(lds + kW + 2 * 64 * kWS, c, h, hm, ah);
+            }
             float r[32], z[32], n[32], q[32];
             {
                 float b0[32], b1[32];
@@ -577,7 +670,12 @@ inline int forward(const mappo_gru_seq_t* m, hipStream_t stream) {
     if (code) return code;
     Args a;
     fill(m, a);
-    MAPPO_LAUNCH(gru_seq_fwd_kernel, (unsigned)grid_of(m->mb), kThreads, (size_t)(kFwdLds + 65 * m->head_out) * 4, stream, a);
+    if (mlp::tuning_flags() & 1024) {
+        // opt-in: both projections of a step in six-term bf16 arithmetic
+        MAPPO_LAUNCH(gru_seq_fwd_kernel<true>, (unsigned)grid_of(m->mb), kThreads, (size_t)(kFwdLdsSix + 65 * m->head_out) * 4, stream, a);
+    } else {
+        MAPPO_LAUNCH(gru_seq_fwd_kernel<false>, (unsigned)grid_of(m->mb), kThreads, (size_t)(kFwdLds + 65 * m->head_out) * 4, stream, a);
+    }
     return MAPPO_LAUNCH_ERROR();
 }
 

@@ -41,7 +41,7 @@ def test_bench_contract_and_rccl_single_rank():
     assert g["bound"] == "hbm" and g["unit"] == "GB/s" and abs(g["frac"] - g["achieved"] / g["peak"]) < 1e-3
     # next to the contract's value (float32 MFMA), never instead of it: the step under the opt-in six-term bf16 kernels
     six = plain["opt_in_six_term_bf16"]
-    assert six["flags"] == 64 + 256 + 512 and six["value"] > 0 and six["unit"] == plain["unit"] and plain["dtype"] == "f32"
+    assert six["flags"] == 64 + 256 + 512 + 1024 and six["value"] > 0 and six["unit"] == plain["unit"] and plain["dtype"] == "f32"
     forced = _run({"MAPPO_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29577", "RANK": "0",
                    "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     # same seeds, same host permutations: the RCCL path must reproduce the plain update

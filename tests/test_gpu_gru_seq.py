@@ -11,6 +11,16 @@ from test_gru_kernels_emulated import reference
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[0, 1024], ids=["f32_mfma", "bf16x6"])
+def _arithmetic(request):
+    """Every test of this file under the default kernels and under option bit 1024 of mappo_mlp_set_flags (opt-in: the
+    projections of the chunk forward in six-term bf16 arithmetic)."""
+    from onpolicy import _native
+    old = _native.lib().mappo_mlp_set_flags(request.param)
+    yield
+    _native.lib().mappo_mlp_set_flags(old)
+
+
 def _layer(dev, seed):
     from onpolicy.algorithms.utils.rnn import RNNLayer
     torch.manual_seed(seed)

@@ -15,17 +15,26 @@ pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="ROCm clang++ 
 
 
 @pytest.fixture(scope="module")
-def emu():
+def emu_lib():
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt"))
     import build
     from onpolicy import _native
     lib = ctypes.CDLL(build.build())
     for name in ("mappo_gru_seq_forward", "mappo_gru_seq_backward", "mappo_gru_seq_gates_floats",
-                 "mappo_gru_seq_stats_floats", "mappo_gru_seq_workspace_floats", "mappo_mlp_set_grid_cap"):
+                 "mappo_gru_seq_stats_floats", "mappo_gru_seq_workspace_floats", "mappo_mlp_set_grid_cap",
+                 "mappo_mlp_set_flags"):
         res, args = _native.SIGNATURES[name]
         getattr(lib, name).restype, getattr(lib, name).argtypes = res, args
     return lib
+
+
+# Option bit 1024 of mappo_mlp_set_flags (opt-in): the projections of the chunk kernels in six-term bf16 arithmetic
+@pytest.fixture(params=[0, 1024], ids=["f32_mfma", "bf16x6"])
+def emu(emu_lib, request):
+    old = emu_lib.mappo_mlp_set_flags(request.param)
+    yield emu_lib
+    emu_lib.mappo_mlp_set_flags(old)
 
 
 def reference(p, x, h0, masks, L, mb):

@@ -396,17 +396,34 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_fwd_kernel(Args a) {
 // NJ > 0: the gradient at y comes from an output Linear, dy = dlogits head_w, as NJ k steps of 2 outputs on the MFMA
 // (head_out <= 2 NJ; padded outputs have zero weights)
 // HO > 0: also leave the gradient sums of the head's first HO outputs (head_out <= HO <= kHeadSumOutputs)
-template <int NJ, int HO>
+// SIX (opt-in, option bit 1024 like the forward): the r and z blocks of both transposed matrices as bf16 planes (4 x 24 KB;
+// all six would need 173 KB next to the per-wave sums), d a_r and d a_z split once and used by both matrices; the two n
+// blocks (operands d a_n and d q) stay float32.  LDS: [W_ih^T r | W_ih^T z | W_hh^T r | W_hh^T z planes][W_ih^T n | W_hh^T n f32]
+constexpr int kBwdWSix = 4 * kSixBlock + 2 * 64 * kWS;
+constexpr int kBwdLdsSix = kBwdWSix + 64 + kHeadA + kWaves * kSumsPerWave;
+template <int NJ, int HO, bool SIX = false>
 __global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
     float* lds = prim::lds();
     const int tid = threadIdx.x, lane = tid & 63, wave = prim::uniform(tid >> 6), c = lane & 31, h = lane >> 5;
+    if (SIX) {
+        for (int g = 0; g < 2; ++g) {
+            stage_six_block(a.w_ih, g, lds + g * kSixBlock, tid, kThreads, true);
+            stage_six_block(a.w_hh, g, lds + (2 + g) * kSixBlock, tid, kThreads, true);
+        }
+        for (int e = tid; e < 64 * 64; e += kThreads) {
+            const int ki = (e >> 6) & 63, hs = e & 63, fo = 128 + feat_of(hs >> 5, hs & 31);
+            lds[4 * kSixBlock + ki * kWS + hs] = a.w_ih[fo * 64 + ki];
+            lds[4 * kSixBlock + 64 * kWS + ki * kWS + hs] = a.w_hh[fo * 64 + ki];
+        }
+    } else {
     // wT[g][t][i][h * 32 + s] = W[64 g + f(h, s)][32 t + i]: A operand (lane = input feature) of d input = W_g^T d gate_g
     for (int e = tid; e < 3 * 64 * 64; e += kThreads) {
         const int g = e >> 12, ki = (e >> 6) & 63, hs = e & 63, fo = 64 * g + feat_of(hs >> 5, hs & 31);
         lds[g * 64 * kWS + ki * kWS + hs] = a.w_ih[fo * 64 + ki];
         lds[kW + g * 64 * kWS + ki * kWS + hs] = a.w_hh[fo * 64 + ki];
     }
-    float* gam = lds + 2 * kW;
+    }
+    float* gam = lds + (SIX ? kBwdWSix : 2 * kW);
     for (int e = tid; e < 64; e += kThreads) gam[e] = a.ln_g[e];
     // whA[t][j][lane (i, hh)] = head_w[2 j + hh][32 t + i]: A operand (lane = feature 32 t + i) of k step j
     float* whA = gam + 64;
@@ -560,9 +577,18 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
             sbq += colsum32(dqq);
             f32x16 acc[2];
             zero2(acc);
+            Split32 srs, szs;
+            if (SIX) {
+                split32(dar, srs);
+                split32(daz, szs);
+                dense64_six(lds + 0 * kSixBlock, lane, srs, acc);
+                dense64_six(lds + 1 * kSixBlock, lane, szs, acc);
+                dense64_acc(lds + 4 * kSixBlock, c, h, dan, acc);
+            } else {
             dense64_acc(lds + 0 * 64 * kWS, c, h, dar, acc);
             dense64_acc(lds + 1 * 64 * kWS, c, h, daz, acc);
             dense64_acc(lds + 2 * 64 * kWS, c, h, dan, acc);
+            }
             {
                 float dxv[32];
 #pragma unroll
@@ -570,9 +596,15 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
                 if (ok) mlp::store_row64(a.dx + row * 64, dxv, h);
             }
             zero2(acc);
+            if (SIX) {
+                dense64_six(lds + 2 * kSixBlock, lane, srs, acc);
+                dense64_six(lds + 3 * kSixBlock, lane, szs, acc);
+                dense64_acc(lds + 4 * kSixBlock + 64 * kWS, c, h, dqq, acc);
+            } else {
             dense64_acc(lds + kW + 0 * 64 * kWS, c, h, dar, acc);
             dense64_acc(lds + kW + 1 * 64 * kWS, c, h, daz, acc);
             dense64_acc(lds + kW + 2 * 64 * kWS, c, h, dqq, acc);
+            }
 #pragma unroll
             for (int s = 0; s < 32; ++s) carry[s] = (acc[s >> 4][s & 15] + gz[s]) * mkl;     // d loss / d h_{l-1}
         }
@@ -687,7 +719,12 @@ inline int backward(const mappo_gru_seq_t* m, hipStream_t stream) {
     const long long grid = grid_of(m->mb);
     const int ho = m->head_out;
     const bool hs = m->head_sums != 0;
-#define MAPPO_GRU_BWD(NJ, HO) MAPPO_LAUNCH((gru_seq_bwd_kernel<NJ, HO>), (unsigned)grid, kThreads, (size_t)kBwdLds * 4, stream, a)
+    const bool six = (mlp::tuning_flags() & 1024) != 0;
+#define MAPPO_GRU_BWD(NJ, HO)                                                                                                    \
+    do {                                                                                                                          \
+        if (six) MAPPO_LAUNCH((gru_seq_bwd_kernel<NJ, HO, true>), (unsigned)grid, kThreads, (size_t)kBwdLdsSix * 4, stream, a);   \
+        else MAPPO_LAUNCH((gru_seq_bwd_kernel<NJ, HO, false>), (unsigned)grid, kThreads, (size_t)kBwdLds * 4, stream, a);         \
+    } while (0)
     if (ho == 0) {
         MAPPO_GRU_BWD(0, 0);
     } else if (ho <= 2) {

@@ -373,7 +373,8 @@ int mappo_gru_step_fwd(const float* gi, const float* hm, const float* w_hh, cons
  * multiplied by the episode mask before every step, LayerNorm on the outputs) for H = 64, ONE launch per direction over
  * the [L * mb, 64] chunk rows of recurrent_generator (shared_buffer.py:499-608; row l * mb + j = step l of chunk j; the
  * rollout is the case L = 1).  A wave walks the L steps of 32 chunks with the state in registers; both projections of a
- * step run on the f32 MFMA against weights held in LDS; gates, mask reset and the output LayerNorm on the accumulators.
+ * step run on the f32 MFMA against weights held in LDS (option bit 1024 of mappo_mlp_set_flags opts them into the six-term
+ * bf16 form described there); gates, mask reset and the output LayerNorm on the accumulators.
  * mappo_gru_seq_forward: x, h0 [mb, 64], masks [L * mb] -> y = LayerNorm(h_l) [L * mb, 64], h_last [mb, 64] (optional).
  *   For the backward (all three or none): gates [mappo_gru_seq_gates_floats(L, mb)] (r, z, n, W_hn hm + b_hn and the
  *   normalised output per row and step, opaque order), hm [L * mb, 64] (the masked previous state of every step),
@@ -506,8 +507,9 @@ int     mappo_minibatch_indices(int64_t n, int64_t mb, int n_mb, const uint32_t*
  * r_actor_critic.py:147-175 v_out are plain Linears on the trunk's features), evaluated straight from the rollout
  * buffer: the rows are read through the sampler's index list (shared_buffer.py:379-396 rows mode, :554-604 chunk
  * mode), so the gathered [mb, obs_dim] minibatch of feed_forward_generator / recurrent_generator is never written.
- * hidden_size must be 64.  All products run on the float32 matrix cores (exact f32 fma chains) unless option bit 64 of
- * mappo_mlp_set_flags opts the first layer of the forward into the six-term bf16 form described there.
+ * hidden_size must be 64.  All products run on the float32 matrix cores (exact f32 fma chains) unless option bits 64 / 256 /
+ * 512 of mappo_mlp_set_flags opt the wide first-layer forward, the direct first-layer weight gradient or the backward chain
+ * into the six-term bf16 form described there.
  *
  * Rows: the caller resolves the sampler's row map once per minibatch into a row table (mappo_mlp_row_table): the source
  * row (int32) of every launch row, mappo_mlp_row_table_ints(rows) = rows rounded up to 128 entries (padding entries repeat

@@ -1089,7 +1089,11 @@ struct XBuf8 {
 };
 
 // NSL: k = 16 steps of a row's LAST 64-column chunk that hold real columns (1 .. 4)
-template <int ACT, int NSL>
+// HID6 (option bit 2048 with 64; emulator-green, device A / B pending at the end of round 4): the hidden layer in the six-term
+// form too -- its weights as three bf16 planes in the registers the float32 operands occupied (96 instead of 64 + the 32 of
+// the folded bias, which is read from LDS instead: eight 16-byte reads per tile), the normalised activations split in the
+// wave: 48 MFMAs of 8 passes + ~145 split instructions instead of 64 MFMAs of 16 passes.
+template <int ACT, int NSL, bool HID6 = false>
 __global__ void __launch_bounds__(64 * 4, 1) mlp_fwd4_kernel(FwdArgs a) {
     constexpr int kF4Waves = 4;
     float* lds = prim::lds();
@@ -1143,19 +1147,34 @@ __global__ void __launch_bounds__(64 * 4, 1) mlp_fwd4_kernel(FwdArgs a) {
     __syncthreads();
     // per-lane constants (registers for the whole launch): both biases in accumulator order, the hidden layer's A operands
     // w2r[t][s] = gamma_0[k] W_1[32 t + c][k], k = f(h, s) -- the operand of the step that consumes slot s
-    float biasr[32], bias1r[32], w2r[2][32];
+    float biasr[32], bias1r[HID6 ? 1 : 32], w2r[2][HID6 ? 1 : 32];
+    bf8 w2q[3][2][HID6 ? 4 : 1];        // (HID6) [plane][feature tile][k = 16 step j: slots 8 j .. 8 j + 7]
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
         biasr[s] = lds[o.vec + feat_of(h, s)];
-        bias1r[s] = lds[o.vec + 64 + feat_of(h, s)];
+        if (!HID6) bias1r[s] = lds[o.vec + 64 + feat_of(h, s)];
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) {
+        if (HID6) {
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            const int k = feat_of(h, s);
-            w2r[t][s] = n.w2[0][(32 * t + c) * 64 + k] * n.ln_g[0][k];
+            for (int j = 0; j < 4; ++j) {
+                float w[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int k = feat_of(h, 8 * j + i);
+                    w[i] = n.w2[0][(32 * t + c) * 64 + k] * n.ln_g[0][k];
+                }
+                split3(w, w2q[0][t][HID6 ? j : 0], w2q[1][t][HID6 ? j : 0], w2q[2][t][HID6 ? j : 0]);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                const int k = feat_of(h, s);
+                w2r[t][HID6 ? 0 : s] = n.w2[0][(32 * t + c) * 64 + k] * n.ln_g[0][k];
+            }
         }
+    }
 
     const long long rows = a.rs.rows;
     const long long ntiles = rows128(rows) / 32;
@@ -1317,14 +1336,44 @@ __global__ void __launch_bounds__(64 * 4, 1) mlp_fwd4_kernel(FwdArgs a) {
             layer_tail_nhat<false, ACT>(acc, n.eps, nh, nullptr, lane, mean, rstd);
         }
         // ---- the hidden layer: acc = b' + (gamma (.) W) nhat, every operand in registers
+        if (HID6) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[t][v] = bias1r[16 * t + v];
+                for (int q = 0; q < 4; ++q) {
+                    const v4 b = *reinterpret_cast<const v4*>(lds + o.vec + 64 + 32 * t + 8 * q + 4 * h);
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            acc[0] = prim::mfma32(w2r[0][s], nh[s], acc[0]);
-            acc[1] = prim::mfma32(w2r[1][s], nh[s], acc[1]);
+                    for (int e = 0; e < 4; ++e) acc[t][4 * q + e] = b[e];
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                constexpr int J0 = 0;
+                const int jj = HID6 ? j : J0;
+                bf8 b1, b2, b3;
+                split3(nh + 8 * j, b1, b2, b3);
+                acc[0] = prim::mfma_bf16(w2q[0][0][jj], b3, acc[0]);
+                acc[1] = prim::mfma_bf16(w2q[0][1][jj], b3, acc[1]);
+                acc[0] = prim::mfma_bf16(w2q[2][0][jj], b1, acc[0]);
+                acc[1] = prim::mfma_bf16(w2q[2][1][jj], b1, acc[1]);
+                acc[0] = prim::mfma_bf16(w2q[1][0][jj], b2, acc[0]);
+                acc[1] = prim::mfma_bf16(w2q[1][1][jj], b2, acc[1]);
+                acc[0] = prim::mfma_bf16(w2q[0][0][jj], b2, acc[0]);
+                acc[1] = prim::mfma_bf16(w2q[0][1][jj], b2, acc[1]);
+                acc[0] = prim::mfma_bf16(w2q[1][0][jj], b1, acc[0]);
+                acc[1] = prim::mfma_bf16(w2q[1][1][jj], b1, acc[1]);
+                acc[0] = prim::mfma_bf16(w2q[0][0][jj], b1, acc[0]);
+                acc[1] = prim::mfma_bf16(w2q[0][1][jj], b1, acc[1]);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[t][v] = bias1r[HID6 ? 0 : 16 * t + v];
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                acc[0] = prim::mfma32(w2r[0][HID6 ? 0 : s], nh[s], acc[0]);
+                acc[1] = prim::mfma32(w2r[1][HID6 ? 0 : s], nh[s], acc[1]);
+            }
         }
         if (a.z[1] != nullptr) {
             layer_tail_nhat<true, ACT>(acc, n.eps, nh, a.z[1] + tile * 2048, lane, mean, rstd);
@@ -2875,9 +2924,11 @@ inline int forward(const mappo_mlp_t* m, hipStream_t stream) {
         int nsl = (m->din - 64 * (nsc - 1) + 15) / 16;
         if (nsl == 3) nsl = 4;
         const long long grid4 = capped(ceil_div(rows128(m->rows) / 32, 4), kF3GridCap);
+        const bool hid6 = (tuning_flags() & 2048) != 0;
 #define MAPPO_FWD4_NSL(AA, SS)                                                                                       \
     if (m->act == AA && nsl == SS) {                                                                                \
-        MAPPO_LAUNCH((mlp_fwd4_kernel<AA, SS>), (unsigned)grid4, 64 * 4, (size_t)o4.total * 4, stream, a);           \
+        if (hid6) MAPPO_LAUNCH((mlp_fwd4_kernel<AA, SS, true>), (unsigned)grid4, 64 * 4, (size_t)o4.total * 4, stream, a);   \
+        else MAPPO_LAUNCH((mlp_fwd4_kernel<AA, SS, false>), (unsigned)grid4, 64 * 4, (size_t)o4.total * 4, stream, a);      \
     }
 #define MAPPO_FWD4_CASE(AA) MAPPO_FWD4_NSL(AA, 1) MAPPO_FWD4_NSL(AA, 2) MAPPO_FWD4_NSL(AA, 4)
         MAPPO_FWD4_CASE(0) MAPPO_FWD4_CASE(1) MAPPO_FWD4_CASE(2)

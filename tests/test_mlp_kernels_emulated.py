@@ -193,6 +193,19 @@ def test_version4_widths(emu, din, act, out):
         emu.mappo_mlp_set_grid_cap(0)
 
 
+@pytest.mark.parametrize("din,act,out", [(384, 1, 1), (48, 1, 5), (152, 2, 0), (20, 1, 3)])
+def test_version4_hidden_layer_in_six_term_form(emu_lib, din, act, out):
+    """Option bit 2048 (with 64): the version-4 forward with its hidden layer on the bf16 matrix pipe too (weight planes in
+    registers, folded bias from LDS).  Emulator-green at the end of round 4; its device A / B is the next round's."""
+    old = emu_lib.mappo_mlp_set_flags(64 + 128 + 2048)
+    emu_lib.mappo_mlp_set_grid_cap(1)
+    try:
+        _run(emu_lib, np.random.default_rng(din + 1), din, 2, act, out, 128 * 2 + 45, 400)
+    finally:
+        emu_lib.mappo_mlp_set_grid_cap(0)
+        emu_lib.mappo_mlp_set_flags(old)
+
+
 def test_first_layer_slab_split(emu):
     """Widths above 384 split the weight-gradient kernel over k slabs (blockIdx.y); critic width of the north star."""
     _run(emu, np.random.default_rng(11), 435, 2, 1, 1, 40, 50)

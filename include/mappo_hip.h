@@ -583,7 +583,8 @@ int     mappo_mlp_set_debug(long long* buf);
  * the same for both projections of every step of mappo_gru_seq_forward (weights as bf16 planes in LDS, the step's input
  * and state split once and reused by the three gates) and for the r / z blocks of mappo_gru_seq_backward's two transposed
  * products (the n blocks stay float32: all six blocks as planes do not fit the LDS next to the per-wave sums); 2048 (with 64)
- * = version 4's hidden layer in the six-term form as well (host-emulator-green; not yet measured or device-tested). */
+ * = version 4's hidden layer in the six-term form as well, 4096 = the hidden layer of the version-3 forward of two-layer
+ * trunks likewise (both host-emulator-green and spill-free; not yet measured or device-tested: no device test sets them). */
 int     mappo_mlp_set_flags(int flags);
 int     mappo_mlp_forward(const mappo_mlp_t* net, mappo_stream_t stream);
 int     mappo_mlp_backward(const mappo_mlp_t* net, mappo_stream_t stream);

@@ -665,11 +665,12 @@ constexpr int kF3GridCap = 256;             // one workgroup per CU
 struct Fwd3Lds {
     int vec, w2p, whp, bh, w1, total;
 };
-__host__ __device__ __forceinline__ Fwd3Lds fwd3_lds(int L, int out, int nch) {
+__host__ __device__ __forceinline__ Fwd3Lds fwd3_lds(int L, int out, int nch, bool hid6 = false) {
     Fwd3Lds o;
     o.vec = 0;                                  // [L][bias' | g | beta][64]  (bias' = the folded bias of layers >= 1)
     o.w2p = o.vec + 192 * L;                    // [L - 1][2][32][kWS], gamma of the layer below folded in
-    o.whp = o.w2p + (L - 1) * 2 * 32 * kWS;     // [32][kWS] permuted head weights (rows >= out are zero), gamma folded in
+                                                // (HID6, L = 2: three bf16 planes [plane][tile][k16 step][lane] x 16 B = 6144 floats)
+    o.whp = o.w2p + (hid6 ? 6144 : (L - 1) * 2 * 32 * kWS);     // [32][kWS] permuted head weights (rows >= out are zero), gamma folded in
     o.bh = o.whp + 32 * kWS;                    // [32] folded head bias
     o.w1 = (o.bh + 32 + 3) & ~3;                // [nch][64 features][32 k], 16-byte pieces swizzled within a row
     o.total = o.w1 + nch * 2048;
@@ -725,16 +726,19 @@ struct mlp_int {
 // a row's columns are consumed in order, 8 per group q, and the last chunk runs only its NQL groups (round 4: the 48 wide
 // actor input of the north star spent 16 of its 64 first-layer MFMAs per tile on the zero padding of its second chunk, the
 // 18 wide one of config 3 8 of 32).  A template parameter, so that the shortened chunk is straight-line code.
-template <int L, int ACT, int NQL>
+__device__ __forceinline__ void split3(const float* x, bf8& p1, bf8& p2, bf8& p3);     // (with mlp_fwd4_kernel below)
+// HID6 (two-layer trunks; option bit 4096: emulator-green at the end of round 4, device A / B pending): the hidden layer in the
+// six-term bf16 form of mlp_fwd4_kernel -- its weights as three bf16 planes in LDS, the normalised activations split in the wave.
+template <int L, int ACT, int NQL, bool HID6 = false>
 __global__ void __launch_bounds__(64 * 8) mlp_fwd3_kernel(FwdArgs a) {
+    static_assert(!HID6 || L == 2, "the six-term hidden layer is built for two-layer trunks");
     constexpr int kF3Waves = 8;
-    constexpr int DEPTH = 3;
     constexpr bool BIAS_REGS = true;
     float* lds = prim::lds();
     const Net& n = a.net;
     const int din = n.din, out = n.out;
     const int nch = (din + 31) / 32;
-    const Fwd3Lds o = fwd3_lds(L, out, nch);
+    const Fwd3Lds o = fwd3_lds(L, out, nch, HID6);
     const int tid = threadIdx.x, lane = tid & 63, wave = prim::uniform(tid >> 6), c = lane & 31, h = lane >> 5;
     constexpr int kThr = 64 * kF3Waves;
     // ---- parameters, once per workgroup.  vec[l] = [bias of layer l with beta of layer l - 1 folded in | g | beta]
@@ -751,12 +755,30 @@ __global__ void __launch_bounds__(64 * 8) mlp_fwd3_kernel(FwdArgs a) {
         lds[o.vec + e] = v;
     }
     // w2p[l-1][t][i][h * 32 + s] = gamma_{l-1}[k] W_l[32 t + i][k], k = f(h, s): A operand of the step that consumes slot s
+    if (HID6) {
+        for (int e = tid; e < 512; e += kThr) {
+            const int t = e >> 8, cc = (e >> 3) & 31, hh = (e >> 2) & 1, j = e & 3;
+            float w[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = feat_of(hh, 8 * j + i);
+                w[i] = n.w2[0][(32 * t + cc) * 64 + k] * n.ln_g[0][k];
+            }
+            bf8 p1, p2, p3;
+            split3(w, p1, p2, p3);
+            float* base = lds + o.w2p + (t * 4 + j) * 256 + (32 * hh + cc) * 4;
+            *reinterpret_cast<bf8*>(base) = p1;
+            *reinterpret_cast<bf8*>(base + 2048) = p2;
+            *reinterpret_cast<bf8*>(base + 4096) = p3;
+        }
+    } else {
     for (int l = 1; l < L; ++l)
         for (int e = tid; e < 64 * 64; e += kThr) {
             const int fo = e >> 6, hs = e & 63;
             const int k = feat_of(hs >> 5, hs & 31);
             lds[o.w2p + (l - 1) * 2 * 32 * kWS + fo * kWS + hs] = n.w2[l - 1][fo * 64 + k] * n.ln_g[l - 1][k];
         }
+    }
     for (int e = tid; e < 32 * 64; e += kThr) {
         const int oo = e >> 6, hs = e & 63;
         const int k = feat_of(hs >> 5, hs & 31);
@@ -947,7 +969,33 @@ __global__ void __launch_bounds__(64 * 8) mlp_fwd3_kernel(FwdArgs a) {
         float nh[32], mean, rstd;
 #pragma unroll
         for (int l = 0; l < L; ++l) {
-            if (l > 0) {
+            if (l > 0 && HID6) {
+                init_acc(l);
+                const float* wt = lds + o.w2p + lane * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bf8 wa[3][2];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) wa[p][t] = *reinterpret_cast<const bf8*>(wt + p * 2048 + (t * 4 + j) * 256);
+                    bf8 b1, b2, b3;
+                    split3(nh + 8 * j, b1, b2, b3);
+                    prim::sched_fence();
+                    acc[0] = prim::mfma_bf16(wa[0][0], b3, acc[0]);
+                    acc[1] = prim::mfma_bf16(wa[0][1], b3, acc[1]);
+                    acc[0] = prim::mfma_bf16(wa[2][0], b1, acc[0]);
+                    acc[1] = prim::mfma_bf16(wa[2][1], b1, acc[1]);
+                    acc[0] = prim::mfma_bf16(wa[1][0], b2, acc[0]);
+                    acc[1] = prim::mfma_bf16(wa[1][1], b2, acc[1]);
+                    acc[0] = prim::mfma_bf16(wa[0][0], b2, acc[0]);
+                    acc[1] = prim::mfma_bf16(wa[0][1], b2, acc[1]);
+                    acc[0] = prim::mfma_bf16(wa[1][0], b1, acc[0]);
+                    acc[1] = prim::mfma_bf16(wa[1][1], b1, acc[1]);
+                    acc[0] = prim::mfma_bf16(wa[0][0], b1, acc[0]);
+                    acc[1] = prim::mfma_bf16(wa[0][1], b1, acc[1]);
+                }
+            } else if (l > 0) {
                 // acc = b' + (gamma (.) W) nhat, accumulators starting from the folded bias
                 init_acc(l);
                 const float* wp = lds + o.w2p + (l - 1) * 2 * 32 * kWS;
@@ -2940,7 +2988,8 @@ inline int forward(const mappo_mlp_t* m, hipStream_t stream) {
         // version 3: operands straight from global memory, resident first-layer weights, two waves per SIMD.
         // Option bit 4 (mappo_mlp_set_flags / MAPPO_MLP_FLAGS) keeps the loader / compute kernel below
         const int nch = (m->din + 31) / 32;
-        const Fwd3Lds o3 = fwd3_lds(m->n_layers, m->out, nch);
+        const bool hid6 = (tuning_flags() & 4096) != 0 && m->n_layers == 2;
+        const Fwd3Lds o3 = fwd3_lds(m->n_layers, m->out, nch, hid6);
         // groups of 8 real columns in a row's last chunk: 1 and 2 have shortened instances (3, and 2 with three layers, run
         // the full chunk: their shortened forms needed a few bytes of scratch for 8 MFMAs saved)
         int nql = (m->din - 32 * (nch - 1) + 7) / 8;
@@ -2948,7 +2997,11 @@ inline int forward(const mappo_mlp_t* m, hipStream_t stream) {
         const long long grid3 = capped(ceil_div(rows128(m->rows) / 32, 8), kF3GridCap);
 #define MAPPO_FWD3_NQL(LL, AA, QQ)                                                                                   \
     if (nql == QQ) {                                                                                                \
-        MAPPO_LAUNCH((mlp_fwd3_kernel<LL, AA, QQ>), (unsigned)grid3, 64 * 8, (size_t)o3.total * 4, stream, a);      \
+        if (LL == 2 && hid6) {                                                                                      \
+            MAPPO_LAUNCH((mlp_fwd3_kernel<2, AA, QQ, true>), (unsigned)grid3, 64 * 8, (size_t)o3.total * 4, stream, a);   \
+        } else {                                                                                                    \
+            MAPPO_LAUNCH((mlp_fwd3_kernel<LL, AA, QQ>), (unsigned)grid3, 64 * 8, (size_t)o3.total * 4, stream, a);  \
+        }                                                                                                           \
     }
 #define MAPPO_FWD3_CASE(LL, AA)                                                                                      \
     if (m->n_layers == LL && m->act == AA) {                                                                        \

@@ -35,7 +35,8 @@ def test_snapshot_has_no_spills_and_expected_occupancy():
     # round 4: the version-3 forward -- 15 instances (layers x activation x groups of 8 columns in a row's last chunk), two
     # waves per SIMD (<= 256 registers), no scratch
     f3 = {k: v for k, v in table.items() if "mlp_fwd3_kernel<" in k}
-    assert len(f3) == 15 and all(v["scratch_bytes"] == 0 and v["occupancy"] == 2 for v in f3.values())
+    # (+ 9 two-layer instances with the hidden layer in the six-term bf16 form: option bit 4096, device A / B pending)
+    assert len(f3) == 24 and all(v["scratch_bytes"] == 0 and v["occupancy"] == 2 for v in f3.values())
     # the opt-in version 4 (first layer on the bf16 matrix pipe): one wave per SIMD with the hidden layer's operands in
     # registers (up to 512), no scratch in its 9 instances (x 2: with the hidden layer in the six-term form too)
     f4 = {k: v for k, v in table.items() if "mlp_fwd4_kernel<" in k}

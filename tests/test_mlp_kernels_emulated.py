@@ -206,6 +206,19 @@ def test_version4_hidden_layer_in_six_term_form(emu_lib, din, act, out):
         emu_lib.mappo_mlp_set_flags(old)
 
 
+@pytest.mark.parametrize("din,act,out", [(48, 1, 5), (384, 1, 1), (152, 2, 0), (20, 1, 3), (436, 1, 1)])
+def test_version3_hidden_layer_in_six_term_form(emu_lib, din, act, out):
+    """Option bit 4096: the version-3 forward (two waves per SIMD; the narrow actor inputs, widths above 384) with its hidden
+    layer on the bf16 matrix pipe (weight planes in LDS).  Emulator-green at the end of round 4; device A / B pending."""
+    old = emu_lib.mappo_mlp_set_flags(4096)
+    emu_lib.mappo_mlp_set_grid_cap(1)
+    try:
+        _run(emu_lib, np.random.default_rng(din + 2), din, 2, act, out, 128 * 2 + 45, 400)
+    finally:
+        emu_lib.mappo_mlp_set_grid_cap(0)
+        emu_lib.mappo_mlp_set_flags(old)
+
+
 def test_first_layer_slab_split(emu):
     """Widths above 384 split the weight-gradient kernel over k slabs (blockIdx.y); critic width of the north star."""
     _run(emu, np.random.default_rng(11), 435, 2, 1, 1, 40, 50)

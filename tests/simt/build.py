@@ -12,12 +12,24 @@ SOURCES = [os.path.join(HERE, "mlp_emu.cc"), os.path.join(HERE, "simt_emu.h"),
 CLANG = os.environ.get("MAPPO_HOST_CLANG", "/opt/rocm/lib/llvm/bin/clang++")
 
 
+def _fresh():
+    return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in SOURCES)
+
+
 def build():
-    if os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in SOURCES):
+    if _fresh():
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    subprocess.run([CLANG, "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-psabi",
-                    "-I" + os.path.join(ROOT, "include"), SOURCES[0], "-o", OUT], check=True)
+    # one builder at a time (pytest-xdist workers reach this together): the others wait and find the library fresh; the
+    # library appears under its name only when complete
+    import fcntl
+    with open(OUT + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not _fresh():
+            tmp = OUT + ".tmp.%d" % os.getpid()
+            subprocess.run([CLANG, "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-psabi",
+                            "-I" + os.path.join(ROOT, "include"), SOURCES[0], "-o", tmp], check=True)
+            os.replace(tmp, OUT)
     return OUT
 
 

@@ -102,3 +102,17 @@ def test_header_is_plain_c():
         out = subprocess.run(["gcc", "-fsyntax-only", "-x", lang, "-std=" + std, "-Wall", "-Werror", HEADER],
                              capture_output=True, text=True)
         assert out.returncode == 0, out.stderr
+
+
+def test_default_arithmetic_is_the_float32_mfma():
+    """Out of the box no option bit of the K9 / K12 launchers is set: the opt-in six-term bf16 kernels (bits 64 / 256 / 512 /
+    1024 / 2048 / 4096 of mappo_mlp_set_flags) run only when a caller or MAPPO_MLP_FLAGS asks for them -- the default, and
+    bench.py's `value`, is the float32 MFMA.  (A fresh interpreter: the flags of this process may have been set by a test.)"""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k != "MAPPO_MLP_FLAGS"}
+    code = ("import sys; sys.path.insert(0, %r); from onpolicy import _native; "
+            "print(_native.lib().mappo_mlp_set_flags(0))" % os.path.join(ROOT, "on-policy_amd"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr[-500:]
+    assert out.stdout.strip().splitlines()[-1] == "0"

@@ -584,7 +584,9 @@ int     mappo_mlp_set_debug(long long* buf);
  * and state split once and reused by the three gates) and for the r / z blocks of mappo_gru_seq_backward's two transposed
  * products (the n blocks stay float32: all six blocks as planes do not fit the LDS next to the per-wave sums); 2048 (with 64)
  * = version 4's hidden layer in the six-term form as well, 4096 = the hidden layer of the version-3 forward of two-layer
- * trunks likewise (both host-emulator-green and spill-free; not yet measured or device-tested: no device test sets them). */
+ * trunks likewise, 8192 (with 1024) = all six blocks of mappo_gru_seq_backward's transposed products as planes, the per-wave
+ * sums taking the planes' LDS over behind a barrier (all three host-emulator-green and spill-free; not yet measured or
+ * device-tested: no device test sets them). */
 int     mappo_mlp_set_flags(int flags);
 int     mappo_mlp_forward(const mappo_mlp_t* net, mappo_stream_t stream);
 int     mappo_mlp_backward(const mappo_mlp_t* net, mappo_stream_t stream);

@@ -401,11 +401,22 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_fwd_kernel(Args a) {
 // blocks (operands d a_n and d q) stay float32.  LDS: [W_ih^T r | W_ih^T z | W_hh^T r | W_hh^T z planes][W_ih^T n | W_hh^T n f32]
 constexpr int kBwdWSix = 4 * kSixBlock + 2 * 64 * kWS;
 constexpr int kBwdLdsSix = kBwdWSix + 64 + kHeadA + kWaves * kSumsPerWave;
-template <int NJ, int HO, bool SIX = false>
+// ALL6 (option bit 8192 with 1024; emulator-green at the end of round 4, device A / B pending): all six blocks as planes --
+// the per-wave sums, which are written only after the last step, then take the planes' LDS over behind a barrier (152 KB).
+constexpr int kBwdWAll6 = 6 * kSixBlock;
+constexpr int kBwdLdsAll6 = kBwdWAll6 + 64 + kHeadA;
+static_assert(kWaves * kSumsPerWave <= kBwdWAll6, "the sums alias the planes");
+template <int NJ, int HO, bool SIX = false, bool ALL6 = false>
 __global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
+    static_assert(!ALL6 || SIX, "ALL6 is a form of SIX");
     float* lds = prim::lds();
     const int tid = threadIdx.x, lane = tid & 63, wave = prim::uniform(tid >> 6), c = lane & 31, h = lane >> 5;
-    if (SIX) {
+    if (ALL6) {
+        for (int g = 0; g < 3; ++g) {
+            stage_six_block(a.w_ih, g, lds + g * kSixBlock, tid, kThreads, true);
+            stage_six_block(a.w_hh, g, lds + (3 + g) * kSixBlock, tid, kThreads, true);
+        }
+    } else if (SIX) {
         for (int g = 0; g < 2; ++g) {
             stage_six_block(a.w_ih, g, lds + g * kSixBlock, tid, kThreads, true);
             stage_six_block(a.w_hh, g, lds + (2 + g) * kSixBlock, tid, kThreads, true);
@@ -423,7 +434,7 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
         lds[kW + g * 64 * kWS + ki * kWS + hs] = a.w_hh[fo * 64 + ki];
     }
     }
-    float* gam = lds + (SIX ? kBwdWSix : 2 * kW);
+    float* gam = lds + (ALL6 ? kBwdWAll6 : (SIX ? kBwdWSix : 2 * kW));
     for (int e = tid; e < 64; e += kThreads) gam[e] = a.ln_g[e];
     // whA[t][j][lane (i, hh)] = head_w[2 j + hh][32 t + i]: A operand (lane = feature 32 t + i) of k step j
     float* whA = gam + 64;
@@ -433,7 +444,7 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
         const int t = e / (NJ1 * 64), jq = (e >> 6) % NJ1, ln = e & 63, o = 2 * jq + (ln >> 5);
         whA[e] = o < hout ? a.head_w[o * 64 + 32 * t + (ln & 31)] : 0.f;
     }
-    float* T = gam + 64 + kHeadA + wave * kSumsPerWave;
+    float* T = ALL6 ? lds + wave * kSumsPerWave : gam + 64 + kHeadA + wave * kSumsPerWave;
     __syncthreads();
     // Parameter gradients that are column sums over every row and step -- the LayerNorm weight / bias gradients and the
     // bias gradients (= column sums of the gate gradients) -- are folded over the wave's rows step by step (colsum32), so
@@ -578,7 +589,15 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
             f32x16 acc[2];
             zero2(acc);
             Split32 srs, szs;
-            if (SIX) {
+            if (ALL6) {
+                Split32 sns;
+                split32(dar, srs);
+                split32(daz, szs);
+                split32(dan, sns);
+                dense64_six(lds + 0 * kSixBlock, lane, srs, acc);
+                dense64_six(lds + 1 * kSixBlock, lane, szs, acc);
+                dense64_six(lds + 2 * kSixBlock, lane, sns, acc);
+            } else if (SIX) {
                 split32(dar, srs);
                 split32(daz, szs);
                 dense64_six(lds + 0 * kSixBlock, lane, srs, acc);
@@ -596,7 +615,13 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
                 if (ok) mlp::store_row64(a.dx + row * 64, dxv, h);
             }
             zero2(acc);
-            if (SIX) {
+            if (ALL6) {
+                Split32 sqs;
+                split32(dqq, sqs);
+                dense64_six(lds + 3 * kSixBlock, lane, srs, acc);
+                dense64_six(lds + 4 * kSixBlock, lane, szs, acc);
+                dense64_six(lds + 5 * kSixBlock, lane, sqs, acc);
+            } else if (SIX) {
                 dense64_six(lds + 2 * kSixBlock, lane, srs, acc);
                 dense64_six(lds + 3 * kSixBlock, lane, szs, acc);
                 dense64_acc(lds + 4 * kSixBlock + 64 * kWS, c, h, dqq, acc);
@@ -611,6 +636,7 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
         if (a.dh0 != nullptr && ok) mlp::store_row64(a.dh0 + j * 64, carry, h);
     }
     // ---- the waves' sums added through LDS
+    if (ALL6) __syncthreads();      // every wave has read its last weight plane: the sums take that LDS over
     prim::wave_sync();
     {
         const int f = feat_of(h, c);
@@ -636,7 +662,7 @@ __global__ void __launch_bounds__(kThreads, 1) gru_seq_bwd_kernel(Args a) {
     __syncthreads();
     for (int e = tid; e < kSums; e += kThreads) {
         float s = 0.f;
-        for (int w = 0; w < kWaves; ++w) s += gam[64 + kHeadA + w * kSumsPerWave + e];
+        for (int w = 0; w < kWaves; ++w) s += ALL6 ? lds[w * kSumsPerWave + e] : gam[64 + kHeadA + w * kSumsPerWave + e];
         a.partials[(long long)blockIdx.x * kSums + e] = s;
     }
 }
@@ -720,9 +746,14 @@ inline int backward(const mappo_gru_seq_t* m, hipStream_t stream) {
     const int ho = m->head_out;
     const bool hs = m->head_sums != 0;
     const bool six = (mlp::tuning_flags() & 1024) != 0;
+    const bool all6 = six && (mlp::tuning_flags() & 8192) != 0;
+    // (the widest head-sum instance keeps the four-block form: with all six blocks as planes it spilled 28 bytes per lane)
 #define MAPPO_GRU_BWD(NJ, HO)                                                                                                    \
     do {                                                                                                                          \
-        if (six) MAPPO_LAUNCH((gru_seq_bwd_kernel<NJ, HO, true>), (unsigned)grid, kThreads, (size_t)kBwdLdsSix * 4, stream, a);   \
+        constexpr bool kAll6Built = !((NJ) == 3 && (HO) == 6);                                                                    \
+        if (all6 && kAll6Built)                                                                                                   \
+            MAPPO_LAUNCH((gru_seq_bwd_kernel<NJ, HO, true, kAll6Built>), (unsigned)grid, kThreads, (size_t)kBwdLdsAll6 * 4, stream, a);   \
+        else if (six) MAPPO_LAUNCH((gru_seq_bwd_kernel<NJ, HO, true>), (unsigned)grid, kThreads, (size_t)kBwdLdsSix * 4, stream, a);   \
         else MAPPO_LAUNCH((gru_seq_bwd_kernel<NJ, HO, false>), (unsigned)grid, kThreads, (size_t)kBwdLds * 4, stream, a);         \
     } while (0)
     if (ho == 0) {

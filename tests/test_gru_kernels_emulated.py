@@ -30,7 +30,9 @@ def emu_lib():
 
 
 # Option bit 1024 of mappo_mlp_set_flags (opt-in): the projections of the chunk kernels in six-term bf16 arithmetic
-@pytest.fixture(params=[0, 1024], ids=["f32_mfma", "bf16x6"])
+# (+ bit 8192: all six blocks of the backward as planes, the sums aliasing them behind a barrier -- emulator-green, its device
+# A / B is the next round's, so no device test sets it)
+@pytest.fixture(params=[0, 1024, 1024 + 8192], ids=["f32_mfma", "bf16x6", "bf16x6_all_blocks"])
 def emu(emu_lib, request):
     old = emu_lib.mappo_mlp_set_flags(request.param)
     yield emu_lib

@@ -53,7 +53,8 @@ def test_snapshot_has_no_spills_and_expected_occupancy():
     assert all(v["occupancy"] == 1 for v in pick("gru_seq_fwd_kernel") + pick("gru_seq_bwd_kernel"))
     # ... its nine backward instances: no head / head of <= 2, 6, 18 outputs x the head's gradient sums on or off (x 2: the
     # opt-in form with the r / z blocks of the transposed weights in six-term bf16 arithmetic, round 4)
-    assert len(pick("gru_seq_bwd_kernel")) == 18 and all(v["scratch_bytes"] == 0 for v in pick("gru_seq_bwd_kernel"))
+    # (+ 8 with all six blocks as planes, option bit 8192, device A / B pending; the ninth would spill and is not built)
+    assert len(pick("gru_seq_bwd_kernel")) == 26 and all(v["scratch_bytes"] == 0 for v in pick("gru_seq_bwd_kernel"))
     assert all(v["occupancy"] >= 7 for v in pick("ppo_loss_kernel"))
     assert all(v["occupancy"] >= 6 for v in pick("gru_fwd_kernel")) and all(v["occupancy"] == 8 for v in pick("gru_bwd_kernel"))
     (step,) = pick("gru_step_fwd_kernel")                                # one workgroup per CU by design: W_hh in LDS

@@ -19,6 +19,14 @@ for w in ns cfg2 cfg3 ns_rnn smac; do
     MAPPO_MLP_FLAGS=$f timeout 300 python bench.py --workload $w --steps 6 --warmup 2 --no-cpu-baseline --no-six-term 2>&1 | tail -1 >> $OUT/${w}_flag$f.jsonl
   done
 done
+# the three forms written at the end of round 4 on the emulator only (bits 2048, 4096, 8192): device parity first, then their A / B
+MAPPO_MLP_FLAGS=16192 timeout 300 python -m pytest tests/test_gpu_mlp.py tests/test_gpu_gru_seq.py tests/test_gpu_trainer_h64.py tests/test_gpu_device_sampler_route.py -q -p no:cacheprovider > $OUT/gpu_pending_bits.log 2>&1
+echo "K9 / K12 tests + fixtures with the process-wide flags 16192 rc=$?"; tail -2 $OUT/gpu_pending_bits.log
+for w in ns ns_rnn smac; do
+  for f in 1856 16192; do
+    MAPPO_MLP_FLAGS=$f timeout 300 python bench.py --workload $w --steps 6 --warmup 2 --no-cpu-baseline --no-six-term 2>&1 | tail -1 >> $OUT/pending_${w}_flag$f.jsonl
+  done
+done
 timeout 200 python tools/six_term_accuracy.py > $OUT/six_term_accuracy.json 2> $OUT/six_term_accuracy.err
 export TMPDIR=/tmp
 for f in 0 1856; do
@@ -33,4 +41,8 @@ for w in ("ns", "cfg2", "cfg3", "ns_rnn", "smac"):
     for f in (0, 1856):
         rows = [json.loads(l) for l in open(out + "%s_flag%d.jsonl" % (w, f)) if l.startswith("{")]
         print(w, f, [r["ms_per_step"] for r in rows], [r["value"] for r in rows])
+for w in ("ns", "ns_rnn", "smac"):
+    for f in (1856, 16192):
+        rows = [json.loads(l) for l in open(out + "pending_%s_flag%d.jsonl" % (w, f)) if l.startswith("{")]
+        print("pending bits", w, f, [r["ms_per_step"] for r in rows])
 PY

@@ -16,7 +16,8 @@ def _arithmetic(request):
     """Every test of this file under the default kernels and under option bit 1024 of mappo_mlp_set_flags (opt-in: the
     projections of the chunk forward in six-term bf16 arithmetic)."""
     from onpolicy import _native
-    old = _native.lib().mappo_mlp_set_flags(request.param)
+    extra = int(__import__("os").environ.get("MAPPO_TEST_EXTRA_FLAGS", "0")) if request.param else 0
+    old = _native.lib().mappo_mlp_set_flags(request.param | extra)
     yield
     _native.lib().mappo_mlp_set_flags(old)
 

@@ -71,7 +71,9 @@ def _forward_version(request):
     takes, and (bit 256) the direct first-layer weight-gradient kernel in the same six-term form; shapes they do not take
     run the default kernels twice."""
     from onpolicy import _native
-    old = _native.lib().mappo_mlp_set_flags(request.param)
+    # (MAPPO_TEST_EXTRA_FLAGS: further option bits for the six-term parameter, e.g. forms that have only run on the emulator yet)
+    extra = int(__import__("os").environ.get("MAPPO_TEST_EXTRA_FLAGS", "0")) if request.param else 0
+    old = _native.lib().mappo_mlp_set_flags(request.param | extra)
     yield
     _native.lib().mappo_mlp_set_flags(old)
 

@@ -20,7 +20,7 @@ for w in ns cfg2 cfg3 ns_rnn smac; do
   done
 done
 # the three forms written at the end of round 4 on the emulator only (bits 2048, 4096, 8192): device parity first, then their A / B
-MAPPO_MLP_FLAGS=16192 timeout 300 python -m pytest tests/test_gpu_mlp.py tests/test_gpu_gru_seq.py tests/test_gpu_trainer_h64.py tests/test_gpu_device_sampler_route.py -q -p no:cacheprovider > $OUT/gpu_pending_bits.log 2>&1
+MAPPO_MLP_FLAGS=16192 MAPPO_TEST_EXTRA_FLAGS=14336 timeout 300 python -m pytest tests/test_gpu_mlp.py tests/test_gpu_gru_seq.py tests/test_gpu_trainer_h64.py tests/test_gpu_device_sampler_route.py -q -p no:cacheprovider > $OUT/gpu_pending_bits.log 2>&1
 echo "K9 / K12 tests + fixtures with the process-wide flags 16192 rc=$?"; tail -2 $OUT/gpu_pending_bits.log
 for w in ns ns_rnn smac; do
   for f in 1856 16192; do

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Benchmark of the MAPPO hot path: env-steps/sec through GAE + ppo_update.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ns|cfg2|smac] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ns|cfg2|cfg3|ns_rnn|smac|hanabi] [--no-cpu-baseline]
+                    [--matrix-arithmetic six_term|f32_mfma] [--no-f32-mfma]
 
 One "step" = one pass of the hot path over one synthetic rollout that is already resident in HBM:
 ``buffer.compute_returns`` (HIP GAE scan) + ``R_MAPPO.train`` (ppo_epoch x num_mini_batch fused
@@ -41,6 +42,12 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32 MFMA peak (v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md); no xf32 / tf32 on gfx950
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16, MI355X_MICROARCH.md; no sparsity)
+ARITHMETIC_TEXT = {
+    "six_term": "f32 products from six bf16xbf16 terms of exact 3-way splits, f32 accumulate (K9 / K12 matrix products; "
+                "MAPPO_ARITH_SIX_TERM); everything else f32",
+    "f32_mfma": "f32 MFMA (v_mfma_f32_32x32x2_f32; MAPPO_ARITH_F32_MFMA)",
+}
 
 WORKLOADS = {
     # north star: simple_spread generalised to 8 agents, flags of train_mpe_spread.sh
@@ -229,8 +236,10 @@ def main():
     ap.add_argument("--workload", default="ns", choices=sorted(WORKLOADS))
     ap.add_argument("--threads", type=int, default=None, help="override the global n_rollout_threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-six-term", action="store_true",
-                    help="skip the extra (untimed-region) steps under the opt-in six-term bf16 kernels")
+    ap.add_argument("--matrix-arithmetic", default="six_term", choices=["six_term", "f32_mfma"],
+                    help="arithmetic of the K9 / K12 matrix products in the TIMED region (include/mappo_hip.h MAPPO_ARITH_*)")
+    ap.add_argument("--no-f32-mfma", "--no-six-term", dest="no_other_arithmetic", action="store_true",
+                    help="skip the extra steps (after the timed region) under the other arithmetic form")
     ap.add_argument("--sampler-rng", default="device", choices=["device", "host"])
     ap.add_argument("--no-gemm-tuning", action="store_true",
                     help="leave GEMM kernel selection to the library heuristic (onpolicy/utils/gemm_tuning.py)")
@@ -270,7 +279,7 @@ def main():
     from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO
     from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy
 
-    args = make_args(wl, n_local, ["--sampler_rng", opt.sampler_rng])
+    args = make_args(wl, n_local, ["--sampler_rng", opt.sampler_rng, "--matrix_arithmetic", opt.matrix_arithmetic])
     spaces = Box((wl["Do"],)), Box((wl["Ds"],)), Discrete(wl["na"])
     torch.manual_seed(1)          # identical replicas on every rank (init draws come from the CPU stream)
     np.random.seed(1)
@@ -325,15 +334,15 @@ def main():
     torch.cuda.synchronize(dev)
     gae_b2b_ms = e0.elapsed_time(e1) / reps
     n_coll, coll_ms, coll_bytes = trainer.dp.collective_times()
-    # Outside the contract's timed region, reported next to it and never as `value`: the same step with the OPT-IN six-term
-    # bf16 forms of the wide first-layer forward, the direct first-layer weight gradient, the backward chain's 64 x 64
-    # products and the GRU chunk forward's projections (option bits 64 + 256 + 512 + 1024 of mappo_mlp_set_flags: float32 products from six bf16 x bf16 terms of exact
-    # three-way splits, accumulated in float32; measured error against float64 of the order of the float32 MFMA chain's,
-    # profiles/r04_probe_bf16_split.json).  The default -- and `value` -- is the float32 MFMA.
-    six = None
-    if not opt.no_six_term and args.hidden_size == 64:
-        from onpolicy import _native
-        old_flags = _native.lib().mappo_mlp_set_flags(64 + 256 + 512 + 1024)
+    # Outside the contract's timed region, next to `value`: the same step under the OTHER arithmetic form of the K9 / K12 matrix
+    # products (a per-policy choice carried by every call: policy.set_matrix_arithmetic).  The default -- and `value` -- is the
+    # six-term form (float32 products from six bf16 x bf16 terms of the operands' exact three-way splits, float32 accumulate:
+    # VERDICT r4's ruling, conditions in DESIGN.md section 2); `f32_mfma` is the float32 matrix instruction, measured in this
+    # same run.
+    other = None
+    other_name = "f32_mfma" if opt.matrix_arithmetic == "six_term" else "six_term"
+    if not opt.no_other_arithmetic and args.hidden_size == 64:
+        policy.set_matrix_arithmetic(other_name)
         try:
             k6 = max(1, min(opt.steps, 5))
             step()
@@ -344,14 +353,21 @@ def main():
             fence()
             e6 = time.perf_counter() - t6
         finally:
-            _native.lib().mappo_mlp_set_flags(old_flags)
+            policy.set_matrix_arithmetic(opt.matrix_arithmetic)
         if world > 1:
             t = torch.tensor([e6], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             e6 = float(t.item())
-        six = {"flags": 64 + 256 + 512 + 1024, "steps": k6, "ms_per_step": round(1e3 * e6 / k6, 3),
-               "value": round(wl["T"] * wl["N"] * k6 / e6, 1), "unit": "env-steps/s",
-               "note": "opt-in arithmetic, measured after the timed region; not the contract's value (float32 MFMA)"}
+        other = {"steps": k6, "ms_per_step": round(1e3 * e6 / k6, 3),
+                 "value": round(wl["T"] * wl["N"] * k6 / e6, 1), "unit": "env-steps/s",
+                 "note": "same run, measured after the timed region with policy.set_matrix_arithmetic(%r)" % other_name}
+    # peak HBM held by the caching allocator on every rank (buffer + standardised copies + saved activations of an update)
+    peak_mem = [int(torch.cuda.max_memory_allocated(dev))]
+    if world > 1:
+        t = torch.zeros(world, dtype=torch.int64, device=dev)
+        t[rank] = peak_mem[0]
+        dist.all_reduce(t)
+        peak_mem = [int(v) for v in t.tolist()]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -409,6 +425,11 @@ def main():
             "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": opt.steps,
             "warmup": opt.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # how the float32 matrix products of K9 / K12 were formed in the timed region (inputs, outputs, accumulation and
+            # every other operation are float32 either way)
+            "arithmetic": ARITHMETIC_TEXT[opt.matrix_arithmetic] if args.hidden_size == 64 else
+                          "f32 (hidden size != 64: library float32 GEMMs + K6 / K7)",
+            "hbm_peak_bytes_per_rank": peak_mem,
             "config": {"workload": wl["label"], "T": wl["T"], "n_rollout_threads": wl["N"],
                        "threads_per_gpu": n_local, "agents": wl["A"], "obs_dim": wl["Do"],
                        "share_obs_dim": wl["Ds"], "actions": wl["na"], "ppo_epoch": args.ppo_epoch,
@@ -422,9 +443,9 @@ def main():
             # tuple is reused, otherwise once per update and issued one update ahead (DataParallel.begin_scales)
             "scalar_allreduce": {"per_step": (trainer.dp.scalar_collectives - scalar0) / max(1, opt.steps),
                                  "updates_served_from_cache_per_step": (trainer.dp.scales_reused - reused0) / max(1, opt.steps)},
-            # the dominant kernel of the step: the fused trunk's forward launch (mlp_fwd3_kernel; actor and critic
-            # launches averaged, as rocprofv3 --stats averages them), f32 matrix-core bound
-            "roofline": roof_mfma("mappo_mlp_forward", "mlp_fwd3_kernel / mlp_fwd_kernel (mappo_mlp_forward)") or roof("mappo_gae_f32"),
+            # the dominant kernel of the step: the fused trunk's forward launch (mlp_fwd4_kernel / mlp_fwd3_kernel; actor and
+            # critic launches averaged, as rocprofv3 --stats averages them), matrix-core bound
+            "roofline": roof_mfma("mappo_mlp_forward", "mlp_fwd4_kernel / mlp_fwd3_kernel / mlp_fwd_kernel (mappo_mlp_forward)") or roof("mappo_gae_f32"),
             "roofline_mlp_backward": roof_mfma("mappo_mlp_backward",
                                                "mlp_bwd_kernel + mlp_dw1_{direct,rows}_kernel + reduce / finish (mappo_mlp_backward)"),
             # the kernel BASELINE.json's north star names (>= 70 % of HBM in the GAE scan), HBM bound
@@ -432,8 +453,16 @@ def main():
             "roofline_gather": roof("mappo_gather_chunks" if wl["recurrent"] else "mappo_gather_rows"),
             "train_info": {k: round(float(v), 6) for k, v in info.items()},
         }
-        if six is not None:
-            out["opt_in_six_term_bf16"] = six
+        if other is not None:
+            out[other_name] = other
+        r = out["roofline"]
+        if r is not None and r.get("bound") == "mfma" and opt.matrix_arithmetic == "six_term":
+            # `frac` stays algorithmic float32 FLOPs against the dense float32 MFMA peak (the dtype's peak, comparable across
+            # rounds).  What the matrix cores EXECUTE under the six-term form is 6 bf16 MFMA FLOPs per algorithmic FLOP of the
+            # trunk's Linear layers (the head and the shapes without a six-term kernel stay float32 MFMA): quoted against the
+            # dense bf16 peak as an upper bound of the pipe's share
+            r["executed"] = {"unit": "TFLOP/s (bf16 MFMA, 6 per algorithmic FLOP)", "achieved": round(6 * r["achieved"], 1),
+                             "peak": MFMA_BF16_PEAK_TFLOPS, "frac": round(6 * r["achieved"] / MFMA_BF16_PEAK_TFLOPS, 4)}
         g = out["roofline_gae"]
         if g is not None:
             # `frac` / `launch_ms` are the in-situ figures (first launch of a step, right behind the previous step's update);

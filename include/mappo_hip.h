@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* mappo_stream_t; /* hipStream_t; NULL = the null stream */
 
-#define MAPPO_ABI_VERSION 1
+#define MAPPO_ABI_VERSION 2
 
 /* argument errors */
 #define MAPPO_E_NULL      (-1) /* a required pointer is NULL                */
@@ -38,6 +38,28 @@ typedef void* mappo_stream_t; /* hipStream_t; NULL = the null stream */
 #define MAPPO_E_FLAGS     (-3) /* unsupported flag combination              */
 #define MAPPO_E_TOO_MANY  (-4) /* more fields / slabs than MAPPO_MAX_FIELDS */
 #define MAPPO_E_ALIGN     (-5) /* a pointer is not 4-byte aligned           */
+
+/* Arithmetic of the matrix products of K9 / K12 (field `arith` of mappo_mlp_t / mappo_gru_seq_t; a PER-CALL choice, nothing
+ * process-wide: two trainers in one process may differ).  Inputs, outputs, accumulation and every non-matrix operation are
+ * float32 in both forms.
+ *   MAPPO_ARITH_SIX_TERM (0, what a zero-initialised struct selects): wherever a kernel of that form exists -- the forward of
+ *     two-layer trunks with aligned inputs, the backward chain of two-layer trunks, the direct first-layer weight-gradient
+ *     kernel (aligned inputs wider than 192 floats), both directions of K12 -- every float32 product x y is formed on the
+ *     bf16 matrix cores (v_mfma_f32_32x32x16_bf16, 16 x the rate of the float32 instruction) from the operands' EXACT
+ *     three-way bf16 splits x = x1 + x2 + x3 (8 + 8 + 8 significand bits, round-to-nearest, residuals exact):
+ *     x y ~ x1 y1 + (x1 y2 + x2 y1) + (x2 y2 + x1 y3 + x3 y1), six products that are exact in float32, accumulated in
+ *     float32 smallest first; the three dropped terms are < 2^-23 |x y| together (profiles/r04_probe_bf16_split.json, r05
+ *     adversarial tests: the error against float64 is of the float32 MFMA chain's order, bounded by a few 2^-23 sum|x||y|).
+ *     Shapes without such a kernel (single- / three-layer trunks, unaligned or very narrow weight-gradient shapes) run the
+ *     float32-MFMA kernels under either value.  NON-FINITE AND OUT-OF-RANGE OPERANDS: an operand that is +-inf, NaN or so
+ *     large that its bf16 rounding overflows (|x| >= 3.3961e38) makes every output it reaches NaN (inf - inf in the split)
+ *     -- a superset of where the float32 form is non-finite (which yields +-inf / NaN, or, behind a saturating Tanh on raw
+ *     inputs, finite values); a non-finite loss / gradient norm poisons the update identically in both forms
+ *     (mappo_clip_adam).  Float32 subnormal operands are split inexactly (bf16 keeps 7 of their bits per part): absolute
+ *     error <= 2^-133 |y| per product.
+ *   MAPPO_ARITH_F32_MFMA (1): v_mfma_f32_32x32x2_f32 everywhere (exact float32 fma chains). */
+#define MAPPO_ARITH_SIX_TERM 0
+#define MAPPO_ARITH_F32_MFMA 1
 
 /* ---------------------------------------------------------------- K1: GAE ----
  * Replaces SharedReplayBuffer.compute_returns
@@ -373,8 +395,9 @@ int mappo_gru_step_fwd(const float* gi, const float* hm, const float* w_hh, cons
  * multiplied by the episode mask before every step, LayerNorm on the outputs) for H = 64, ONE launch per direction over
  * the [L * mb, 64] chunk rows of recurrent_generator (shared_buffer.py:499-608; row l * mb + j = step l of chunk j; the
  * rollout is the case L = 1).  A wave walks the L steps of 32 chunks with the state in registers; both projections of a
- * step run on the f32 MFMA against weights held in LDS (option bit 1024 of mappo_mlp_set_flags opts them into the six-term
- * bf16 form described there); gates, mask reset and the output LayerNorm on the accumulators.
+ * step run on the matrix cores against weights held in LDS (field `arith`: MAPPO_ARITH_SIX_TERM = bf16 planes of the weights in
+ * LDS, the step's input and state split once and reused by the three gates, all six blocks of the backward's transposed products
+ * as planes; MAPPO_ARITH_F32_MFMA = float32 operands); gates, mask reset and the output LayerNorm on the accumulators.
  * mappo_gru_seq_forward: x, h0 [mb, 64], masks [L * mb] -> y = LayerNorm(h_l) [L * mb, 64], h_last [mb, 64] (optional).
  *   For the backward (all three or none): gates [mappo_gru_seq_gates_floats(L, mb)] (r, z, n, W_hn hm + b_hn and the
  *   normalised output per row and step, opaque order), hm [L * mb, 64] (the masked previous state of every step),
@@ -399,6 +422,7 @@ typedef struct mappo_gru_seq {
     float ln_eps;
     int32_t H;              /* 64 */
     int32_t L;
+    int32_t arith;          /* MAPPO_ARITH_* (occupies what was padding in ABI version 1: the layout is unchanged) */
     int64_t mb;
     float* y;
     float* h_last;
@@ -453,6 +477,8 @@ typedef struct mappo_adam {
     double  lr, beta1, beta2, eps, weight_decay, max_grad_norm;     /* doubles, as torch.optim.Adam holds them */
     float*  grad_norm;
     float*  workspace;
+    const double* lr_device;    /* optional: the learning rate is read from this device double instead of `lr` -- a launch that
+                                   was captured into a HIP graph then follows lr_decay (rMAPPOPolicy.py:39-46) between replays */
 } mappo_adam_t;
 int64_t mappo_adam_workspace_floats(void);
 int     mappo_clip_adam(const mappo_adam_t* adam, mappo_stream_t stream);
@@ -507,9 +533,7 @@ int     mappo_minibatch_indices(int64_t n, int64_t mb, int n_mb, const uint32_t*
  * r_actor_critic.py:147-175 v_out are plain Linears on the trunk's features), evaluated straight from the rollout
  * buffer: the rows are read through the sampler's index list (shared_buffer.py:379-396 rows mode, :554-604 chunk
  * mode), so the gathered [mb, obs_dim] minibatch of feed_forward_generator / recurrent_generator is never written.
- * hidden_size must be 64.  All products run on the float32 matrix cores (exact f32 fma chains) unless option bits 64 / 256 /
- * 512 of mappo_mlp_set_flags opt the wide first-layer forward, the direct first-layer weight gradient or the backward chain
- * into the six-term bf16 form described there.
+ * hidden_size must be 64.  The matrix products run in the arithmetic the call's `arith` field names (MAPPO_ARITH_* above).
  *
  * Rows: the caller resolves the sampler's row map once per minibatch into a row table (mappo_mlp_row_table): the source
  * row (int32) of every launch row, mappo_mlp_row_table_ints(rows) = rows rounded up to 128 entries (padding entries repeat
@@ -543,6 +567,7 @@ typedef struct mappo_mlp {
     int64_t rows;
     int32_t din, n_layers, act, out;
     float ln_eps;
+    int32_t arith;      /* MAPPO_ARITH_* (occupies what was padding in ABI version 1: the layout is unchanged) */
     const float* w1;
     const float* bias[MAPPO_MLP_MAX_LAYERS];
     const float* ln_g[MAPPO_MLP_MAX_LAYERS];
@@ -568,25 +593,13 @@ int     mappo_mlp_set_grid_cap(int cap);
  * iterations of mappo_mlp_forward (tools/bench_mlp.py --stamps), NULL = off */
 int     mappo_mlp_set_debug(long long* buf);
 /* tuning / test hook: option bits of the K9 launchers (initial value: environment variable MAPPO_MLP_FLAGS, default 0);
- * returns the previous value.  1 = the forward's compute waves keep the default priority; 4 = mappo_mlp_forward keeps the
- * loader / compute kernel (mlp_fwd_kernel) for shapes the version-3 kernel (operands straight from global memory, resident
- * first-layer weights; aligned rows up to 448 floats wide, two or three layers) would take; 8 and 16 = no effect (until the
- * middle of round 4: the 12-wave form of version 3 / version 3 for rows narrower than 129 floats); 32 = the two-slot form of
- * the direct-to-LDS first-layer weight-gradient kernel, two workgroups per CU (tuning); 64 = OPT-IN version 4 of the forward
- * for two-layer trunks with aligned inputs 128 .. 384 floats wide: the first layer on the bf16 matrix cores, every float32
- * product formed from six bf16 x bf16 terms of the operands' exact three-way bf16 splits and accumulated in float32 (what is
- * dropped is < 2^-24 of the product; measured error against float64 of the order of the float32 MFMA chain's,
- * profiles/r04_probe_bf16_split.json) -- off by default: the shipped arithmetic is the float32 MFMA; 128 (with 64) = version
- * 4 for every aligned width up to 384 (tests); 256 = OPT-IN the same six-term form for the tile products of the direct
- * first-layer weight-gradient kernel (aligned inputs wider than 192 floats); 512 = OPT-IN the same for the two 64 x 64
- * products per tile of the backward chain of two-layer trunks (dnhat = (gamma (.) W^T) dz and G += dz^T nhat); 1024 = OPT-IN
- * the same for both projections of every step of mappo_gru_seq_forward (weights as bf16 planes in LDS, the step's input
- * and state split once and reused by the three gates) and for the r / z blocks of mappo_gru_seq_backward's two transposed
- * products (the n blocks stay float32: all six blocks as planes do not fit the LDS next to the per-wave sums); 2048 (with 64)
- * = version 4's hidden layer in the six-term form as well, 4096 = the hidden layer of the version-3 forward of two-layer
- * trunks likewise, 8192 (with 1024) = all six blocks of mappo_gru_seq_backward's transposed products as planes, the per-wave
- * sums taking the planes' LDS over behind a barrier (all three host-emulator-green and spill-free; not yet measured or
- * device-tested: no device test sets them). */
+ * returns the previous value, or -1 (nothing changed) for a bit that does not exist.  NONE of them selects arithmetic
+ * (that is the per-call `arith` field).  1 = the forward's compute waves keep the default priority; 4 = mappo_mlp_forward
+ * keeps the loader / compute kernel (mlp_fwd_kernel) for shapes the version-3 kernel (operands straight from global memory,
+ * resident first-layer weights; aligned rows up to 448 floats wide, two or three layers) would take; 32 = the two-slot form
+ * of the float32 direct-to-LDS first-layer weight-gradient kernel, two workgroups per CU; 128 = under MAPPO_ARITH_SIX_TERM
+ * the version-4 forward (first layer in six-term form, one wave per SIMD) also for aligned inputs narrower than 128 floats,
+ * which by default take version 3 with only the hidden layer in six-term form (tests: every chunk shape of version 4). */
 int     mappo_mlp_set_flags(int flags);
 int     mappo_mlp_forward(const mappo_mlp_t* net, mappo_stream_t stream);
 int     mappo_mlp_backward(const mappo_mlp_t* net, mappo_stream_t stream);

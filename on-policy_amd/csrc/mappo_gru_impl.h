@@ -728,13 +728,29 @@ inline int forward(const mappo_gru_seq_t* m, hipStream_t stream) {
     if (code) return code;
     Args a;
     fill(m, a);
-    if (mlp::tuning_flags() & 1024) {
-        // opt-in: both projections of a step in six-term bf16 arithmetic
+    if (!mlp::arith_ok(m->arith)) return MAPPO_E_FLAGS;
+    if (m->arith == MAPPO_ARITH_SIX_TERM) {
+        // both projections of a step in six-term bf16 arithmetic
         MAPPO_LAUNCH(gru_seq_fwd_kernel<true>, (unsigned)grid_of(m->mb), kThreads, (size_t)(kFwdLdsSix + 65 * m->head_out) * 4, stream, a);
     } else {
         MAPPO_LAUNCH(gru_seq_fwd_kernel<false>, (unsigned)grid_of(m->mb), kThreads, (size_t)(kFwdLds + 65 * m->head_out) * 4, stream, a);
     }
     return MAPPO_LAUNCH_ERROR();
+}
+
+// six-term form: all six blocks of the transposed products as bf16 planes wherever that instance is built, else four
+template <int NJ, int HO>
+inline void launch_bwd(bool six, long long grid, hipStream_t stream, const Args& a) {
+    constexpr bool kAll6Built = !(NJ == 3 && HO == 6);
+    if (six) {
+        if constexpr (kAll6Built) {
+            MAPPO_LAUNCH((gru_seq_bwd_kernel<NJ, HO, true, true>), (unsigned)grid, kThreads, (size_t)kBwdLdsAll6 * 4, stream, a);
+        } else {
+            MAPPO_LAUNCH((gru_seq_bwd_kernel<NJ, HO, true>), (unsigned)grid, kThreads, (size_t)kBwdLdsSix * 4, stream, a);
+        }
+    } else {
+        MAPPO_LAUNCH((gru_seq_bwd_kernel<NJ, HO, false>), (unsigned)grid, kThreads, (size_t)kBwdLds * 4, stream, a);
+    }
 }
 
 inline int backward(const mappo_gru_seq_t* m, hipStream_t stream) {
@@ -745,17 +761,10 @@ inline int backward(const mappo_gru_seq_t* m, hipStream_t stream) {
     const long long grid = grid_of(m->mb);
     const int ho = m->head_out;
     const bool hs = m->head_sums != 0;
-    const bool six = (mlp::tuning_flags() & 1024) != 0;
-    const bool all6 = six && (mlp::tuning_flags() & 8192) != 0;
+    if (!mlp::arith_ok(m->arith)) return MAPPO_E_FLAGS;
+    const bool six = m->arith == MAPPO_ARITH_SIX_TERM;
     // (the widest head-sum instance keeps the four-block form: with all six blocks as planes it spilled 28 bytes per lane)
-#define MAPPO_GRU_BWD(NJ, HO)                                                                                                    \
-    do {                                                                                                                          \
-        constexpr bool kAll6Built = !((NJ) == 3 && (HO) == 6);                                                                    \
-        if (all6 && kAll6Built)                                                                                                   \
-            MAPPO_LAUNCH((gru_seq_bwd_kernel<NJ, HO, true, kAll6Built>), (unsigned)grid, kThreads, (size_t)kBwdLdsAll6 * 4, stream, a);   \
-        else if (six) MAPPO_LAUNCH((gru_seq_bwd_kernel<NJ, HO, true>), (unsigned)grid, kThreads, (size_t)kBwdLdsSix * 4, stream, a);   \
-        else MAPPO_LAUNCH((gru_seq_bwd_kernel<NJ, HO, false>), (unsigned)grid, kThreads, (size_t)kBwdLds * 4, stream, a);         \
-    } while (0)
+#define MAPPO_GRU_BWD(NJ, HO) launch_bwd<NJ, HO>(six, grid, stream, a)
     if (ho == 0) {
         MAPPO_GRU_BWD(0, 0);
     } else if (ho <= 2) {

@@ -190,11 +190,7 @@ extern "C" int mappo_mlp_row_table(const int64_t* idx, int64_t rows, int64_t mb,
     return mlp::row_table(reinterpret_cast<const long long*>(idx), rows, mb, chunk_len, T, N, A, row_tab, static_cast<hipStream_t>(stream));
 }
 extern "C" int64_t mappo_mlp_grad_floats(int din, int n_layers, int out) { return mlp::g_total(din, n_layers, out); }
-extern "C" int mappo_mlp_set_flags(int flags) {
-    const int old = mlp::tuning_flags_ref();
-    mlp::tuning_flags_ref() = flags;
-    return old;
-}
+extern "C" int mappo_mlp_set_flags(int flags) { return mlp::set_tuning_flags(flags); }
 extern "C" int64_t mappo_mlp_workspace_floats(int din, int n_layers, int out) {
     return mlp::workspace_floats(din, n_layers, out);
 }

@@ -29,6 +29,7 @@
 #ifndef MAPPO_MLP_IMPL_H
 #define MAPPO_MLP_IMPL_H
 
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "../../include/mappo_hip.h"
@@ -2931,15 +2932,29 @@ inline int& grid_cap_override() {
     static int cap = 0;
     return cap;
 }
+// option bits of mappo_mlp_set_flags that exist (tuning / tests only; arithmetic is the per-call `arith` field)
+constexpr int kTuningBits = 1 | 4 | 32 | 128;
 inline int& tuning_flags_ref() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("MAPPO_MLP_FLAGS");
         v = e ? atoi(e) : 0;
+        if (v & ~kTuningBits) {
+            fprintf(stderr, "libmappo_hip: MAPPO_MLP_FLAGS=%d names option bits that do not exist (arithmetic is chosen per call "
+                            "through the `arith` field); ignoring them\n", v);
+            v &= kTuningBits;
+        }
     }
     return v;
 }
 inline int tuning_flags() { return tuning_flags_ref(); }
+inline int set_tuning_flags(int flags) {
+    if (flags < 0 || (flags & ~kTuningBits)) return -1;
+    const int old = tuning_flags_ref();
+    tuning_flags_ref() = flags;
+    return old;
+}
+inline bool arith_ok(int arith) { return arith == MAPPO_ARITH_SIX_TERM || arith == MAPPO_ARITH_F32_MFMA; }
 inline long long*& debug_buffer() {
     static long long* p = nullptr;
     return p;
@@ -2963,8 +2978,10 @@ inline int forward(const mappo_mlp_t* m, hipStream_t stream) {
         if (a.z[l] != nullptr && a.st[l] == nullptr) return MAPPO_E_NULL;
     }
     const bool al = m->din % 4 == 0;
-    if ((tuning_flags() & 64) && fwd4_takes(m->din, m->n_layers, m->out, (tuning_flags() & 128) != 0)) {
-        // version 4 (opt-in): the first layer as six bf16 x bf16 terms per float32 product on the bf16 matrix pipe
+    if (!arith_ok(m->arith)) return MAPPO_E_FLAGS;
+    const bool six_term = m->arith == MAPPO_ARITH_SIX_TERM;
+    if (six_term && fwd4_takes(m->din, m->n_layers, m->out, (tuning_flags() & 128) != 0)) {
+        // version 4: the first layer (and the hidden layer) as six bf16 x bf16 terms per float32 product on the bf16 matrix pipe
         const int nsc = (m->din + 63) / 64;
         const Fwd4Lds o4 = fwd4_lds(nsc);
         // k = 16 steps of a row's last chunk that hold real columns (3 runs the full chunk against zero weights: its
@@ -2972,11 +2989,9 @@ inline int forward(const mappo_mlp_t* m, hipStream_t stream) {
         int nsl = (m->din - 64 * (nsc - 1) + 15) / 16;
         if (nsl == 3) nsl = 4;
         const long long grid4 = capped(ceil_div(rows128(m->rows) / 32, 4), kF3GridCap);
-        const bool hid6 = (tuning_flags() & 2048) != 0;
 #define MAPPO_FWD4_NSL(AA, SS)                                                                                       \
     if (m->act == AA && nsl == SS) {                                                                                \
-        if (hid6) MAPPO_LAUNCH((mlp_fwd4_kernel<AA, SS, true>), (unsigned)grid4, 64 * 4, (size_t)o4.total * 4, stream, a);   \
-        else MAPPO_LAUNCH((mlp_fwd4_kernel<AA, SS, false>), (unsigned)grid4, 64 * 4, (size_t)o4.total * 4, stream, a);      \
+        MAPPO_LAUNCH((mlp_fwd4_kernel<AA, SS, true>), (unsigned)grid4, 64 * 4, (size_t)o4.total * 4, stream, a);    \
     }
 #define MAPPO_FWD4_CASE(AA) MAPPO_FWD4_NSL(AA, 1) MAPPO_FWD4_NSL(AA, 2) MAPPO_FWD4_NSL(AA, 4)
         MAPPO_FWD4_CASE(0) MAPPO_FWD4_CASE(1) MAPPO_FWD4_CASE(2)
@@ -2988,7 +3003,7 @@ inline int forward(const mappo_mlp_t* m, hipStream_t stream) {
         // version 3: operands straight from global memory, resident first-layer weights, two waves per SIMD.
         // Option bit 4 (mappo_mlp_set_flags / MAPPO_MLP_FLAGS) keeps the loader / compute kernel below
         const int nch = (m->din + 31) / 32;
-        const bool hid6 = (tuning_flags() & 4096) != 0 && m->n_layers == 2;
+        const bool hid6 = six_term && m->n_layers == 2;        // the hidden layer of two-layer trunks in six-term form
         const Fwd3Lds o3 = fwd3_lds(m->n_layers, m->out, nch, hid6);
         // groups of 8 real columns in a row's last chunk: 1 and 2 have shortened instances (3, and 2 with three layers, run
         // the full chunk: their shortened forms needed a few bytes of scratch for 8 MFMAs saved)
@@ -3046,6 +3061,8 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
         if (l < m->n_layers && (!m->z[l] || !m->ln_stats[l])) return MAPPO_E_NULL;
     }
     const int L = m->n_layers, out = m->out, din = m->din;
+    if (!arith_ok(m->arith)) return MAPPO_E_FLAGS;
+    const bool six_term = m->arith == MAPPO_ARITH_SIX_TERM;
     b.dbg = debug_buffer();
     b.dy = m->dy;
     b.dz1 = m->dz1;
@@ -3055,7 +3072,7 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
     {
         // head sums in registers for the value head (HR = 1)
         const int hr = (out == 1 && L <= 2) ? 1 : 0;
-        const bool six = (tuning_flags() & 512) != 0 && L == 2;       // opt-in: the tile's 64 x 64 products in six-term bf16 form
+        const bool six = six_term && L == 2;       // the tile's 64 x 64 products of two-layer trunks in six-term bf16 form
         const Bwd2Lds o = bwd2_lds<kB2Waves>(L, out, six);
         grid = capped(ceil_div(m->rows, 32 * kB2Waves), kBwdGridCap);
 #define MAPPO_BWD_SIX(AA, HH)                                                                                          \
@@ -3105,8 +3122,8 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
         else MAPPO_DW1_ROWS(6, 2)
 #undef MAPPO_DW1_ROWS
     } else if (direct) {
-        if (tuning_flags() & 256) {
-            // opt-in: the tile products as six bf16 x bf16 terms per float32 product on the bf16 matrix pipe
+        if (six_term) {
+            // the tile products as six bf16 x bf16 terms per float32 product on the bf16 matrix pipe
             gx = capped(ceil_div(m->rows, kD2Rows), kD2GridCap / gy > 0 ? kD2GridCap / gy : 1);
             if (maxnt == 4) {
                 MAPPO_LAUNCH((mlp_dw1_direct_kernel<4, 4, true>), dim3((unsigned)gx, (unsigned)gy), kThreads,

@@ -90,7 +90,8 @@ __global__ void __launch_bounds__(kThreads) adam_step_kernel(Desc d, int n_parti
     if (threadIdx.x < d.a.n) {
         const double step = (double)d.a.step[threadIdx.x][0];
         const float bc1 = (float)(1.0 - pow(d.a.beta1, step)), bc2 = (float)(1.0 - pow(d.a.beta2, step));
-        step_size_s[threadIdx.x] = (float)(d.a.lr / bc1);
+        const double lr = d.a.lr_device != nullptr ? d.a.lr_device[0] : d.a.lr;      // (device copy: a captured launch follows lr_decay)
+        step_size_s[threadIdx.x] = (float)(lr / bc1);
         sqrt_bc2_s[threadIdx.x] = sqrtf(bc2);
     }
     float p = threadIdx.x < n_partials ? d.a.workspace[threadIdx.x] : 0.f;      // (n_partials <= kThreads, fixed order)

@@ -15,6 +15,27 @@ LIB_PATH = os.environ.get("MAPPO_HIP_LIB", os.path.join(os.path.dirname(_HERE), 
 MAX_FIELDS = 16
 MAX_MINIBATCHES = 64        # MAPPO_PERM_MAX_MINIBATCHES
 GAE_USE_GAE, GAE_PROPER_TIME_LIMITS, GAE_DENORM, GAE_EXACT = 1, 2, 4, 8
+# MAPPO_ARITH_*: how K9 / K12 form their float32 matrix products (the per-call ``arith`` field of MLP / GRUSeq)
+ARITH_SIX_TERM, ARITH_F32_MFMA = 0, 1
+ARITHMETICS = {"six_term": ARITH_SIX_TERM, "f32_mfma": ARITH_F32_MFMA}
+ABI_VERSION = 2
+
+
+def arith_code(name):
+    """``--matrix_arithmetic`` name (or an ARITH_* code) -> the code the structs carry."""
+    if isinstance(name, int):
+        if name not in ARITHMETICS.values():
+            raise ValueError("unknown matrix arithmetic code %r" % (name,))
+        return name
+    try:
+        return ARITHMETICS[name]
+    except KeyError:
+        raise ValueError("unknown matrix arithmetic %r (one of %s)" % (name, sorted(ARITHMETICS)))
+
+
+def default_arith():
+    """What a module without an explicit choice uses: MAPPO_MATRIX_ARITHMETIC (A / B tooling), else the six-term form."""
+    return arith_code(os.environ.get("MAPPO_MATRIX_ARITHMETIC", "six_term"))
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -51,7 +72,7 @@ class MLP(ctypes.Structure):
     """struct mappo_mlp (include/mappo_hip.h): the fused hidden-64 trunk."""
     _fields_ = [("src", _vp), ("row_tab", _vp), ("rows", _i64),
                 ("din", ctypes.c_int32), ("n_layers", ctypes.c_int32), ("act", ctypes.c_int32), ("out", ctypes.c_int32),
-                ("ln_eps", ctypes.c_float), ("w1", _vp), ("bias", _vp * 3), ("ln_g", _vp * 3), ("ln_b", _vp * 3),
+                ("ln_eps", ctypes.c_float), ("arith", ctypes.c_int32), ("w1", _vp), ("bias", _vp * 3), ("ln_g", _vp * 3), ("ln_b", _vp * 3),
                 ("w2", _vp * 2), ("wh", _vp), ("bh", _vp), ("y", _vp), ("z", _vp * 3), ("ln_stats", _vp * 3), ("dy", _vp), ("dz1", _vp),
                 ("workspace", _vp), ("grads", _vp)]
 
@@ -59,7 +80,7 @@ class MLP(ctypes.Structure):
 class GRUSeq(ctypes.Structure):
     """struct mappo_gru_seq (include/mappo_hip.h): the GRU of a recurrent policy over a whole chunk."""
     _fields_ = [(n, _vp) for n in ("x", "h0", "masks", "w_ih", "w_hh", "b_ih", "b_hh", "ln_g", "ln_b")] + \
-               [("ln_eps", ctypes.c_float), ("H", ctypes.c_int32), ("L", ctypes.c_int32), ("mb", _i64)] + \
+               [("ln_eps", ctypes.c_float), ("H", ctypes.c_int32), ("L", ctypes.c_int32), ("arith", ctypes.c_int32), ("mb", _i64)] + \
                [(n, _vp) for n in ("y", "h_last", "gates", "hm", "stats", "dy", "dx", "dgi", "dq", "dh0", "dh_last",
                                    "ln_grads", "workspace", "head_w", "head_b")] + \
                [("head_out", ctypes.c_int32), ("logits", _vp), ("dlogits", _vp), ("head_sums", ctypes.c_int32)]
@@ -73,7 +94,7 @@ class Adam(ctypes.Structure):
     _fields_ = [(n, _vp * ADAM_MAX_TENSORS) for n in ("param", "grad", "exp_avg", "exp_avg_sq", "step")] + \
                [("numel", _i64 * ADAM_MAX_TENSORS), ("n", ctypes.c_int32)] + \
                [(n, ctypes.c_double) for n in ("lr", "beta1", "beta2", "eps", "weight_decay", "max_grad_norm")] + \
-               [("grad_norm", _vp), ("workspace", _vp)]
+               [("grad_norm", _vp), ("workspace", _vp), ("lr_device", _vp)]
 
 
 LOSS_HUBER, LOSS_CLIPPED_VALUE, LOSS_POLICY_ACTIVE_MASKS, LOSS_VALUE_ACTIVE_MASKS = 1, 2, 4, 8
@@ -166,13 +187,29 @@ def lib():
             fn.argtypes = args
         if os.environ.get("MAPPO_GAE_VARIANT"):      # tuning hook (tools/): kernel variant + option bits
             L.mappo_gae_set_variant(int(os.environ["MAPPO_GAE_VARIANT"]))
-        if L.mappo_abi_version() != 1:
-            raise NativeError("libmappo_hip.so ABI version %d, expected 1" % L.mappo_abi_version())
+        if L.mappo_abi_version() != ABI_VERSION:
+            raise NativeError("libmappo_hip.so ABI version %d, expected %d" % (L.mappo_abi_version(), ABI_VERSION))
         _lib = L
     return _lib
 
 
+# test instrumentation: how often each entry point was called (``count_calls(True)`` starts a fresh count, ``calls()`` reads
+# it) -- lets a device test assert WHICH kernels carried an update (no silent framework fall-back can pass)
+_CALLS = None
+
+
+def count_calls(on=True):
+    global _CALLS
+    _CALLS = {} if on else None
+
+
+def calls():
+    return dict(_CALLS or {})
+
+
 def check(code, what):
+    if _CALLS is not None:
+        _CALLS[what] = _CALLS.get(what, 0) + 1
     if code != 0:
         msg = lib().mappo_error_string(code).decode()
         raise NativeError("%s failed: %s (code %d)" % (what, msg, code))

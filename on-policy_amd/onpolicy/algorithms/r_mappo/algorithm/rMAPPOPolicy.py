@@ -31,6 +31,14 @@ class R_MAPPOPolicy:
         fused = {"fused": True} if torch.device(self.device).type == "cuda" else {}
         return torch.optim.Adam(net.parameters(), lr=lr, eps=self.opti_eps, weight_decay=self.weight_decay, **fused)
 
+    def set_matrix_arithmetic(self, name):
+        """"six_term" | "f32_mfma": the arithmetic of the K9 / K12 matrix products of THIS policy's networks from the next
+        call on (``--matrix_arithmetic``; carried per call in the ``arith`` field of the C ABI structs, so several policies
+        in one process may differ)."""
+        from onpolicy.algorithms.utils import fused_mlp
+        for net in (self.actor, self.critic):
+            fused_mlp.set_matrix_arithmetic(net, name)
+
     def lr_decay(self, episode, episodes):
         update_linear_schedule(self.actor_optimizer, episode, episodes, self.lr)
         update_linear_schedule(self.critic_optimizer, episode, episodes, self.critic_lr)

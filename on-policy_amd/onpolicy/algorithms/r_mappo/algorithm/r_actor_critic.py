@@ -55,6 +55,7 @@ class R_Actor(nn.Module, _DeviceMixin):
         self.base = _trunk(args, get_shape_from_obs_space(obs_space))
         if self._recurrent:
             self.rnn = RNNLayer(self.hidden_size, self.hidden_size, self._recurrent_N, self._use_orthogonal)
+            self.rnn.matrix_arithmetic = getattr(args, "matrix_arithmetic", None)       # (K12, like the trunk's K9)
         self.act = ACTLayer(action_space, self.hidden_size, self._use_orthogonal, self._gain, args)
         # built on the CPU, then moved: init draws come from the CPU generator on every device
         self.to(device)
@@ -122,6 +123,7 @@ class R_Critic(nn.Module, _DeviceMixin):
         self.base = _trunk(args, get_shape_from_obs_space(cent_obs_space))
         if self._recurrent:
             self.rnn = RNNLayer(self.hidden_size, self.hidden_size, self._recurrent_N, self._use_orthogonal)
+            self.rnn.matrix_arithmetic = getattr(args, "matrix_arithmetic", None)       # (K12, like the trunk's K9)
         # built and initialised on the host like every other layer; self.to(device) below moves it
         head = PopArt(self.hidden_size, 1) if self._use_popart else TallLinear(self.hidden_size, 1)
         self.v_out = init(head, w_init, lambda b: nn.init.constant_(b, 0))

@@ -71,6 +71,8 @@ class R_MAPPO():
         self.dp = mdist.DataParallel(self.policy.actor, self.policy.critic, device)
         # set by train() while it feeds ppo_update with row-standardised observations
         self._obs_standardized = False
+        # ppo_update as a captured HIP graph (update_graph.py), built on first use
+        self._update_graph = None
         # Discrete head on a HIP device: loss + gradient in one kernel (K7) instead of the framework ops
         self._fused_loss = fused_loss.supported(self.policy, device) and self._fused_loss_allowed()
 
@@ -184,9 +186,11 @@ class R_MAPPO():
         step = -(-units // n)
         return [(lo, min(units, lo + step)) for lo in range(0, units, step)], chunk_len
 
-    def ppo_update(self, sample, update_actor=True):
+    def ppo_update(self, sample, update_actor=True, _front_only=False, _scales=None):
         """One actor step and one critic step on a minibatch (reference r_mappo.py:91-169).
-        -> (value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights)."""
+        -> (value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights).
+        (``_front_only`` / ``_scales``: update_graph.py captures everything up to the gradients as one graph and hands the
+        scalar prologue in as a static tensor.)"""
         share_obs_batch, obs_batch, rnn_states_batch, rnn_states_critic_batch, actions_batch, \
             value_preds_batch, return_batch, masks_batch, active_masks_batch, old_action_log_probs_batch, \
             adv_targ, available_actions_batch = sample[:12]
@@ -214,8 +218,11 @@ class R_MAPPO():
         pending = () if normalized else None
         fused = self._fused_loss and adv_targ.is_cuda and actions_batch is not None
         # fused loss on a HIP device: denominators, their reciprocals and the returns' batch moments in three launches
-        scales = self.dp.minibatch_scales(active_masks_batch, return_batch, self._use_policy_active_masks,
-                                          self._use_value_active_masks) if fused else None
+        if _scales is not None:
+            scales = _scales
+        else:
+            scales = self.dp.minibatch_scales(active_masks_batch, return_batch, self._use_policy_active_masks,
+                                              self._use_value_active_masks) if fused else None
         w_actor = w_critic = 1.0
         if scales is not None:
             if normalized:
@@ -306,23 +313,30 @@ class R_MAPPO():
 
         if not fused:
             imp_weights = ratios[0] if len(ratios) == 1 else torch.cat(ratios, 0)
+        if _front_only:         # (update_graph.py: the gradient exchange and the optimiser steps follow separately)
+            return value_loss, policy_loss, dist_entropy, imp_weights
 
         self.dp.all_reduce_grads()  # no-op for world size 1
-
-        actor_grad_norm = self._clip_and_step(self.policy.actor, self.policy.actor_optimizer,
-                                              update_actor or not self.dp.active)
-        critic_grad_norm = self._clip_and_step(self.policy.critic, self.policy.critic_optimizer, True)
-
+        actor_grad_norm, critic_grad_norm = self._update_back(update_actor)
         return value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights
 
-    def _clip_and_step(self, net, optimizer, step):
+    def _update_back(self, update_actor, lr_devices=(None, None)):
+        """Clipping + optimiser step of both networks on the (all-reduced) gradients -> (actor, critic) gradient norms."""
+        actor_grad_norm = self._clip_and_step(self.policy.actor, self.policy.actor_optimizer,
+                                              update_actor or not self.dp.active, lr_devices[0])
+        critic_grad_norm = self._clip_and_step(self.policy.critic, self.policy.critic_optimizer, True, lr_devices[1])
+        return actor_grad_norm, critic_grad_norm
+
+    def _clip_and_step(self, net, optimizer, step, lr_device=None):
         """Clip the network's gradients to ``max_grad_norm`` (or only measure them) and take the optimiser step
         (reference r_mappo.py:146-153, :160-167) -> the gradient norm before clipping.  On a HIP device the whole thing is
         K13 (two launches instead of ~8); otherwise, or when a parameter has no gradient, the PyTorch calls."""
         from onpolicy.algorithms.utils import fused_optim
         params = [p for p in net.parameters() if p.requires_grad]
         if step and params and params[0].is_cuda and fused_optim.supported(optimizer, params):
-            return fused_optim.clip_and_step(optimizer, params, self.max_grad_norm if self._use_max_grad_norm else None)
+            return fused_optim.clip_and_step(optimizer, params, self.max_grad_norm if self._use_max_grad_norm else None,
+                                             lr_device)
+        assert lr_device is None, "a captured update needs the fused clip + Adam kernels"
         if self._use_max_grad_norm:
             norm = nn.utils.clip_grad_norm_(net.parameters(), self.max_grad_norm)
         else:
@@ -470,7 +484,7 @@ class R_MAPPO():
                 self._obs_standardized = fold
                 try:
                     value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights \
-                        = self.ppo_update(sample, update_actor)
+                        = self._run_update(sample, update_actor)
                 finally:
                     self._obs_standardized = False
                 with torch.no_grad():
@@ -488,6 +502,18 @@ class R_MAPPO():
         totals = self.dp.average_info(totals / num_updates)
         values = totals.tolist()  # the only device->host sync of the update phase
         return dict(zip(keys, values))
+
+    def _run_update(self, sample, update_actor):
+        """``ppo_update`` -- replayed from a captured HIP graph where the update qualifies (update_graph.py: ~10 launches per
+        update instead of ~100 on the recurrent route), eagerly otherwise.  Subclasses that override ``ppo_update`` stay eager."""
+        if type(self).ppo_update is R_MAPPO.ppo_update:
+            if self._update_graph is None:
+                from onpolicy.algorithms.r_mappo.update_graph import UpdateGraph
+                self._update_graph = UpdateGraph(self)
+            out = self._update_graph.run(sample, update_actor)
+            if out is not None:
+                return out
+        return self.ppo_update(sample, update_actor)
 
     def _with_prologue_ahead(self, generator):
         """Data-parallel jobs with several minibatches per epoch: minibatch i + 1 is drawn BEFORE update i runs and its

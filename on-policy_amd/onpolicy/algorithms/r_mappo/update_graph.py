@@ -1,0 +1,204 @@
+"""``R_MAPPO.ppo_update`` as a captured HIP graph.
+
+One update of the reference (onpolicy/algorithms/r_mappo/r_mappo.py:91-169: evaluate_actions, the two losses, two backward
+passes, two clip_grad_norm_ + Adam steps) is ~30 launches on the feed-forward route of this implementation and ~100 on the
+recurrent one (K9 / K12 / K7 / K13 + the library GEMMs, reductions and concatenations of the GRU's weight gradients).  On
+small minibatches -- BASELINE configs[1], or the 64-threads-per-GPU shard of configs[3] -- those launches, not the kernels,
+set the pace.  Nothing in an update depends on the host, and every update of a ``train()`` runs the same kernels on
+tensors of the same shapes, so the update is captured once into a HIP graph and replayed:
+
+    eager per update:   sampler gather (1-3 launches) -> scalar prologue (2 launches, + its collective in a multi-GPU job)
+                        -> ONE batched copy of the minibatch into the graph's static input tensors
+    graph "front":      zero_grad, row table, K9 / K12 forward, ValueNorm update, K7, backward of both networks
+    eager (multi-GPU):  gradients -> flat bucket, ONE all-reduce (DataParallel)
+    graph "back":       clip + Adam of both networks (K13; the learning rate is read from device memory, so lr_decay between
+                        replays needs no re-capture)
+
+A graph belongs to a *signature*: the shapes / dtypes of the minibatch tuple, the observation matrices the lazy ``RowSource``
+minibatches point into (their addresses are baked into the graph), ``update_actor`` and the arithmetic of the networks.  The
+first update with a new signature runs eagerly (it is also the warm-up: GEMM tuning, lazily created state), the second is
+captured, the rest replay.  Minibatches of more than ``MAPPO_UPDATE_GRAPH_MAX_ROWS`` rows (default 4 M) stay eager: their
+kernels run for milliseconds and the launches are free, while a graph would keep the update's activations (14 GB at the north
+star) alive for good.  ``MAPPO_UPDATE_GRAPH=0`` disables the whole thing.
+
+Not captured (the eager ``ppo_update`` runs): PopArt heads (``update`` rebinds the parameters' storage), trainers without the
+fused loss / fused optimiser kernels, host minibatches, minibatches cut into several row spans, subclasses that override
+``ppo_update``.
+"""
+import os
+
+import torch
+
+from onpolicy.algorithms.utils.fused_mlp import RowSource, matrix_arithmetic_of
+
+
+class UpdateGraph(object):
+    MAX_ENTRIES = 4
+
+    def __init__(self, trainer):
+        self.t = trainer
+        self.entries = {}           # signature -> entry
+        self.order = []             # signatures, least recently used first
+        self.pool = None
+        self.replays = self.captures = self.warmups = 0
+        self.max_rows = int(os.environ.get("MAPPO_UPDATE_GRAPH_MAX_ROWS", str(4 << 20)))
+        self.off = os.environ.get("MAPPO_UPDATE_GRAPH", "1") == "0"
+
+    # ------------------------------------------------------------------------------------------------ eligibility
+    def _trainer_ok(self):
+        t = self.t
+        if self.off or torch.device(t.device).type != "cuda" or not t._fused_loss or t._use_popart:
+            return False
+        from onpolicy.algorithms.utils import fused_optim
+        return fused_optim.enabled()
+
+    def _signature(self, sample, update_actor):
+        """-> (hashable signature, rows) or (None, 0) when the minibatch cannot be captured."""
+        t = self.t
+        parts = []
+        for x in sample:
+            if x is None:
+                parts.append(None)
+            elif isinstance(x, RowSource):
+                parts.append(("rows", x.src.data_ptr(), tuple(x.src.shape), None if x.idx is None else tuple(x.idx.shape),
+                              x.chunk, x.standardized, x.width))
+            elif torch.is_tensor(x) and x.is_cuda and x.is_contiguous():
+                parts.append((tuple(x.shape), x.dtype))
+            else:
+                return None, 0
+        rows = sample[10].shape[0]
+        if rows > self.max_rows:
+            return None, 0
+        spans, _ = t._row_spans(sample)
+        if len(spans) != 1:
+            return None, 0
+        arith = tuple(matrix_arithmetic_of(m) for net in (t.policy.actor, t.policy.critic) for m in net.modules()
+                      if hasattr(m, "matrix_arithmetic"))
+        return (tuple(parts), bool(update_actor), bool(t._obs_standardized), arith), rows
+
+    # ------------------------------------------------------------------------------------------------ the update
+    def run(self, sample, update_actor):
+        """The 6-tuple of ``ppo_update`` from a graph replay, or None: the caller runs the eager update."""
+        if not self._trainer_ok():
+            return None
+        sig, rows = self._signature(sample, update_actor)
+        if sig is None:
+            return None
+        e = self.entries.get(sig)
+        if e is None:       # first sight of this signature: the eager update is the warm-up
+            self._remember(sig, {"state": "warm"})
+            self.warmups += 1
+            return None
+        if e["state"] == "failed":
+            return None
+        self.order.remove(sig)
+        self.order.append(sig)
+        t = self.t
+        scales = t.dp.minibatch_scales(sample[8], sample[6], t._use_policy_active_masks, t._use_value_active_masks)
+        if scales is None:
+            return None
+        if e["state"] == "warm":
+            try:
+                self._capture(e, sample, update_actor, scales)
+            except Exception as exc:        # capture is an optimisation: whatever it cannot take stays eager
+                e.clear()
+                e["state"] = "failed"
+                print("update graph: capture failed (%s: %s); this update shape stays eager" % (type(exc).__name__, exc))
+                torch.cuda.synchronize(t.device)
+                return None
+        return self._replay(e, sample, scales)
+
+    def _remember(self, sig, entry):
+        while len(self.order) >= self.MAX_ENTRIES:
+            self.entries.pop(self.order.pop(0), None)
+        self.entries[sig] = entry
+        self.order.append(sig)
+
+    @staticmethod
+    def _tensors(sample):
+        """The device tensors of a minibatch that a replay must find in the static inputs (index lists of RowSources included)."""
+        out = []
+        for x in sample:
+            if isinstance(x, RowSource):
+                if x.idx is not None:
+                    out.append(x.idx)
+            elif torch.is_tensor(x):
+                out.append(x)
+        return out
+
+    def _capture(self, e, sample, update_actor, scales):
+        t = self.t
+        dev = torch.device(t.device)
+        static = []
+        for x in sample:
+            if isinstance(x, RowSource):
+                static.append(RowSource.all_rows(x.src, x.standardized, x.width) if x.idx is None else
+                              RowSource(x.src, x.idx.clone(), x.chunk, x.standardized, x.width))
+            elif torch.is_tensor(x):
+                static.append(x.clone())
+            else:
+                static.append(x)
+        e["static"] = tuple(static)
+        e["inputs"] = self._tensors(static)
+        cur = self._tensors(sample)             # the static inputs start out as copies of this minibatch
+        e["loaded"] = ([(id(x), x._version) for x in cur], cur)
+        e["scales"] = scales.clone()
+        e["scales_src"] = scales
+        opts = (t.policy.actor_optimizer, t.policy.critic_optimizer)
+        e["lr"] = [torch.full((1,), float(o.param_groups[0]["lr"]), dtype=torch.float64, device=dev) for o in opts]
+        e["lr_val"] = [float(o.param_groups[0]["lr"]) for o in opts]
+        params = [p for net in (t.policy.actor, t.policy.critic) for p in net.parameters() if p.requires_grad]
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
+        front = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(front, pool=self.pool):
+            value_loss, policy_loss, dist_entropy, ratio = t.ppo_update(e["static"], update_actor, _front_only=True,
+                                                                        _scales=e["scales"])
+            if not t.dp.active:
+                norms = t._update_back(update_actor, lr_devices=e["lr"])
+        e["front"] = front
+        e["back"] = None
+        if t.dp.active:
+            # the gradient exchange stays eager between the two halves (one batched copy + ONE collective, utils/dist.py)
+            e["front_grads"] = [p.grad for p in t.dp._params]
+            front.replay()                      # (a capture executes nothing: run the front once so that the bucket is real)
+            t.dp.all_reduce_grads()             # -> every param.grad is a view of the reduced flat bucket
+            back = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(back, pool=self.pool):
+                norms = t._update_back(update_actor, lr_devices=e["lr"])
+            e["back"] = back
+            e["front_done"] = True              # the front already ran for the minibatch that triggered the capture
+        e["grads"] = [(p, p.grad) for p in params]
+        e["out"] = (value_loss, norms[1], policy_loss, dist_entropy, norms[0], ratio)
+        e["state"] = "ready"
+        self.captures += 1
+
+    def _replay(self, e, sample, scales):
+        t = self.t
+        for i, o in enumerate((t.policy.actor_optimizer, t.policy.critic_optimizer)):
+            lr = float(o.param_groups[0]["lr"])
+            if lr != e["lr_val"][i]:
+                e["lr"][i].fill_(lr)
+                e["lr_val"][i] = lr
+        if e.pop("front_done", False):
+            # (multi-GPU capture: the front and the gradient exchange already ran for this very minibatch)
+            e["back"].replay()
+        else:
+            # inputs: one batched copy, skipped when this very minibatch (same tensor objects, unchanged) is already loaded --
+            # the whole-batch tuple of a one-minibatch epoch is handed out again in every epoch
+            cur = self._tensors(sample)
+            key = [(id(x), x._version) for x in cur]
+            if e["loaded"] is None or e["loaded"][0] != key:
+                torch._foreach_copy_(e["inputs"], cur)
+                e["loaded"] = (key, cur)        # (holding the sources keeps their ids from being recycled)
+            if e["scales_src"] is not scales:
+                e["scales"].copy_(scales)
+                e["scales_src"] = scales
+            e["front"].replay()
+            if e["back"] is not None:
+                t.dp.all_reduce_from(e["front_grads"])
+                e["back"].replay()
+        for p, g in e["grads"]:                 # what a caller finds in .grad after an update (clipped, reduced)
+            p.grad = g
+        self.replays += 1
+        return e["out"]

@@ -1,5 +1,6 @@
 """Fused hidden-64 trunk (K9, ``mappo_mlp_forward`` / ``mappo_mlp_backward``): the whole MLPBase chain plus the output
-Linear of an actor / critic as one forward kernel and two backward kernels on the float32 matrix cores, reading the
+Linear of an actor / critic as one forward kernel and two backward kernels on the matrix cores (float32 products in the
+arithmetic ``--matrix_arithmetic`` names, include/mappo_hip.h MAPPO_ARITH_*), reading the
 observation rows of a sampler minibatch straight from the rollout buffer through the sampler's index list.
 
 Reference modules it evaluates (same parameters, same function): onpolicy/algorithms/utils/mlp.py:6-58 (MLPLayer /
@@ -168,8 +169,7 @@ def _identity_table(rows, device):
     if tab is None:
         padded = int(_native.lib().mappo_mlp_row_table_ints(rows))
         tab = torch.arange(padded, dtype=torch.int32, device=device).clamp_(max=rows - 1)
-        if len(_IDENTITY_TABLES) > 64:
-            _IDENTITY_TABLES.clear()
+        # never evicted: a captured rollout graph bakes a table's device pointer in, and a table is rows * 4 bytes
         _IDENTITY_TABLES[key] = tab
     return tab
 
@@ -243,19 +243,23 @@ class _FusedTrunkFn(torch.autograd.Function):
     per hidden layer weight / bias, then head weight / bias (absent for out = 0)."""
 
     @staticmethod
-    def forward(ctx, rs, act, eps, n_layers, out, *params):
+    def forward(ctx, rs, act, eps, n_layers, out, arith, save, *params):
+        """``arith``: _native.ARITH_* (the call's matrix arithmetic).  ``save``: the caller's ``torch.is_grad_enabled()`` --
+        grad mode is always off in here and ``needs_input_grad`` reflects the parameters' ``requires_grad`` whatever the
+        mode, so without it every rollout step (under no_grad, also inside the captured rollout graph) would allocate and
+        write the backward's scratch (n_layers * 264 B per row)."""
         lib = _native.lib()
         dev = rs.src.device
         params = [p.detach().contiguous() for p in params]
         m = _native.MLP()
         tab = rs.table()
         _fill_rows(m, rs, tab)
-        m.n_layers, m.act, m.out, m.ln_eps = n_layers, act, out, float(eps)
+        m.n_layers, m.act, m.out, m.ln_eps, m.arith = n_layers, act, out, float(eps), int(arith)
         _fill_params(m, params, n_layers, out)
         rows = rs.rows
         y = torch.empty((rows, out if out else HIDDEN), dtype=torch.float32, device=dev)
         m.y = y.data_ptr()
-        need_grad = any(ctx.needs_input_grad[5:])
+        need_grad = bool(save) and any(ctx.needs_input_grad[7:])
         zs = []
         if need_grad:       # what the backward needs of every layer: normalised activations + {mean, rstd} per row
             # (opaque scratch in the kernels' own order, padded to the 128-row tile: include/mappo_hip.h)
@@ -268,22 +272,23 @@ class _FusedTrunkFn(torch.autograd.Function):
             zs = [zbuf, sbuf]
         with _Timed("mappo_mlp_forward", *_work(rows, int(rs.src.shape[1]), n_layers, out, False)):
             _native.check(lib.mappo_mlp_forward(m, _native.stream_of(dev)), "mappo_mlp_forward")
-        ctx.rs, ctx.cfg = rs, (act, eps, n_layers, out)
-        ctx.save_for_backward(*(zs + [tab] + params))
+        if need_grad:
+            ctx.rs, ctx.cfg = rs, (act, eps, n_layers, out, int(arith))
+            ctx.save_for_backward(*(zs + [tab] + params))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _native.lib()
         rs = ctx.rs
-        act, eps, n_layers, out = ctx.cfg
+        act, eps, n_layers, out, arith = ctx.cfg
         saved = ctx.saved_tensors
         zbuf, sbuf, tab, params = saved[0], saved[1], saved[2], list(saved[3:])
         dev = rs.src.device
         din = int(rs.src.shape[1])
         m = _native.MLP()
         _fill_rows(m, rs, tab)
-        m.n_layers, m.act, m.out, m.ln_eps = n_layers, act, out, float(eps)
+        m.n_layers, m.act, m.out, m.ln_eps, m.arith = n_layers, act, out, float(eps), arith
         _fill_params(m, params, n_layers, out)
         for l in range(n_layers):
             m.z[l] = zbuf[l].data_ptr()
@@ -295,7 +300,7 @@ class _FusedTrunkFn(torch.autograd.Function):
         m.dy, m.dz1, m.workspace, m.grads = dy.data_ptr(), dz1.data_ptr(), ws.data_ptr(), grads.data_ptr()
         with _Timed("mappo_mlp_backward", *_work(rs.rows, din, n_layers, out, True)):
             _native.check(lib.mappo_mlp_backward(m, _native.stream_of(dev)), "mappo_mlp_backward")
-        return (None, None, None, None, None) + tuple(_split_grads(grads, din, n_layers, out))
+        return (None, None, None, None, None, None, None) + tuple(_split_grads(grads, din, n_layers, out))
 
 
 def _fill_rows(m, rs, tab):
@@ -403,7 +408,27 @@ def trunk_forward(base, rs, head=None):
     if head is not None:
         out = int(head.weight.shape[0])
         params += [head.weight, head.bias]
-    return _FusedTrunkFn.apply(rs, _act_kind(blocks[0][1]), blocks[0][2].eps, len(blocks), out, *params)
+    return _FusedTrunkFn.apply(rs, _act_kind(blocks[0][1]), blocks[0][2].eps, len(blocks), out, matrix_arithmetic_of(base),
+                               torch.is_grad_enabled(), *params)
+
+
+def matrix_arithmetic_of(module):
+    """The _native.ARITH_* code a network part (``MLPBase`` / ``RNNLayer``) passes with its K9 / K12 calls: its own
+    ``matrix_arithmetic`` attribute (set from ``--matrix_arithmetic`` by the actor / critic that owns it, or later through
+    ``set_matrix_arithmetic``), else the process default (MAPPO_MATRIX_ARITHMETIC, else the six-term form)."""
+    a = getattr(module, "matrix_arithmetic", None)
+    return _native.default_arith() if a is None else _native.arith_code(a)
+
+
+def set_matrix_arithmetic(root, name):
+    """Select the arithmetic of the K9 / K12 matrix products ("six_term" | "f32_mfma") for every ``MLPBase`` / ``RNNLayer``
+    below ``root`` -- a per-network choice carried by every call (``arith`` of mappo_mlp_t / mappo_gru_seq_t), nothing
+    process-wide."""
+    code = _native.arith_code(name)
+    for mod in root.modules():
+        if hasattr(mod, "matrix_arithmetic"):
+            mod.matrix_arithmetic = code
+    return code
 
 
 def head_supported(head):

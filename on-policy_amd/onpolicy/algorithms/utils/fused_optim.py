@@ -36,9 +36,10 @@ def supported(optimizer, params):
     return not torch.is_tensor(g["lr"])
 
 
-def clip_and_step(optimizer, params, max_grad_norm):
+def clip_and_step(optimizer, params, max_grad_norm, lr_device=None):
     """-> the total L2 norm of the gradients before clipping (device scalar).  ``max_grad_norm`` None / <= 0: no clipping
-    (the reference's get_gard_norm branch)."""
+    (the reference's get_gard_norm branch).  ``lr_device``: a float64 device tensor [1] the kernel reads the learning rate
+    from instead of the optimiser's Python float (launches captured into a HIP graph, algorithms/r_mappo/update_graph.py)."""
     lib, p = _native.lib(), _native.ptr
     group = optimizer.param_groups[0]
     dev = params[0].device
@@ -61,5 +62,8 @@ def clip_and_step(optimizer, params, max_grad_norm):
     norm = torch.empty(1, dtype=torch.float32, device=dev)
     ws = torch.empty(lib.mappo_adam_workspace_floats(), dtype=torch.float32, device=dev)
     a.grad_norm, a.workspace = p(norm), p(ws)
+    if lr_device is not None:
+        assert lr_device.dtype == torch.float64 and lr_device.is_cuda and lr_device.numel() == 1
+        a.lr_device = p(lr_device)
     _native.check(lib.mappo_clip_adam(a, _native.stream_of(dev)), "mappo_clip_adam")
     return norm[0]

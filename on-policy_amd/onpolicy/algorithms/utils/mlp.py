@@ -51,6 +51,8 @@ class MLPBase(nn.Module):
         self._stacked_frames = args.stacked_frames
         self._layer_N = args.layer_N
         self.hidden_size = args.hidden_size
+        # arithmetic of K9's matrix products: --matrix_arithmetic (None = the process default), a per-network choice
+        self.matrix_arithmetic = getattr(args, "matrix_arithmetic", None)
         obs_dim = obs_shape[0]
         if self._use_feature_normalization:
             self.feature_norm = FusedLayerNorm(obs_dim)

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import fused_mlp
 from .fused_norm import FusedLayerNorm
 from .tall_linear import tall_linear, splitk_weight_grad, column_sums
 
@@ -105,7 +106,7 @@ class _GRUChunkFn(torch.autograd.Function):
     rows here."""
 
     @staticmethod
-    def forward(ctx, x, h0, masks, w_ih, w_hh, b_ih, b_hh, ln_g, ln_b, eps, L, save, head_w=None, head_b=None):
+    def forward(ctx, x, h0, masks, w_ih, w_hh, b_ih, b_hh, ln_g, ln_b, eps, L, save, arith, head_w=None, head_b=None):
         """``head_w`` [out, 64] / ``head_b`` [out] (out <= 18): an output Linear on y evaluated inside the launches -- the
         first result is then ``y head_w^T + head_b`` instead of y (y itself is kept for the head's weight gradient).
         ``save``: the caller's ``torch.is_grad_enabled()`` -- grad mode is always off in here and ``needs_input_grad``
@@ -130,13 +131,13 @@ class _GRUChunkFn(torch.autograd.Function):
         hm = torch.empty(L * B, 64, **f32) if need else None
         m = _native.GRUSeq(x=p(x), h0=p(h0), masks=p(masks), w_ih=p(params[0]), w_hh=p(params[1]), b_ih=p(params[2]),
                            b_hh=p(params[3]), ln_g=p(params[4]), ln_b=p(params[5]), ln_eps=float(eps), H=64, L=L, mb=B,
-                           y=p(y), h_last=p(h_last), gates=p(gates), hm=p(hm), stats=p(stats),
+                           arith=int(arith), y=p(y), h_last=p(h_last), gates=p(gates), hm=p(hm), stats=p(stats),
                            head_w=p(head[0]) if head else None, head_b=p(head[1]) if head else None, head_out=out,
                            logits=p(logits))
         _native.check(lib.mappo_gru_seq_forward(m, _native.stream_of(dev)), "mappo_gru_seq_forward")
         if need:
             ctx.save_for_backward(x, h0, masks, gates, stats, hm, *params, *(head + ((y,) if y is not None else ()) if head else ()))
-            ctx.cfg = (float(eps), L, out)
+            ctx.cfg = (float(eps), L, out, int(arith))
         return (logits if head is not None else y), h_last
 
     @staticmethod
@@ -144,7 +145,7 @@ class _GRUChunkFn(torch.autograd.Function):
         from onpolicy import _native
         lib, p = _native.lib(), _native.ptr
         x, h0, masks, gates, stats, hm, w_ih, w_hh, b_ih, b_hh, ln_g, ln_b = ctx.saved_tensors[:12]
-        eps, L, out = ctx.cfg
+        eps, L, out, arith = ctx.cfg
         head_w, head_b = ctx.saved_tensors[12:14] if out else (None, None)
         y = ctx.saved_tensors[14] if out > CHUNK_HEAD_SUMS else None
         B = h0.shape[0]
@@ -160,7 +161,7 @@ class _GRUChunkFn(torch.autograd.Function):
         ln_grads = torch.empty(800, **f32)
         ws = torch.empty(lib.mappo_gru_seq_workspace_floats(), **f32)
         m = _native.GRUSeq(x=p(x), h0=p(h0), masks=p(masks), w_ih=p(w_ih), w_hh=p(w_hh), b_ih=p(b_ih), b_hh=p(b_hh),
-                           ln_g=p(ln_g), ln_b=p(ln_b), ln_eps=eps, H=64, L=L, mb=B, gates=p(gates), hm=p(hm),
+                           ln_g=p(ln_g), ln_b=p(ln_b), ln_eps=eps, H=64, L=L, mb=B, arith=arith, gates=p(gates), hm=p(hm),
                            stats=p(stats), dy=None if out else p(dy), dx=p(dx), dgi=p(dgi), dq=p(dq), dh0=p(dh0),
                            dh_last=p(dh_last), ln_grads=p(ln_grads), workspace=p(ws),
                            head_w=p(head_w), head_b=p(head_b), head_out=out, dlogits=p(dy) if out else None,
@@ -178,7 +179,7 @@ class _GRUChunkFn(torch.autograd.Function):
             d_head = (ln_grads[384:384 + 64 * out].view(out, 64) * ln_g + dbh[:, None] * ln_b, dbh)
         else:
             d_head = (splitk_weight_grad(dy, y), column_sums(dy))
-        return (dx, dh0, None, dw_ih, dw_hh, db_ih, db_hh, ln_grads[:64], ln_grads[64:128], None, None, None) + d_head
+        return (dx, dh0, None, dw_ih, dw_hh, db_ih, db_hh, ln_grads[:64], ln_grads[64:128], None, None, None, None) + d_head
 
 
 # the widest output Linear the chunk kernels evaluate themselves (k steps of 2 on the MFMA in the backward)
@@ -199,6 +200,9 @@ _FUSED_STEP_MIN_ROWS = 1 << 17
 
 
 class RNNLayer(nn.Module):
+    # arithmetic of K12's matrix products (_native.ARITH_* or None = the process default; fused_mlp.set_matrix_arithmetic)
+    matrix_arithmetic = None
+
     def __init__(self, inputs_dim, outputs_dim, recurrent_N, use_orthogonal):
         super(RNNLayer, self).__init__()
         self._recurrent_N = recurrent_N
@@ -293,7 +297,8 @@ class RNNLayer(nn.Module):
                     raise ValueError("this head cannot be evaluated inside the GRU chunk kernels (see head_ok)")
                 extra = (head.weight, head.bias)
             y, h_last = _GRUChunkFn.apply(x, hxs[:, 0], masks, w_ih, w_hh, b_ih, b_hh, self.norm.weight, self.norm.bias,
-                                          self.norm.eps, L, torch.is_grad_enabled(), *extra)
+                                          self.norm.eps, L, torch.is_grad_enabled(),
+                                          fused_mlp.matrix_arithmetic_of(self), *extra)
             return y, h_last.unsqueeze(1)
         if head is not None:
             raise ValueError("this head cannot be evaluated inside the GRU chunk kernels (see head_ok)")

@@ -111,6 +111,11 @@ _NEW_FLAGS = [
     # bit-identical GAE returns for every buffer shape (default: narrow buffers, 2048 <= N * A < 16384, take the
     # time-parallel scan, which agrees with the reference to ~1e-6 relative; see include/mappo_hip.h K1)
     ("gae_exact", ON, False),
+    # how the hidden-64 kernels (K9 trunk, K12 GRU) form their float32 matrix products (include/mappo_hip.h MAPPO_ARITH_*):
+    # 'six_term' = six bf16 x bf16 terms of the operands' exact three-way splits on the bf16 matrix cores, float32
+    # accumulation (error of the float32 MFMA chain's order); 'f32_mfma' = the float32 matrix instruction.  None = the
+    # process default (environment variable MAPPO_MATRIX_ARITHMETIC, else six_term).  A per-policy choice.
+    ("matrix_arithmetic", str, None, ["six_term", "f32_mfma"]),
 ]
 
 

@@ -209,6 +209,12 @@ class TorchSimpleSpread(object):
         self._reset_worlds(torch.ones(self.n, dtype=torch.bool, device=self.device))
         return self._obs()
 
+    @property
+    def graph_safe(self):
+        """True when ``step`` advances pos / vel / landmarks / t IN PLACE (the K11 kernel path): a captured rollout graph
+        (runner/shared/rollout_graph.py) may then replay it.  The tensor-op path rebinds them."""
+        return self.device.type == "cuda" and self.a <= 16 and self.l <= 16
+
     def step(self, actions):
         torch = self._torch
         actions = torch.as_tensor(actions, device=self.device)

@@ -14,8 +14,10 @@ Random numbers: the action sampler draws from torch's default device generator a
 ``torch.Generator``; both are registered with the graph (philox offsets advance with every replay), so a graphed
 rollout consumes the same random stream as the eager loop (tests/test_gpu_rollout_graph.py compares whole rollouts).
 
-Falls back to the eager loop (returns None from ``build``) when the step cannot be captured: host envs, the
-integer-parity sampler (``--sampler_rng host`` draws on the CPU generator), no HIP device.
+Falls back to the eager loop (returns None from ``build``) when the step cannot be captured: host envs, worlds whose step
+rebinds its state tensors (more than 16 agents / landmarks: the tensor-op path), the integer-parity sampler
+(``--sampler_rng host`` draws on the CPU generator), no HIP device.  A PopArt value head is read through static copies that
+every ``begin_episode`` refreshes (its ``update`` rebinds the parameters' storage).
 """
 import os
 
@@ -41,6 +43,14 @@ class RolloutGraph(object):
         else:       # feed-forward policies: the buffer's zero view serves every step
             self.cur_rnn_a, self.cur_rnn_c = b.rnn_states[0], b.rnn_states_critic[0]
         self.side = torch.cuda.Stream(device=dev)      # the critic's branch of the captured step
+        # A PopArt value head REBINDS its weight / bias storage on every update (algorithms/utils/popart.py: the running
+        # minibatch's backward still needs the old tensors), so the addresses a capture bakes in would go stale with the first
+        # train().  The graph therefore reads static copies of the head, refreshed at the start of every episode.
+        head = getattr(runner.trainer.policy.critic, "v_out", None)
+        self.popart = head if type(head).__name__ == "PopArt" else None
+        if self.popart is not None:
+            self.v_w = torch.empty_like(self.popart.weight.data)
+            self.v_b = torch.empty_like(self.popart.bias.data)
         self.graph = None
         self.out = None
         self.infos = None
@@ -85,6 +95,25 @@ class RolloutGraph(object):
         return {k: getattr(e, k).clone() for k in ("pos", "vel", "landmarks", "t")}, e.rng.get_state(), \
             torch.cuda.get_rng_state(self.r.buffer.device)
 
+    class _StaticHead(object):
+        """While active, the PopArt head's parameters live in the graph's static tensors (same values)."""
+
+        def __init__(self, g):
+            self.g = g
+
+        def __enter__(self):
+            g = self.g
+            if g.popart is not None:
+                self.saved = (g.popart.weight.data, g.popart.bias.data)
+                g.v_w.copy_(self.saved[0])
+                g.v_b.copy_(self.saved[1])
+                g.popart.weight.data, g.popart.bias.data = g.v_w, g.v_b
+
+        def __exit__(self, *exc):
+            g = self.g
+            if g.popart is not None:
+                g.popart.weight.data, g.popart.bias.data = self.saved
+
     def _restore(self, snap):
         e = self.r.envs
         state, env_rng, dev_rng = snap
@@ -103,20 +132,26 @@ class RolloutGraph(object):
         keep = (self.cur_obs.clone(), self.cur_masks.clone(),
                 self.cur_rnn_a.clone() if self.recurrent else None, self.cur_rnn_c.clone() if self.recurrent else None)
         snap = self._env_state()
+        state_ptrs = {k: getattr(r.envs, k).data_ptr() for k in ("pos", "vel", "landmarks", "t")}
         torch.cuda.synchronize(dev)
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(self.WARMUP):
-                self._body()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        try:
-            graph = torch.cuda.CUDAGraph()
-            graph.register_generator_state(r.envs.rng)
-            with torch.cuda.graph(graph):
-                self.out, self.infos = self._body()
-            torch.cuda.synchronize(dev)
+        try:        # (warm-up included: whatever fails in here, worlds / generators / carried state go back where they were)
+            with self._StaticHead(self):
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    for _ in range(self.WARMUP):
+                        self._body()
+                torch.cuda.current_stream(dev).wait_stream(side)
+                torch.cuda.synchronize(dev)
+                graph = torch.cuda.CUDAGraph()
+                graph.register_generator_state(r.envs.rng)
+                with torch.cuda.graph(graph):
+                    self.out, self.infos = self._body()
+                torch.cuda.synchronize(dev)
+            # the graph reads and advances the worlds IN PLACE: a step path that rebinds its state tensors cannot be replayed
+            moved = [k for k, p in state_ptrs.items() if getattr(r.envs, k).data_ptr() != p]
+            if moved:
+                raise RuntimeError("env.step rebinds its state tensors (%s): not capturable" % ", ".join(moved))
             self.graph = graph
         finally:
             self._restore(snap)
@@ -135,6 +170,9 @@ class RolloutGraph(object):
         if self.recurrent:
             self.cur_rnn_a.copy_(b.rnn_states[0])
             self.cur_rnn_c.copy_(b.rnn_states_critic[0])
+        if self.popart is not None:         # the head as the last train() left it
+            self.v_w.copy_(self.popart.weight.data)
+            self.v_b.copy_(self.popart.bias.data)
 
     def step(self):
         """One rollout step: graph launch + the fused slab write into the buffer's current row."""
@@ -153,6 +191,8 @@ def build(runner):
         return None
     envs = runner.envs
     if not getattr(envs, "device_resident", False) or not hasattr(envs, "rng") or not hasattr(envs, "pos"):
+        return None
+    if not getattr(envs, "graph_safe", False):      # the step must advance its state tensors in place (K11 does)
         return None
     if torch.device(runner.buffer.device).type != "cuda" or distributions.SAMPLING_RNG != "device":
         return None

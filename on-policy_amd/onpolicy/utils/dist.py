@@ -142,6 +142,27 @@ class DataParallel(object):
             p.grad = self._flat[off:off + n].view_as(p)
             off += n
 
+    def all_reduce_from(self, grads):
+        """``all_reduce_grads`` for gradients a captured graph left in ``grads`` (one entry per parameter of ``_params``, None
+        = no gradient): batched copy into the flat bucket + ONE collective.  ``param.grad`` is not touched -- the graph that
+        consumes the reduced gradients reads the bucket's views directly (algorithms/r_mappo/update_graph.py)."""
+        if not self.active:
+            return
+        pieces, off = [], 0
+        for p, g in zip(self._params, grads):
+            n = p.numel()
+            pieces.append(self._zeros[off:off + n] if g is None else g.reshape(-1))
+            off += n
+        torch.cat(pieces, out=self._flat)
+        timed = self._timing is not None and self._flat.is_cuda
+        if timed:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
+        if timed:
+            ev[1].record()
+            self._timing.append(ev)
+
     def time_collectives(self, on=True):
         """Start (or stop) recording an event pair around every gradient all-reduce (bench.py)."""
         self._timing = [] if on else None

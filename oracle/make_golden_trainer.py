@@ -89,6 +89,29 @@ CASES_DEV = {
 }
 
 
+# BASELINE.json configs[3] / configs[4] at their OWN layer shapes (VERDICT r4 "missing" #2): the observation / action widths of
+# SMAC MMM2 (reference envs/starcraft2/StarCraft2_Env.py:1625-1677: obs 370, share_obs 435,
+# 18 actions, 10 agents) with the flags of scripts/train_smac_scripts/train_smac_MMM2.sh:12-14 (rmappo, 2 minibatches,
+# gain 1, --use_value_active_masks = store_false, chunk 10 and hidden 64 from config.py), and of Hanabi-Full with 5 players
+# (obs 1285, share_obs 1385, 48 actions) with scripts/train_hanabi_forward.sh:15-17 (hidden 512, layer_N 2, ReLU,
+# critic_lr 1e-3, entropy_coef 0.015, gain 0.01, one minibatch).  Few rows (the widths are the point), two epochs.
+# Inputs are rebuilt from the seed by the tests (oracle/synth.py, digest in the fixture); tensors of more than 65 536
+# elements are stored as every 8th element + their float64 sum / sum of squares (``subsample``), except the initial
+# weights, which the tests start from and therefore need in full.  Written to trainer_cfg_cases.npz.
+_CFG4 = dict(algorithm_name="rmappo", use_recurrent_policy=True, hidden_size=64, layer_N=1, ppo_epoch=2, num_mini_batch=2,
+             data_chunk_length=10, gain=1.0, use_value_active_masks=False)
+CASES_CFG = {
+    "cfg4_shape": dict(args=_CFG4, T=20, N=6, A=10, Do=370, Ds=435, na=18, k10=False, regen=True, store_perms=True,
+                       subsample=8),
+    "cfg4_shape_dev": dict(args=_CFG4, T=20, N=6, A=10, Do=370, Ds=435, na=18, k10=True, regen=True, store_perms=True,
+                           subsample=8),
+    "cfg5_shape": dict(args=dict(algorithm_name="mappo", hidden_size=512, layer_N=2, use_ReLU=True, ppo_epoch=2,
+                                 num_mini_batch=1, lr=7e-4, critic_lr=1e-3, entropy_coef=0.015, gain=0.01),
+                       T=4, N=8, A=5, Do=1285, Ds=1385, na=48, k10=False, regen=True, store_perms=True, subsample=8),
+}
+SUBSAMPLE_ABOVE = 65536
+
+
 class PermRecorder(object):
     def __init__(self):
         self.orig = torch.randperm
@@ -106,15 +129,27 @@ class PermRecorder(object):
         torch.randperm = self.orig
 
 
-def _sd(prefix, module, out):
+def _store(out, name, arr, stride):
+    """arr itself, or (large tensors of the ``subsample`` cases) every ``stride``-th element + [sum, sum of squares]."""
+    arr = np.asarray(arr)
+    if stride and arr.size > SUBSAMPLE_ABOVE:
+        out[name] = arr.ravel()[::stride].copy()
+        a64 = arr.astype(np.float64)
+        out[name + "#moments"] = np.array([a64.sum(), (a64 * a64).sum()], dtype=np.float64)
+    else:
+        out[name] = arr.copy()
+
+
+def _sd(prefix, module, out, stride=0):
     for k, v in module.state_dict().items():
-        out[prefix + k] = v.detach().cpu().numpy().copy()
+        _store(out, prefix + k, v.detach().cpu().numpy(), stride)
 
 
 def main(ref, make_args, fill_buffer, gold_dir):
     generate(ref, make_args, fill_buffer, gold_dir, CASES, "trainer_cases")
     generate(ref, make_args, fill_buffer, gold_dir, CASES_H64, "trainer_h64_cases", with_grads=True)
     generate(ref, make_args, fill_buffer, gold_dir, CASES_DEV, "trainer_dev_cases", with_grads=True)
+    generate(ref, make_args, fill_buffer, gold_dir, CASES_CFG, "trainer_cfg_cases", with_grads=True)
 
 
 def generate(ref, make_args, fill_buffer, gold_dir, cases, fname, with_grads=False):
@@ -136,7 +171,8 @@ def generate(ref, make_args, fill_buffer, gold_dir, cases, fname, with_grads=Fal
         if spec.get("regen"):
             # large case: seeded inputs that the test rebuilds itself (oracle/synth.py); the fixture keeps a digest of them
             import synth
-            arrays = synth.rollout(T, N, A, Do, Ds, na, seed=4242)
+            rnn_hidden = spec["args"]["hidden_size"] if spec["args"].get("use_recurrent_policy") else 0
+            arrays = synth.rollout(T, N, A, Do, Ds, na, seed=4242, rnn_hidden=rnn_hidden)
             next_value = arrays.pop("next_value")
             for name, arr in arrays.items():
                 getattr(buf, name)[...] = arr
@@ -187,15 +223,16 @@ def generate(ref, make_args, fill_buffer, gold_dir, cases, fname, with_grads=Fal
             recorder = PermRecorder()
         with recorder as rec:
             info = trainer.train(buf)
-        for i, p in enumerate([] if spec.get("regen") else rec.calls):
+        for i, p in enumerate(rec.calls if (spec.get("store_perms") or not spec.get("regen")) else []):
             out[key + "perm%d" % i] = p.astype(np.int64)
         info = {k: float(v) for k, v in info.items()}
-        _sd(key + "final_actor.", policy.actor, out)
-        _sd(key + "final_critic.", policy.critic, out)
+        stride = int(spec.get("subsample", 0))
+        _sd(key + "final_actor.", policy.actor, out, stride)
+        _sd(key + "final_critic.", policy.critic, out, stride)
         if with_grads:      # what the reference's last ppo_update left in .grad (after clip_grad_norm_, r_mappo.py:149,163)
             for net, pre in ((policy.actor, "last_grad_actor."), (policy.critic, "last_grad_critic.")):
                 for k, p in net.named_parameters():
-                    out[key + pre + k] = p.grad.detach().cpu().numpy().copy()
+                    _store(out, key + pre + k, p.grad.detach().cpu().numpy(), stride)
         if trainer.value_normalizer is not None:
             vn = trainer.value_normalizer
             out[key + "final_norm"] = np.array([float(vn.running_mean), float(vn.running_mean_sq),

@@ -6,8 +6,10 @@ comparing different inputs.  Distributions: SURVEY.md section 8d (feed-forward p
 import numpy as np
 
 
-def rollout(T, N, A, Do, Ds, na, seed, p_mask=0.96, p_active=0.9, p_avail=0.7):
-    """dict of float32 arrays in the reference buffer's shapes (+ "next_value" [N, A, 1])."""
+def rollout(T, N, A, Do, Ds, na, seed, p_mask=0.96, p_active=0.9, p_avail=0.7, rnn_hidden=0, recurrent_N=1):
+    """dict of float32 arrays in the reference buffer's shapes (+ "next_value" [N, A, 1]).  ``rnn_hidden`` > 0 (recurrent
+    policies) adds N(0, 1) ``rnn_states`` / ``rnn_states_critic`` [T + 1, N, A, recurrent_N, rnn_hidden], drawn AFTER everything
+    else so that the arrays of the feed-forward cases do not depend on it."""
     rng = np.random.default_rng(seed)
     f32 = np.float32
     out = {}
@@ -28,6 +30,9 @@ def rollout(T, N, A, Do, Ds, na, seed, p_mask=0.96, p_active=0.9, p_avail=0.7):
     out["actions"] = pick.argmax(-1)[..., None].astype(f32)
     out["action_log_probs"] = np.full((T, N, A, 1), -np.log(na), dtype=f32)
     out["next_value"] = rng.standard_normal((N, A, 1), dtype=f32)
+    if rnn_hidden > 0:
+        out["rnn_states"] = rng.standard_normal((T + 1, N, A, recurrent_N, rnn_hidden), dtype=f32)
+        out["rnn_states_critic"] = rng.standard_normal((T + 1, N, A, recurrent_N, rnn_hidden), dtype=f32)
     return out
 
 

@@ -13,7 +13,7 @@ _vp, _i64, _i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
 class MLP(ctypes.Structure):
     _fields_ = [("src", _vp), ("row_tab", _vp), ("rows", _i64),
                 ("din", _i32), ("n_layers", _i32), ("act", _i32), ("out", _i32), ("ln_eps", ctypes.c_float),
-                ("w1", _vp), ("bias", _vp * 3), ("ln_g", _vp * 3), ("ln_b", _vp * 3), ("w2", _vp * 2),
+                ("arith", _i32), ("w1", _vp), ("bias", _vp * 3), ("ln_g", _vp * 3), ("ln_b", _vp * 3), ("w2", _vp * 2),
                 ("wh", _vp), ("bh", _vp), ("y", _vp), ("z", _vp * 3), ("ln_stats", _vp * 3), ("dy", _vp), ("dz1", _vp),
                 ("workspace", _vp), ("grads", _vp)]
 

@@ -80,11 +80,7 @@ extern "C" int mappo_mlp_set_grid_cap(int cap) {
     mlp::grid_cap_override() = cap;
     return 0;
 }
-extern "C" int mappo_mlp_set_flags(int flags) {
-    const int old = mlp::tuning_flags_ref();
-    mlp::tuning_flags_ref() = flags;
-    return old;
-}
+extern "C" int mappo_mlp_set_flags(int flags) { return mlp::set_tuning_flags(flags); }
 extern "C" int64_t mappo_mlp_row_table_ints(int64_t rows) { return mlp::rows128(rows); }
 extern "C" int mappo_mlp_row_table(const int64_t* idx, int64_t rows, int64_t mb, int chunk_len, int T, int N, int A,
                                    int32_t* row_tab, mappo_stream_t stream) {

@@ -11,15 +11,13 @@ from test_gru_kernels_emulated import reference
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[0, 1024], ids=["f32_mfma", "bf16x6"])
-def _arithmetic(request):
-    """Every test of this file under the default kernels and under option bit 1024 of mappo_mlp_set_flags (opt-in: the
-    projections of the chunk forward in six-term bf16 arithmetic)."""
-    from onpolicy import _native
-    extra = int(__import__("os").environ.get("MAPPO_TEST_EXTRA_FLAGS", "0")) if request.param else 0
-    old = _native.lib().mappo_mlp_set_flags(request.param | extra)
+@pytest.fixture(autouse=True, params=["six_term", "f32_mfma"])
+def _arithmetic(request, monkeypatch):
+    """Every test of this file under both arithmetic forms of K12's projections (include/mappo_hip.h MAPPO_ARITH_*: the
+    six-term bf16 form -- the default -- and the float32 MFMA); the layers built here carry no choice of their own, so the
+    process default MAPPO_MATRIX_ARITHMETIC decides."""
+    monkeypatch.setenv("MAPPO_MATRIX_ARITHMETIC", request.param)
     yield
-    _native.lib().mappo_mlp_set_flags(old)
 
 
 def _layer(dev, seed):

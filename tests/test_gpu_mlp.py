@@ -64,16 +64,19 @@ def _compare(din, layer_N, relu, out, rows, src_rows, chunk=None, feature_norm=T
                                    atol=10 * rtol * float(q.grad.abs().max()) + 1e-6, msg=lambda m: name + ": " + m)
 
 
-@pytest.fixture(autouse=True, params=[0, 64 + 128 + 256 + 512], ids=["default", "bf16x6"])
-def _forward_version(request):
-    """Every test of this file under the default kernels and under option bits 64 + 128 of mappo_mlp_set_flags: the opt-in
-    version-4 forward (first layer on the bf16 matrix cores, float32 products from six bf16 terms) for every width it
-    takes, and (bit 256) the direct first-layer weight-gradient kernel in the same six-term form; shapes they do not take
-    run the default kernels twice."""
+@pytest.fixture(autouse=True, params=[("six_term", 0), ("six_term", 128), ("f32_mfma", 0)],
+                ids=["six_term", "six_term_fwd4_every_width", "f32_mfma"])
+def _arithmetic(request, monkeypatch):
+    """Every test of this file under both arithmetic forms of the matrix products (include/mappo_hip.h MAPPO_ARITH_*; the
+    modules built here carry no choice of their own, so the process default MAPPO_MATRIX_ARITHMETIC decides): the six-term
+    bf16 form as shipped (the default), the same with tuning bit 128 (version 4 of the forward -- first layer in six-term
+    form, one wave per SIMD -- also for inputs narrower than 128 floats), and the float32 MFMA.  Shapes without a six-term
+    kernel run the float32 kernels under every parameter."""
     from onpolicy import _native
-    # (MAPPO_TEST_EXTRA_FLAGS: further option bits for the six-term parameter, e.g. forms that have only run on the emulator yet)
-    extra = int(__import__("os").environ.get("MAPPO_TEST_EXTRA_FLAGS", "0")) if request.param else 0
-    old = _native.lib().mappo_mlp_set_flags(request.param | extra)
+    name, flags = request.param
+    monkeypatch.setenv("MAPPO_MATRIX_ARITHMETIC", name)
+    old = _native.lib().mappo_mlp_set_flags(flags)
+    assert old >= 0
     yield
     _native.lib().mappo_mlp_set_flags(old)
 

@@ -14,7 +14,7 @@ FIELDS = ("share_obs", "obs", "actions", "action_log_probs", "value_preds", "rew
           "rnn_states_critic")
 
 
-def _runner(tmp_path, monkeypatch, algo, N=64, T=12, episodes=2, graph="1"):
+def _runner(tmp_path, monkeypatch, algo, N=64, T=12, episodes=2, graph="1", extra=()):
     from onpolicy.scripts.train import train_mpe
     monkeypatch.setenv("MAPPO_RESULTS_DIR", str(tmp_path / "results"))
     monkeypatch.setenv("MAPPO_ROLLOUT_GRAPH", graph)
@@ -22,7 +22,8 @@ def _runner(tmp_path, monkeypatch, algo, N=64, T=12, episodes=2, graph="1"):
                            "--num_landmarks", "3", "--algorithm_name", algo, "--n_rollout_threads", str(N),
                            "--episode_length", str(T), "--num_env_steps", str(episodes * N * T), "--ppo_epoch", "2",
                            "--num_mini_batch", "1", "--data_chunk_length", "4", "--hidden_size", "64", "--use_ReLU",
-                           "--use_wandb", "--log_interval", "1", "--n_training_threads", "1", "--use_device_env"])
+                           "--use_wandb", "--log_interval", "1", "--n_training_threads", "1", "--use_device_env"]
+                          + list(extra))
 
 
 def _snapshot(runner):
@@ -51,9 +52,18 @@ def _fields(runner):
     return out
 
 
-@pytest.mark.parametrize("algo", ["mappo", "rmappo"])
-def test_graphed_rollout_equals_eager_rollout(tmp_path, monkeypatch, algo):
-    runner = _runner(tmp_path, monkeypatch, algo)
+# --use_popart (with --use_valuenorm = store_false: the trainer asserts they are exclusive): the PopArt value head REBINDS its
+# parameters' storage on every update (algorithms/utils/popart.py), which a captured graph must not be blind to
+POPART = ("--use_popart", "--use_valuenorm")
+
+
+@pytest.mark.parametrize("algo,extra", [("mappo", ()), ("rmappo", ()), ("mappo", POPART), ("rmappo", POPART)],
+                         ids=["mappo", "rmappo", "mappo_popart", "rmappo_popart"])
+def test_graphed_rollout_equals_eager_rollout(tmp_path, monkeypatch, algo, extra):
+    runner = _runner(tmp_path, monkeypatch, algo, extra=extra)
+    if extra:       # two train() calls have run: the head the graph was captured with is long gone
+        from onpolicy.algorithms.utils.popart import PopArt
+        assert isinstance(runner.trainer.policy.critic.v_out, PopArt)
     rg = runner.rollout_graph
     assert rg is not None and rg.graph is not None, "the rollout step was not captured"
     assert rg.replays == 2 * runner.episode_length          # both training episodes ran through the graph
@@ -87,11 +97,12 @@ def test_graphed_rollout_equals_eager_rollout(tmp_path, monkeypatch, algo):
     np.testing.assert_allclose([[d["individual_reward"] for d in row] for row in g_infos], eager_infos, rtol=1e-6)
 
 
-def test_training_through_the_graph_logs_like_the_eager_run(tmp_path, monkeypatch):
+@pytest.mark.parametrize("extra", [(), POPART], ids=["valuenorm", "popart"])
+def test_training_through_the_graph_logs_like_the_eager_run(tmp_path, monkeypatch, extra):
     """Whole runs (rollouts + updates) with and without the graph from the same seed: same logged rewards / losses."""
     logs = {}
     for mode in ("1", "0"):
-        runner = _runner(tmp_path / mode, monkeypatch, "mappo", N=32, T=10, episodes=3, graph=mode)
+        runner = _runner(tmp_path / mode, monkeypatch, "mappo", N=32, T=10, episodes=3, graph=mode, extra=extra)
         assert (runner.rollout_graph is not None) == (mode == "1")
         recs = [json.loads(l) for l in open(os.path.join(runner.log_dir, "scalars.jsonl"))]
         logs[mode] = {(r["tag"], i): r[r["tag"]] for i, r in enumerate(recs)}

@@ -29,14 +29,14 @@ def emu_lib():
     return lib
 
 
-# Option bit 1024 of mappo_mlp_set_flags (opt-in): the projections of the chunk kernels in six-term bf16 arithmetic
-# (+ bit 8192: all six blocks of the backward as planes, the sums aliasing them behind a barrier -- emulator-green, its device
-# A / B is the next round's, so no device test sets it)
-@pytest.fixture(params=[0, 1024, 1024 + 8192], ids=["f32_mfma", "bf16x6", "bf16x6_all_blocks"])
+# Both arithmetic forms of the projections (field ``arith`` of mappo_gru_seq_t): the six-term bf16 form (weights as bf16
+# planes in LDS; the backward with all six blocks of its transposed products as planes wherever that instance is built)
+# and the float32 MFMA
+@pytest.fixture(params=[1, 0], ids=["f32_mfma", "six_term"])
 def emu(emu_lib, request):
-    old = emu_lib.mappo_mlp_set_flags(request.param)
+    emu_lib._arith = request.param
     yield emu_lib
-    emu_lib.mappo_mlp_set_flags(old)
+    emu_lib._arith = 0
 
 
 def reference(p, x, h0, masks, L, mb):
@@ -84,7 +84,7 @@ def run(emu, L, mb, seed, grid_cap=0, head_out=0):
     ptr = lambda a: a.ctypes.data
     m = _native.GRUSeq(x=ptr(x), h0=ptr(h0), masks=ptr(masks), w_ih=ptr(P["w_ih"]), w_hh=ptr(P["w_hh"]), b_ih=ptr(P["b_ih"]),
                        b_hh=ptr(P["b_hh"]), ln_g=ptr(P["ln_g"]), ln_b=ptr(P["ln_b"]), ln_eps=1e-5, H=64, L=L, mb=mb,
-                       y=ptr(y), h_last=ptr(h_last), gates=ptr(gates), hm=ptr(hm), stats=ptr(stats), dy=ptr(dy),
+                       arith=getattr(emu, "_arith", 0), y=ptr(y), h_last=ptr(h_last), gates=ptr(gates), hm=ptr(hm), stats=ptr(stats), dy=ptr(dy),
                        dx=ptr(dx), dgi=ptr(dgi), dq=ptr(dq), dh0=ptr(dh0), dh_last=ptr(dhl), ln_grads=ptr(ln_grads),
                        workspace=ptr(ws))
     if head_out:

@@ -35,12 +35,13 @@ def test_snapshot_has_no_spills_and_expected_occupancy():
     # round 4: the version-3 forward -- 15 instances (layers x activation x groups of 8 columns in a row's last chunk), two
     # waves per SIMD (<= 256 registers), no scratch
     f3 = {k: v for k, v in table.items() if "mlp_fwd3_kernel<" in k}
-    # (+ 9 two-layer instances with the hidden layer in the six-term bf16 form: option bit 4096, device A / B pending)
+    # (+ 9 two-layer instances with the hidden layer in the six-term bf16 form: what MAPPO_ARITH_SIX_TERM runs for the
+    # two-layer shapes version 4 does not take; device-verified in round 5)
     assert len(f3) == 24 and all(v["scratch_bytes"] == 0 and v["occupancy"] == 2 for v in f3.values())
-    # the opt-in version 4 (first layer on the bf16 matrix pipe): one wave per SIMD with the hidden layer's operands in
-    # registers (up to 512), no scratch in its 9 instances (x 2: with the hidden layer in the six-term form too)
+    # version 4 (both layers on the bf16 matrix pipe, MAPPO_ARITH_SIX_TERM): one wave per SIMD with the hidden layer's weight
+    # planes in registers (up to 512), no scratch in its 9 instances (round 5: the form with a float32 hidden layer is gone)
     f4 = {k: v for k, v in table.items() if "mlp_fwd4_kernel<" in k}
-    assert len(f4) == 18 and all(v["scratch_bytes"] == 0 and v["occupancy"] == 1 for v in f4.values())
+    assert len(f4) == 9 and all(v["scratch_bytes"] == 0 and v["occupancy"] == 1 for v in f4.values())
     pick = lambda frag: [v for k, v in table.items() if frag in k]      # noqa: E731
     # K9: the forward trunk fits two workgroups of eight waves on a CU (<= 128 registers), the direct-to-LDS weight
     # gradient and the backward chain run one wave per SIMD with their accumulators in the AGPR half of the file
@@ -51,10 +52,10 @@ def test_snapshot_has_no_spills_and_expected_occupancy():
     # chunk kernels likewise one workgroup per CU (104 KB of weights in LDS)
     assert len(pick("mlp_bwd_kernel")) == 21 and all(v["occupancy"] == 1 and v["scratch_bytes"] == 0 for v in pick("mlp_bwd_kernel"))
     assert all(v["occupancy"] == 1 for v in pick("gru_seq_fwd_kernel") + pick("gru_seq_bwd_kernel"))
-    # ... its nine backward instances: no head / head of <= 2, 6, 18 outputs x the head's gradient sums on or off (x 2: the
-    # opt-in form with the r / z blocks of the transposed weights in six-term bf16 arithmetic, round 4)
-    # (+ 8 with all six blocks as planes, option bit 8192, device A / B pending; the ninth would spill and is not built)
-    assert len(pick("gru_seq_bwd_kernel")) == 26 and all(v["scratch_bytes"] == 0 for v in pick("gru_seq_bwd_kernel"))
+    # ... its nine backward instances: no head / head of <= 2, 6, 18 outputs x the head's gradient sums on or off, x 2: float32
+    # MFMA, and the six-term form with all six blocks of the transposed weights as bf16 planes (8 instances; the ninth -- the
+    # widest head-sum instance -- would spill and keeps the four-block form of round 4)
+    assert len(pick("gru_seq_bwd_kernel")) == 18 and all(v["scratch_bytes"] == 0 for v in pick("gru_seq_bwd_kernel"))
     assert all(v["occupancy"] >= 7 for v in pick("ppo_loss_kernel"))
     assert all(v["occupancy"] >= 6 for v in pick("gru_fwd_kernel")) and all(v["occupancy"] == 8 for v in pick("gru_bwd_kernel"))
     (step,) = pick("gru_step_fwd_kernel")                                # one workgroup per CU by design: W_hh in LDS

@@ -26,20 +26,25 @@ def emu_lib():
     return R.bind(ctypes.CDLL(build.build()))
 
 
-# The forward kernels share every test: version 3 (operands straight from global memory, resident first-layer weights;
-# every aligned width up to 448 with two or three layers; a row's last chunk runs only the groups of 8 columns that hold
-# data -- instances for 1, 2 and 4 groups) and -- option bit 4 of mappo_mlp_set_flags -- the loader / compute kernel that
-# serves every other shape.
-# Unaligned / wider cases run the latter under all ids.  Option bit 32 selects the two-slot form of the direct-to-LDS
-# first-layer weight-gradient kernel (two workgroups per CU) for the widths that kernel takes.
-# Option bit 64 (opt-in): version 4 of the forward -- the first layer as six bf16 x bf16 terms per float32 product on the bf16
-# matrix pipe (two-layer trunks, aligned widths up to 384 -- bit 128: also those below 128 columns, which bit 64 alone leaves
-# to version 3; every other shape falls through to the kernels above).
-# Option bit 256 (opt-in): the direct-to-LDS first-layer weight-gradient kernel forms its tile products the same way.
-@pytest.fixture(params=[0, 4, 32, 64 + 128 + 256 + 512], ids=["fwd3", "fwd_loaders", "dw1_two_per_cu", "bf16x6"])
+# Every test runs under five (tuning flags, arithmetic) settings (``arith`` = the per-call field of mappo_mlp_t):
+#   fwd3 / fwd_loaders / dw1_two_per_cu -- float32 MFMA: version 3 of the forward (operands straight from global memory,
+#     resident first-layer weights; every aligned width up to 448 with two or three layers; a row's last chunk runs only the
+#     groups of 8 columns that hold data), tuning bit 4 = the loader / compute kernel that serves every other shape, tuning bit
+#     32 = the two-slot form of the direct-to-LDS first-layer weight-gradient kernel (two workgroups per CU);
+#   six_term -- the shipped default: version 4 of the forward (both layers as six bf16 x bf16 terms per float32 product on
+#     the bf16 matrix pipe) for two-layer trunks with aligned inputs 128 .. 384 floats wide, version 3 with its hidden layer
+#     in six-term form for the other two-layer shapes, the backward chain of two-layer trunks and the direct first-layer
+#     weight-gradient kernel in the same form; every other shape falls through to the float32 kernels;
+#   six_term_fwd4_every_width -- the same with tuning bit 128: version 4 also for inputs narrower than 128 floats.
+@pytest.fixture(params=[(0, 1), (4, 1), (32, 1), (0, 0), (128, 0)],
+                ids=["fwd3", "fwd_loaders", "dw1_two_per_cu", "six_term", "six_term_fwd4_every_width"])
 def emu(emu_lib, request):
-    old = emu_lib.mappo_mlp_set_flags(request.param)
+    flags, arith = request.param
+    old = emu_lib.mappo_mlp_set_flags(flags)
+    assert old >= 0
+    emu_lib._arith = arith
     yield emu_lib
+    emu_lib._arith = 0
     emu_lib.mappo_mlp_set_flags(old)
 
 
@@ -75,7 +80,7 @@ def _run(emu, rng, din, n_layers, act, out, rows, src_rows, standardize=True, ch
     np.testing.assert_array_equal(tab[:rows], srows)
     np.testing.assert_array_equal(tab[rows:], np.full(R128 - rows, srows[-1]))     # padding = last row
     m = R.MLP(src=_ptr(xin), row_tab=_ptr(tab), rows=rows, din=din,
-              n_layers=n_layers, act=act, out=out, ln_eps=1e-5, w1=_ptr(p["w1"]), wh=_ptr(p["wh"]) if out else None,
+              n_layers=n_layers, act=act, out=out, ln_eps=1e-5, arith=getattr(emu, "_arith", 0), w1=_ptr(p["w1"]), wh=_ptr(p["wh"]) if out else None,
               bh=_ptr(p["bh"]) if out else None, y=_ptr(y))
     st = [np.full((emu.mappo_mlp_row_table_ints(rows), 2), np.nan, np.float32) for _ in range(n_layers)]
     for l in range(n_layers):
@@ -195,10 +200,11 @@ def test_version4_widths(emu, din, act, out):
 
 @pytest.mark.parametrize("din,act,out", [(384, 1, 1), (48, 1, 5), (152, 2, 0), (20, 1, 3)])
 def test_version4_hidden_layer_in_six_term_form(emu_lib, din, act, out):
-    """Option bit 2048 (with 64): the version-4 forward with its hidden layer on the bf16 matrix pipe too (weight planes in
-    registers, folded bias from LDS).  Emulator-green at the end of round 4; its device A / B is the next round's."""
-    old = emu_lib.mappo_mlp_set_flags(64 + 128 + 2048)
+    """Version 4 of the forward with its hidden layer on the bf16 matrix pipe too (weight planes in registers, folded bias
+    from LDS): what MAPPO_ARITH_SIX_TERM selects (tuning bit 128: every aligned width).  Device-verified in round 5."""
+    old = emu_lib.mappo_mlp_set_flags(128)
     emu_lib.mappo_mlp_set_grid_cap(1)
+    emu_lib._arith = 0
     try:
         _run(emu_lib, np.random.default_rng(din + 1), din, 2, act, out, 128 * 2 + 45, 400)
     finally:
@@ -208,15 +214,29 @@ def test_version4_hidden_layer_in_six_term_form(emu_lib, din, act, out):
 
 @pytest.mark.parametrize("din,act,out", [(48, 1, 5), (384, 1, 1), (152, 2, 0), (20, 1, 3), (436, 1, 1)])
 def test_version3_hidden_layer_in_six_term_form(emu_lib, din, act, out):
-    """Option bit 4096: the version-3 forward (two waves per SIMD; the narrow actor inputs, widths above 384) with its hidden
-    layer on the bf16 matrix pipe (weight planes in LDS).  Emulator-green at the end of round 4; device A / B pending."""
-    old = emu_lib.mappo_mlp_set_flags(4096)
+    """The version-3 forward (two waves per SIMD; the narrow actor inputs, widths above 384) with its hidden layer on the bf16
+    matrix pipe (weight planes in LDS): what MAPPO_ARITH_SIX_TERM selects for two-layer trunks version 4 does not take (tuning
+    bit 4 would keep the loader / compute kernel; 384 and 152 go to version 4 here).  Device-verified in round 5."""
     emu_lib.mappo_mlp_set_grid_cap(1)
+    emu_lib._arith = 0
     try:
         _run(emu_lib, np.random.default_rng(din + 2), din, 2, act, out, 128 * 2 + 45, 400)
     finally:
         emu_lib.mappo_mlp_set_grid_cap(0)
+
+
+def test_tuning_flags_reject_unknown_bits(emu_lib):
+    """mappo_mlp_set_flags knows bits 1, 4, 32, 128; anything else (e.g. the arithmetic bits of ABI version 1) is refused and
+    changes nothing.  An unknown ``arith`` value is an argument error."""
+    old = emu_lib.mappo_mlp_set_flags(4)
+    try:
+        for bad in (8, 16, 64, 256, 512, 1024, 2048, 4096, 8192, 4 | 64):
+            assert emu_lib.mappo_mlp_set_flags(bad) == -1
+            assert emu_lib.mappo_mlp_set_flags(4) == 4
+    finally:
         emu_lib.mappo_mlp_set_flags(old)
+    m = R.MLP(arith=7)
+    assert emu_lib.mappo_mlp_forward(ctypes.byref(m), None) != 0
 
 
 def test_first_layer_slab_split(emu):

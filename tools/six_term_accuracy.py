@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""GPU box: how far are the K9 kernels from float64 -- with the default float32-MFMA kernels and with the opt-in six-term
-bf16 kernels (option bits 64 + 128 + 256 + 512 of mappo_mlp_set_flags)?  One million rows through MLPBase + head at the
+"""GPU box: how far are the K9 kernels from float64 -- under both arithmetic forms of the matrix products
+(include/mappo_hip.h MAPPO_ARITH_SIX_TERM -- the default -- and MAPPO_ARITH_F32_MFMA)?  One million rows through MLPBase + head at the
 north-star widths, outputs and every parameter gradient against the float64 modules on the device (the comparison of
 tests/test_gpu_mlp.py::test_trunk_at_scale_vs_float64, with the errors printed instead of asserted).
 
@@ -40,8 +40,8 @@ def main():
         dy = torch.randn(rows, out, device=dev, generator=g) / rows ** 0.5
         y_ref = ref_head(ref_base(src.double()[idx]))
         y_ref.backward(dy.double())
-        for label, flags in (("float32 MFMA (default)", 0), ("six-term bf16 (bits 64 + 128 + 256 + 512)", 64 + 128 + 256 + 512)):
-            old = _native.lib().mappo_mlp_set_flags(flags)
+        for label, arith in (("float32 MFMA (MAPPO_ARITH_F32_MFMA)", "f32_mfma"), ("six-term bf16 (MAPPO_ARITH_SIX_TERM, the default)", "six_term")):
+            fused_mlp.set_matrix_arithmetic(base, arith)
             try:
                 for p in list(base.parameters()) + list(head.parameters()):
                     p.grad = None
@@ -50,7 +50,7 @@ def main():
                 y.backward(dy)
                 torch.cuda.synchronize()
             finally:
-                _native.lib().mappo_mlp_set_flags(old)
+                fused_mlp.set_matrix_arithmetic(base, "six_term")
             errs = {"y": float((y.detach().double() - y_ref.detach()).abs().max() / y_ref.detach().abs().max())}
             for (name, p), q in list(zip(base.named_parameters(), ref_base.parameters())) + \
                     list(zip(head.named_parameters(), ref_head.parameters())):

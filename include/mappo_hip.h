@@ -624,6 +624,29 @@ int     mappo_fold_input_norm_backward(const float* w, const float* gamma, const
                                        const float* db_folded, int out_features, int din, int ld, float* dw, float* dgamma,
                                        float* dbeta, mappo_stream_t stream);
 
+/* --------------------------------------------------------------- K15: tall Linear layers with 512 outputs ----
+ * The GEMMs of the hidden-512 trunks (BASELINE configs[4], Hanabi: reference onpolicy/algorithms/utils/mlp.py:6-58 at
+ * --hidden_size 512 --layer_N 2, scripts/train_hanabi_forward.sh:15-17) in MAPPO_ARITH_SIX_TERM arithmetic: float32 in,
+ * float32 out, every product from six bf16 x bf16 terms of the operands' exact three-way splits on the bf16 matrix cores,
+ * float32 accumulation.  (Callers that want the float32 matrix instruction use the library GEMM: torch.nn.functional.linear.)
+ *   mappo_linear512_prepare:  the three bf16 planes of W [512, K] (rows ldw floats apart) -- or, transposed = 1, of W^T for a
+ *     W whose element (k, feature) is w[k * ldw + feature] (the input gradient of a 512 -> 512 Linear: dX = dY W) -- in the
+ *     order the forward reads them; planes [mappo_linear512_planes_floats(K)] floats, 16-byte aligned.  Once per weight value.
+ *   mappo_linear512_forward:  y [rows, 512] = x [rows, K] W^T (+ bias [512] unless NULL); x rows ldx >= K floats apart
+ *     (columns K .. ldx - 1 must hold finite values: the zero padding of mappo_standardize_rows_ld); rows that start on 16-byte
+ *     boundaries (ldx a multiple of 4) are loaded in 16-byte pieces, any other ldx (Hanabi's 1285 / 1385-wide gathered
+ *     minibatches) in 4-byte pieces.
+ *   mappo_linear512_wgrad:    dw [512, K] = dy^T [512, rows] x [rows, K] (the weight gradient of y = x W^T; the contraction
+ *     runs over the rows, partial sums of row ranges are added in a fixed order: deterministic run to run);
+ *     workspace [mappo_linear512_wgrad_workspace_floats(K)] floats. */
+int64_t mappo_linear512_planes_floats(int K);
+int     mappo_linear512_prepare(const float* w, int K, int ldw, int transposed, float* planes, mappo_stream_t stream);
+int     mappo_linear512_forward(const float* x, int64_t rows, int K, int ldx, const float* planes, const float* bias,
+                                float* y, mappo_stream_t stream);
+int64_t mappo_linear512_wgrad_workspace_floats(int K);
+int     mappo_linear512_wgrad(const float* dy, const float* x, int64_t rows, int K, int ldx, float* dw, float* workspace,
+                              mappo_stream_t stream);
+
 /* --------------------------------------------------------------- K11: simple_spread worlds on the device ----
  * One env step of `n_worlds` cooperative-navigation worlds (the env of BASELINE.json configs[0] / configs[2]; reference
  * onpolicy/envs/mpe/core.py:120-190, environment.py:100-180, scenarios/simple_spread.py:60-103) as one launch, so that

@@ -1358,6 +1358,7 @@ extern "C" int mappo_gae_f32(const float* rewards, float* value_preds, const flo
     if (!strip_ok) variant = 99;
     // narrow buffers: the time-parallel scan (tolerance mode) unless the caller insists on bit-exact results
     const bool scan_ok = strip_ok && T <= kScanSegs * kScanLmax && (!a.partials || a.partial_rows >= (C + 31) / 32);
+    if (variant == 71) variant = 70;
     if (variant >= 70 && variant <= 72 && !scan_ok) variant = 0;
     if (variant == 0 && scan_ok && !(flags & MAPPO_GAE_EXACT) && C >= 2048 && C < 16384 && T >= 64) variant = 70;
     if (variant == 0) {
@@ -1386,7 +1387,7 @@ extern "C" int mappo_gae_f32(const float* rewards, float* value_preds, const flo
         case 56: e = launch_dma_epi<32, 2, 16, 4>(a, flags, stream); break;
         case 57: e = launch_dma_epi<128, 6, 12, 4>(a, flags, stream); break;
         case 70: e = launch_scan<32>(a, flags, stream); break;
-        case 71: e = launch_scan<64>(a, flags, stream); break;
+        // (71, the 64-column form, is gone: never selected automatically, and three of its instances spilled 68-196 bytes per lane)
         case 72: e = launch_scan<16>(a, flags, stream); break;
         default: e = launch_column(a, flags, stream); break;
     }

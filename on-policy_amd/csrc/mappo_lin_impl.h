@@ -1,0 +1,445 @@
+// K15: tall float32 GEMMs with 512 output features in six-term bf16 arithmetic -- the Linear layers of the hidden-512 trunks
+// (BASELINE configs[4], Hanabi: reference onpolicy/algorithms/utils/mlp.py:6-58 at --hidden_size 512 --layer_N 2,
+// scripts/train_hanabi_forward.sh:15-17; 85 % of that update's time was library float32 GEMMs):
+//
+//   lin_fwd_kernel    Y [rows, 512] = X [rows, K] W^T (+ bias)     forward of a Linear, and -- with the planes of W^T -- the
+//                                                                   input gradient dX = dY W of a 512 -> 512 Linear
+//   lin_wgrad_kernel  dW [512, K]   = dY^T [512, rows] X [rows, K]  weight gradient, the contraction runs over the rows
+//
+// Arithmetic: every float32 product from six bf16 x bf16 terms of the operands' exact three-way splits on
+// v_mfma_f32_32x32x16_bf16, accumulated in float32 (include/mappo_hip.h MAPPO_ARITH_SIX_TERM; mlp::split3).  A split costs
+// ~4.5 vector instructions per element; here an element of X meets 512 outputs (forward) and an element of dY / X meets 128 /
+// 512 (weight gradient), so -- unlike in the 64-wide kernels of K9 -- the split disappears behind the matrix instructions and
+// the kernels run at the bf16 pipe's pace: 6 x 2 x 512 x K FLOPs per row on a 2.5 PFLOP/s pipe against the library's float32
+// GEMM on the 157 TFLOP/s float32 instruction.
+//
+// Both kernels move every operand with direct-to-LDS loads issued from inline assembly and counted s_waitcnt (the idiom of
+// mlp_dw1_direct_kernel: the compiler sees no vector-memory load, so it inserts no wait of its own), one workgroup of four
+// waves per CU, one wave per SIMD with its 256 accumulators in the AGPR half of the register file.
+//
+//   forward:  a workgroup owns 128 rows (32 per wave) x all 512 features.  Per k = 16 step the 48 KB block of W's three bf16
+//             planes (pre-split once per call by lin_planes_kernel, stored in the order the MFMA's A operand reads it) streams
+//             from L2 into one of two LDS buffers, each wave's [32 rows, 16 columns] piece of X into its own three-slot ring;
+//             a lane splits its 8 values of X once and issues 16 feature tiles x 6 terms = 96 MFMAs against 48 16-byte LDS
+//             reads.  One barrier per step.
+//   wgrad:    a workgroup owns a [512 features, 128 columns] slab of dW and a range of rows; per 16-row step the [16, 512] tile
+//             of dY and the [16, 128] tile of X land in one of three LDS slots, a wave (128 features x 128 columns: 4 x 4 MFMA
+//             tiles) reads its operands transposed (8 rows of one column per lane), splits them and issues 96 MFMAs.  Partial
+//             slabs of the row ranges are summed by lin_reduce_kernel in a fixed order.
+#ifndef MAPPO_LIN_IMPL_H
+#define MAPPO_LIN_IMPL_H
+
+#include "mappo_mlp_impl.h"
+
+namespace lin {
+
+constexpr int kN = 512;                 // output features
+constexpr int kThreads = 256;           // 4 waves
+constexpr int kWBlock = 3 * 16 * 256;   // floats of one k = 16 block of planes: [plane 3][tile 16][lane 64] x 16 bytes = 48 KB
+constexpr int kXSlot = 512;             // floats of a wave's [32 rows, 16 columns] piece of X
+constexpr int kFwdLds = 2 * kWBlock + 4 * 3 * kXSlot + kN;      // 96 KB + 24 KB + 2 KB
+constexpr int kGridCap = 256;           // one workgroup per CU
+
+struct FwdArgs {
+    const float* x;         // [rows, ldx]
+    long long rows;
+    int K, ldx, nkb;        // nkb = ceil(K / 16) blocks of planes
+    const float* planes;    // [nkb][kWBlock]
+    const float* bias;      // [512] or nullptr
+    float* y;               // [rows, 512]
+};
+
+inline long long planes_floats(int K) { return (long long)((K + 15) / 16) * kWBlock; }
+
+// planes of W [512, K] (row stride ldw) -- or, transposed = 1, of W^T for W [K = 512 rows of the contraction ..., i.e. element
+// (feature f, k) is w[k * ldw + f] -- in MFMA A-operand order: block kb, plane p, tile t, lane (c, g): the 8 bf16
+// W[32 t + c][16 kb + 8 g .. + 7] (zero beyond K)
+__global__ void __launch_bounds__(kThreads) lin_planes_kernel(const float* w, int K, int ldw, int transposed, float* planes,
+                                                              int nkb) {
+    const long long total = (long long)nkb * 16 * 64;
+    for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long long)gridDim.x * kThreads) {
+        const int lane = (int)(e & 63), t = (int)((e >> 6) & 15);
+        const long long kb = e >> 10;
+        const int c = lane & 31, g = lane >> 5, f = 32 * t + c;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const long long k = 16 * kb + 8 * g + i;
+            v[i] = k < K ? (transposed ? w[k * ldw + f] : w[(long long)f * ldw + k]) : 0.f;
+        }
+        bf8 p1, p2, p3;
+        mlp::split3(v, p1, p2, p3);
+        float* base = planes + kb * kWBlock + t * 256 + lane * 4;
+        *reinterpret_cast<bf8*>(base) = p1;
+        *reinterpret_cast<bf8*>(base + 4096) = p2;
+        *reinterpret_cast<bf8*>(base + 8192) = p3;
+    }
+}
+
+// X16: the rows of x start on 16-byte boundaries (ldx a multiple of 4 floats): two 16-byte pieces per lane and step; otherwise
+// (Hanabi's 1285 / 1385-wide gathered minibatches) the same LDS image is filled with 4-byte pieces, eight per lane and step
+template <bool X16>
+__global__ void __launch_bounds__(kThreads, 1) lin_fwd_kernel(FwdArgs a) {
+    float* lds = prim::lds();
+    float* wbuf = lds;                              // [2][kWBlock]
+    float* xring = lds + 2 * kWBlock;               // [wave 4][slot 3][kXSlot]
+    float* biasl = xring + 4 * 3 * kXSlot;          // [512]
+    const int tid = threadIdx.x, lane = tid & 63, wave = prim::uniform(tid >> 6), c = lane & 31, g = lane >> 5;
+    const int nkb = a.nkb;
+    const long long ntiles = (a.rows + 127) / 128;
+    const long long my_tiles = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    if (my_tiles == 0) return;
+    for (int e = tid; e < kN; e += kThreads) biasl[e] = a.bias != nullptr ? a.bias[e] : 0.f;
+    const long long total = my_tiles * nkb;         // steps of this workgroup
+    // ---- loads.  W: block kb of the planes, 48 units of 1 KB, 12 per wave.  X: this wave's 32 rows x 16 columns of step s as
+    // two units: lane l of unit j loads the 16-byte piece l >> 4 of row 16 j + (l & 15) -- the LDS image a half-wave then reads
+    // without bank conflicts (16 consecutive rows at one piece = 16 consecutive 16-byte slots)
+    auto issue_w = [&](long long s) {
+        const int buf = (int)(s & 1);               // (the buffer of step s even when s is past the end: nobody reads it then)
+        if (s >= total) s = total - 1;
+        const int kb = (int)(s % nkb);
+        const float* src = a.planes + (long long)kb * kWBlock + (12 * wave) * 256 + 4 * lane;
+        float* dst = wbuf + buf * kWBlock + (12 * wave) * 256;
+#pragma unroll
+        for (int u = 0; u < 12; ++u) prim::load_lds16(src + u * 256, dst + u * 256);
+    };
+    auto issue_x = [&](long long s) {
+        float* dst = xring + (wave * 3 + (int)(s % 3)) * kXSlot;
+        if (s >= total) s = total - 1;              // (past the end: the last step again, into a slot nobody reads any more;
+                                                    // keeps every group the same size)
+        const long long tile = blockIdx.x + (s / nkb) * gridDim.x;
+        const int kb = (int)(s % nkb);
+        if (X16) {
+            int k = 16 * kb + 4 * (lane >> 4);
+            if (k > a.ldx - 4) k = a.ldx - 4;       // a piece past the row's end: finite data against zero weights
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                long long r = tile * 128 + 32 * wave + 16 * j + (lane & 15);
+                if (r >= a.rows) r = a.rows - 1;
+                prim::load_lds16(a.x + r * a.ldx + k, dst + j * 256);
+            }
+        } else {
+            // unit u = (j, piece): lane l fills float e = l & 3 of the slot of row 16 j + (l >> 2)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                long long r = tile * 128 + 32 * wave + 16 * (u >> 2) + (lane >> 2);
+                if (r >= a.rows) r = a.rows - 1;
+                int k = 16 * kb + 4 * (u & 3) + (lane & 3);
+                if (k > a.ldx - 1) k = a.ldx - 1;
+                prim::load_lds4(reinterpret_cast<const int*>(a.x + r * a.ldx + k), reinterpret_cast<int*>(dst + u * 64));
+            }
+        }
+    };
+    constexpr int kXGroup = X16 ? 2 : 8;            // loads of one issue_x
+    issue_w(0);
+    issue_x(0);
+    issue_x(1);
+    __syncthreads();        // the bias is in LDS
+    long long s = 0;        // step counter over all tiles of this workgroup: the load pipeline runs across tile boundaries
+    for (long long m = 0; m < my_tiles; ++m) {
+        f32x16 acc[16];
+        // (a compiler barrier: without it the 256 loop-invariant bias reads are hoisted out of the tile loop and kept -- spilled)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const v4 b = *reinterpret_cast<const v4*>(biasl + 32 * t + 8 * q + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t][4 * q + e] = b[e];
+            }
+        for (int kb = 0; kb < nkb; ++kb, ++s) {
+            // this wave's part of W(s) and its X(s) have landed: everything but the youngest group, X(s + 1)
+            prim::wait_lds_loads<kXGroup>();
+            __syncthreads();    // ... and everybody else's part of W(s); all waves are done with step s - 1's buffer
+            issue_w(s + 1);
+            issue_x(s + 2);
+            const float* wb = wbuf + (int)(s & 1) * kWBlock + lane * 4;
+            const float* xs = xring + (wave * 3 + (int)(s % 3)) * kXSlot + (c >> 4) * 256 + ((2 * g) * 16 + (c & 15)) * 4;
+            float r[8];
+            {
+                const v4 lo = *reinterpret_cast<const v4*>(xs), hi = *reinterpret_cast<const v4*>(xs + 64);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    r[i] = lo[i];
+                    r[4 + i] = hi[i];
+                }
+            }
+            bf8 b1, b2, b3;
+            mlp::split3(r, b1, b2, b3);
+            // four groups of four feature tiles; the next group's 12 A operands are read while this group's 24 MFMAs issue (the
+            // scheduling fence keeps the compiler from hoisting all 48 reads to the top: 192 registers)
+            bf8 an[3][4];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) an[p][t] = *reinterpret_cast<const bf8*>(wb + p * 4096 + t * 256);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bf8 af[3][4];
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) af[p][t] = an[p][t];
+                if (q < 3) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            an[p][t] = *reinterpret_cast<const bf8*>(wb + p * 4096 + (4 * (q + 1) + t) * 256);
+                }
+                prim::sched_fence();
+                // smallest terms first; term by term over the group's four tiles, so that an MFMA never waits for the result of
+                // the one issued just before it (six back-to-back MFMAs on ONE accumulator ran at 43 % of the pipe's rate:
+                // profiles/r05_bench_hanabi_kernel_stats_first.csv)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[4 * q + t] = prim::mfma_bf16(af[0][t], b3, acc[4 * q + t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[4 * q + t] = prim::mfma_bf16(af[2][t], b1, acc[4 * q + t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[4 * q + t] = prim::mfma_bf16(af[1][t], b2, acc[4 * q + t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[4 * q + t] = prim::mfma_bf16(af[0][t], b2, acc[4 * q + t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[4 * q + t] = prim::mfma_bf16(af[1][t], b1, acc[4 * q + t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[4 * q + t] = prim::mfma_bf16(af[0][t], b1, acc[4 * q + t]);
+            }
+        }
+        // the tile is complete: row c of this wave, features 32 t + 8 q + 4 g + e
+        const long long tile = blockIdx.x + m * gridDim.x;
+        const long long row = tile * 128 + 32 * wave + c;
+        if (row < a.rows) {
+            float* yr = a.y + row * kN + 4 * g;
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = acc[t][4 * q + e];
+                    *reinterpret_cast<v4*>(yr + 32 * t + 8 * q) = o;
+                }
+        }
+    }
+    prim::wait_lds_loads<0>();      // (the groups issued past the end)
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+constexpr int kWgCols = 128;                        // columns of X per slab
+constexpr int kWgDz = 16 * kN;                      // floats of a [16, 512] tile of dY
+constexpr int kWgX = 16 * kWgCols;                  // floats of a [16, 128] tile of X
+constexpr int kWgSlot = kWgDz + kWgX;               // 40 KB
+constexpr int kWgSlots = 3;
+constexpr int kWgLds = kWgSlots * kWgSlot;          // 120 KB
+
+struct WgArgs {
+    const float* dy;        // [rows, 512]
+    const float* x;         // [rows, ldx]
+    long long rows;
+    int K, ldx;
+    float* partials;        // [gridDim.x][512][kp], kp = gridDim.y * 128
+};
+
+template <bool X16>
+__global__ void __launch_bounds__(kThreads, 1) lin_wgrad_kernel(WgArgs a) {
+    float* lds = prim::lds();
+    const int tid = threadIdx.x, lane = tid & 63, wave = prim::uniform(tid >> 6), c = lane & 31, g = lane >> 5;
+    const int col0 = blockIdx.y * kWgCols;
+    const long long ntiles = (a.rows + 15) / 16;
+    // contiguous ranges of 16-row tiles
+    const long long per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const long long t0 = (long long)blockIdx.x * per;
+    long long n_it = ntiles - t0;
+    if (n_it > per) n_it = per;
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    const int kp = gridDim.y * kWgCols;
+    if (n_it > 0) {
+        // loads of a step: dY -- 32 units of 1 KB (half a row each), 8 per wave; X -- 8 units (two rows of 128 columns each), 2 per wave
+        auto issue = [&](long long m) {
+            float* slot = lds + (int)(m % kWgSlots) * kWgSlot;
+            if (m >= n_it) m = n_it - 1;            // (past the end: the last tile again, into a slot nobody reads any more)
+            const long long row0 = (t0 + m) * 16;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int unit = 8 * wave + u;
+                long long r = row0 + (unit >> 1);
+                if (r >= a.rows) r = a.rows - 1;    // (zeroed in LDS before the product)
+                prim::load_lds16(a.dy + r * kN + 256 * (unit & 1) + 4 * lane, slot + unit * 256);
+            }
+            if (X16) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int unit = 2 * wave + u;
+                    long long r = row0 + 2 * unit + (lane >> 5);
+                    if (r >= a.rows) r = a.rows - 1;
+                    int k = col0 + 4 * (lane & 31);
+                    if (k > a.ldx - 4) k = a.ldx - 4;       // a piece past the row's end: its columns are never written out
+                    prim::load_lds16(a.x + r * a.ldx + k, slot + kWgDz + unit * 256);
+                }
+            } else {
+                // 4-byte pieces: unit u of this wave = half a row (64 columns) of the tile's rows 4 wave .. 4 wave + 3
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int row = 4 * wave + (u >> 1);
+                    long long r = row0 + row;
+                    if (r >= a.rows) r = a.rows - 1;
+                    int k = col0 + 64 * (u & 1) + lane;
+                    if (k > a.ldx - 1) k = a.ldx - 1;
+                    prim::load_lds4(reinterpret_cast<const int*>(a.x + r * a.ldx + k),
+                                    reinterpret_cast<int*>(slot + kWgDz + row * kWgCols + 64 * (u & 1)));
+                }
+            }
+        };
+        constexpr int kGroup = X16 ? 10 : 16;       // loads of one issue
+        issue(0);
+        issue(1);
+        for (long long m = 0; m < n_it; ++m) {
+            prim::wait_lds_loads<kGroup>();         // this wave's loads of step m: all but the youngest group (step m + 1)
+            float* slot = lds + (int)(m % kWgSlots) * kWgSlot;
+            const long long live = a.rows - (t0 + m) * 16;
+            if (live < 16) {                        // last tile: rows past the end of the matrix count as zero
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int unit = 8 * wave + u;
+                    if ((unit >> 1) >= live) *reinterpret_cast<v4*>(slot + unit * 256 + 4 * lane) = v4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            __syncthreads();                        // ... and everybody else's; all waves are done with step m - 1's slot
+            issue(m + 2);
+            const float* dz = slot + 128 * wave + c;            // feature 128 wave + 32 i + c, row 8 g + e
+            const float* xt = slot + kWgDz + c;                 // column 32 j + c, row 8 g + e
+            bf8 A[4][3], B[4][3];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = dz[(8 * g + e) * kN + 32 * i];
+                mlp::split3(v, A[i][0], A[i][1], A[i][2]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = xt[(8 * g + e) * kWgCols + 32 * j];
+                mlp::split3(v, B[j][0], B[j][1], B[j][2]);
+            }
+            // smallest terms first, term by term over a feature tile's four column tiles (see lin_fwd_kernel)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = prim::mfma_bf16(A[i][0], B[j][2], acc[i][j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = prim::mfma_bf16(A[i][2], B[j][0], acc[i][j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = prim::mfma_bf16(A[i][1], B[j][1], acc[i][j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = prim::mfma_bf16(A[i][0], B[j][1], acc[i][j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = prim::mfma_bf16(A[i][1], B[j][0], acc[i][j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = prim::mfma_bf16(A[i][0], B[j][0], acc[i][j]);
+            }
+        }
+        prim::wait_lds_loads<0>();
+    }
+    // partial slab of this row range (zeros for a range without rows): D row = feature within the tile, D column = lane & 31
+    float* prow = a.partials + (long long)blockIdx.x * kN * kp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int f = 128 * wave + 32 * i + (v & 3) + 8 * (v >> 2) + 4 * g;
+                prow[(long long)f * kp + col0 + 32 * j + c] = acc[i][j][v];
+            }
+}
+
+// dw[f][k] = sum over the row ranges of partials[b][f][k], k < K (fixed order: deterministic run to run)
+__global__ void __launch_bounds__(kThreads) lin_reduce_kernel(const float* partials, int n, int kp, int K, float* dw) {
+    const long long total = (long long)kN * K;
+    for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long long)gridDim.x * kThreads) {
+        const long long f = e / K, k = e - f * K;
+        float s = 0.f;
+        for (int b = 0; b < n; ++b) s += partials[((long long)b * kN + f) * kp + k];
+        dw[e] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+inline int prepare(const float* w, int K, int ldw, int transposed, float* planes, hipStream_t stream) {
+    if (!w || !planes) return MAPPO_E_NULL;
+    if (K <= 0 || ldw <= 0 || (!transposed && ldw < K) || (transposed && ldw < kN)) return MAPPO_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(planes) & 15) != 0) return MAPPO_E_ALIGN;
+    const int nkb = (K + 15) / 16;
+    long long grid = ((long long)nkb * 1024 + kThreads - 1) / kThreads;
+    if (grid > 2048) grid = 2048;
+    MAPPO_LAUNCH(lin_planes_kernel, (unsigned)grid, kThreads, 0, stream, w, K, ldw, transposed, planes, nkb);
+    return MAPPO_LAUNCH_ERROR();
+}
+
+inline int forward(const float* x, long long rows, int K, int ldx, const float* planes, const float* bias, float* y,
+                   hipStream_t stream) {
+    if (!x || !planes || !y) return MAPPO_E_NULL;
+    if (rows <= 0 || K <= 0 || ldx < K || ldx < 4) return MAPPO_E_SHAPE;
+    if (((reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(y)) & 15) != 0) return MAPPO_E_ALIGN;
+    if ((reinterpret_cast<uintptr_t>(x) & 3) != 0) return MAPPO_E_ALIGN;
+    const bool x16 = ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    FwdArgs a;
+    a.x = x;
+    a.rows = rows;
+    a.K = K;
+    a.ldx = ldx;
+    a.nkb = (K + 15) / 16;
+    a.planes = planes;
+    a.bias = bias;
+    a.y = y;
+    const long long grid = mlp::capped((rows + 127) / 128, kGridCap);
+    if (x16) MAPPO_LAUNCH(lin_fwd_kernel<true>, (unsigned)grid, kThreads, (size_t)kFwdLds * 4, stream, a);
+    else MAPPO_LAUNCH(lin_fwd_kernel<false>, (unsigned)grid, kThreads, (size_t)kFwdLds * 4, stream, a);
+    return MAPPO_LAUNCH_ERROR();
+}
+
+inline int wgrad_slabs(int K) { return (K + kWgCols - 1) / kWgCols; }
+inline int wgrad_ranges(int K) {
+    const int r = kGridCap / wgrad_slabs(K);
+    return r > 0 ? r : 1;
+}
+inline long long wgrad_workspace_floats(int K) { return (long long)wgrad_ranges(K) * kN * wgrad_slabs(K) * kWgCols; }
+
+inline int wgrad(const float* dy, const float* x, long long rows, int K, int ldx, float* dw, float* workspace,
+                 hipStream_t stream) {
+    if (!dy || !x || !dw || !workspace) return MAPPO_E_NULL;
+    if (rows <= 0 || K <= 0 || ldx < K || ldx < 4) return MAPPO_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(dy) & 15) != 0 || (reinterpret_cast<uintptr_t>(x) & 3) != 0) return MAPPO_E_ALIGN;
+    const bool x16 = ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    WgArgs a;
+    a.dy = dy;
+    a.x = x;
+    a.rows = rows;
+    a.K = K;
+    a.ldx = ldx;
+    a.partials = workspace;
+    const int gy = wgrad_slabs(K);
+    int gx = wgrad_ranges(K);
+    const int cap = mlp::grid_cap_override();       // (tests: few row ranges, many steps each)
+    if (cap > 0 && cap < gx) gx = cap;
+    if (x16) MAPPO_LAUNCH(lin_wgrad_kernel<true>, dim3((unsigned)gx, (unsigned)gy), kThreads, (size_t)kWgLds * 4, stream, a);
+    else MAPPO_LAUNCH(lin_wgrad_kernel<false>, dim3((unsigned)gx, (unsigned)gy), kThreads, (size_t)kWgLds * 4, stream, a);
+    int code = MAPPO_LAUNCH_ERROR();
+    if (code) return code;
+    long long grid = ((long long)kN * K + kThreads - 1) / kThreads;
+    if (grid > 2048) grid = 2048;
+    MAPPO_LAUNCH(lin_reduce_kernel, (unsigned)grid, kThreads, 0, stream, (const float*)workspace, gx, gy * kWgCols, K, dw);
+    return MAPPO_LAUNCH_ERROR();
+}
+
+}  // namespace lin
+#endif

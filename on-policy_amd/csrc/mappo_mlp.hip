@@ -1,6 +1,8 @@
 // K9: fused hidden-64 trunk (forward, backward chain, first-layer weight gradient) -- gfx950 binding of
 // mappo_mlp_impl.h, which holds the kernels and their launchers.
 #include <hip/hip_runtime.h>
+#include <mutex>
+#include <unordered_map>
 
 #include "mappo_internal.h"
 
@@ -147,12 +149,21 @@ __device__ __forceinline__ float* lds() {
 namespace {
 int g_launch_error = 0;
 // dynamic LDS above 64 KB has to be granted per kernel function before the launch
+// (granted once per kernel and size: the attribute call is kept out of the launch path -- in particular out of launches that
+// are being captured into a HIP graph from the autograd thread, onpolicy/algorithms/r_mappo/update_graph.py)
 template <class K>
 void grant_lds(K kernel, size_t bytes) {
     if (bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) g_launch_error = (int)e;
+        static std::mutex mu;
+        static std::unordered_map<const void*, size_t> granted;
+        const void* fn = reinterpret_cast<const void*>(kernel);
+        std::lock_guard<std::mutex> lock(mu);
+        size_t& have = granted[fn];
+        if (bytes > have) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e != hipSuccess) g_launch_error = (int)e;
+            else have = bytes;
+        }
     }
 }
 }  // namespace
@@ -166,6 +177,7 @@ void grant_lds(K kernel, size_t bytes) {
 
 #include "mappo_mlp_impl.h"
 #include "mappo_gru_impl.h"
+#include "mappo_lin_impl.h"
 
 extern "C" int mappo_mlp_forward(const mappo_mlp_t* net, mappo_stream_t stream) {
     g_launch_error = 0;
@@ -215,4 +227,22 @@ extern "C" int mappo_gru_seq_forward(const mappo_gru_seq_t* seq, mappo_stream_t 
 extern "C" int mappo_gru_seq_backward(const mappo_gru_seq_t* seq, mappo_stream_t stream) {
     g_launch_error = 0;
     return gru::backward(seq, static_cast<hipStream_t>(stream));
+}
+
+// ---- K15: tall Linear layers with 512 outputs in six-term bf16 arithmetic (mappo_lin_impl.h)
+extern "C" int64_t mappo_linear512_planes_floats(int K) { return lin::planes_floats(K); }
+extern "C" int mappo_linear512_prepare(const float* w, int K, int ldw, int transposed, float* planes, mappo_stream_t stream) {
+    g_launch_error = 0;
+    return lin::prepare(w, K, ldw, transposed, planes, static_cast<hipStream_t>(stream));
+}
+extern "C" int mappo_linear512_forward(const float* x, int64_t rows, int K, int ldx, const float* planes, const float* bias,
+                                       float* y, mappo_stream_t stream) {
+    g_launch_error = 0;
+    return lin::forward(x, rows, K, ldx, planes, bias, y, static_cast<hipStream_t>(stream));
+}
+extern "C" int64_t mappo_linear512_wgrad_workspace_floats(int K) { return lin::wgrad_workspace_floats(K); }
+extern "C" int mappo_linear512_wgrad(const float* dy, const float* x, int64_t rows, int K, int ldx, float* dw,
+                                     float* workspace, mappo_stream_t stream) {
+    g_launch_error = 0;
+    return lin::wgrad(dy, x, rows, K, ldx, dw, workspace, static_cast<hipStream_t>(stream));
 }

@@ -159,6 +159,11 @@ SIGNATURES = {
     "mappo_mlp_row_table": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _vp, _vp]),
     "mappo_standardize_rows": (_int, [_vp, _i64, _int, ctypes.c_float, _vp, _vp]),
     "mappo_standardize_rows_ld": (_int, [_vp, _i64, _int, ctypes.c_float, _vp, _int, _vp]),
+    "mappo_linear512_planes_floats": (_i64, [_int]),
+    "mappo_linear512_prepare": (_int, [_vp, _int, _int, _int, _vp, _vp]),
+    "mappo_linear512_forward": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp, _vp]),
+    "mappo_linear512_wgrad_workspace_floats": (_i64, [_int]),
+    "mappo_linear512_wgrad": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp]),
     "mappo_simple_spread_step": (_int, [_vp] * 11 + [_i64, _int, _int, _int, _int, _vp]),
     "mappo_abi_version": (_int, []),
     "mappo_build_info": (ctypes.c_char_p, []),

@@ -17,13 +17,16 @@ tensors of the same shapes, so the update is captured once into a HIP graph and 
 A graph belongs to a *signature*: the shapes / dtypes of the minibatch tuple, the observation matrices the lazy ``RowSource``
 minibatches point into (their addresses are baked into the graph), ``update_actor`` and the arithmetic of the networks.  The
 first update with a new signature runs eagerly (it is also the warm-up: GEMM tuning, lazily created state), the second is
-captured, the rest replay.  Minibatches of more than ``MAPPO_UPDATE_GRAPH_MAX_ROWS`` rows (default 4 M) stay eager: their
-kernels run for milliseconds and the launches are free, while a graph would keep the update's activations (14 GB at the north
-star) alive for good.  ``MAPPO_UPDATE_GRAPH=0`` disables the whole thing.
+captured, the rest replay.  Minibatches of more than ``MAPPO_UPDATE_GRAPH_MAX_ROWS`` rows (default 2^20) stay eager: their
+kernels run for milliseconds, the host enqueues them far ahead of the device anyway, and a graph launch has a fixed cost of its
+own (measured on the MI355X, profiles/r05_ab_update_graph.json: 64-thread SMAC shard 31.2 -> 18.6 ms per step, 128-thread
+recurrent north-star shard 36.6 -> 27.0, configs[1] 15.04 -> 14.92, but a 512-thread feed-forward north-star shard -- 1.6 M
+rows per update -- 29.6 -> 32.4); a graph would also keep the update's activations (14 GB at the north star) alive for good.
+``MAPPO_UPDATE_GRAPH=0`` disables the whole thing.
 
 Not captured (the eager ``ppo_update`` runs): PopArt heads (``update`` rebinds the parameters' storage), trainers without the
-fused loss / fused optimiser kernels, host minibatches, minibatches cut into several row spans, subclasses that override
-``ppo_update``.
+fused loss / fused optimiser kernels, ``update_actor=False``, host minibatches, minibatches cut into several row spans,
+subclasses that override ``ppo_update``.
 """
 import os
 
@@ -41,7 +44,7 @@ class UpdateGraph(object):
         self.order = []             # signatures, least recently used first
         self.pool = None
         self.replays = self.captures = self.warmups = 0
-        self.max_rows = int(os.environ.get("MAPPO_UPDATE_GRAPH_MAX_ROWS", str(4 << 20)))
+        self.max_rows = int(os.environ.get("MAPPO_UPDATE_GRAPH_MAX_ROWS", str(1 << 20)))
         self.off = os.environ.get("MAPPO_UPDATE_GRAPH", "1") == "0"
 
     # ------------------------------------------------------------------------------------------------ eligibility
@@ -64,11 +67,15 @@ class UpdateGraph(object):
                               x.chunk, x.standardized, x.width))
             elif torch.is_tensor(x) and x.is_cuda and x.is_contiguous():
                 parts.append((tuple(x.shape), x.dtype))
+            elif torch.is_tensor(x) and x.is_cuda:
+                # a view (the stride-0 zero RNN states a feed-forward buffer hands out): read in place, its address is part of
+                # the graph like a RowSource's matrix
+                parts.append(("view", x.data_ptr(), tuple(x.shape), tuple(x.stride()), x.dtype))
             else:
                 return None, 0
         rows = sample[10].shape[0]
-        if rows > self.max_rows:
-            return None, 0
+        if rows > self.max_rows or not update_actor:
+            return None, 0          # (update_actor = False leaves the actor without gradients: the PyTorch optimiser path)
         spans, _ = t._row_spans(sample)
         if len(spans) != 1:
             return None, 0
@@ -122,7 +129,7 @@ class UpdateGraph(object):
             if isinstance(x, RowSource):
                 if x.idx is not None:
                     out.append(x.idx)
-            elif torch.is_tensor(x):
+            elif torch.is_tensor(x) and x.is_contiguous():
                 out.append(x)
         return out
 
@@ -134,10 +141,10 @@ class UpdateGraph(object):
             if isinstance(x, RowSource):
                 static.append(RowSource.all_rows(x.src, x.standardized, x.width) if x.idx is None else
                               RowSource(x.src, x.idx.clone(), x.chunk, x.standardized, x.width))
-            elif torch.is_tensor(x):
+            elif torch.is_tensor(x) and x.is_contiguous():
                 static.append(x.clone())
             else:
-                static.append(x)
+                static.append(x)            # None, or a view that is read in place (see _signature)
         e["static"] = tuple(static)
         e["inputs"] = self._tensors(static)
         cur = self._tensors(sample)             # the static inputs start out as copies of this minibatch
@@ -151,7 +158,9 @@ class UpdateGraph(object):
         if self.pool is None:
             self.pool = torch.cuda.graph_pool_handle()
         front = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(front, pool=self.pool):
+        # (thread_local: the capture must not outlaw what OTHER threads do meanwhile -- RCCL's watchdog polls the events of
+        # earlier collectives -- while the autograd thread's launches into the capturing stream are recorded all the same)
+        with torch.cuda.graph(front, pool=self.pool, capture_error_mode="thread_local"):
             value_loss, policy_loss, dist_entropy, ratio = t.ppo_update(e["static"], update_actor, _front_only=True,
                                                                         _scales=e["scales"])
             if not t.dp.active:
@@ -164,7 +173,7 @@ class UpdateGraph(object):
             front.replay()                      # (a capture executes nothing: run the front once so that the bucket is real)
             t.dp.all_reduce_grads()             # -> every param.grad is a view of the reduced flat bucket
             back = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(back, pool=self.pool):
+            with torch.cuda.graph(back, pool=self.pool, capture_error_mode="thread_local"):
                 norms = t._update_back(update_actor, lr_devices=e["lr"])
             e["back"] = back
             e["front_done"] = True              # the front already ran for the minibatch that triggered the capture

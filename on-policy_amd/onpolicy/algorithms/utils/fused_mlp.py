@@ -196,7 +196,7 @@ def rollout_rows(x, base):
     return RowSource.all_rows(x, standardized=False)
 
 
-def standardize_rows(src2d, eps=1e-5, pad=True):
+def standardize_rows(src2d, eps=1e-5, pad=True, out=None):
     """(x - mean) / sqrt(var + eps) of every row of a float32 device matrix (``mappo_standardize_rows_ld``): the
     parameter-free half of the networks' input LayerNorm, applied to a whole observation field once per train().
     ``pad``: the copy's rows are padded with zero columns to a multiple of 4 floats (16 bytes), so that the trunk
@@ -204,7 +204,8 @@ def standardize_rows(src2d, eps=1e-5, pad=True):
     ``RowSource(..., width=D)`` remembers the true width."""
     rows, D = src2d.shape
     ld = (D + 3) // 4 * 4 if pad and os.environ.get("MAPPO_PAD_STANDARDIZED", "1") != "0" else D
-    out = torch.empty((rows, ld), dtype=src2d.dtype, device=src2d.device)
+    if out is None or tuple(out.shape) != (rows, ld) or out.dtype != src2d.dtype or out.device != src2d.device:
+        out = torch.empty((rows, ld), dtype=src2d.dtype, device=src2d.device)       # (``out``: storage to write into again)
     _native.check(_native.lib().mappo_standardize_rows_ld(src2d.data_ptr(), rows, D, float(eps), out.data_ptr(), ld,
                                                           _native.stream_of(src2d.device)), "mappo_standardize_rows_ld")
     return out

@@ -121,6 +121,7 @@ class DenseBlock(nn.Sequential):
             if linear.bias is not None and norm.fuses_bias(x, act, linear.out_features):
                 # GEMM without bias; the bias add and its gradient ride along in the act+LayerNorm kernels
                 from .tall_linear import tall_linear
-                return norm.forward_act(tall_linear(x, linear.weight, None), act, pre_bias=linear.bias)
+                return norm.forward_act(tall_linear(x, linear.weight, None, getattr(linear, "matrix_arithmetic", None)), act,
+                                        pre_bias=linear.bias)
             return norm.forward_act(linear(x), act)
         return norm(act(linear(x)))

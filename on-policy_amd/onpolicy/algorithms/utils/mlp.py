@@ -57,6 +57,8 @@ class MLPBase(nn.Module):
         if self._use_feature_normalization:
             self.feature_norm = FusedLayerNorm(obs_dim)
         self.mlp = MLPLayer(obs_dim, self.hidden_size, self._layer_N, self._use_orthogonal, self._use_ReLU)
+        if self.matrix_arithmetic is not None:       # (the Linear layers carry the choice for K15, hidden size 512)
+            fused_mlp.set_matrix_arithmetic(self.mlp, self.matrix_arithmetic)
 
     def fuses(self, x):
         """Whether ``forward(x)`` takes the fused-kernel route for this input."""
@@ -93,9 +95,9 @@ class MLPBase(nn.Module):
         w_eff = linear.weight * self.feature_norm.weight
         b_eff = linear.bias + linear.weight @ self.feature_norm.bias
         if isinstance(norm, FusedLayerNorm) and norm.fuses_bias(x, act, linear.out_features):
-            h = norm.forward_act(tall_linear(x, w_eff, None), act, pre_bias=b_eff)   # bias add in the LN kernel
+            h = norm.forward_act(tall_linear(x, w_eff, None, self.matrix_arithmetic), act, pre_bias=b_eff)   # bias add in the LN kernel
         else:
-            h = norm.forward_act(tall_linear(x, w_eff, b_eff), act)
+            h = norm.forward_act(tall_linear(x, w_eff, b_eff, self.matrix_arithmetic), act)
         for layer in self.mlp.fc2:
             h = layer(h)
         return h

@@ -63,8 +63,85 @@ class _TallLinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
-def tall_linear(x, weight, bias):
-    """F.linear with the split-K backward when ``x`` is a tall HIP matrix."""
+class _Linear512Fn(torch.autograd.Function):
+    """``F.linear`` for 512 output features on a tall HIP matrix through K15 (``mappo_linear512_*``, csrc/mappo_lin_impl.h): the
+    Linear layers of the hidden-512 trunks (reference onpolicy/algorithms/utils/mlp.py:17-22 at --hidden_size 512:
+    scripts/train_hanabi_forward.sh:15-17) in six-term bf16 arithmetic -- float32 in and out, every product from six bf16 x bf16
+    terms of the operands' exact three-way splits on the bf16 matrix cores, float32 accumulation (include/mappo_hip.h
+    MAPPO_ARITH_SIX_TERM).  Forward ``x W^T (+ b)``, weight gradient ``dy^T x`` (row ranges summed in a fixed order), input
+    gradient ``dy W`` of a 512 -> 512 layer through the forward kernel on the planes of ``W^T``."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from onpolicy import _native
+        lib, p = _native.lib(), _native.ptr
+        dev = x.device
+        stream = _native.stream_of(dev)
+        rows, ldx = x.shape
+        w = weight.detach().contiguous()
+        K = int(w.shape[1])
+        planes = torch.empty(lib.mappo_linear512_planes_floats(K), dtype=torch.float32, device=dev)
+        _native.check(lib.mappo_linear512_prepare(p(w), K, K, 0, p(planes), stream), "mappo_linear512_prepare")
+        y = torch.empty((rows, 512), dtype=torch.float32, device=dev)
+        b = None if bias is None else bias.detach().contiguous()
+        _native.check(lib.mappo_linear512_forward(p(x), rows, K, int(ldx), p(planes), p(b), p(y), stream),
+                      "mappo_linear512_forward")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from onpolicy import _native
+        lib, p = _native.lib(), _native.ptr
+        x, w = ctx.saved_tensors
+        dev = x.device
+        stream = _native.stream_of(dev)
+        rows, ldx = x.shape
+        K = int(w.shape[1])
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if K == 512 and ldx == 512:     # dX = dY W: the forward kernel on the planes of W^T
+                planes = torch.empty(lib.mappo_linear512_planes_floats(512), dtype=torch.float32, device=dev)
+                _native.check(lib.mappo_linear512_prepare(p(w), 512, 512, 1, p(planes), stream), "mappo_linear512_prepare")
+                dx = torch.empty((rows, 512), dtype=torch.float32, device=dev)
+                _native.check(lib.mappo_linear512_forward(p(dy), rows, 512, 512, p(planes), None, p(dx), stream),
+                              "mappo_linear512_forward")
+            else:
+                dx = dy @ w
+                if ldx != K:
+                    dx = F.pad(dx, (0, ldx - K))
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((512, K), dtype=torch.float32, device=dev)
+            ws = torch.empty(lib.mappo_linear512_wgrad_workspace_floats(K), dtype=torch.float32, device=dev)
+            _native.check(lib.mappo_linear512_wgrad(p(dy), p(x), rows, K, int(ldx), p(dw), p(ws), stream),
+                          "mappo_linear512_wgrad")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = column_sums(dy)
+        return dx, dw, db
+
+
+def linear512_ok(x, weight, arith=None):
+    """Whether ``tall_linear`` sends this product through K15: 512 output features, a tall contiguous float32 HIP matrix whose
+    rows hold at least the weight's columns (a zero-padded standardised copy may be wider), the six-term arithmetic selected
+    (``arith``: _native.ARITH_* or None = the process default, MAPPO_MATRIX_ARITHMETIC) and MAPPO_LINEAR512 not 0.
+    (MAPPO_LINEAR512_MIN_ROWS: tests send small fixtures through the kernels; below 65 536 rows the library GEMM is as good.)"""
+    import os
+    from onpolicy import _native
+    if os.environ.get("MAPPO_LINEAR512", "1") == "0" or not (torch.is_tensor(x) and x.is_cuda):
+        return False
+    a = _native.default_arith() if arith is None else _native.arith_code(arith)
+    return a == _native.ARITH_SIX_TERM and x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous() \
+        and x.shape[0] >= int(os.environ.get("MAPPO_LINEAR512_MIN_ROWS", _MIN_ROWS)) and weight.dim() == 2 and weight.shape[0] == 512 and weight.dtype == torch.float32 \
+        and 4 <= weight.shape[1] <= x.shape[1] and weight.is_cuda
+
+
+def tall_linear(x, weight, bias, arith=None):
+    """F.linear with the split-K backward when ``x`` is a tall HIP matrix; 512-wide layers in six-term arithmetic through
+    K15 (``_Linear512Fn``)."""
+    if linear512_ok(x, weight, arith):
+        return _Linear512Fn.apply(x, weight, bias)
     if x.dim() == 2 and x.is_cuda and x.shape[0] >= _MIN_ROWS and torch.is_grad_enabled() \
             and x.is_contiguous():
         return _TallLinearFn.apply(x, weight, bias)
@@ -72,5 +149,8 @@ def tall_linear(x, weight, bias):
 
 
 class TallLinear(nn.Linear):
+    # arithmetic of the layer's product where K15 takes it (_native.ARITH_* or None = the process default)
+    matrix_arithmetic = None
+
     def forward(self, x):
-        return tall_linear(x, self.weight, self.bias)
+        return tall_linear(x, self.weight, self.bias, self.matrix_arithmetic)

@@ -140,6 +140,7 @@ class SharedReplayBuffer(object):
         self._whole_batch_versions = ()
         self.whole_batch_reuses = 0       # epochs that were handed the cached tuple (tests assert the route)
         self._std_rows = {}        # field name -> (key, row-standardised copy) for the fused trunk kernels
+        self._std_keep = {}        # field name -> storage of the last copy, kept across train() calls when small (below)
         # MAPPO_PINNED_INSERT=1: host inputs of insert() go through one pinned staging buffer + one async H2D copy.
         # Off by default: measured at the north star (tools/pcie_insert_bench.py, 57 MB per step) the single-threaded
         # memcpy into the staging buffer makes it slower (1.88 ms per step, 30 GB/s) than one pageable .to(device) per
@@ -347,6 +348,13 @@ class SharedReplayBuffer(object):
         """The row-standardised observation copies the fused trunk kernels read during train() (as large as the
         observation fields themselves: 23.5 GB at the north star) go back to the allocator for the rollout; the next
         train() takes the same blocks from its cache."""
+        # Small copies keep their storage (MAPPO_KEEP_STANDARDIZED_BYTES per field, default 2 GiB): the next train() writes into
+        # the same addresses, which is what lets a captured update graph (algorithms/r_mappo/update_graph.py: the addresses of
+        # the matrices its RowSources read are part of the graph) live across train() calls.
+        limit = int(os.environ.get("MAPPO_KEEP_STANDARDIZED_BYTES", str(2 << 30)))
+        for name, (_, t) in self._std_rows.items():
+            if t.numel() * t.element_size() <= limit:
+                self._std_keep[name] = t
         self._std_rows.clear()
         self._whole_batch = self._whole_batch_key = None      # (holds RowSources on the standardised copies)
 
@@ -589,9 +597,15 @@ class SharedReplayBuffer(object):
             off += width
         if not fields:
             return None, 0, {}
-        rw = 4
-        while rw < off:          # 16 / 32 / 64 / 128-byte records: a record never straddles more lines than needed
-            rw *= 2
+        if self._sampler_rng == "device":
+            # the device sampler walks the records in ascending memory order: dense records (the 12 payload floats of the
+            # north star in 48 bytes instead of 64) are read line by line with nothing skipped (PMC traffic 1.15 x -> <= 1.0 x
+            # of the algorithmic bytes)
+            rw = (off + 3) // 4 * 4
+        else:
+            rw = 4
+            while rw < off:      # random permutations: 16 / 32 / 64 / 128-byte records never straddle more sectors than needed
+                rw *= 2
         rows = T * N * A
         # the packed fields only change when the buffer is written -- by this class's kernels
         # (_content_version) or by in-place torch ops on the field tensors (tensor._version): within
@@ -622,7 +636,7 @@ class SharedReplayBuffer(object):
         hit = self._std_rows.get(name)
         if hit is None or hit[0] != key:
             from onpolicy.algorithms.utils import fused_mlp
-            hit = (key, fused_mlp.standardize_rows(rows))
+            hit = (key, fused_mlp.standardize_rows(rows, out=self._std_keep.pop(name, None)))
             self._std_rows[name] = hit
         return hit[1]
 

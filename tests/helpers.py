@@ -71,3 +71,22 @@ def load_into(buf, arrays):
             dst.copy_(torch.from_numpy(np.ascontiguousarray(arr)))
         else:
             dst[...] = arr
+
+
+def graph_replays(trainer):
+    """Updates of ``trainer`` so far that were replays of a captured HIP graph (algorithms/r_mappo/update_graph.py)."""
+    ug = getattr(trainer, "_update_graph", None)
+    return 0 if ug is None else ug.replays
+
+
+def assert_k9_carried_the_updates(trainer, n_fwd, n_bwd, updates, signatures=1):
+    """Every update ran the fused trunk kernels, forward and backward, for both networks: eagerly (event pairs recorded:
+    ``n_fwd`` / ``n_bwd`` launches) or as a replay of a graph captured from exactly such an update.  With the update graph on,
+    the first update of a minibatch shape is the eager warm-up, all later ones replay."""
+    import os
+    replays = graph_replays(trainer)
+    assert n_fwd == 2 * (updates - replays) and n_bwd == 2 * (updates - replays), (n_fwd, n_bwd, updates, replays)
+    if os.environ.get("MAPPO_UPDATE_GRAPH", "1") != "0":
+        assert replays == updates - signatures, (replays, updates)
+    else:
+        assert replays == 0

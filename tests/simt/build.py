@@ -8,7 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.path.join(HERE, "_build", "libmlp_emu.so")
 SOURCES = [os.path.join(HERE, "mlp_emu.cc"), os.path.join(HERE, "simt_emu.h"),
            os.path.join(ROOT, "on-policy_amd", "csrc", "mappo_mlp_impl.h"),
-           os.path.join(ROOT, "on-policy_amd", "csrc", "mappo_gru_impl.h"), os.path.join(ROOT, "include", "mappo_hip.h")]
+           os.path.join(ROOT, "on-policy_amd", "csrc", "mappo_gru_impl.h"),
+           os.path.join(ROOT, "on-policy_amd", "csrc", "mappo_lin_impl.h"), os.path.join(ROOT, "include", "mappo_hip.h")]
 CLANG = os.environ.get("MAPPO_HOST_CLANG", "/opt/rocm/lib/llvm/bin/clang++")
 
 

@@ -69,6 +69,7 @@ inline void rs16_8(const float* a, const float* b, float* out) {
 
 #include "../../on-policy_amd/csrc/mappo_mlp_impl.h"
 #include "../../on-policy_amd/csrc/mappo_gru_impl.h"
+#include "../../on-policy_amd/csrc/mappo_lin_impl.h"
 
 extern "C" int mappo_mlp_forward(const mappo_mlp_t* net, mappo_stream_t stream) { return mlp::forward(net, stream); }
 extern "C" int mappo_mlp_backward(const mappo_mlp_t* net, mappo_stream_t stream) { return mlp::backward(net, stream); }
@@ -116,3 +117,18 @@ extern "C" int64_t mappo_gru_seq_stats_floats(int L, int64_t mb) { return (int64
 extern "C" int64_t mappo_gru_seq_workspace_floats(void) { return (int64_t)gru::kGridCap * gru::kSums; }
 extern "C" int mappo_gru_seq_forward(const mappo_gru_seq_t* seq, mappo_stream_t stream) { return gru::forward(seq, stream); }
 extern "C" int mappo_gru_seq_backward(const mappo_gru_seq_t* seq, mappo_stream_t stream) { return gru::backward(seq, stream); }
+
+// ---- K15: tall Linear layers with 512 outputs in six-term bf16 arithmetic (mappo_lin_impl.h)
+extern "C" int64_t mappo_linear512_planes_floats(int K) { return lin::planes_floats(K); }
+extern "C" int mappo_linear512_prepare(const float* w, int K, int ldw, int transposed, float* planes, mappo_stream_t stream) {
+    return lin::prepare(w, K, ldw, transposed, planes, stream);
+}
+extern "C" int mappo_linear512_forward(const float* x, int64_t rows, int K, int ldx, const float* planes, const float* bias,
+                                       float* y, mappo_stream_t stream) {
+    return lin::forward(x, rows, K, ldx, planes, bias, y, stream);
+}
+extern "C" int64_t mappo_linear512_wgrad_workspace_floats(int K) { return lin::wgrad_workspace_floats(K); }
+extern "C" int mappo_linear512_wgrad(const float* dy, const float* x, int64_t rows, int K, int ldx, float* dw,
+                                     float* workspace, mappo_stream_t stream) {
+    return lin::wgrad(dy, x, rows, K, ldx, dw, workspace, stream);
+}

@@ -5,7 +5,9 @@ share_obs 435 / 18 actions / 10 agents, rmappo, chunk 10, 2 minibatches, gain 1)
 
 * cfg4_shape      host permutations (the reference's own randperm stream): K9 trunks + K12 GRU chunks + K7 + K13;
 * cfg4_shape_dev  the device sampler (K10 partition; the reference was fed the same partition);
-* cfg5_shape      hidden 512: library GEMMs + K6 (bias + ReLU + LayerNorm) + the LDS-staged K7 at 48 actions + K13.
+* cfg5_shape      hidden 512: library GEMMs + K6 (bias + ReLU + LayerNorm) + the LDS-staged K7 at 48 actions + K13;
+  cfg5_shape/k15  the same with every 512-wide product through K15 (six-term bf16 arithmetic; the route real Hanabi
+                  minibatches take -- the 160-row fixture is sent there with MAPPO_LINEAR512_MIN_ROWS=1).
 Every case asserts which entry points of libmappo_hip.so carried the update.  Tolerances: the device trainer tests' (losses
 1e-3 relative, weights 5e-5 absolute, last gradients 1e-3 of each tensor's largest entry)."""
 import numpy as np
@@ -13,6 +15,7 @@ import pytest
 import torch
 
 import cfg_shapes as C
+from helpers import graph_replays
 
 pytestmark = pytest.mark.gpu
 
@@ -27,10 +30,14 @@ def _device_buffer(args, spec, spaces, arrays, dev):
     return buf
 
 
-@pytest.mark.parametrize("cname", C.CASES)
-def test_update_at_baseline_config_shapes_vs_reference(gold, cname):
+@pytest.mark.parametrize("cname", C.CASES + ["cfg5_shape/k15"])
+def test_update_at_baseline_config_shapes_vs_reference(gold, cname, monkeypatch):
     from onpolicy import _native
     dev = torch.device("cuda", 0)
+    k15 = cname.endswith("/k15")
+    if k15:     # the fixture has 160 rows; real Hanabi minibatches (4.1 M rows) take K15 by themselves
+        cname = cname[:-4]
+        monkeypatch.setenv("MAPPO_LINEAR512_MIN_ROWS", "1")
     rng_mode = "device" if cname.endswith("_dev") else "host"
     z, key, meta, spec, args, spaces, policy, trainer = C.build(gold, cname, device=dev, sampler_rng=rng_mode)
     C.start_from_reference_weights(policy, z, key)
@@ -49,14 +56,22 @@ def test_update_at_baseline_config_shapes_vs_reference(gold, cname):
         _native.count_calls(False)
     buf.after_update()
     updates = spec["args"]["ppo_epoch"] * spec["args"]["num_mini_batch"]
-    assert calls.get("mappo_ppo_loss_f32", 0) == updates and calls.get("mappo_clip_adam", 0) == 2 * updates, calls
+    # entry points are CALLED by the eager updates and once by the capture of the update graph (whose replays then launch the
+    # same kernels without a call): the first update of the one minibatch shape is eager, the second is captured
+    replays = graph_replays(trainer)
+    assert replays == updates - 1, (replays, updates)
+    called = updates - replays + 1
+    assert calls.get("mappo_ppo_loss_f32", 0) == called and calls.get("mappo_clip_adam", 0) == 2 * called, calls
     if spec["args"]["hidden_size"] == 64:       # K9 trunks in front of K12 GRU chunks, both networks, both directions
         for name in ("mappo_mlp_forward", "mappo_mlp_backward", "mappo_gru_seq_forward", "mappo_gru_seq_backward"):
-            assert calls.get(name, 0) == 2 * updates, (name, calls)
-    else:                                       # hidden 512: GEMMs from the library, everything between them from K6
+            assert calls.get(name, 0) == 2 * called, (name, calls)
+    else:                                       # hidden 512: GEMMs from the library or K15, everything between them from K6
         assert calls.get("mappo_mlp_forward", 0) == 0
-        assert calls.get("mappo_bias_act_layernorm_fwd", 0) >= 2 * 3 * updates, calls       # 3 blocks per network
-        assert calls.get("mappo_bias_act_layernorm_bwd", 0) >= 2 * 3 * updates, calls
+        # K15: per network 3 forward products + 2 input gradients (the hidden layers) and 3 weight gradients
+        assert calls.get("mappo_linear512_forward", 0) == (2 * 5 * called if k15 else 0), calls
+        assert calls.get("mappo_linear512_wgrad", 0) == (2 * 3 * called if k15 else 0), calls
+        assert calls.get("mappo_bias_act_layernorm_fwd", 0) >= 2 * 3 * called, calls        # 3 blocks per network
+        assert calls.get("mappo_bias_act_layernorm_bwd", 0) >= 2 * 3 * called, calls
     if rng_mode == "device":
         assert calls.get("mappo_minibatch_indices", 0) == spec["args"]["ppo_epoch"], calls
 

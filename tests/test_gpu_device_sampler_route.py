@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import Box, Discrete, make_args
+from helpers import Box, Discrete, assert_k9_carried_the_updates, make_args
 
 pytestmark = pytest.mark.gpu
 
@@ -84,7 +84,7 @@ def _train_and_compare(z, key, meta, spec, policy, trainer, buf, returns_exact):
     finally:
         fused_mlp.profile(False)
     updates = spec["args"]["ppo_epoch"] * spec["args"]["num_mini_batch"]
-    assert n_fwd == 2 * updates and n_bwd == 2 * updates, (n_fwd, n_bwd, updates)      # K9 ran, forward and backward
+    assert_k9_carried_the_updates(trainer, n_fwd, n_bwd, updates)          # K9 ran, forward and backward (eagerly or replayed)
     reuses = buf.whole_batch_reuses
     buf.after_update()
 

@@ -92,9 +92,12 @@ def test_device_worlds_with_the_fused_hidden64_kernels(tmp_path, monkeypatch, al
     finally:
         fused_mlp.profile(False)
     assert type(runner.envs).__name__ == "TorchSimpleSpread" and runner.envs.pos.is_cuda
-    # 3 iterations x 4 epochs x 2 networks in the update
-    assert launches.get("mappo_mlp_backward", (0,))[0] == 3 * 4 * 2, launches
-    assert launches.get("mappo_mlp_forward", (0,))[0] >= 3 * 4 * 2, launches
+    # 3 iterations x 4 epochs x 2 networks in the update: launched eagerly (event pairs) or replayed from the update graph
+    from helpers import graph_replays
+    replays = graph_replays(runner.trainer)
+    assert 0 < replays <= 3 * 4 - 1, replays
+    assert launches.get("mappo_mlp_backward", (0,))[0] == (3 * 4 - replays) * 2, (launches, replays)
+    assert launches.get("mappo_mlp_forward", (0,))[0] >= (3 * 4 - replays) * 2, (launches, replays)
     if algo == "rmappo":
         assert runner.policy.actor.rnn._chunk_kernel_ok(torch.zeros(4, 64, device="cuda"))
     assert runner.buffer.whole_batch_reuses == 3 * 3            # epochs 2..4 of each train() reuse the gathered batch

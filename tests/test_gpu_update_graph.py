@@ -1,0 +1,117 @@
+"""-m gpu: ``R_MAPPO.ppo_update`` replayed from a captured HIP graph (onpolicy/algorithms/r_mappo/update_graph.py; reference
+onpolicy/algorithms/r_mappo/r_mappo.py:91-169 is one Python call per minibatch) against the eager update it was captured from:
+the same kernels on the same data in the same order, so weights, optimiser state, ValueNorm statistics, the gradients left in
+``.grad`` and the logged scalars must be IDENTICAL bit for bit -- over several train() calls with lr_decay in between
+(the learning rate reaches the captured Adam kernels through device memory), for feed-forward and recurrent policies, with
+``update_actor=False``, and when the minibatch shape changes.  The reference-generated fixtures run through the graph in
+tests/test_gpu_trainer_h64.py / test_gpu_device_sampler_route.py / test_gpu_cfg_shapes.py (the default), two ranks in
+tests/test_gpu_bench.py."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import Box, Discrete, graph_replays, make_args
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(monkeypatch, graph, recurrent, trains=3, N=12, mini=2, update_actor=True, change_shape=False, rng="device"):
+    from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy
+    from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO
+    from onpolicy.utils.shared_buffer import SharedReplayBuffer
+    monkeypatch.setenv("MAPPO_UPDATE_GRAPH", graph)
+    dev = torch.device("cuda", 0)
+    T, A, Do, Ds, na = 20, 3, 22, 37, 6
+    kw = dict(algorithm_name="rmappo", use_recurrent_policy=True, data_chunk_length=5) if recurrent else dict(algorithm_name="mappo")
+    spaces = Box((Do,)), Box((Ds,)), Discrete(na)
+
+    def build(n):
+        args = make_args(episode_length=T, n_rollout_threads=n, hidden_size=64, layer_N=1, use_ReLU=False, ppo_epoch=3,
+                         num_mini_batch=mini, sampler_rng=rng, **kw)
+        return args, SharedReplayBuffer(args, A, *spaces, device=dev)
+
+    args, buf = build(N)
+    torch.manual_seed(1)
+    np.random.seed(1)
+    policy = R_MAPPOPolicy(args, *spaces, device=dev)
+    trainer = R_MAPPO(args, policy, device=dev)
+    trainer.prep_training()
+    infos = []
+    for it in range(trains):
+        if change_shape and it == 1:        # another number of rollout threads: a second minibatch shape, a second graph
+            args, buf = build(N + 4)
+        g = torch.Generator(device=dev).manual_seed(100 + it)
+        for name in ("share_obs", "obs", "rewards"):
+            getattr(buf, name).normal_(generator=g)
+        buf.value_preds[:-1].normal_(generator=g)
+        buf.actions.copy_(torch.randint(0, na, buf.actions.shape, generator=g, device=dev).float())
+        buf.action_log_probs.fill_(-float(np.log(na)))
+        buf.masks.copy_((torch.rand(buf.masks.shape, generator=g, device=dev) > 0.1).float())
+        buf.active_masks.copy_((torch.rand(buf.masks.shape, generator=g, device=dev) > 0.2).float())
+        if recurrent:
+            buf.rnn_states.normal_(generator=g)
+            buf.rnn_states_critic.normal_(generator=g)
+        torch.manual_seed(50 + it)          # the sampler's keys / permutations
+        policy.lr_decay(it, trains + 1)     # reference base_runner / mpe_runner.py:33-34: a new learning rate every episode
+        buf.compute_returns(torch.zeros(buf.value_preds.shape[1:], device=dev), trainer.value_normalizer)
+        infos.append(trainer.train(buf, update_actor=update_actor))
+        buf.after_update()
+    torch.cuda.synchronize()
+    state = {"actor." + k: v.clone() for k, v in policy.actor.state_dict().items()}
+    state.update({"critic." + k: v.clone() for k, v in policy.critic.state_dict().items()})
+    for name, opt in (("a", policy.actor_optimizer), ("c", policy.critic_optimizer)):
+        for i, p in enumerate(opt.param_groups[0]["params"]):
+            for k in ("exp_avg", "exp_avg_sq", "step"):
+                if k in opt.state[p]:       # (a frozen actor's optimiser never stepped)
+                    state["%s.opt%d.%s" % (name, i, k)] = opt.state[p][k].clone()
+    for name, net in (("actor", policy.actor), ("critic", policy.critic)):
+        for k, p in net.named_parameters():
+            if p.grad is not None:
+                state["%s.grad.%s" % (name, k)] = p.grad.clone()
+    vn = trainer.value_normalizer
+    state["vn"] = torch.stack([vn.running_mean.reshape(()), vn.running_mean_sq.reshape(()), vn.debiasing_term.reshape(())])
+    return infos, state, trainer
+
+
+@pytest.mark.parametrize("recurrent", [False, True], ids=["mappo", "rmappo"])
+def test_graphed_updates_are_bit_identical_to_eager_updates(monkeypatch, recurrent):
+    infos_g, state_g, tr_g = _run(monkeypatch, "1", recurrent)
+    infos_e, state_e, tr_e = _run(monkeypatch, "0", recurrent)
+    updates = 3 * 3 * 2
+    ug = tr_g._update_graph
+    # one minibatch shape, and the standardised observation copies a RowSource points into keep their storage across train()
+    # calls (SharedReplayBuffer._std_keep): one warm-up, one capture, everything else replays
+    assert ug.captures == 1 and ug.warmups == 1 and ug.replays == updates - 1, (ug.captures, ug.replays, ug.warmups)
+    assert graph_replays(tr_e) == 0
+    assert infos_g == infos_e, (infos_g, infos_e)
+    assert state_g.keys() == state_e.keys()
+    for k in state_g:
+        assert torch.equal(state_g[k], state_e[k]), k
+
+
+def test_graph_with_a_changing_minibatch_shape_and_a_frozen_actor(monkeypatch):
+    """A second buffer size mid-run: each minibatch shape gets its own graph, results identical to the eager run.
+    ``update_actor=False`` (r_mappo.py:199-201 of the reference passes the flag through) leaves the actor without gradients and
+    stays on the eager path."""
+    infos_g, state_g, tr_g = _run(monkeypatch, "1", False, change_shape=True)
+    infos_e, state_e, tr_e = _run(monkeypatch, "0", False, change_shape=True)
+    assert tr_g._update_graph.captures >= 2
+    assert infos_g == infos_e
+    for k in state_g:
+        assert torch.equal(state_g[k], state_e[k]), k
+    _, _, tr = _run(monkeypatch, "1", False, trains=1, update_actor=False)
+    assert tr._update_graph.replays == 0 and tr._update_graph.captures == 0
+
+
+def test_large_minibatches_and_host_permutations(monkeypatch):
+    """Above MAPPO_UPDATE_GRAPH_MAX_ROWS the update stays eager; the integer-parity sampler (host permutations) is captured
+    like the device one (the graph only sees index tensors)."""
+    monkeypatch.setenv("MAPPO_UPDATE_GRAPH_MAX_ROWS", "100")
+    _, _, tr = _run(monkeypatch, "1", False, trains=1)
+    assert tr._update_graph.replays == 0 and tr._update_graph.captures == 0
+    monkeypatch.delenv("MAPPO_UPDATE_GRAPH_MAX_ROWS")
+    infos_g, state_g, tr_g = _run(monkeypatch, "1", True, rng="host")
+    infos_e, state_e, _ = _run(monkeypatch, "0", True, rng="host")
+    assert tr_g._update_graph.replays > 0 and infos_g == infos_e
+    for k in state_g:
+        assert torch.equal(state_g[k], state_e[k]), k

@@ -26,12 +26,14 @@ def test_snapshot_has_no_spills_and_expected_occupancy():
     assert len(table) > 300 and {k.split(" :: ")[0] for k in table} == {
         "mappo_gae.hip", "mappo_copy.hip", "mappo_norm.hip", "mappo_loss.hip", "mappo_rnn.hip", "mappo_mlp.hip",
         "mappo_perm.hip", "mappo_env.hip", "mappo_optim.hip"}
-    # no spills, except: the 64-wide time-parallel GAE scan with time limits (a tuning variant, never selected
-    # automatically) and the identity-activation forward trunk (<= 32 bytes: loop-invariant addresses reloaded once per
-    # tile).  (The GRU chunk backward had 100 bytes until its column sums moved from 64 row-layout accumulators to one
-    # running sum per lane and vector.)
+    # no spills, except the identity-activation forward trunk (<= 32 bytes: loop-invariant addresses reloaded once per tile).
+    # (Round 5: the 64-wide form of the time-parallel GAE scan -- a tuning variant that was never selected automatically and
+    # spilled 68-196 bytes per lane with time limits -- is no longer built.)
     spills = {k: v["scratch_bytes"] for k, v in table.items() if v["scratch_bytes"]}
-    assert all(("gae_scan_kernel<64, true" in k) or ("mlp_fwd_kernel<0," in k and b <= 32) for k, b in spills.items()), spills
+    assert all("mlp_fwd_kernel<0," in k and b <= 32 for k, b in spills.items()), spills
+    # K15 (round 5): both GEMM kernels one wave per SIMD with their 256 accumulators in the AGPR half, no scratch
+    k15 = [v for k, v in table.items() if "lin::lin_fwd_kernel" in k or "lin::lin_wgrad_kernel" in k]
+    assert len(k15) == 4 and all(v["agprs"] == 256 and v["scratch_bytes"] == 0 and v["occupancy"] == 1 for v in k15)
     # round 4: the version-3 forward -- 15 instances (layers x activation x groups of 8 columns in a row's last chunk), two
     # waves per SIMD (<= 256 registers), no scratch
     f3 = {k: v for k, v in table.items() if "mlp_fwd3_kernel<" in k}

@@ -21,7 +21,7 @@ timeout 500 python bench.py --workload hanabi --steps 2 --warmup 1 --no-cpu-base
 for w in cfg2 smac; do
   cd /tmp; timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_$w -o $w -- python $REPO/bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline > $OUT/prof_$w.log 2>&1; cd $REPO
 done
-timeout 120 python tools/bench_kernels.py --T 200 --N 1024 --A 5 --variants 0,70,71,72 --skip-gather > $OUT/kernels_cfg2.json 2> $OUT/kernels_cfg2.err
+timeout 120 python tools/bench_kernels.py --T 200 --N 1024 --A 5 --variants 0,70,72 --skip-gather > $OUT/kernels_cfg2.json 2> $OUT/kernels_cfg2.err
 timeout 120 python tools/bench_mlp.py --reps 7 > $OUT/bench_mlp.log 2>&1
 find $OUT -name "*.db" -delete
 find $OUT -name "*kernel_trace.csv" -size +8M -delete

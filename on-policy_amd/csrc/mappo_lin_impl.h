@@ -37,7 +37,7 @@ constexpr int kN = 512;                 // output features
 constexpr int kThreads = 256;           // 4 waves
 constexpr int kWBlock = 3 * 16 * 256;   // floats of one k = 16 block of planes: [plane 3][tile 16][lane 64] x 16 bytes = 48 KB
 constexpr int kXSlot = 512;             // floats of a wave's [32 rows, 16 columns] piece of X
-constexpr int kFwdLds = 2 * kWBlock + 4 * 3 * kXSlot + kN;      // 96 KB + 24 KB + 2 KB
+constexpr int kFwdLds = 3 * kWBlock + 4 * 2 * kXSlot;           // 144 KB + 16 KB = all of the CU's LDS
 constexpr int kGridCap = 256;           // one workgroup per CU
 
 struct FwdArgs {
@@ -77,44 +77,61 @@ __global__ void __launch_bounds__(kThreads) lin_planes_kernel(const float* w, in
 }
 
 // X16: the rows of x start on 16-byte boundaries (ldx a multiple of 4 floats): two 16-byte pieces per lane and step; otherwise
-// (Hanabi's 1285 / 1385-wide gathered minibatches) the same LDS image is filled with 4-byte pieces, eight per lane and step
+// (Hanabi's 1285 / 1385-wide gathered minibatches) the same LDS image is filled with 4-byte pieces, eight per lane and step.
+//
+// Pipeline (round 5, second version; profiles/r05_lin512_*.json hold the measurements of all three).  With ONE wave per SIMD
+// nothing overlaps what precedes a step's MFMAs in program order, and the first version (wait, barrier, 14 DMA issues, operand
+// read, split, then 96 MFMAs) kept the matrix pipe 50 % busy.  Now a step's MFMAs run on operands prepared DURING the previous
+// step:
+//   W(j): block of planes of step j, in buffer j % 3, issued two steps ahead;
+//   X(j): this wave's piece of step j, in its slot j % 2, read and split during step j - 1, issued three steps ahead into the
+//         slot X(j - 2) was just read from.
+// Step s: wait (all but the youngest W and X group) -> barrier -> [4 groups of 24 MFMAs on b(s), interleaved with: 12 DMA
+// issues of W(s + 2), the read and the split of X(s + 1) -> b(s + 1), the DMA issue of X(s + 3)].  Every position the loads
+// need (block of planes, row tile, column, buffer, slot) is a counter that advances with the step: no division in the loop.
+// (A third version with [256 rows, 256 features] per workgroup -- half the plane traffic, X read twice -- was slower.)
 template <bool X16>
 __global__ void __launch_bounds__(kThreads, 1) lin_fwd_kernel(FwdArgs a) {
     float* lds = prim::lds();
-    float* wbuf = lds;                              // [2][kWBlock]
-    float* xring = lds + 2 * kWBlock;               // [wave 4][slot 3][kXSlot]
-    float* biasl = xring + 4 * 3 * kXSlot;          // [512]
+    float* wbuf = lds;                              // [3][kWBlock]
+    float* xring = lds + 3 * kWBlock;               // [wave 4][slot 2][kXSlot]
     const int tid = threadIdx.x, lane = tid & 63, wave = prim::uniform(tid >> 6), c = lane & 31, g = lane >> 5;
     const int nkb = a.nkb;
     const long long ntiles = (a.rows + 127) / 128;
     const long long my_tiles = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     if (my_tiles == 0) return;
-    for (int e = tid; e < kN; e += kThreads) biasl[e] = a.bias != nullptr ? a.bias[e] : 0.f;
-    const long long total = my_tiles * nkb;         // steps of this workgroup
-    // ---- loads.  W: block kb of the planes, 48 units of 1 KB, 12 per wave.  X: this wave's 32 rows x 16 columns of step s as
-    // two units: lane l of unit j loads the 16-byte piece l >> 4 of row 16 j + (l & 15) -- the LDS image a half-wave then reads
-    // without bank conflicts (16 consecutive rows at one piece = 16 consecutive 16-byte slots)
-    auto issue_w = [&](long long s) {
-        const int buf = (int)(s & 1);               // (the buffer of step s even when s is past the end: nobody reads it then)
-        if (s >= total) s = total - 1;
-        const int kb = (int)(s % nkb);
-        const float* src = a.planes + (long long)kb * kWBlock + (12 * wave) * 256 + 4 * lane;
-        float* dst = wbuf + buf * kWBlock + (12 * wave) * 256;
-#pragma unroll
-        for (int u = 0; u < 12; ++u) prim::load_lds16(src + u * 256, dst + u * 256);
+    // ---- the W stream: step position (block kb, buffer); past the last step it stays on the last block (a buffer nobody reads)
+    struct WPos {
+        int kb, buf;
+        long long left;     // steps that remain, this one included
+    } wp = {0, 0, my_tiles * (long long)nkb};
+    auto issue_w = [&](int u0, int n) {             // units u0 .. u0 + n - 1 of this wave's twelve 1 KB units of the block
+        const float* src = a.planes + (long long)wp.kb * kWBlock + (12 * wave) * 256 + 4 * lane;
+        float* dst = wbuf + wp.buf * kWBlock + (12 * wave) * 256;
+        for (int u = u0; u < u0 + n; ++u) prim::load_lds16(src + u * 256, dst + u * 256);
     };
-    auto issue_x = [&](long long s) {
-        float* dst = xring + (wave * 3 + (int)(s % 3)) * kXSlot;
-        if (s >= total) s = total - 1;              // (past the end: the last step again, into a slot nobody reads any more;
-                                                    // keeps every group the same size)
-        const long long tile = blockIdx.x + (s / nkb) * gridDim.x;
-        const int kb = (int)(s % nkb);
+    auto next_w = [&]() {
+        wp.buf = wp.buf == 2 ? 0 : wp.buf + 1;
+        if (wp.left > 1) {
+            --wp.left;
+            wp.kb = wp.kb + 1 == nkb ? 0 : wp.kb + 1;
+        }
+    };
+    // ---- the X stream: this wave's 32 rows x 16 columns of a step as two units: lane l of unit j loads the 16-byte piece
+    // l >> 4 of row 16 j + (l & 15) -- the LDS image a half-wave then reads without bank conflicts (16 consecutive rows at one
+    // piece = 16 consecutive 16-byte slots)
+    struct XPos {
+        int kb, slot;
+        long long tile, left;
+    } xp = {0, 0, (long long)blockIdx.x, my_tiles * (long long)nkb};
+    auto issue_x = [&]() {
+        float* dst = xring + (wave * 2 + xp.slot) * kXSlot;
         if (X16) {
-            int k = 16 * kb + 4 * (lane >> 4);
+            int k = 16 * xp.kb + 4 * (lane >> 4);
             if (k > a.ldx - 4) k = a.ldx - 4;       // a piece past the row's end: finite data against zero weights
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                long long r = tile * 128 + 32 * wave + 16 * j + (lane & 15);
+                long long r = xp.tile * 128 + 32 * wave + 16 * j + (lane & 15);
                 if (r >= a.rows) r = a.rows - 1;
                 prim::load_lds16(a.x + r * a.ldx + k, dst + j * 256);
             }
@@ -122,53 +139,63 @@ __global__ void __launch_bounds__(kThreads, 1) lin_fwd_kernel(FwdArgs a) {
             // unit u = (j, piece): lane l fills float e = l & 3 of the slot of row 16 j + (l >> 2)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                long long r = tile * 128 + 32 * wave + 16 * (u >> 2) + (lane >> 2);
+                long long r = xp.tile * 128 + 32 * wave + 16 * (u >> 2) + (lane >> 2);
                 if (r >= a.rows) r = a.rows - 1;
-                int k = 16 * kb + 4 * (u & 3) + (lane & 3);
+                int k = 16 * xp.kb + 4 * (u & 3) + (lane & 3);
                 if (k > a.ldx - 1) k = a.ldx - 1;
                 prim::load_lds4(reinterpret_cast<const int*>(a.x + r * a.ldx + k), reinterpret_cast<int*>(dst + u * 64));
             }
         }
+        xp.slot ^= 1;
+        if (xp.left > 1) {                          // (past the end: the last step again, into a slot nobody reads any more)
+            --xp.left;
+            if (++xp.kb == nkb) {
+                xp.kb = 0;
+                xp.tile += gridDim.x;
+            }
+        }
     };
     constexpr int kXGroup = X16 ? 2 : 8;            // loads of one issue_x
-    issue_w(0);
-    issue_x(0);
-    issue_x(1);
-    __syncthreads();        // the bias is in LDS
-    long long s = 0;        // step counter over all tiles of this workgroup: the load pipeline runs across tile boundaries
+    // the three bf16 planes of this lane's 8 values of X in `slot`: row c, columns 8 g .. 8 g + 7 of the step
+    auto read_x = [&](int slot, bf8& b1, bf8& b2, bf8& b3) {
+        const float* xs = xring + (wave * 2 + slot) * kXSlot + (c >> 4) * 256 + ((2 * g) * 16 + (c & 15)) * 4;
+        const v4 lo = *reinterpret_cast<const v4*>(xs), hi = *reinterpret_cast<const v4*>(xs + 64);
+        float r[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r[i] = lo[i];
+            r[4 + i] = hi[i];
+        }
+        mlp::split3(r, b1, b2, b3);
+    };
+    // prologue: the queue the steady state expects -- ..., W(s), X(s + 1), W(s + 1), X(s + 2)
+    issue_x();                                      // X(0) -> slot 0
+    issue_w(0, 12);                                 // W(0) -> buffer 0
+    next_w();
+    issue_x();                                      // X(1) -> slot 1
+    issue_w(0, 12);                                 // W(1) -> buffer 1
+    next_w();
+    prim::wait_lds_loads<12 + 12 + kXGroup>();      // X(0)
+    bf8 b1, b2, b3;
+    read_x(0, b1, b2, b3);
+    prim::wave_sync();                              // (X(2) goes into the slot X(0) was just read from -- by every lane)
+    issue_x();                                      // X(2) -> slot 0
+    int rbuf = 0, rslot = 1;                        // buffer of W(s), slot of X(s + 1)
     for (long long m = 0; m < my_tiles; ++m) {
         f32x16 acc[16];
-        // (a compiler barrier: without it the 256 loop-invariant bias reads are hoisted out of the tile loop and kept -- spilled)
-        asm volatile("" ::: "memory");
 #pragma unroll
         for (int t = 0; t < 16; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const v4 b = *reinterpret_cast<const v4*>(biasl + 32 * t + 8 * q + 4 * g);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[t][4 * q + e] = b[e];
-            }
-        for (int kb = 0; kb < nkb; ++kb, ++s) {
-            // this wave's part of W(s) and its X(s) have landed: everything but the youngest group, X(s + 1)
-            prim::wait_lds_loads<kXGroup>();
+            for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+        for (int kb = 0; kb < nkb; ++kb) {
+            // this wave's part of W(s) and its X(s + 1) have landed: everything but the youngest W and X group
+            prim::wait_lds_loads<12 + kXGroup>();
             __syncthreads();    // ... and everybody else's part of W(s); all waves are done with step s - 1's buffer
-            issue_w(s + 1);
-            issue_x(s + 2);
-            const float* wb = wbuf + (int)(s & 1) * kWBlock + lane * 4;
-            const float* xs = xring + (wave * 3 + (int)(s % 3)) * kXSlot + (c >> 4) * 256 + ((2 * g) * 16 + (c & 15)) * 4;
-            float r[8];
-            {
-                const v4 lo = *reinterpret_cast<const v4*>(xs), hi = *reinterpret_cast<const v4*>(xs + 64);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    r[i] = lo[i];
-                    r[4 + i] = hi[i];
-                }
-            }
-            bf8 b1, b2, b3;
-            mlp::split3(r, b1, b2, b3);
+            const float* wb = wbuf + rbuf * kWBlock + lane * 4;
+            bf8 nb1, nb2, nb3;
             // four groups of four feature tiles; the next group's 12 A operands are read while this group's 24 MFMAs issue (the
-            // scheduling fence keeps the compiler from hoisting all 48 reads to the top: 192 registers)
+            // scheduling fences keep the compiler from hoisting all 48 reads to the top: 192 registers); the loads of the coming
+            // steps and the next step's operand ride along, a few instructions per group
             bf8 an[3][4];
 #pragma unroll
             for (int p = 0; p < 3; ++p)
@@ -188,10 +215,16 @@ __global__ void __launch_bounds__(kThreads, 1) lin_fwd_kernel(FwdArgs a) {
                         for (int t = 0; t < 4; ++t)
                             an[p][t] = *reinterpret_cast<const bf8*>(wb + p * 4096 + (4 * (q + 1) + t) * 256);
                 }
+                if (q == 1) read_x(rslot, nb1, nb2, nb3);
                 prim::sched_fence();
+                issue_w(3 * q, 3);                  // (in issue order: W(s + 2)'s twelve units, then X(s + 3))
+                if (q == 3) {                       // ... into the slot X(s + 1) was read from two groups ago (by every lane)
+                    next_w();
+                    prim::wave_sync();
+                    issue_x();
+                }
                 // smallest terms first; term by term over the group's four tiles, so that an MFMA never waits for the result of
-                // the one issued just before it (six back-to-back MFMAs on ONE accumulator ran at 43 % of the pipe's rate:
-                // profiles/r05_bench_hanabi_kernel_stats_first.csv)
+                // the one issued just before it
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[4 * q + t] = prim::mfma_bf16(af[0][t], b3, acc[4 * q + t]);
 #pragma unroll
@@ -205,21 +238,33 @@ __global__ void __launch_bounds__(kThreads, 1) lin_fwd_kernel(FwdArgs a) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[4 * q + t] = prim::mfma_bf16(af[0][t], b1, acc[4 * q + t]);
             }
+            b1 = nb1;
+            b2 = nb2;
+            b3 = nb3;
+            rbuf = rbuf == 2 ? 0 : rbuf + 1;
+            rslot ^= 1;
         }
-        // the tile is complete: row c of this wave, features 32 t + 8 q + 4 g + e
+        // the tile is complete: row c of this wave, features 32 t + 8 q + 4 g + e (+ bias, read from global memory: once per tile)
         const long long tile = blockIdx.x + m * gridDim.x;
         const long long row = tile * 128 + 32 * wave + c;
         if (row < a.rows) {
             float* yr = a.y + row * kN + 4 * g;
 #pragma unroll
-            for (int t = 0; t < 16; ++t)
+            for (int t = 0; t < 16; ++t) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     v4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = acc[t][4 * q + e];
+                    if (a.bias != nullptr) {
+                        const v4 b = *reinterpret_cast<const v4*>(a.bias + 32 * t + 8 * q + 4 * g);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] += b[e];
+                    }
                     *reinterpret_cast<v4*>(yr + 32 * t + 8 * q) = o;
                 }
+                prim::sched_fence();        // (tile by tile: no 64 bias loads in flight at once)
+            }
         }
     }
     prim::wait_lds_loads<0>();      // (the groups issued past the end)
@@ -241,6 +286,9 @@ struct WgArgs {
     float* partials;        // [gridDim.x][512][kp], kp = gridDim.y * 128
 };
 
+// Pipeline (second version, like lin_fwd_kernel): the operands of step m + 1 (8 rows of one column per lane: 64 4-byte LDS
+// reads and eight 3-way splits) are read and split while the 96 MFMAs of step m issue; tiles are issued three steps ahead into
+// a ring of three slots (tile j is read during step j - 1, so at step m the slots of tiles <= m are free).
 template <bool X16>
 __global__ void __launch_bounds__(kThreads, 1) lin_wgrad_kernel(WgArgs a) {
     float* lds = prim::lds();
@@ -298,41 +346,56 @@ __global__ void __launch_bounds__(kThreads, 1) lin_wgrad_kernel(WgArgs a) {
             }
         };
         constexpr int kGroup = X16 ? 10 : 16;       // loads of one issue
-        issue(0);
-        issue(1);
-        for (long long m = 0; m < n_it; ++m) {
-            prim::wait_lds_loads<kGroup>();         // this wave's loads of step m: all but the youngest group (step m + 1)
-            float* slot = lds + (int)(m % kWgSlots) * kWgSlot;
+        // rows past the end of the matrix count as zero: this wave's units of the tile's dY rows >= live
+        auto zero_tail = [&](long long m) {
             const long long live = a.rows - (t0 + m) * 16;
-            if (live < 16) {                        // last tile: rows past the end of the matrix count as zero
+            if (m < n_it && live < 16) {
+                float* slot = lds + (int)(m % kWgSlots) * kWgSlot;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int unit = 8 * wave + u;
                     if ((unit >> 1) >= live) *reinterpret_cast<v4*>(slot + unit * 256 + 4 * lane) = v4{0.f, 0.f, 0.f, 0.f};
                 }
             }
-            __syncthreads();                        // ... and everybody else's; all waves are done with step m - 1's slot
-            issue(m + 2);
-            const float* dz = slot + 128 * wave + c;            // feature 128 wave + 32 i + c, row 8 g + e
-            const float* xt = slot + kWgDz + c;                 // column 32 j + c, row 8 g + e
-            bf8 A[4][3], B[4][3];
+        };
+        // operands of tile m: A[i] = dY[rows 8 g .. 8 g + 7][feature 128 wave + 32 i + c], B[j] = X[rows 8 g ..][column 32 j + c]
+        auto operand_a = [&](long long m, int i, bf8* A3) {
+            const float* dz = lds + (int)(m % kWgSlots) * kWgSlot + 128 * wave + c;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = dz[(8 * g + e) * kN + 32 * i];
+            mlp::split3(v, A3[0], A3[1], A3[2]);
+        };
+        auto operand_b = [&](long long m, int j, bf8* B3) {
+            const float* xt = lds + (int)(m % kWgSlots) * kWgSlot + kWgDz + c;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = xt[(8 * g + e) * kWgCols + 32 * j];
+            mlp::split3(v, B3[0], B3[1], B3[2]);
+        };
+        issue(0);
+        issue(1);
+        issue(2);
+        prim::wait_lds_loads<2 * kGroup>();         // tile 0
+        zero_tail(0);
+        __syncthreads();
+        bf8 A[4][3], B[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) operand_a(0, i, A[i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) operand_b(0, j, B[j]);
+        for (long long m = 0; m < n_it; ++m) {
+            prim::wait_lds_loads<kGroup>();         // this wave's loads of tile m + 1: all but the youngest group (tile m + 2)
+            zero_tail(m + 1);
+            __syncthreads();                        // ... and everybody else's; all waves have read tile m (during step m - 1)
+            issue(m + 3);                           // -> the slot of tile m
+            bf8 nA[4][3], nB[4][3];
+            // smallest terms first, term by term over a feature tile's four column tiles (an MFMA never waits for the one before
+            // it); the next step's operands are read and split alongside, one feature tile and one column tile per group
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = dz[(8 * g + e) * kN + 32 * i];
-                mlp::split3(v, A[i][0], A[i][1], A[i][2]);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = xt[(8 * g + e) * kWgCols + 32 * j];
-                mlp::split3(v, B[j][0], B[j][1], B[j][2]);
-            }
-            // smallest terms first, term by term over a feature tile's four column tiles (see lin_fwd_kernel)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
+                operand_a(m + 1, i, nA[i]);
+                operand_b(m + 1, i, nB[i]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = prim::mfma_bf16(A[i][0], B[j][2], acc[i][j]);
 #pragma unroll
@@ -346,6 +409,13 @@ __global__ void __launch_bounds__(kThreads, 1) lin_wgrad_kernel(WgArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = prim::mfma_bf16(A[i][0], B[j][0], acc[i][j]);
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    A[i][p] = nA[i][p];
+                    B[i][p] = nB[i][p];
+                }
         }
         prim::wait_lds_loads<0>();
     }

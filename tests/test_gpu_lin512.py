@@ -113,5 +113,8 @@ def test_hidden512_trunk_vs_float64_and_vs_the_library_route(monkeypatch, relu):
     for k in res["six_term"]:
         # (a three-block ReLU / LayerNorm trunk in float32 sits 1e-3 from float64 on its input LayerNorm's gradient -- under
         # either arithmetic; what matters is that the six-term route is no further away than the library route)
-        assert res["six_term"][k] < 5e-3 and res["f32_mfma"][k] < 5e-3, (k, res["six_term"][k], res["f32_mfma"][k])
+        # (ReLU: a pre-activation within rounding of zero flips its unit on or off, whatever the arithmetic -- both routes sit
+        # ~1e-2 from float64 there; Tanh is smooth)
+        lim = 5e-2 if relu else 5e-3
+        assert res["six_term"][k] < lim and res["f32_mfma"][k] < lim, (k, res["six_term"][k], res["f32_mfma"][k])
         assert res["six_term"][k] <= 4.0 * res["f32_mfma"][k] + 2e-6, (k, res["six_term"][k], res["f32_mfma"][k])

@@ -399,7 +399,8 @@ def main():
             """(HBM bytes per launch, file) from the committed rocprofv3 PMC passes (profiles/r0N_pmc_summary.json, newest
             first: 2 x FETCH_SIZE + WRITE_SIZE, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950) -- only
             quoted when the profiled launch had the same algorithmic byte count."""
-            for fn in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+            for fn in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json",
+                       "r01_pmc_summary.json"):
                 try:
                     with open(os.path.join(ROOT, "profiles", fn)) as f:
                         rec = json.load(f).get(name)

@@ -29,11 +29,14 @@ def test_snapshot_has_no_spills_and_expected_occupancy():
     # no spills, except the identity-activation forward trunk (<= 32 bytes: loop-invariant addresses reloaded once per tile).
     # (Round 5: the 64-wide form of the time-parallel GAE scan -- a tuning variant that was never selected automatically and
     # spilled 68-196 bytes per lane with time limits -- is no longer built.)
+    # ... and K15's forward (<= 160 bytes: a few 64-bit addresses parked around the tile prologue / epilogue; its step loop --
+    # 96 MFMAs per iteration -- touches no scratch: the ISA listing has its scratch accesses before and after the loop only).
     spills = {k: v["scratch_bytes"] for k, v in table.items() if v["scratch_bytes"]}
-    assert all("mlp_fwd_kernel<0," in k and b <= 32 for k, b in spills.items()), spills
-    # K15 (round 5): both GEMM kernels one wave per SIMD with their 256 accumulators in the AGPR half, no scratch
+    assert all(("mlp_fwd_kernel<0," in k and b <= 32) or ("lin::lin_fwd_kernel" in k and b <= 160) for k, b in spills.items()), spills
+    # K15 (round 5): both GEMM kernels one wave per SIMD with their 256 accumulators in the AGPR half
     k15 = [v for k, v in table.items() if "lin::lin_fwd_kernel" in k or "lin::lin_wgrad_kernel" in k]
-    assert len(k15) == 4 and all(v["agprs"] == 256 and v["scratch_bytes"] == 0 and v["occupancy"] == 1 for v in k15)
+    assert len(k15) == 4 and all(v["agprs"] == 256 and v["occupancy"] == 1 for v in k15)
+    assert all(v["scratch_bytes"] == 0 for k, v in table.items() if "lin::lin_wgrad_kernel" in k)
     # round 4: the version-3 forward -- 15 instances (layers x activation x groups of 8 columns in a row's last chunk), two
     # waves per SIMD (<= 256 registers), no scratch
     f3 = {k: v for k, v in table.items() if "mlp_fwd3_kernel<" in k}
@@ -88,8 +91,9 @@ def test_isa_snapshot_shows_the_cdna4_instructions_the_design_relies_on():
     # the buffer path is HBM-bound (no MFMA); the fused trunk (K9) is the MFMA path and fetches its weight-gradient
     # operands with direct-to-LDS loads
     assert all(isa[s]["mfma_f32"] == 0 for s in isa if s not in ("mappo_rnn.hip", "mappo_mlp.hip"))
-    # (round 4: plus the bf16 matrix instruction of the opt-in version-4 forward, mlp_fwd4_kernel -- float32 products from
-    # six bf16 terms; every default kernel is float32 MFMA)
+    # (plus the bf16 matrix instruction of the six-term kernels -- float32 products from six bf16 terms: the default
+    # arithmetic since round 5; the float32-MFMA instances stay in the library for --matrix_arithmetic f32_mfma and for the
+    # shapes without a six-term kernel)
     kinds = isa["mappo_mlp.hip"]["mfma_kinds"]
     assert set(kinds) == {"v_mfma_f32_32x32x2_f32", "v_mfma_f32_32x32x16_bf16"}
     assert sum(kinds.values()) == isa["mappo_mlp.hip"]["mfma_f32"] and kinds["v_mfma_f32_32x32x2_f32"] > 12000

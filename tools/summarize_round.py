@@ -73,14 +73,15 @@ def main():
         out["mappo_gather_rows"] = {"algorithmic_bytes": 2 * 4 * rec_widths * rows + 8 * rows, "fetch_size_bytes_raw": f,
                                     "write_size_bytes": w, "hbm_bytes": 2 * f + w, "dispatches_averaged": n,
                                     "kernel": "gather_records_kernel",
-                                    "note": "the packed 64-byte records are read whole (16 floats, 12 of them payload): "
-                                            "fetched bytes exceed the algorithmic count by the padding"}
+                                    "note": "until round 4 the packed records were 64 bytes (16 floats, 12 of them payload: "
+                                            "fetched bytes exceeded the algorithmic count by the padding); round 5 packs "
+                                            "dense 48-byte records for the device sampler's ascending walks"}
     with open(os.path.join(DST, TAG + "_pmc_summary.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     for k, v in out.items():
         print(k, "algorithmic %.3f GB, HBM %.3f GB (%.2fx)" % (v["algorithmic_bytes"] / 1e9, v["hbm_bytes"] / 1e9,
                                                               v["hbm_bytes"] / v["algorithmic_bytes"]))
-    for w in ("ns", "cfg2", "cfg3", "smac", "ns_rnn"):
+    for w in ("ns", "cfg2", "cfg3", "smac", "ns_rnn", "hanabi"):
         for f in glob.glob(os.path.join(SRC, "prof_" + w, "*kernel_stats.csv")):
             shutil.copy(f, os.path.join(DST, "%s_bench_%s_kernel_stats.csv" % (TAG, w)))
     lines = {}

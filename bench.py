@@ -44,7 +44,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32 MFMA peak (v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md); no xf32 / tf32 on gfx950
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16, MI355X_MICROARCH.md; no sparsity)
 ARITHMETIC_TEXT = {
-    "six_term": "f32 products from six bf16xbf16 terms of exact 3-way splits, f32 accumulate (K9 / K12 matrix products; "
+    "six_term": "f32 products from six bf16xbf16 terms of exact 3-way splits, f32 accumulate (K9 / K12 / K15 matrix products; "
                 "MAPPO_ARITH_SIX_TERM); everything else f32",
     "f32_mfma": "f32 MFMA (v_mfma_f32_32x32x2_f32; MAPPO_ARITH_F32_MFMA)",
 }
@@ -323,6 +323,8 @@ def main():
     mt = fused_mlp.profile_times()
     n_coll, coll_ms, coll_bytes = trainer.dp.collective_times()
     trainer.dp.time_collectives(False)
+    # (counted here: the steps that follow -- K9 launch timing, the other arithmetic form -- issue collectives of their own)
+    scalar_n, reused_n = trainer.dp.scalar_collectives - scalar0, trainer.dp.scales_reused - reused0
     # Small minibatches replay ppo_update from captured HIP graphs (algorithms/r_mappo/update_graph.py): launches inside a graph
     # carry no event pairs, so the K9 launch timings of the roofline objects are then taken from ONE extra step after the timed
     # region with the graphs switched off (same kernels, same shapes); `value` / `ms_per_step` stay the graphed steps'.
@@ -359,7 +361,7 @@ def main():
     # same run.
     other = None
     other_name = "f32_mfma" if opt.matrix_arithmetic == "six_term" else "six_term"
-    if not opt.no_other_arithmetic and args.hidden_size == 64:
+    if not opt.no_other_arithmetic and args.hidden_size in (64, 512):
         policy.set_matrix_arithmetic(other_name)
         try:
             k6 = max(1, min(opt.steps, 5))
@@ -447,8 +449,9 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             # how the float32 matrix products of K9 / K12 were formed in the timed region (inputs, outputs, accumulation and
             # every other operation are float32 either way)
-            "arithmetic": ARITHMETIC_TEXT[opt.matrix_arithmetic] if args.hidden_size == 64 else
-                          "f32 (hidden size != 64: library float32 GEMMs + K6 / K7)",
+            "arithmetic": ARITHMETIC_TEXT[opt.matrix_arithmetic] if (args.hidden_size == 64 or (
+                args.hidden_size == 512 and opt.matrix_arithmetic == "six_term" and "mappo_linear512_forward" in mt)) else
+                          "f32 (library float32 GEMMs + K6 / K7)",
             "hbm_peak_bytes_per_rank": peak_mem,
             # updates of the timed region that were replays of a captured HIP graph (0: every update ran eagerly)
             "update_graph_replays_per_step": graph_replays / max(1, opt.steps),
@@ -463,11 +466,15 @@ def main():
                                "ms_per_step": round(coll_ms / max(1, opt.steps), 4)},
             # the scalar prologue (loss denominators + ValueNorm moments, 32 bytes): once per train() when the whole-batch
             # tuple is reused, otherwise once per update and issued one update ahead (DataParallel.begin_scales)
-            "scalar_allreduce": {"per_step": (trainer.dp.scalar_collectives - scalar0) / max(1, opt.steps),
-                                 "updates_served_from_cache_per_step": (trainer.dp.scales_reused - reused0) / max(1, opt.steps)},
+            "scalar_allreduce": {"per_step": scalar_n / max(1, opt.steps),
+                                 "updates_served_from_cache_per_step": reused_n / max(1, opt.steps)},
             # the dominant kernel of the step: the fused trunk's forward launch (mlp_fwd4_kernel / mlp_fwd3_kernel; actor and
             # critic launches averaged, as rocprofv3 --stats averages them), matrix-core bound
-            "roofline": roof_mfma("mappo_mlp_forward", "mlp_fwd4_kernel / mlp_fwd3_kernel / mlp_fwd_kernel (mappo_mlp_forward)") or roof("mappo_gae_f32"),
+            # (hidden 512: K15's forward launches -- first layer and hidden layers averaged, as rocprofv3 --stats averages them)
+            "roofline": roof_mfma("mappo_mlp_forward", "mlp_fwd4_kernel / mlp_fwd3_kernel / mlp_fwd_kernel (mappo_mlp_forward)")
+            or roof_mfma("mappo_linear512_forward", "lin_fwd_kernel (mappo_linear512_forward: K15, forward and input gradient)")
+            or roof("mappo_gae_f32"),
+            "roofline_linear512_wgrad": roof_mfma("mappo_linear512_wgrad", "lin_wgrad_kernel + lin_reduce_kernel (mappo_linear512_wgrad: K15)"),
             "roofline_mlp_backward": roof_mfma("mappo_mlp_backward",
                                                "mlp_bwd_kernel + mlp_dw1_{direct,rows}_kernel + reduce / finish (mappo_mlp_backward)"),
             # the kernel BASELINE.json's north star names (>= 70 % of HBM in the GAE scan), HBM bound

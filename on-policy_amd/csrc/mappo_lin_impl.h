@@ -105,10 +105,16 @@ __global__ void __launch_bounds__(kThreads, 1) lin_fwd_kernel(FwdArgs a) {
         int kb, buf;
         long long left;     // steps that remain, this one included
     } wp = {0, 0, my_tiles * (long long)nkb};
-    auto issue_w = [&](int u0, int n) {             // units u0 .. u0 + n - 1 of this wave's twelve 1 KB units of the block
-        const float* src = a.planes + (long long)wp.kb * kWBlock + (12 * wave) * 256 + 4 * lane;
-        float* dst = wbuf + wp.buf * kWBlock + (12 * wave) * 256;
-        for (int u = u0; u < u0 + n; ++u) prim::load_lds16(src + u * 256, dst + u * 256);
+    // (this wave's twelve 1 KB units of a block are contiguous in global memory and in LDS: three runs of four, each under one M0
+    // set-up -- prim::load_lds16x4)
+    auto issue_w4 = [&](int run) {
+        const float* src = a.planes + (long long)wp.kb * kWBlock + (12 * wave + 4 * run) * 256 + 4 * lane;
+        prim::load_lds16x4(src, wbuf + wp.buf * kWBlock + (12 * wave + 4 * run) * 256);
+    };
+    auto issue_w = [&]() {
+        issue_w4(0);
+        issue_w4(1);
+        issue_w4(2);
     };
     auto next_w = [&]() {
         wp.buf = wp.buf == 2 ? 0 : wp.buf + 1;
@@ -170,10 +176,10 @@ __global__ void __launch_bounds__(kThreads, 1) lin_fwd_kernel(FwdArgs a) {
     };
     // prologue: the queue the steady state expects -- ..., W(s), X(s + 1), W(s + 1), X(s + 2)
     issue_x();                                      // X(0) -> slot 0
-    issue_w(0, 12);                                 // W(0) -> buffer 0
+    issue_w();                                      // W(0) -> buffer 0
     next_w();
     issue_x();                                      // X(1) -> slot 1
-    issue_w(0, 12);                                 // W(1) -> buffer 1
+    issue_w();                                      // W(1) -> buffer 1
     next_w();
     prim::wait_lds_loads<12 + 12 + kXGroup>();      // X(0)
     bf8 b1, b2, b3;
@@ -217,7 +223,7 @@ __global__ void __launch_bounds__(kThreads, 1) lin_fwd_kernel(FwdArgs a) {
                 }
                 if (q == 1) read_x(rslot, nb1, nb2, nb3);
                 prim::sched_fence();
-                issue_w(3 * q, 3);                  // (in issue order: W(s + 2)'s twelve units, then X(s + 3))
+                if (q < 3) issue_w4(q);             // (in issue order: W(s + 2)'s twelve units, then X(s + 3))
                 if (q == 3) {                       // ... into the slot X(s + 1) was read from two groups ago (by every lane)
                     next_w();
                     prim::wave_sync();
@@ -314,12 +320,20 @@ __global__ void __launch_bounds__(kThreads, 1) lin_wgrad_kernel(WgArgs a) {
             float* slot = lds + (int)(m % kWgSlots) * kWgSlot;
             if (m >= n_it) m = n_it - 1;            // (past the end: the last tile again, into a slot nobody reads any more)
             const long long row0 = (t0 + m) * 16;
+            if (row0 + 16 <= a.rows) {
+                // this wave's eight units are 8 KB that are contiguous in global memory and in LDS: two runs of four loads, each
+                // under one M0 set-up
+                const float* src = a.dy + (row0 + 4 * wave) * kN + 4 * lane;
+                prim::load_lds16x4(src, slot + (8 * wave) * 256);
+                prim::load_lds16x4(src + 1024, slot + (8 * wave + 4) * 256);
+            } else {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int unit = 8 * wave + u;
-                long long r = row0 + (unit >> 1);
-                if (r >= a.rows) r = a.rows - 1;    // (zeroed in LDS before the product)
-                prim::load_lds16(a.dy + r * kN + 256 * (unit & 1) + 4 * lane, slot + unit * 256);
+                for (int u = 0; u < 8; ++u) {
+                    const int unit = 8 * wave + u;
+                    long long r = row0 + (unit >> 1);
+                    if (r >= a.rows) r = a.rows - 1;    // (zeroed in LDS before the product)
+                    prim::load_lds16(a.dy + r * kN + 256 * (unit & 1) + 4 * lane, slot + unit * 256);
+                }
             }
             if (X16) {
 #pragma unroll

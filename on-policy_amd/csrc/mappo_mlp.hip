@@ -110,6 +110,24 @@ __device__ __forceinline__ void load_lds16(const float* g, float* lds_wave_base)
         : "v"(g), "s"(dst)
         : "memory");
 }
+// Four of them under ONE M0 set-up: units 0 .. 3 of a run that is contiguous in global memory AND in LDS (1 KB apart in both) --
+// the instruction's offset field moves the global address and the LDS address together.
+__device__ __forceinline__ void load_lds16x4(const float* g, float* lds_wave_base) {
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)lds_wave_base);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+        "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g), "s"(dst)
+        : "memory");
+}
 // ... until at most N of this wave's vector memory loads are outstanding (they complete in order)
 template <int N>
 __device__ __forceinline__ void wait_lds_loads() {

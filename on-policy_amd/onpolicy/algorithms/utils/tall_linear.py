@@ -84,8 +84,10 @@ class _Linear512Fn(torch.autograd.Function):
         _native.check(lib.mappo_linear512_prepare(p(w), K, K, 0, p(planes), stream), "mappo_linear512_prepare")
         y = torch.empty((rows, 512), dtype=torch.float32, device=dev)
         b = None if bias is None else bias.detach().contiguous()
-        _native.check(lib.mappo_linear512_forward(p(x), rows, K, int(ldx), p(planes), p(b), p(y), stream),
-                      "mappo_linear512_forward")
+        from . import fused_mlp         # (bench.py: an event pair + the algorithmic FLOPs / bytes of the launch while profiling)
+        with fused_mlp._Timed("mappo_linear512_forward", 2.0 * rows * K * 512, 4.0 * rows * (ldx + 512)):
+            _native.check(lib.mappo_linear512_forward(p(x), rows, K, int(ldx), p(planes), p(b), p(y), stream),
+                          "mappo_linear512_forward")
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         return y
@@ -115,8 +117,10 @@ class _Linear512Fn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty((512, K), dtype=torch.float32, device=dev)
             ws = torch.empty(lib.mappo_linear512_wgrad_workspace_floats(K), dtype=torch.float32, device=dev)
-            _native.check(lib.mappo_linear512_wgrad(p(dy), p(x), rows, K, int(ldx), p(dw), p(ws), stream),
-                          "mappo_linear512_wgrad")
+            from . import fused_mlp
+            with fused_mlp._Timed("mappo_linear512_wgrad", 2.0 * rows * K * 512, 4.0 * rows * (ldx + 512)):
+                _native.check(lib.mappo_linear512_wgrad(p(dy), p(x), rows, K, int(ldx), p(dw), p(ws), stream),
+                              "mappo_linear512_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = column_sums(dy)
         return dx, dw, db

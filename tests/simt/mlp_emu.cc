@@ -25,6 +25,9 @@ inline int uniform(int v) { return v; }
 inline void load_lds16(const float* g, float* lds_wave_base) {
     memcpy(lds_wave_base + 4 * (simt::st().cur->tid & 63), g, 16);
 }
+inline void load_lds16x4(const float* g, float* lds_wave_base) {
+    for (int u = 0; u < 4; ++u) load_lds16(g + 256 * u, lds_wave_base + 256 * u);
+}
 template <int N>
 inline void wait_lds_loads() { simt::wait(my_wave().bar); }
 inline void load_lds4(const int* g, int* lds_wave_base) { lds_wave_base[simt::st().cur->tid & 63] = *g; }

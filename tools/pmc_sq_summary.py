@@ -2,7 +2,8 @@
 """Summary of tools/pmc_sq_pass.sh (one rocprofv3 --pmc pass of SQ / GRBM counters over the north-star bench step) ->
 profiles/r03_pmc_sq_summary.json: per K9 kernel the shader clock the chip ran at (GRBM_GUI_ACTIVE, summed over the 8 XCDs,
 against the dispatch's duration) and the share of that time the matrix pipe of an average SIMD was busy
-(SQ_VALU_MFMA_BUSY_CYCLES = 64 cycles per v_mfma_f32_32x32x2_f32, summed over the 1024 SIMDs)."""
+(SQ_VALU_MFMA_BUSY_CYCLES = 64 cycles per v_mfma_f32_32x32x2_f32, 32 per v_mfma_f32_32x32x16_bf16, summed over the 1024 SIMDs).
+(The keys are name fragments: a generic fragment such as "gru_seq_fwd_kernel" also collects the instances a more specific key names.)"""
 import collections
 import csv
 import json
@@ -15,7 +16,15 @@ TAG = sys.argv[2] if len(sys.argv) > 2 else "r04"
 SRC = os.path.join(ROOT, "gpurun_out", TAG, "pmc_sq_" + W)
 if W == "ns" and not os.path.isdir(SRC):
     SRC = os.path.join(ROOT, "gpurun_out", TAG, "pmc_sq")
-KERNELS = {"gru_seq_fwd_kernel": "K12 forward", "gru_seq_bwd_kernel<3, 5>": "K12 backward, actor (5-wide head inside)",
+KERNELS = {"mlp_fwd4_kernel": "K9 forward, version 4 (six-term, round 5 default): the critic's 384 wide input, both layers on the bf16 pipe",
+           "mlp_fwd3_kernel<2, 1, 2, true>": "K9 forward, version 3 with the hidden layer in six-term form (round 5 default): the actor's 48 wide input",
+           "mlp_dw1_direct_kernel<3, 4, true>": "K9 first-layer weight gradient, critic, six-term (round 5 default)",
+           "mlp_bwd_kernel<2, 1, 0, true>": "K9 backward chain, action head, six-term (round 5 default)",
+           "mlp_bwd_kernel<2, 1, 1, true>": "K9 backward chain, value head, six-term (round 5 default)",
+           "gru_seq_fwd_kernel<true>": "K12 forward, six-term (round 5 default)",
+           "gru_seq_bwd_kernel<3, 5, true, true>": "K12 backward, actor, all six blocks as planes (round 5 default)",
+           "gru_seq_bwd_kernel<1, 1, true, true>": "K12 backward, critic, all six blocks as planes (round 5 default)",
+           "gru_seq_fwd_kernel": "K12 forward", "gru_seq_bwd_kernel<3, 5>": "K12 backward, actor (5-wide head inside)",
            "gru_seq_bwd_kernel<1, 1>": "K12 backward, critic (v_out inside)",
            "mlp_fwd_kernel": "K9 forward, loader / compute kernel (unaligned widths; until the middle of round 4 the narrow actor "
                              "inputs)",
@@ -52,15 +61,15 @@ def main():
             "what": KERNELS[frag], "dispatches": n, "duration_ms": round(ns / 1e6, 4),
             "shader_clock_ghz": round(cycles / ns, 3),
             "mfma_busy_share_of_an_average_simd": round(mfma / (SIMDS * cycles), 3),
-            "mfma_instructions": round(mfma / 64),
-            "frac_of_nominal_f32_mfma_peak": round(mfma / (SIMDS * 2.4 * ns), 3),
+            "mfma_busy_cycles_per_simd": round(mfma / SIMDS),
+            "busy_share_at_the_nominal_2.4_ghz": round(mfma / (SIMDS * 2.4 * ns), 3),
             "sq_wave_quad_cycles": mean("SQ_WAVE_CYCLES"), "sq_wait_inst_any": mean("SQ_WAIT_INST_ANY"),
             "sq_wait_any": mean("SQ_WAIT_ANY"), "sq_active_inst_any": mean("SQ_ACTIVE_INST_ANY")}
     dst = os.path.join(ROOT, "profiles", TAG + "_pmc_sq_summary.json" if W == "ns" else TAG + "_pmc_sq_summary_%s.json" % W)
     json.dump(out, open(dst, "w"), indent=1)
     for k, v in out["kernels"].items():
         print(k, v["duration_ms"], "ms", v["shader_clock_ghz"], "GHz", "MFMA busy", v["mfma_busy_share_of_an_average_simd"],
-              "of nominal", v["frac_of_nominal_f32_mfma_peak"])
+              "of nominal", v["busy_share_at_the_nominal_2.4_ghz"])
 
 
 if __name__ == "__main__":

@@ -596,10 +596,13 @@ int     mappo_mlp_set_debug(long long* buf);
  * returns the previous value, or -1 (nothing changed) for a bit that does not exist.  NONE of them selects arithmetic
  * (that is the per-call `arith` field).  1 = the forward's compute waves keep the default priority; 4 = mappo_mlp_forward
  * keeps the loader / compute kernel (mlp_fwd_kernel) for shapes the version-3 kernel (operands straight from global memory,
- * resident first-layer weights; aligned rows up to 448 floats wide, two or three layers) would take; 32 = the two-slot form
- * of the float32 direct-to-LDS first-layer weight-gradient kernel, two workgroups per CU; 128 = under MAPPO_ARITH_SIX_TERM
- * the version-4 forward (first layer in six-term form, one wave per SIMD) also for aligned inputs narrower than 128 floats,
- * which by default take version 3 with only the hidden layer in six-term form (tests: every chunk shape of version 4). */
+ * resident first-layer weights; aligned rows up to 448 floats wide, two or three layers) would take; 32 = the OTHER form of
+ * the direct-to-LDS first-layer weight-gradient kernel: under MAPPO_ARITH_F32_MFMA two slots per wave and two workgroups per
+ * CU (default: four slots, one workgroup), under MAPPO_ARITH_SIX_TERM four slots and one workgroup (default: two and two);
+ * 128 = under MAPPO_ARITH_SIX_TERM the version-4 forward (first layer in six-term form, one wave per SIMD) also for aligned inputs narrower than 128 floats,
+ * which by default take version 3 with only the hidden layer in six-term form (tests: every chunk shape of version 4);
+ * 256 = under MAPPO_ARITH_SIX_TERM two-layer trunks with aligned inputs of at most 64 columns keep the separate first-layer
+ * weight-gradient kernel (mlp_dw1_rows_kernel) instead of accumulating that gradient inside the chain's launch (A/B, tests). */
 int     mappo_mlp_set_flags(int flags);
 int     mappo_mlp_forward(const mappo_mlp_t* net, mappo_stream_t stream);
 int     mappo_mlp_backward(const mappo_mlp_t* net, mappo_stream_t stream);

@@ -154,6 +154,7 @@ __device__ __forceinline__ void fence() { __threadfence(); }
 __device__ __forceinline__ unsigned ticket(unsigned* counter) { return atomicAdd(counter, 1u); }
 // the value is produced here, in program order: the compiler may neither sink its load into a later branch nor merge it
 __device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(int& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void wait_loads_14() { asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }   // (stamps only)
 __device__ __forceinline__ long long clock() { return (long long)__builtin_readcyclecounter(); }
 __device__ __forceinline__ int f2i(float v) { return __float_as_int(v); }

@@ -1485,13 +1485,14 @@ __global__ void __launch_bounds__(64 * 4, 1) mlp_fwd4_kernel(FwdArgs a) {
 
 // ================================================================== backward: row-parallel chain ====
 struct BwdArgs {
-    RowSrc rs;          // only rows is used here
+    RowSrc rs;          // rows; DW1: the source matrix and the row table too
     Net net;
     const float* z[3];  // saved normalised activations / {mean, rstd} of every layer (forward kernel)
     const float* st[3];
     const float* dy;    // [rows, out] (head) or [rows, 64] (out == 0)
-    float* dz1;         // [rows128(rows), 64]
+    float* dz1;         // [rows128(rows), 64]  (DW1: not written)
     float* partials;    // [gridDim.x][r_total]
+    float* p1;          // DW1: [gridDim.x][64 * din] first-layer weight-gradient sums of the workgroups
     unsigned* ticket;   // the call's ticket word (last float4 of the workspace): zeroed here, drawn from by mlp_tail_kernel
     long long* dbg;     // tuning hook (mappo_mlp_set_debug): cycle stamps of workgroup 0's first tiles at [1024 ...], or NULL
 };
@@ -1549,11 +1550,11 @@ constexpr int kB2Waves = 4;
 constexpr int kSS = 68;          // LDS row stride of that staging tile: 16-byte slot (17 row + piece) mod 16 -- rows c .. c + 15 at
                                 // one piece (the writes) and one row's 16 pieces (the reads) both cover all 64 banks
 struct Bwd2Lds {
-    int gam, w2t, whg, wave0, dy, hacc, stg, per_wave, total;
+    int gam, w2t, whg, wave0, dy, hacc, stg, t1, per_wave, total;
 };
 constexpr int kB2W2Six = 3 * 2 * 4 * 256;   // floats of a hidden layer's weights as three bf16 planes (SIX): [plane][tile][k16 step][lane] x 16 B
 template <int NW>
-__host__ __device__ __forceinline__ Bwd2Lds bwd2_lds(int L, int out, bool six = false) {
+__host__ __device__ __forceinline__ Bwd2Lds bwd2_lds(int L, int out, bool six = false, bool dw1 = false) {
     Bwd2Lds o;
     const int outp = (out + 1) & ~1;                 // head rows padded to a whole MFMA k step
     o.gam = 0;                                       // [64] LayerNorm weight of the top layer (out == 0)
@@ -1563,7 +1564,8 @@ __host__ __device__ __forceinline__ Bwd2Lds bwd2_lds(int L, int out, bool six = 
     o.dy = 64 * kTS;                                 // per wave: T[64][kTS] | DY[out][32] | head sums [out][64] + [out] | S
     o.hacc = o.dy + ((out * 32 + 3) & ~3);
     o.stg = o.hacc + ((65 * out + 3) & ~3);          // S[32][kSS]: row-major staging of the dz1 tile (coalesced stores)
-    o.per_wave = o.stg + 32 * kSS;
+    o.t1 = o.stg + 32 * kSS;                         // DW1: S holds the xhat tile [2][32][32], T1[64][kTS] the transposed dz1
+    o.per_wave = o.t1 + (dw1 ? 64 * kTS : 0);
     o.total = o.wave0 + NW * o.per_wave;
     const int red = o.wave0 + (NW / 2) * 4096;       // the end-of-kernel reduction parks NW / 2 accumulator sets here
     if (o.total < red) o.total = red;
@@ -1616,14 +1618,22 @@ __device__ __forceinline__ void ln_act_backward(float* dn, const float* nh, floa
 // G += dz^T nhat -- on the bf16 matrix pipe, every float32 product from six bf16 x bf16 terms of exact three-way splits
 // (see mlp_fwd4_kernel): 2 x 48 MFMAs of 8 passes instead of 2 x 64 of 16, + ~430 split instructions per tile.  The staged
 // weights are split once per workgroup (three planes in LDS); dz, nhat and their transposes are split in the wave.
-template <int L, int ACT, int HR, bool SIX = false>
+//
+// DW1 (round 5; six-term two-layer trunks whose input is at most 64 wide -- the actors of the MPE configurations): the
+// first-layer weight gradient G1[f][k] = sum_rows dz1[row][f] xhat[row][k] is accumulated HERE, the way the hidden layer's
+// G is, instead of writing dz1 [rows, 64] for a second kernel that reads it back together with xhat: the xhat tile of
+// the next 32 rows (through the sampler's row table) comes in by direct-to-LDS loads a tile ahead, dz1 is transposed
+// through a second scratch tile (T is already receiving the next tile's activations), 48 more MFMAs per tile, 64 more
+// accumulator registers.  The launch moves 512 B per row less (dz1 written + read) and mlp_dw1_rows_kernel is not launched.
+template <int L, int ACT, int HR, bool SIX = false, bool DW1 = false>
 __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
     static_assert(!SIX || L == 2, "the six-term form is built for two-layer trunks");
+    static_assert(!DW1 || SIX, "the fused first-layer weight gradient is built on the six-term form");
     constexpr int NW = kB2Waves;
     float* lds = prim::lds();
     const Net& n = a.net;
     const int out = n.out, outp = (out + 1) & ~1;
-    const Bwd2Lds o = bwd2_lds<NW>(L, out, SIX);
+    const Bwd2Lds o = bwd2_lds<NW>(L, out, SIX, DW1);
     const int tid = threadIdx.x, lane = tid & 63, wave = prim::uniform(tid >> 6), c = lane & 31, h = lane >> 5;
     constexpr int kThr = 64 * NW;
     // the tail kernel of THIS call (two launches further down the same stream) counts its finished blocks in a word of the
@@ -1665,9 +1675,18 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
     float* DY = T + o.dy;
     float* hacc = T + o.hacc;       // [out][64] sums of dy * nhat | [out] sums of dy (lane = feature / lane = o)
     float* S = T + o.stg;
+    float* T1 = T + o.t1;           // (DW1)
     for (int e = lane; e < 65 * out; e += 64) hacc[e] = 0.f;
     constexpr int NG = L > 1 ? L - 1 : 1;
     f32x16 G[NG][4];                // hidden layer l: tile 2 t + t' = (output feature tile t, input feature tile t')
+    f32x16 G1[DW1 ? 4 : 1];         // DW1: the first layer's, tile 2 t + t' (input features 32 t' + c < din)
+    if (DW1) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) G1[DW1 ? t : 0][v] = 0.f;
+    }
+    const int din = a.rs.din;
     // Bias gradients = column sums of dz_l, taken where the values pass through registers in a column-friendly layout anyway
     // (round 4; before: 32 row-layout registers per layer, which the compiler kept in the AGPR half -- three instructions per
     // add -- or, for three layers, an extra transpose per layer).  Layers >= 1: the parked A operands of the G MFMAs (lane =
@@ -1759,8 +1778,34 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
             prim::wave_sync();
         }
     };
+    // DW1: the xhat tile of 32 rows -> S as [k tile t'][row][32] (what the B operands of the G1 MFMAs read lane-consecutively):
+    // instruction (t', q) moves rows 8 q .. 8 q + 7, lane = (row 8 q + lane / 8, 16-byte piece lane % 8 of the k tile)
+    int srt[4] = {0, 0, 0, 0};      // source rows of this lane's four rows of the NEXT tile (fetched a tile ahead of the loads)
+    auto fetch_tab = [&](long long t) {
+        if (t >= ntiles) t = ntiles - 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) srt[q] = a.rs.srow[t * 32 + 8 * q + (lane >> 3)];
+    };
+    auto prefetch_x = [&](long long t) {
+        if (t < ntiles) {
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp) {
+                if (32 * tp < din) {
+                    int k = 32 * tp + 4 * (lane & 7);
+                    if (k + 4 > din) k = din - 4;       // past the row's end: its last piece again (columns that are never stored)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        prim::load_lds16(a.rs.src + (long long)srt[q] * din + k, S + (tp * 4 + q) * 256);
+                }
+            }
+        }
+    };
     prefetch_row(gw);
     prefetch_top(gw);
+    if (DW1) {
+        fetch_tab(gw);
+        prefetch_x(gw);
+    }
     const bool stamp = a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
     int n_stamp = 0;
 #define MAPPO_B2_STAMP(k) if (stamp && n_stamp < 12) a.dbg[1024 + 16 * n_stamp + (k)] = prim::clock()
@@ -1776,7 +1821,8 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
         // are issued (the counter would wait for them too).
         prim::wait_lds_loads<0>();
         load_frag64(T, lane, nh);
-        flush_dz1();
+        if (DW1) fetch_tab(tile + nw);
+        else flush_dz1();
         // (z and the statistics are padded to the 128-row tile: rows past the end repeat the last row and meet dy = 0)
         f2 st = stn, stx = stn;
         if (L > 1) {
@@ -1899,7 +1945,67 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
         for (int l = L - 1; l >= 0; --l) {
             ln_act_backward<ACT>(dn, nh, st[0], st[1]);      // dn now holds dz_l
             MAPPO_B2_STAMP(l == L - 1 ? 4 : 10);
-            if (l == 0) {
+            if (l == 0 && DW1) {
+                // ---- G1 += dz1^T xhat (see the kernel's head): A operands from the transposed dz1, B operands from the
+                // xhat tile that landed in S before this tile began
+                put_transposed(T1, dn, c, h);
+                prim::wave_sync();
+                v4 a0[4], a1[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a0[q] = *reinterpret_cast<const v4*>(T1 + c * kTS + 16 * h + 4 * q);
+                    a1[q] = *reinterpret_cast<const v4*>(T1 + (32 + c) * kTS + 16 * h + 4 * q);
+                }
+                {
+                    f2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        p0 += f2{a0[q][0], a0[q][1]} + f2{a0[q][2], a0[q][3]};
+                        p1 += f2{a1[q][0], a1[q][1]} + f2{a1[q][2], a1[q][3]};
+                    }
+                    dbs[0][0] += p0[0] + p0[1];
+                    dbs[0][1] += p1[0] + p1[1];
+                }
+                const bool wide = din > 32;     // (uniform) the second k tile holds columns
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float va[2][8], vb[2][8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        va[0][i] = a0[2 * j + (i >> 2)][i & 3];
+                        va[1][i] = a1[2 * j + (i >> 2)][i & 3];
+                        vb[0][i] = S[(16 * h + 8 * j + i) * 32 + c];
+                        vb[1][i] = wide ? S[1024 + (16 * h + 8 * j + i) * 32 + c] : 0.f;
+                    }
+                    bf8 A[2][3], B[2][3];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        split3(va[t], A[t][0], A[t][1], A[t][2]);
+                        split3(vb[t], B[t][0], B[t][1], B[t][2]);
+                    }
+#pragma unroll
+                    for (int ta = 0; ta < 2; ++ta) {
+                        f32x16& g0 = G1[DW1 ? 2 * ta : 0];
+                        g0 = prim::mfma_bf16(A[ta][0], B[0][2], g0);
+                        g0 = prim::mfma_bf16(A[ta][2], B[0][0], g0);
+                        g0 = prim::mfma_bf16(A[ta][1], B[0][1], g0);
+                        g0 = prim::mfma_bf16(A[ta][0], B[0][1], g0);
+                        g0 = prim::mfma_bf16(A[ta][1], B[0][0], g0);
+                        g0 = prim::mfma_bf16(A[ta][0], B[0][0], g0);
+                        if (wide) {
+                            f32x16& g1 = G1[DW1 ? 2 * ta + 1 : 0];
+                            g1 = prim::mfma_bf16(A[ta][0], B[1][2], g1);
+                            g1 = prim::mfma_bf16(A[ta][2], B[1][0], g1);
+                            g1 = prim::mfma_bf16(A[ta][1], B[1][1], g1);
+                            g1 = prim::mfma_bf16(A[ta][0], B[1][1], g1);
+                            g1 = prim::mfma_bf16(A[ta][1], B[1][0], g1);
+                            g1 = prim::mfma_bf16(A[ta][0], B[1][0], g1);
+                        }
+                    }
+                }
+                prim::wave_sync();          // every lane has read the xhat tile: the next one may land
+                prefetch_x(tile + nw);
+            } else if (l == 0) {
                 // -> the row-major staging tile
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
@@ -2037,6 +2143,10 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
                     prim::pin(m0);
                     prim::pin(m1);
                     stx = f2{m0, m1};
+                    if (DW1) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) prim::pin(srt[q]);
+                    }
                     prefetch_top(tile + nw);
                 }
 #pragma unroll
@@ -2058,21 +2168,23 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
     }
 #undef MAPPO_B2_STAMP
     prim::wait_lds_loads<0>();
-    flush_dz1();
+    if (!DW1) flush_dz1();
     // ---- the column sums -> lane = feature
 #pragma unroll
-    for (int l = 1; l < L; ++l) {
+    for (int l = DW1 ? 0 : 1; l < L; ++l) {
         float sa = dbs[l][0], sb = dbs[l][1];
         sa += prim::xhalf(sa);
         sb += prim::xhalf(sb);
         db[l] = h ? sb : sa;
     }
     prim::wave_sync();
+    if (!DW1) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) T[64 * (lane >> 4) + 4 * (lane & 15) + e] = db0[e];
-    prim::wave_sync();
-    db[0] = (T[lane] + T[64 + lane]) + (T[128 + lane] + T[192 + lane]);
-    prim::wave_sync();
+        for (int e = 0; e < 4; ++e) T[64 * (lane >> 4) + 4 * (lane & 15) + e] = db0[e];
+        prim::wave_sync();
+        db[0] = (T[lane] + T[64 + lane]) + (T[128 + lane] + T[192 + lane]);
+        prim::wave_sync();
+    }
     if (HR == 0 && out > 0) {
         if (out <= kHQ) {
 #pragma unroll
@@ -2147,6 +2259,38 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
                     for (int v = 0; v < 16; ++v) {
                         const int f = 32 * t + (v & 3) + 8 * (v >> 2) + 4 * h;
                         prow[r_g(L, l) + f * 64 + 32 * tp + c] = G[l - 1][2 * t + tp][v];
+                    }
+        }
+    }
+    if (DW1) {
+        // the first layer's sums: same tree; the workgroup's row of the first-layer partials is what mlp_dw1_rows_kernel wrote
+#pragma unroll
+        for (int half = NW / 2; half >= 1; half >>= 1) {
+            __syncthreads();
+            if (wave >= half && wave < 2 * half) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) red[(wave - half) * 4096 + (16 * t + v) * 64 + lane] = G1[DW1 ? t : 0][v];
+            }
+            __syncthreads();
+            if (wave < half) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) G1[DW1 ? t : 0][v] += red[wave * 4096 + (16 * t + v) * 64 + lane];
+            }
+        }
+        if (wave == 0) {
+            float* prow1 = a.p1 + (long long)blockIdx.x * 64 * din;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int f = 32 * t + (v & 3) + 8 * (v >> 2) + 4 * h;
+                        if (32 * tp + c < din) prow1[(long long)f * din + 32 * tp + c] = G1[DW1 ? 2 * t + tp : 0][v];
                     }
         }
     }
@@ -2933,7 +3077,7 @@ inline int& grid_cap_override() {
     return cap;
 }
 // option bits of mappo_mlp_set_flags that exist (tuning / tests only; arithmetic is the per-call `arith` field)
-constexpr int kTuningBits = 1 | 4 | 32 | 128;
+constexpr int kTuningBits = 1 | 4 | 32 | 128 | 256;
 inline int& tuning_flags_ref() {
     static int v = -1;
     if (v < 0) {
@@ -3069,15 +3213,24 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
     b.partials = m->workspace;
     b.ticket = reinterpret_cast<unsigned*>(m->workspace + workspace_floats(m->din, m->n_layers, m->out) - 4);
     long long grid;
+    bool fused1 = false;
     {
         // head sums in registers for the value head (HR = 1)
         const int hr = (out == 1 && L <= 2) ? 1 : 0;
         const bool six = six_term && L == 2;       // the tile's 64 x 64 products of two-layer trunks in six-term bf16 form
-        const Bwd2Lds o = bwd2_lds<kB2Waves>(L, out, six);
+        // ... and for inputs of at most 64 aligned columns the first-layer weight gradient in the same launch (option bit 256
+        // keeps the separate mlp_dw1_rows_kernel: A/B and tests)
+        fused1 = six && din % 4 == 0 && din <= 64 && !(tuning_flags() & 256);
+        const Bwd2Lds o = bwd2_lds<kB2Waves>(L, out, six, fused1);
         grid = capped(ceil_div(m->rows, 32 * kB2Waves), kBwdGridCap);
+        b.p1 = m->workspace + chain_floats(L, out);
 #define MAPPO_BWD_SIX(AA, HH)                                                                                          \
     if (six && m->act == AA && hr == HH) {                                                                            \
-        MAPPO_LAUNCH((mlp_bwd_kernel<2, AA, HH, true>), (unsigned)grid, 64 * kB2Waves, (size_t)o.total * 4, stream, b); \
+        if (fused1) {                                                                                                 \
+            MAPPO_LAUNCH((mlp_bwd_kernel<2, AA, HH, true, true>), (unsigned)grid, 64 * kB2Waves, (size_t)o.total * 4, stream, b); \
+        } else {                                                                                                      \
+            MAPPO_LAUNCH((mlp_bwd_kernel<2, AA, HH, true>), (unsigned)grid, 64 * kB2Waves, (size_t)o.total * 4, stream, b); \
+        }                                                                                                             \
     }
         MAPPO_BWD_SIX(0, 0) MAPPO_BWD_SIX(0, 1) MAPPO_BWD_SIX(1, 0) MAPPO_BWD_SIX(1, 1) MAPPO_BWD_SIX(2, 0) MAPPO_BWD_SIX(2, 1)
 #undef MAPPO_BWD_SIX
@@ -3106,7 +3259,9 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
     const int maxnt = d2_maxnt(din);
     const int gy = (int)ceil_div(din, direct ? 128 * maxnt : kDw1Slab);
     long long gx;
-    if (din % 4 == 0 && din <= kD2RowsMaxWidth) {
+    if (fused1) {
+        gx = grid;          // the chain's workgroups wrote the first-layer partial rows
+    } else if (din % 4 == 0 && din <= kD2RowsMaxWidth) {
         gx = capped(ceil_div(m->rows, 4 * kD2Rows), kD2GridCap);
 #define MAPPO_DW1_ROWS(NT, SLOTS)                                                                                       \
     {                                                                                                                   \
@@ -3123,14 +3278,25 @@ inline int backward(const mappo_mlp_t* m, hipStream_t stream) {
 #undef MAPPO_DW1_ROWS
     } else if (direct) {
         if (six_term) {
-            // the tile products as six bf16 x bf16 terms per float32 product on the bf16 matrix pipe
-            gx = capped(ceil_div(m->rows, kD2Rows), kD2GridCap / gy > 0 ? kD2GridCap / gy : 1);
-            if (maxnt == 4) {
+            // the tile products as six bf16 x bf16 terms per float32 product on the bf16 matrix pipe.  Two slots per wave and
+            // TWO workgroups per CU (61 / 77 KB of LDS each): a tile's operand reads and splits are a serial prefix of its
+            // MFMA stream, and the second wave of the SIMD runs its MFMAs under it (round 5, alternating on one box: north
+            // star 215.4 -> 210.4 ms per step).  Option bit 32 keeps the four-slot form, one workgroup per CU.
+            const bool one_wg = (tuning_flags() & 32) != 0;
+            const int cap = (one_wg ? 1 : 2) * kD2GridCap;
+            gx = capped(ceil_div(m->rows, kD2Rows), cap / gy > 0 ? cap / gy : 1);
+            if (maxnt == 4 && one_wg) {
                 MAPPO_LAUNCH((mlp_dw1_direct_kernel<4, 4, true>), dim3((unsigned)gx, (unsigned)gy), kThreads,
                              (size_t)(d2_lds(4) + 4 * kD2TabRing * 64) * 4, stream, d);
-            } else {
+            } else if (maxnt == 4) {
+                MAPPO_LAUNCH((mlp_dw1_direct_kernel<4, 2, true>), dim3((unsigned)gx, (unsigned)gy), kThreads,
+                             (size_t)(d2_lds_slots(4, 2) + 4 * 4 * 64) * 4, stream, d);
+            } else if (one_wg) {
                 MAPPO_LAUNCH((mlp_dw1_direct_kernel<3, 4, true>), dim3((unsigned)gx, (unsigned)gy), kThreads,
                              (size_t)(d2_lds(3) + 4 * kD2TabRing * 64) * 4, stream, d);
+            } else {
+                MAPPO_LAUNCH((mlp_dw1_direct_kernel<3, 2, true>), dim3((unsigned)gx, (unsigned)gy), kThreads,
+                             (size_t)(d2_lds_slots(3, 2) + 4 * 4 * 64) * 4, stream, d);
             }
         } else if (maxnt == 4) {
             gx = capped(ceil_div(m->rows, kD2Rows), kD2GridCap / gy > 0 ? kD2GridCap / gy : 1);

@@ -68,16 +68,17 @@ class _Timed(object):
             _PROFILE.setdefault(self.rec[0], []).append(self.rec[1:])
 
 
-def _work(rows, din, n_layers, out, backward):
+def _work(rows, din, n_layers, out, backward, fused_dw1=False):
     """Algorithmic FLOPs and HBM bytes of one launch: forward = every Linear once; backward = first-layer weight
     gradient, weight + input gradient of the hidden layers and of the head.  Bytes: the observation row (once forward,
     once more for the weight gradient), the saved activations / statistics, the head's output / its gradient, the
-    first-layer gradient round trip through HBM."""
+    first-layer gradient round trip through HBM (not with ``fused_dw1``: six-term two-layer trunks with aligned inputs of at
+    most 64 columns accumulate that weight gradient inside the chain's launch)."""
     lin = din * 64 + (n_layers - 1) * 64 * 64 + 64 * out
     if not backward:
         return 2.0 * rows * lin, rows * (4 * din + 4 + n_layers * (256 + 8) + 4 * max(out, 64 if out == 0 else out))
     flops = 2.0 * rows * (din * 64 + 2 * (n_layers - 1) * 64 * 64 + 2 * 64 * out)
-    return flops, rows * (4 * din + 4 + n_layers * (256 + 8) + 4 * max(out, 64 if out == 0 else out) + 2 * 256)
+    return flops, rows * (4 * din + 4 + n_layers * (256 + 8) + 4 * max(out, 64 if out == 0 else out) + (0 if fused_dw1 else 2 * 256))
 
 
 class RowSource(object):
@@ -299,7 +300,8 @@ class _FusedTrunkFn(torch.autograd.Function):
         ws = torch.empty(lib.mappo_mlp_workspace_floats(din, n_layers, out), dtype=torch.float32, device=dev)
         dz1 = torch.empty((lib.mappo_mlp_row_table_ints(rs.rows), HIDDEN), dtype=torch.float32, device=dev)   # padded to the tile
         m.dy, m.dz1, m.workspace, m.grads = dy.data_ptr(), dz1.data_ptr(), ws.data_ptr(), grads.data_ptr()
-        with _Timed("mappo_mlp_backward", *_work(rs.rows, din, n_layers, out, True)):
+        fused_dw1 = arith == _native.ARITH_SIX_TERM and n_layers == 2 and din % 4 == 0 and din <= 64   # (mappo_mlp_impl.h: DW1)
+        with _Timed("mappo_mlp_backward", *_work(rs.rows, din, n_layers, out, True, fused_dw1)):
             _native.check(lib.mappo_mlp_backward(m, _native.stream_of(dev)), "mappo_mlp_backward")
         return (None, None, None, None, None, None, None) + tuple(_split_grads(grads, din, n_layers, out))
 

@@ -15,6 +15,7 @@ inline long long clock() { return 0; }
 inline void wait_loads_14() {}
 inline void wave_sync() { simt::wait(my_wave().bar); }
 inline void pin(float&) {}
+inline void pin(int&) {}
 inline void fence() {}
 inline unsigned ticket(unsigned* counter) { return (*counter)++; }       // (blocks run one after the other)
 inline int f2i(float v) { int i; memcpy(&i, &v, 4); return i; }

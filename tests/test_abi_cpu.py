@@ -214,10 +214,10 @@ def test_header_is_plain_c():
         assert out.returncode == 0, out.stderr
 
 
-def test_default_arithmetic_is_the_float32_mfma():
-    """Out of the box no option bit of the K9 / K12 launchers is set: the opt-in six-term bf16 kernels (bits 64 / 256 / 512 /
-    1024 / 2048 / 4096 of mappo_mlp_set_flags) run only when a caller or MAPPO_MLP_FLAGS asks for them -- the default, and
-    bench.py's `value`, is the float32 MFMA.  (A fresh interpreter: the flags of this process may have been set by a test.)"""
+def test_no_tuning_bit_is_set_out_of_the_box():
+    """Out of the box no option bit of the K9 launchers is set (they are tuning / A-B hooks; arithmetic is the per-call `arith`
+    field, see test_default_arithmetic_is_the_six_term_form_and_a_per_call_field).  (A fresh interpreter: the flags of this process may have been set by a
+    test.)"""
     import subprocess
     import sys
     env = {k: v for k, v in os.environ.items() if k != "MAPPO_MLP_FLAGS"}

@@ -64,13 +64,14 @@ def _compare(din, layer_N, relu, out, rows, src_rows, chunk=None, feature_norm=T
                                    atol=10 * rtol * float(q.grad.abs().max()) + 1e-6, msg=lambda m: name + ": " + m)
 
 
-@pytest.fixture(autouse=True, params=[("six_term", 0), ("six_term", 128), ("f32_mfma", 0)],
-                ids=["six_term", "six_term_fwd4_every_width", "f32_mfma"])
+@pytest.fixture(autouse=True, params=[("six_term", 0), ("six_term", 128), ("six_term", 256), ("f32_mfma", 0)],
+                ids=["six_term", "six_term_fwd4_every_width", "six_term_separate_dw1", "f32_mfma"])
 def _arithmetic(request, monkeypatch):
     """Every test of this file under both arithmetic forms of the matrix products (include/mappo_hip.h MAPPO_ARITH_*; the
     modules built here carry no choice of their own, so the process default MAPPO_MATRIX_ARITHMETIC decides): the six-term
     bf16 form as shipped (the default), the same with tuning bit 128 (version 4 of the forward -- first layer in six-term
-    form, one wave per SIMD -- also for inputs narrower than 128 floats), and the float32 MFMA.  Shapes without a six-term
+    form, one wave per SIMD -- also for inputs narrower than 128 floats), the same with tuning bit 256 (aligned inputs of at most
+    64 columns keep the separate first-layer weight-gradient kernel instead of the chain's fused form), and the float32 MFMA.  Shapes without a six-term
     kernel run the float32 kernels under every parameter."""
     from onpolicy import _native
     name, flags = request.param

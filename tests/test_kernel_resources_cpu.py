@@ -53,9 +53,10 @@ def test_snapshot_has_no_spills_and_expected_occupancy():
     assert all(v["occupancy"] == 4 and v["vgprs"] <= 128 for v in pick("mlp_fwd_kernel"))
     assert all(v["agprs"] >= 32 for v in pick("mlp_dw1_direct_kernel") + pick("mlp_dw1_rows_kernel"))
     # round 3: the backward chain -- one wave per SIMD by design (measured: a second wave only stretches every phase),
-    # no scratch in any of its 15 instances (+ 6 opt-in six-term bf16 instances of the two-layer chain, round 4); the GRU
-    # chunk kernels likewise one workgroup per CU (104 KB of weights in LDS)
-    assert len(pick("mlp_bwd_kernel")) == 21 and all(v["occupancy"] == 1 and v["scratch_bytes"] == 0 for v in pick("mlp_bwd_kernel"))
+    # no scratch in any of its 15 instances (+ 6 six-term bf16 instances of the two-layer chain, round 4, + 6 that also
+    # accumulate the first-layer weight gradient of narrow inputs, round 5: 256 + 241 registers at most); the GRU chunk kernels
+    # likewise one workgroup per CU (104 KB of weights in LDS)
+    assert len(pick("mlp_bwd_kernel")) == 27 and all(v["occupancy"] == 1 and v["scratch_bytes"] == 0 for v in pick("mlp_bwd_kernel"))
     assert all(v["occupancy"] == 1 for v in pick("gru_seq_fwd_kernel") + pick("gru_seq_bwd_kernel"))
     # ... its nine backward instances: no head / head of <= 2, 6, 18 outputs x the head's gradient sums on or off, x 2: float32
     # MFMA, and the six-term form with all six blocks of the transposed weights as bf16 planes (8 instances; the ninth -- the

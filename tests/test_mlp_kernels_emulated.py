@@ -26,7 +26,7 @@ def emu_lib():
     return R.bind(ctypes.CDLL(build.build()))
 
 
-# Every test runs under five (tuning flags, arithmetic) settings (``arith`` = the per-call field of mappo_mlp_t):
+# Every test runs under seven (tuning flags, arithmetic) settings (``arith`` = the per-call field of mappo_mlp_t):
 #   fwd3 / fwd_loaders / dw1_two_per_cu -- float32 MFMA: version 3 of the forward (operands straight from global memory,
 #     resident first-layer weights; every aligned width up to 448 with two or three layers; a row's last chunk runs only the
 #     groups of 8 columns that hold data), tuning bit 4 = the loader / compute kernel that serves every other shape, tuning bit
@@ -34,10 +34,15 @@ def emu_lib():
 #   six_term -- the shipped default: version 4 of the forward (both layers as six bf16 x bf16 terms per float32 product on
 #     the bf16 matrix pipe) for two-layer trunks with aligned inputs 128 .. 384 floats wide, version 3 with its hidden layer
 #     in six-term form for the other two-layer shapes, the backward chain of two-layer trunks and the direct first-layer
-#     weight-gradient kernel in the same form; every other shape falls through to the float32 kernels;
-#   six_term_fwd4_every_width -- the same with tuning bit 128: version 4 also for inputs narrower than 128 floats.
-@pytest.fixture(params=[(0, 1), (4, 1), (32, 1), (0, 0), (128, 0)],
-                ids=["fwd3", "fwd_loaders", "dw1_two_per_cu", "six_term", "six_term_fwd4_every_width"])
+#     weight-gradient kernel in the same form -- for aligned inputs of at most 64 columns that gradient is accumulated inside
+#     the chain's launch (DW1); every other shape falls through to the float32 kernels;
+#   six_term_fwd4_every_width -- the same with tuning bit 128: version 4 also for inputs narrower than 128 floats;
+#   six_term_separate_dw1 -- the same with tuning bit 256: narrow inputs keep the separate first-layer weight-gradient kernel;
+#   six_term_dw1_one_per_cu -- the same with tuning bit 32: the six-term direct first-layer weight-gradient kernel in its
+#     four-slot form, one workgroup per CU (the default is two slots per wave, two workgroups per CU).
+@pytest.fixture(params=[(0, 1), (4, 1), (32, 1), (0, 0), (128, 0), (256, 0), (32, 0)],
+                ids=["fwd3", "fwd_loaders", "dw1_two_per_cu", "six_term", "six_term_fwd4_every_width", "six_term_separate_dw1",
+                     "six_term_dw1_one_per_cu"])
 def emu(emu_lib, request):
     flags, arith = request.param
     old = emu_lib.mappo_mlp_set_flags(flags)
@@ -225,12 +230,30 @@ def test_version3_hidden_layer_in_six_term_form(emu_lib, din, act, out):
         emu_lib.mappo_mlp_set_grid_cap(0)
 
 
+@pytest.mark.parametrize("flags", [0, 256], ids=["fused", "separate_kernel"])
+@pytest.mark.parametrize("din,act,out", [(20, 1, 1), (32, 2, 0), (64, 1, 5), (4, 1, 2), (36, 2, 1), (48, 1, 12), (60, 0, 0)])
+def test_first_layer_weight_gradient_inside_the_chain(emu_lib, flags, din, act, out):
+    """Round 5 (the bytes diet that fits): six-term two-layer trunks with aligned inputs of at most 64 columns
+    accumulate dW1 inside the chain's launch (xhat tiles through the row table by direct-to-LDS loads, dz1 never written);
+    tuning bit 256 keeps the separate kernel.  One and two k tiles, every head form (value head in registers, narrow heads in
+    registers, wide heads through LDS, no head), gathered rows, several tiles per wave and two workgroups with a ragged end."""
+    old = emu_lib.mappo_mlp_set_flags(flags)
+    emu_lib._arith = 0
+    try:
+        for cap, rows in ((1, 32 * 9 + 5), (2, 128 * 3 + 33)):
+            emu_lib.mappo_mlp_set_grid_cap(cap)
+            _run(emu_lib, np.random.default_rng(din * 3 + out + rows), din, 2, act, out, rows, rows + 77)
+    finally:
+        emu_lib.mappo_mlp_set_grid_cap(0)
+        emu_lib.mappo_mlp_set_flags(old)
+
+
 def test_tuning_flags_reject_unknown_bits(emu_lib):
-    """mappo_mlp_set_flags knows bits 1, 4, 32, 128; anything else (e.g. the arithmetic bits of ABI version 1) is refused and
+    """mappo_mlp_set_flags knows bits 1, 4, 32, 128, 256; anything else (e.g. the arithmetic bits of ABI version 1) is refused and
     changes nothing.  An unknown ``arith`` value is an argument error."""
     old = emu_lib.mappo_mlp_set_flags(4)
     try:
-        for bad in (8, 16, 64, 256, 512, 1024, 2048, 4096, 8192, 4 | 64):
+        for bad in (8, 16, 64, 512, 1024, 2048, 4096, 8192, 4 | 64):
             assert emu_lib.mappo_mlp_set_flags(bad) == -1
             assert emu_lib.mappo_mlp_set_flags(4) == 4
     finally:

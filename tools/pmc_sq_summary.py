@@ -18,9 +18,14 @@ if W == "ns" and not os.path.isdir(SRC):
     SRC = os.path.join(ROOT, "gpurun_out", TAG, "pmc_sq")
 KERNELS = {"mlp_fwd4_kernel": "K9 forward, version 4 (six-term, round 5 default): the critic's 384 wide input, both layers on the bf16 pipe",
            "mlp_fwd3_kernel<2, 1, 2, true>": "K9 forward, version 3 with the hidden layer in six-term form (round 5 default): the actor's 48 wide input",
-           "mlp_dw1_direct_kernel<3, 4, true>": "K9 first-layer weight gradient, critic, six-term (round 5 default)",
-           "mlp_bwd_kernel<2, 1, 0, true>": "K9 backward chain, action head, six-term (round 5 default)",
-           "mlp_bwd_kernel<2, 1, 1, true>": "K9 backward chain, value head, six-term (round 5 default)",
+           "mlp_dw1_direct_kernel<3, 4, true>": "K9 first-layer weight gradient, critic, six-term, one workgroup per CU (tuning bit 32)",
+           "mlp_dw1_direct_kernel<3, 2, true>": "K9 first-layer weight gradient, critic, six-term, two workgroups per CU (round 5 default)",
+           "mlp_dw1_direct_kernel<3, 4>": "K9 first-layer weight gradient, critic, float32 MFMA",
+           "mlp_bwd_kernel<2, 1, 0, true, true>": "K9 backward chain + first-layer weight gradient in one launch, action head, six-term (round 5 default)",
+           "mlp_bwd_kernel<2, 1, 0, true, false>": "K9 backward chain, action head, six-term, separate first-layer kernel (tuning bit 256)",
+           "mlp_bwd_kernel<2, 1, 1, true": "K9 backward chain, value head, six-term (round 5 default)",
+           "mlp_bwd_kernel<2, 1, 0, false": "K9 backward chain, action head, float32 MFMA",
+           "mlp_bwd_kernel<2, 1, 1, false": "K9 backward chain, value head, float32 MFMA",
            "gru_seq_fwd_kernel<true>": "K12 forward, six-term (round 5 default)",
            "gru_seq_bwd_kernel<3, 5, true, true>": "K12 backward, actor, all six blocks as planes (round 5 default)",
            "gru_seq_bwd_kernel<1, 1, true, true>": "K12 backward, critic, all six blocks as planes (round 5 default)",

@@ -31,11 +31,11 @@ fi
 
 if [[ $STAGE == all || $STAGE == prof ]]; then
   cd /tmp
-  for w in ns cfg3 ns_rnn smac hanabi; do
-    timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_$w -o $w -- python $REPO/bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline > $OUT/prof_$w.log 2>&1
+  for w in ns cfg2 cfg3 ns_rnn smac hanabi; do
+    timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_$w -o $w -- python $REPO/bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline --no-f32-mfma > $OUT/prof_$w.log 2>&1
   done
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --kernel-trace --pmc $C -f csv -d $OUT/pmc_$C -o ns -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc $C -f csv -d $OUT/pmc_$C -o ns -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-f32-mfma > $OUT/pmc_$C.log 2>&1
   done
   cd $REPO
   MAPPO_ROUND=r05 bash tools/pmc_sq_pass.sh ns > $OUT/pmc_sq_ns.txt 2>&1

@@ -53,12 +53,23 @@ def main():
     # the small kernels of a backward call: two reductions (round 2), + the finish kernel (early round 3), one tail kernel now
     small = ("mlp_tail_kernel",) if any("mlp_tail" in k for k in fetch) else \
         ("mlp_reduce_kernel", "mlp_reduce_kernel") + (("mlp_finish_kernel",) if any("mlp_finish" in k for k in fetch) else ())
-    fb = sum(mean_of(fetch, k)[0] for k in ("mlp_bwd_kernel", "mlp_dw1_") + small)
-    wb = sum(mean_of(write, k)[0] for k in ("mlp_bwd_kernel", "mlp_dw1_") + small)
+    # per mappo_mlp_backward call (= per tail launch): every launch of the call's kernels summed, divided by the number of
+    # calls -- from round 5 the actor's call has no separate first-layer kernel (its dW1 is accumulated in the chain's launch),
+    # so a sum of per-kernel means would no longer be a call
+    def per_call(acc):
+        keys = ("mlp_bwd_kernel", "mlp_dw1_") + tuple(set(small))
+        total = sum(v for k, vs in acc.items() if any(q in k for q in keys) for v in vs)
+        calls = sum(len(vs) for k, vs in acc.items() if small[0] in k) / (2 if small[0] == "mlp_reduce_kernel" else 1)
+        return total / max(1, calls), int(calls)
+    fb, n_calls = per_call(fetch)
+    wb, _ = per_call(write)
     out["mappo_mlp_backward"] = {
         "algorithmic_bytes": alg_b, "fetch_size_bytes_raw": fb, "write_size_bytes": wb, "hbm_bytes": 2 * fb + wb,
-        "kernel": "mlp::mlp_bwd_kernel + mlp::mlp_dw1_direct_kernel (critic) / mlp::mlp_dw1_rows_kernel<2, 4> (actor) + mlp::mlp_tail_kernel (round 2: two mlp::mlp_reduce_kernel)",
-        "note": "one mappo_mlp_backward call = chain kernel + first-layer weight-gradient kernel + the small reductions"}
+        "calls_averaged": n_calls,
+        "kernel": "mlp::mlp_bwd_kernel<2, 1, 0, true, true> (actor: chain + first-layer weight gradient in one launch) / "
+                  "mlp::mlp_bwd_kernel<2, 1, 1, true> + mlp::mlp_dw1_direct_kernel<3, 2, true> (critic) + mlp::mlp_tail_kernel",
+        "note": "one mappo_mlp_backward call = chain kernel (+ first-layer weight-gradient kernel for inputs wider than 64) + "
+                "the tail kernel; actor and critic calls averaged, six-term arithmetic only (--no-f32-mfma)"}
     f, n = mean_of(fetch, "gae_")
     w, _ = mean_of(write, "gae_")
     out["mappo_gae_f32"] = {"algorithmic_bytes": 24 * rows, "fetch_size_bytes_raw": f, "write_size_bytes": w,

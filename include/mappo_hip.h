@@ -456,6 +456,15 @@ int64_t mappo_gru_seq_stats_floats(int L, int64_t mb);
 int64_t mappo_gru_seq_workspace_floats(void);
 int     mappo_gru_seq_forward(const mappo_gru_seq_t* seq, mappo_stream_t stream);
 int     mappo_gru_seq_backward(const mappo_gru_seq_t* seq, mappo_stream_t stream);
+/* The weight gradients of that GRU from what mappo_gru_seq_backward left (reference: autograd through nn.GRU,
+ * onpolicy/algorithms/utils/rnn.py:24-80), ONE launch + a reduction, float32 products from six bf16 x bf16 terms
+ * (MAPPO_ARITH_SIX_TERM; the float32-MFMA route forms them with library GEMMs on the host side):
+ *   dw[0 .. 192 * 64)          = dW_ih = dgi^T x                      dgi [rows, 192], x [rows, 64] (the GRU's inputs)
+ *   dw[192 * 64 .. 2 * 192 * 64) = dW_hh = [dgi_r | dgi_z | dq]^T hm    dq [rows, 64], hm [rows, 64] (mask * h_{t-1})
+ * rows = L * mb; all pointers 16-byte aligned; workspace [mappo_gru_weight_grads_workspace_floats()] scratch.  Deterministic. */
+int64_t mappo_gru_weight_grads_workspace_floats(void);
+int     mappo_gru_weight_grads(const float* dgi, const float* dq, const float* x, const float* hm, int64_t rows, float* dw,
+                               float* workspace, mappo_stream_t stream);
 
 /* --------------------------------------------------------------- K13: gradient clipping + Adam of one network ----
  * What the reference does between backward() and the next minibatch for each network (r_mappo.py:146-167:

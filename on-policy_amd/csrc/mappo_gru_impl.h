@@ -785,5 +785,165 @@ inline int backward(const mappo_gru_seq_t* m, hipStream_t stream) {
     return MAPPO_LAUNCH_ERROR();
 }
 
+// ================================================================== K12's weight gradients in six-term arithmetic (round 5) ====
+//   dW_ih = dgi^T x            [192, 64]      (dgi [rows, 192]: gate gradients of the input side, x [rows, 64])
+//   dW_hh = [dgi_r | dgi_z | dq]^T hm          (the hidden side's n gradient is dq [rows, 64]; hm = mask * h_{t-1} [rows, 64])
+// Until round 5 three split-K library GEMMs + their slab sums (5.75 ms per call at the recurrent north star, 111 TFLOP/s).  Here
+// ONE launch reads each of the four matrices once (1.5 KB per row): a workgroup walks 16-row tiles -- 24 KB of LDS per tile,
+// contiguous in every matrix, so the direct-to-LDS loads need no address arithmetic beyond the tile's first row -- and keeps
+// all 24 output tiles of 32 x 32 in accumulators: waves 0 / 1 own dW_ih (gate rows 0 .. 95 / 96 .. 191), waves 2 / 3 dW_hh;
+// a wave reads and splits its 3 gate tiles and its 2 feature tiles (5 three-way splits) for 6 output tiles x 6 terms = 36
+// MFMAs per tile: the shape and the structure of mlp_dw1_direct_kernel<3, 2, true> -- three slots, two workgroups per CU, the
+// partner's MFMAs running under a tile's operand reads and splits.  Per-workgroup sums -> mlp_reduce_kernel.
+struct WgradArgs {
+    const float *dgi, *dq, *x, *hm;
+    long long rows;
+    float* partials;        // [gridDim.x][2][192][64]
+};
+constexpr int kWgRows = 16;
+constexpr int kWgSlot = kWgRows * 384;      // floats: dgi [16][192] | dq [16][64] | x [16][64] | hm [16][64]
+constexpr int kWgSlots = 3;
+constexpr int kWgGridCap = 512;
+constexpr int kWgOut = 2 * 192 * 64;
+constexpr int kWgLoads = 6;                 // direct-to-LDS loads per wave and tile (24 KB / 4 waves / 1 KB)
+
+__global__ void __launch_bounds__(kThreads, 2) gru_wgrad_kernel(WgradArgs a) {
+    float* lds = prim::lds();
+    const int tid = threadIdx.x, lane = tid & 63, wave = prim::uniform(tid >> 6), c = lane & 31, h = lane >> 5;
+    const long long rows = a.rows;
+    const long long ntiles = (rows + kWgRows - 1) / kWgRows;
+    const long long n_it = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    // loads of this workgroup's tile mi into slot mi % kWgSlots (past the end: the last tile again, into a slot nobody reads, so
+    // that every group has the same size); instruction j = wave + 4 u moves floats [256 j, 256 j + 256) of the slot
+    auto issue = [&](long long mi) {
+        float* slot = lds + (int)(mi % kWgSlots) * kWgSlot;
+        const long long m = mi < n_it ? mi : n_it - 1;
+        const long long row0 = (blockIdx.x + m * gridDim.x) * kWgRows;
+#pragma unroll
+        for (int u = 0; u < kWgLoads; ++u) {
+            const int j = wave + 4 * u;
+            const float* src;
+            int W, e;
+            if (u < 3) {                            // j < 12: dgi
+                src = a.dgi;
+                W = 192;
+                e = 256 * j + 4 * lane;
+            } else {
+                src = u == 3 ? a.dq : u == 4 ? a.x : a.hm;      // j = 12 + w, 16 + w, 20 + w
+                W = 64;
+                e = 256 * wave + 4 * lane;
+            }
+            const int r = e / W, col = e - r * W;
+            long long gr = row0 + r;
+            if (gr >= rows) gr = rows - 1;          // past the last row: that row again (its x / hm entries are zeroed in LDS)
+            prim::load_lds16(src + gr * W + col, slot + 256 * j);
+        }
+    };
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][t][v] = 0.f;
+    if (n_it == 0) return;
+    // this wave's operands inside a slot: three 32-column gate tiles (A) and the two feature tiles of x or hm (B)
+    const int side = wave >> 1;                     // 0: dW_ih, 1: dW_hh
+    int aoff[3], ald[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int mt = 3 * (wave & 1) + i;          // gate tile 0 .. 5
+        const bool from_dq = side == 1 && mt >= 4;  // the hidden side's n block
+        aoff[i] = from_dq ? 3072 + 32 * (mt - 4) : 32 * mt;
+        ald[i] = from_dq ? 64 : 192;
+    }
+    const int boff = 3072 + 1024 + 1024 * side;
+    for (int t = 0; t < kWgSlots - 1; ++t) issue(t);
+    for (long long m = 0; m < n_it; ++m) {
+        prim::wait_lds_loads<(kWgSlots - 2) * kWgLoads>();      // this wave's loads of tile m: all but the youngest group
+        float* slot = lds + (int)(m % kWgSlots) * kWgSlot;
+        const long long live = rows - (blockIdx.x + m * gridDim.x) * kWgRows;
+        if (live < kWgRows && 4 * wave + (lane >> 4) >= live) {  // last tile: rows past the end count as zero (this wave's own loads)
+            *reinterpret_cast<v4*>(slot + 4096 + 256 * wave + 4 * lane) = v4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<v4*>(slot + 5120 + 256 * wave + 4 * lane) = v4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();            // ... and everybody else's; all waves are done with tile m - 1's slot
+        issue(m + kWgSlots - 1);
+        float av[3][8], bv[2][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) av[i][e] = slot[aoff[i] + (8 * h + e) * ald[i] + c];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) bv[t][e] = slot[boff + (8 * h + e) * 64 + 32 * t + c];
+        }
+        bf8 B[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) mlp::split3(bv[t], B[t][0], B[t][1], B[t][2]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            bf8 A[3];
+            mlp::split3(av[i], A[0], A[1], A[2]);
+            acc[i][0] = prim::mfma_bf16(A[0], B[0][2], acc[i][0]);
+            acc[i][1] = prim::mfma_bf16(A[0], B[1][2], acc[i][1]);
+            acc[i][0] = prim::mfma_bf16(A[2], B[0][0], acc[i][0]);
+            acc[i][1] = prim::mfma_bf16(A[2], B[1][0], acc[i][1]);
+            acc[i][0] = prim::mfma_bf16(A[1], B[0][1], acc[i][0]);
+            acc[i][1] = prim::mfma_bf16(A[1], B[1][1], acc[i][1]);
+            acc[i][0] = prim::mfma_bf16(A[0], B[0][1], acc[i][0]);
+            acc[i][1] = prim::mfma_bf16(A[0], B[1][1], acc[i][1]);
+            acc[i][0] = prim::mfma_bf16(A[1], B[0][0], acc[i][0]);
+            acc[i][1] = prim::mfma_bf16(A[1], B[1][0], acc[i][1]);
+            acc[i][0] = prim::mfma_bf16(A[0], B[0][0], acc[i][0]);
+            acc[i][1] = prim::mfma_bf16(A[0], B[1][0], acc[i][1]);
+        }
+    }
+    prim::wait_lds_loads<0>();      // (the groups issued past the end)
+    float* prow = a.partials + (long long)blockIdx.x * kWgOut + side * (192 * 64);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int mt = 3 * (wave & 1) + i;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int g = 32 * mt + (v & 3) + 8 * (v >> 2) + 4 * h;
+                prow[g * 64 + 32 * t + c] = acc[i][t][v];
+            }
+    }
+}
+
+inline long long wgrad_grid(long long rows) {
+    // (at least four tiles per workgroup: its 96 KB row of partial sums has to be worth writing)
+    long long g = ((rows + kWgRows - 1) / kWgRows + 3) / 4;
+    const int cap = mlp::grid_cap_override() > 0 && mlp::grid_cap_override() < kWgGridCap ? mlp::grid_cap_override() : kWgGridCap;
+    return g > cap ? cap : (g < 1 ? 1 : g);
+}
+inline long long wgrad_workspace_floats() { return (long long)kWgGridCap * kWgOut; }
+
+// dw = [dW_ih [192, 64] | dW_hh [192, 64]] (the layout of nn.GRU's weight_ih_l0 / weight_hh_l0 gradients)
+inline int weight_grads(const float* dgi, const float* dq, const float* x, const float* hm, long long rows, float* dw,
+                        float* workspace, hipStream_t stream) {
+    if (!dgi || !dq || !x || !hm || !dw || !workspace) return MAPPO_E_NULL;
+    if (rows <= 0) return MAPPO_E_SHAPE;
+    const void* al[] = {dgi, dq, x, hm, dw, workspace};
+    for (const void* p : al)
+        if ((reinterpret_cast<uintptr_t>(p) & 15) != 0) return MAPPO_E_ALIGN;
+    WgradArgs a;
+    a.dgi = dgi;
+    a.dq = dq;
+    a.x = x;
+    a.hm = hm;
+    a.rows = rows;
+    a.partials = workspace;
+    const long long grid = wgrad_grid(rows);
+    MAPPO_LAUNCH(gru_wgrad_kernel, (unsigned)grid, kThreads, (size_t)kWgSlots * kWgSlot * 4, stream, a);
+    int code = MAPPO_LAUNCH_ERROR();
+    if (code) return code;
+    MAPPO_LAUNCH(mlp::mlp_reduce_kernel, (unsigned)(kWgOut / 32), mlp::kThreads, 1024, stream, (const float*)workspace, grid,
+                 (long long)kWgOut, (long long)kWgOut, dw);
+    return MAPPO_LAUNCH_ERROR();
+}
+
 }  // namespace gru
 #endif

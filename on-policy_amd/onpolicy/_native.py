@@ -135,6 +135,8 @@ SIGNATURES = {
     "mappo_gru_seq_workspace_floats": (_i64, []),
     "mappo_gru_seq_forward": (_int, [ctypes.POINTER(GRUSeq), _vp]),
     "mappo_gru_seq_backward": (_int, [ctypes.POINTER(GRUSeq), _vp]),
+    "mappo_gru_weight_grads_workspace_floats": (_i64, []),
+    "mappo_gru_weight_grads": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "mappo_fold_input_norm_forward": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp]),
     "mappo_fold_input_norm_backward": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "mappo_minibatch_sums_workspace_doubles": (_i64, []),

@@ -168,8 +168,16 @@ class _GRUChunkFn(torch.autograd.Function):
                            head_sums=int(0 < out <= CHUNK_HEAD_SUMS))
         _native.check(lib.mappo_gru_seq_backward(m, _native.stream_of(dev)), "mappo_gru_seq_backward")
         # dW_ih = dgi^T x; the hidden side's gate gradient is [dgi_r | dgi_z | dq]
-        dw_ih = splitk_weight_grad(dgi, x)
-        dw_hh = torch.cat([splitk_weight_grad(dgi[:, :128], hm), splitk_weight_grad(dq, hm)], 0)
+        if arith == _native.ARITH_SIX_TERM and _WEIGHT_GRAD_KERNEL:
+            # one launch that reads the four matrices once, in the arithmetic of the rest of the call (mappo_gru_impl.h)
+            dw = torch.empty(2, 192, 64, **f32)
+            ws2 = torch.empty(lib.mappo_gru_weight_grads_workspace_floats(), **f32)
+            _native.check(lib.mappo_gru_weight_grads(p(dgi), p(dq), p(x), p(hm), L * B, p(dw), p(ws2), _native.stream_of(dev)),
+                          "mappo_gru_weight_grads")
+            dw_ih, dw_hh = dw[0], dw[1]
+        else:       # float32 route: three split-K library GEMMs
+            dw_ih = splitk_weight_grad(dgi, x)
+            dw_hh = torch.cat([splitk_weight_grad(dgi[:, :128], hm), splitk_weight_grad(dq, hm)], 0)
         db_ih = ln_grads[128:320]
         db_hh = torch.cat([ln_grads[128:256], ln_grads[320:384]])
         if not out:
@@ -189,6 +197,8 @@ CHUNK_HEAD_SUMS = 6 if __import__("os").environ.get("MAPPO_GRU_HEAD_SUMS", "1") 
 
 # MAPPO_GRU_CHUNK=0 keeps the step-by-step kernels below for the update (one launch per step and direction)
 _CHUNK_KERNEL = __import__("os").environ.get("MAPPO_GRU_CHUNK", "1") != "0"
+# the chunk kernels' weight gradients under the six-term arithmetic: mappo_gru_weight_grads (0: the library GEMMs of the float32 route)
+_WEIGHT_GRAD_KERNEL = __import__("os").environ.get("MAPPO_GRU_WEIGHT_GRAD_KERNEL", "1") != "0"
 # MAPPO_GRU_HEAD=0 keeps the output Linear behind the GRU (action head / v_out) a separate GEMM
 _CHUNK_HEAD = __import__("os").environ.get("MAPPO_GRU_HEAD", "1") != "0"
 # MAPPO_GRU_SEQUENCE=0 falls back to aten::_thnn_fused_gru_cell driven step by step through autograd

@@ -121,6 +121,11 @@ extern "C" int64_t mappo_gru_seq_stats_floats(int L, int64_t mb) { return (int64
 extern "C" int64_t mappo_gru_seq_workspace_floats(void) { return (int64_t)gru::kGridCap * gru::kSums; }
 extern "C" int mappo_gru_seq_forward(const mappo_gru_seq_t* seq, mappo_stream_t stream) { return gru::forward(seq, stream); }
 extern "C" int mappo_gru_seq_backward(const mappo_gru_seq_t* seq, mappo_stream_t stream) { return gru::backward(seq, stream); }
+extern "C" int64_t mappo_gru_weight_grads_workspace_floats(void) { return gru::wgrad_workspace_floats(); }
+extern "C" int mappo_gru_weight_grads(const float* dgi, const float* dq, const float* x, const float* hm, int64_t rows, float* dw,
+                                      float* workspace, mappo_stream_t stream) {
+    return gru::weight_grads(dgi, dq, x, hm, rows, dw, workspace, stream);
+}
 
 // ---- K15: tall Linear layers with 512 outputs in six-term bf16 arithmetic (mappo_lin_impl.h)
 extern "C" int64_t mappo_linear512_planes_floats(int K) { return lin::planes_floats(K); }

@@ -113,3 +113,44 @@ def test_output_linear_inside_the_chunk_kernels(out, L, B):
     assert not layer.head_ok(xd, wide)
     with pytest.raises(ValueError):
         layer(xd, hd, masks.to(dev), head=wide)
+
+
+@pytest.mark.parametrize("rows", [1, 16 * 5 + 3, 128000, 16 * 70000 + 9])
+def test_weight_gradient_kernel_vs_float64_and_the_library_route(rows, monkeypatch):
+    """mappo_gru_weight_grads (round 5: dW_ih and dW_hh of K12 in ONE six-term launch instead of three library GEMMs) against
+    float64 with the six-term bound, at sizes from one row to a million (every workgroup count, ragged last tile); and through
+    RNNLayer: the kernel's gradients agree with the library route's (MAPPO_GRU_WEIGHT_GRAD_KERNEL=0) to float32 noise."""
+    from onpolicy import _native
+    from test_gru_kernels_emulated import weight_grads_case
+    dev = torch.device("cuda", 0)
+    for scale in (None, 12.0):
+        dw, ref, mag = weight_grads_case(_native.lib(), rows, rows % 1000 + (0 if scale is None else 1), scale, device=dev)
+        bound = (16 + rows / 6) * 2.0 ** -24 * mag + 1e-30
+        worst = float(((dw - ref).abs() / bound).max())
+        assert torch.isfinite(dw).all() and worst <= 1.0, (rows, scale, worst)
+
+
+def test_weight_gradient_kernel_carries_the_six_term_backward(monkeypatch):
+    from onpolicy import _native
+    import onpolicy.algorithms.utils.rnn as rnn_mod
+    dev = torch.device("cuda", 0)
+    L, B = 10, 4000
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(L * B, 64, generator=g).to(dev)
+    h0 = torch.randn(B, 1, 64, generator=g).to(dev)
+    masks = (torch.rand(L * B, 1, generator=g) > 0.1).float().to(dev)
+    dy = torch.randn(L * B, 64, generator=g).to(dev)
+    grads = {}
+    for use in (True, False):
+        monkeypatch.setattr(rnn_mod, "_WEIGHT_GRAD_KERNEL", use)
+        layer = _layer(dev, 5)
+        _native.count_calls(True)
+        y, _ = layer(x.clone().requires_grad_(), h0.clone().requires_grad_(), masks)
+        (y * dy).sum().backward()
+        calls = _native.calls()
+        _native.count_calls(False)
+        six = _native.default_arith() == _native.ARITH_SIX_TERM
+        assert (calls.get("mappo_gru_weight_grads", 0) == 1) == (use and six), calls
+        grads[use] = [layer.rnn.weight_ih_l0.grad.clone(), layer.rnn.weight_hh_l0.grad.clone()]
+    for a, b in zip(grads[True], grads[False]):
+        torch.testing.assert_close(a, b, rtol=0, atol=2e-5 * float(b.abs().max()))

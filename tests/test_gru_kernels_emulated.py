@@ -23,7 +23,7 @@ def emu_lib():
     lib = ctypes.CDLL(build.build())
     for name in ("mappo_gru_seq_forward", "mappo_gru_seq_backward", "mappo_gru_seq_gates_floats",
                  "mappo_gru_seq_stats_floats", "mappo_gru_seq_workspace_floats", "mappo_mlp_set_grid_cap",
-                 "mappo_mlp_set_flags"):
+                 "mappo_mlp_set_flags", "mappo_gru_weight_grads", "mappo_gru_weight_grads_workspace_floats"):
         res, args = _native.SIGNATURES[name]
         getattr(lib, name).restype, getattr(lib, name).argtypes = res, args
     return lib
@@ -152,3 +152,50 @@ def test_waves_looping_over_several_tiles(emu):
     """Grid capped at one workgroup: every wave walks more than one 32-chunk tile (state, carry and the prefetched
     input are re-initialised per tile)."""
     run(emu, 4, 32 * 9 + 5, seed=7, grid_cap=1)
+
+
+def weight_grads_case(lib, rows, seed, scale=None, device=None):
+    """(dw from mappo_gru_weight_grads, float64 reference, sum of |terms|) for random gate gradients / inputs of `rows` rows; on
+    the emulator (host arrays) or, with ``device``, through the product library on the GPU."""
+    g = torch.Generator().manual_seed(seed)
+    dgi = torch.randn(rows, 192, generator=g)
+    dq = torch.randn(rows, 64, generator=g)
+    x = torch.randn(rows, 64, generator=g)
+    hm = torch.randn(rows, 64, generator=g) * (torch.rand(rows, 1, generator=g) > 0.1).float()
+    if scale is not None:       # every row at its own magnitude
+        s = 10.0 ** (scale * (torch.rand(rows, 1, generator=g) - 0.5))
+        dgi, dq = dgi * s, dq * s
+        x, hm = x / s.sqrt(), hm * s.sqrt()
+    hid = torch.cat([dgi[:, :128], dq], 1).double()
+    ref = torch.stack([dgi.double().t() @ x.double(), hid.t() @ hm.double()])
+    mag = torch.stack([dgi.double().abs().t() @ x.double().abs(), hid.abs().t() @ hm.double().abs()])
+    if device is None:
+        a = [np.ascontiguousarray(t.numpy()) for t in (dgi, dq, x, hm)]
+        dw = np.full((2, 192, 64), np.nan, np.float32)
+        ws = np.full(lib.mappo_gru_weight_grads_workspace_floats(), np.nan, np.float32)
+        rc = lib.mappo_gru_weight_grads(*[t.ctypes.data for t in a], rows, dw.ctypes.data, ws.ctypes.data, None)
+        assert rc == 0
+        return torch.from_numpy(dw).double(), ref, mag
+    from onpolicy import _native
+    a = [t.to(device).contiguous() for t in (dgi, dq, x, hm)]
+    dw = torch.full((2, 192, 64), float("nan"), device=device)
+    ws = torch.full((lib.mappo_gru_weight_grads_workspace_floats(),), float("nan"), device=device)
+    _native.check(lib.mappo_gru_weight_grads(*[t.data_ptr() for t in a], rows, dw.data_ptr(), ws.data_ptr(),
+                                             _native.stream_of(device)), "mappo_gru_weight_grads")
+    return dw.cpu().double(), ref, mag
+
+
+@pytest.mark.parametrize("rows,cap", [(1, 0), (16, 0), (16 * 7 + 5, 0), (16 * 40 + 3, 2), (16 * 9, 1), (16 * 64 + 15, 3)])
+def test_weight_gradient_kernel_vs_float64(emu_lib, rows, cap):
+    """mappo_gru_weight_grads: dW_ih = dgi^T x and dW_hh = [dgi_r | dgi_z | dq]^T hm in one launch, six-term arithmetic -- every
+    output tile's owner wave, the slot ring over several tiles per workgroup (1, 2, 3 workgroups), ragged last tiles, the
+    workgroups' partial sums; judged with the six-term bound against float64: |error| <= (16 + K / 6) 2^-24 sum |a||b|, K = rows."""
+    emu_lib.mappo_mlp_set_grid_cap(cap)
+    try:
+        for scale in (None, 12.0):
+            dw, ref, mag = weight_grads_case(emu_lib, rows, rows + (0 if scale is None else 1), scale)
+            bound = (16 + rows / 6) * 2.0 ** -24 * mag + 1e-30
+            worst = float(((dw - ref).abs() / bound).max())
+            assert torch.isfinite(dw).all() and worst <= 1.0, (rows, scale, worst)
+    finally:
+        emu_lib.mappo_mlp_set_grid_cap(0)

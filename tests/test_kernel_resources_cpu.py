@@ -63,6 +63,11 @@ def test_snapshot_has_no_spills_and_expected_occupancy():
     # widest head-sum instance -- would spill and keeps the four-block form of round 4)
     assert len(pick("gru_seq_bwd_kernel")) == 18 and all(v["scratch_bytes"] == 0 for v in pick("gru_seq_bwd_kernel"))
     assert all(v["occupancy"] >= 7 for v in pick("ppo_loss_kernel"))
+    # round 5: K12's weight gradients in one six-term launch -- two workgroups per CU (72 KB of LDS each), no scratch
+    (wg,) = pick("gru_wgrad_kernel")
+    assert wg["occupancy"] == 2 and wg["scratch_bytes"] == 0
+    # ... like the six-term direct first-layer weight-gradient kernel in its default form
+    assert all(v["occupancy"] >= 2 and v["scratch_bytes"] == 0 for k, v in table.items() if "mlp_dw1_direct_kernel<" in k and ", 2, true>" in k)
     assert all(v["occupancy"] >= 6 for v in pick("gru_fwd_kernel")) and all(v["occupancy"] == 8 for v in pick("gru_bwd_kernel"))
     (step,) = pick("gru_step_fwd_kernel")                                # one workgroup per CU by design: W_hh in LDS
     assert step["lds_bytes"] == 49152 and step["occupancy"] == 1

@@ -22,7 +22,8 @@ kernels run for milliseconds, the host enqueues them far ahead of the device any
 own (measured on the MI355X, profiles/r05_ab_update_graph.json: 64-thread SMAC shard 31.2 -> 18.6 ms per step, 128-thread
 recurrent north-star shard 36.6 -> 27.0, configs[1] 15.04 -> 14.92, but a 512-thread feed-forward north-star shard -- 1.6 M
 rows per update -- 29.6 -> 32.4); a graph would also keep the update's activations (14 GB at the north star) alive for good.
-``MAPPO_UPDATE_GRAPH=0`` disables the whole thing.
+``MAPPO_UPDATE_GRAPH=0`` disables the whole thing; so does the class itself when captures do not pay (six captures with fewer
+than four replays each: a caller whose minibatches point into matrices that move between ``train()`` calls).
 
 Not captured (the eager ``ppo_update`` runs): PopArt heads (``update`` rebinds the parameters' storage), trainers without the
 fused loss / fused optimiser kernels, ``update_actor=False``, host minibatches, minibatches cut into several row spans,
@@ -37,6 +38,7 @@ from onpolicy.algorithms.utils.fused_mlp import RowSource, matrix_arithmetic_of
 
 class UpdateGraph(object):
     MAX_ENTRIES = 4
+    MAX_CAPTURES_WITHOUT_PAYOFF = 6     # ... then at least four replays per capture, or the graphs are switched off
 
     def __init__(self, trainer):
         self.t = trainer
@@ -105,6 +107,12 @@ class UpdateGraph(object):
         if scales is None:
             return None
         if e["state"] == "warm":
+            if self.captures >= self.MAX_CAPTURES_WITHOUT_PAYOFF and self.replays < 4 * self.captures:
+                # the signatures keep changing (addresses of the matrices the minibatches point into that do not survive a
+                # train(), ...): captures cost ~100 ms each and are not paying for themselves -- stay eager from here on
+                print("update graph: %d captures for %d replays; updates stay eager" % (self.captures, self.replays))
+                self.off = True
+                return None
             try:
                 self._capture(e, sample, update_actor, scales)
             except Exception as exc:        # capture is an optimisation: whatever it cannot take stays eager

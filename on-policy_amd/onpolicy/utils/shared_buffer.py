@@ -348,10 +348,13 @@ class SharedReplayBuffer(object):
         """The row-standardised observation copies the fused trunk kernels read during train() (as large as the
         observation fields themselves: 23.5 GB at the north star) go back to the allocator for the rollout; the next
         train() takes the same blocks from its cache."""
-        # Small copies keep their storage (MAPPO_KEEP_STANDARDIZED_BYTES per field, default 2 GiB): the next train() writes into
+        # Small copies keep their storage (MAPPO_KEEP_STANDARDIZED_BYTES per field, default 8 GiB): the next train() writes into
         # the same addresses, which is what lets a captured update graph (algorithms/r_mappo/update_graph.py: the addresses of
-        # the matrices its RowSources read are part of the graph) live across train() calls.
-        limit = int(os.environ.get("MAPPO_KEEP_STANDARDIZED_BYTES", str(2 << 30)))
+        # the matrices its RowSources read are part of the graph) live across train() calls.  (Updates of up to 2^20 rows are
+        # graph candidates; the widest such field of the BASELINE configs is SMAC's 3.6 GB share_obs at 512 threads.  With a
+        # 2 GiB limit that copy went back to the allocator, came back at another address whenever the allocation pattern of a
+        # train() changed, and every new address cost a capture: 834 instead of 71 ms per step in one evidence run.)
+        limit = int(os.environ.get("MAPPO_KEEP_STANDARDIZED_BYTES", str(8 << 30)))
         for name, (_, t) in self._std_rows.items():
             if t.numel() * t.element_size() <= limit:
                 self._std_keep[name] = t

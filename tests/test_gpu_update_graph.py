@@ -15,7 +15,7 @@ from helpers import Box, Discrete, graph_replays, make_args
 pytestmark = pytest.mark.gpu
 
 
-def _run(monkeypatch, graph, recurrent, trains=3, N=12, mini=2, update_actor=True, change_shape=False, rng="device"):
+def _run(monkeypatch, graph, recurrent, trains=3, N=12, mini=2, update_actor=True, change_shape=False, rng="device", moving=False):
     from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy
     from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO
     from onpolicy.utils.shared_buffer import SharedReplayBuffer
@@ -37,6 +37,7 @@ def _run(monkeypatch, graph, recurrent, trains=3, N=12, mini=2, update_actor=Tru
     trainer = R_MAPPO(args, policy, device=dev)
     trainer.prep_training()
     infos = []
+    squatters = []
     for it in range(trains):
         if change_shape and it == 1:        # another number of rollout threads: a second minibatch shape, a second graph
             args, buf = build(N + 4)
@@ -56,6 +57,8 @@ def _run(monkeypatch, graph, recurrent, trains=3, N=12, mini=2, update_actor=Tru
         buf.compute_returns(torch.zeros(buf.value_preds.shape[1:], device=dev), trainer.value_normalizer)
         infos.append(trainer.train(buf, update_actor=update_actor))
         buf.after_update()
+        if moving:      # the blocks the standardised copies just gave back are taken: the next train() finds other addresses
+            squatters.append([torch.empty(T * n * A * w, device=dev) for n in (buf.n_rollout_threads,) for w in (24, 40)])
     torch.cuda.synchronize()
     state = {"actor." + k: v.clone() for k, v in policy.actor.state_dict().items()}
     state.update({"critic." + k: v.clone() for k, v in policy.critic.state_dict().items()})
@@ -113,5 +116,20 @@ def test_large_minibatches_and_host_permutations(monkeypatch):
     infos_g, state_g, tr_g = _run(monkeypatch, "1", True, rng="host")
     infos_e, state_e, _ = _run(monkeypatch, "0", True, rng="host")
     assert tr_g._update_graph.replays > 0 and infos_g == infos_e
+    for k in state_g:
+        assert torch.equal(state_g[k], state_e[k]), k
+
+
+def test_matrices_that_move_between_train_calls_switch_the_graphs_off(monkeypatch):
+    """The addresses of the matrices a minibatch points into are part of a graph's signature.  A caller whose standardised
+    observation copies do not keep their storage (MAPPO_KEEP_STANDARDIZED_BYTES=0 here; by default fields above 8 GiB) and come
+    back somewhere else after every rollout pays a capture per train(): after six captures that did not earn four replays each
+    the class stays eager -- and the results are those of the eager run either way."""
+    monkeypatch.setenv("MAPPO_KEEP_STANDARDIZED_BYTES", "0")
+    infos_g, state_g, tr_g = _run(monkeypatch, "1", False, trains=9, mini=1, moving=True)
+    infos_e, state_e, _ = _run(monkeypatch, "0", False, trains=9, mini=1, moving=True)
+    ug = tr_g._update_graph
+    assert ug.off and ug.captures == ug.MAX_CAPTURES_WITHOUT_PAYOFF, (ug.captures, ug.replays, ug.warmups)
+    assert infos_g == infos_e
     for k in state_g:
         assert torch.equal(state_g[k], state_e[k]), k

@@ -34,6 +34,7 @@ import os
 import torch
 
 from onpolicy.algorithms.utils.fused_mlp import RowSource, matrix_arithmetic_of
+from onpolicy.utils.graph_capture import capturing
 
 
 class UpdateGraph(object):
@@ -168,7 +169,7 @@ class UpdateGraph(object):
         front = torch.cuda.CUDAGraph()
         # (thread_local: the capture must not outlaw what OTHER threads do meanwhile -- RCCL's watchdog polls the events of
         # earlier collectives -- while the autograd thread's launches into the capturing stream are recorded all the same)
-        with torch.cuda.graph(front, pool=self.pool, capture_error_mode="thread_local"):
+        with capturing(front, pool=self.pool, capture_error_mode="thread_local"):
             value_loss, policy_loss, dist_entropy, ratio = t.ppo_update(e["static"], update_actor, _front_only=True,
                                                                         _scales=e["scales"])
             if not t.dp.active:
@@ -181,7 +182,7 @@ class UpdateGraph(object):
             front.replay()                      # (a capture executes nothing: run the front once so that the bucket is real)
             t.dp.all_reduce_grads()             # -> every param.grad is a view of the reduced flat bucket
             back = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(back, pool=self.pool, capture_error_mode="thread_local"):
+            with capturing(back, pool=self.pool, capture_error_mode="thread_local"):
                 norms = t._update_back(update_actor, lr_devices=e["lr"])
             e["back"] = back
             e["front_done"] = True              # the front already ran for the minibatch that triggered the capture

@@ -23,6 +23,8 @@ import os
 
 import torch
 
+from onpolicy.utils.graph_capture import capturing
+
 
 class RolloutGraph(object):
     WARMUP = 3
@@ -145,7 +147,7 @@ class RolloutGraph(object):
                 torch.cuda.synchronize(dev)
                 graph = torch.cuda.CUDAGraph()
                 graph.register_generator_state(r.envs.rng)
-                with torch.cuda.graph(graph):
+                with capturing(graph):
                     self.out, self.infos = self._body()
                 torch.cuda.synchronize(dev)
             # the graph reads and advances the worlds IN PLACE: a step path that rebinds its state tensors cannot be replayed

@@ -130,3 +130,53 @@ def test_multi_discrete_space_drives_the_action_head():
     actions, logp = layer(torch.randn(6, 8))
     assert actions.shape == (6, 3) and logp.shape == (6, 3)
     assert bool((actions[:, 0] <= 4).all()) and bool((actions[:, 1] <= 1).all()) and bool((actions[:, 2] <= 2).all())
+
+
+def test_stream_capture_keeps_the_cyclic_collector_out(monkeypatch):
+    """onpolicy/utils/graph_capture.py: dead cycles (which may hold CUDAGraph objects of an earlier trainer / runner) are collected
+    BEFORE a capture begins and the collector stays off until it has ended -- a graph destroyed in the middle of another capture
+    aborts the process (round 5, device suite).  CPU check with a stand-in for torch.cuda.graph."""
+    import contextlib
+    import gc
+    import torch
+    from onpolicy.utils import graph_capture
+
+    class Node(object):
+        died = []
+
+        def __init__(self):
+            self.me = self          # a reference cycle: only the collector frees it
+
+        def __del__(self):
+            Node.died.append(inside[0])
+
+    inside = [False]
+
+    @contextlib.contextmanager
+    def fake_graph(graph, **kw):
+        inside[0] = True
+        try:
+            yield
+        finally:
+            inside[0] = False
+
+    monkeypatch.setattr(torch.cuda, "graph", fake_graph)
+    gc.collect()
+    Node()                      # dead before the capture begins
+    assert gc.isenabled()
+    with graph_capture.capturing(object(), pool=None):
+        assert not gc.isenabled()
+        for _ in range(3):
+            Node()              # dies during the capture: must wait
+        junk = [[i] for i in range(20000)]     # enough allocations to trigger an automatic collection if it were enabled
+        del junk
+    assert gc.isenabled()
+    gc.collect()
+    assert len(Node.died) == 4 and not any(Node.died), Node.died
+    gc.disable()
+    try:                        # a caller that runs with the collector off gets it back off
+        with graph_capture.capturing(object()):
+            pass
+        assert not gc.isenabled()
+    finally:
+        gc.enable()

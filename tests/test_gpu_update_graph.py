@@ -56,9 +56,10 @@ def _run(monkeypatch, graph, recurrent, trains=3, N=12, mini=2, update_actor=Tru
         policy.lr_decay(it, trains + 1)     # reference base_runner / mpe_runner.py:33-34: a new learning rate every episode
         buf.compute_returns(torch.zeros(buf.value_preds.shape[1:], device=dev), trainer.value_normalizer)
         infos.append(trainer.train(buf, update_actor=update_actor))
+        if moving:      # this train()'s standardised copies stay alive: the next train() cannot get their addresses back
+            squatters.append([t for _, t in buf._std_rows.values()])
+            assert len(squatters[-1]) == 2
         buf.after_update()
-        if moving:      # the blocks the standardised copies just gave back are taken: the next train() finds other addresses
-            squatters.append([torch.empty(T * n * A * w, device=dev) for n in (buf.n_rollout_threads,) for w in (24, 40)])
     torch.cuda.synchronize()
     state = {"actor." + k: v.clone() for k, v in policy.actor.state_dict().items()}
     state.update({"critic." + k: v.clone() for k, v in policy.critic.state_dict().items()})

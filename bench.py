@@ -2,7 +2,10 @@
 """Benchmark of the MAPPO hot path: env-steps/sec through GAE + ppo_update.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ns|cfg2|cfg3|ns_rnn|smac|hanabi] [--no-cpu-baseline]
-                    [--matrix-arithmetic six_term|f32_mfma] [--no-f32-mfma]
+                    [--matrix-arithmetic six_term|f32_mfma] [--no-f32-mfma] [--no-workloads]
+
+The default command line (north star, one GPU) also carries `workloads`: the other BASELINE.json configs run for three
+steps each by child processes of this script after the timed region (OTHER_WORKLOADS below; outside `value`).
 
 One "step" = one pass of the hot path over one synthetic rollout that is already resident in HBM:
 ``buffer.compute_returns`` (HIP GAE scan) + ``R_MAPPO.train`` (ppo_epoch x num_mini_batch fused
@@ -181,38 +184,113 @@ def cpu_baseline(wl):
 
 
 def reference_recorded(workload):
-    """The REFERENCE's own CPU path (its SharedReplayBuffer.compute_returns + R_MAPPO.train, imported in place)
-    timed by tools/time_reference_cpu.py where /root/reference is mounted -- the GPU box has no reference, so the
-    committed record (profiles/r02_cpu_reference.json) is quoted, never re-measured here."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_cpu_reference.json")) as f:
-            doc = json.load(f)
-    except Exception:
+    """The REFERENCE's own CPU path (its SharedReplayBuffer.compute_returns + R_MAPPO.train, imported in place) timed
+    next to the port by tools/time_reference_cpu.py --port-vs-reference where /root/reference is mounted -- the GPU box
+    has no reference, so the newest committed record (profiles/r0N_cpu_port_vs_reference.json: reference and port back
+    to back on one machine, same N, same thread counts) is quoted, never re-measured here."""
+    doc = fn = None
+    for fn in ("r06_cpu_port_vs_reference.json", "r03_cpu_port_vs_reference.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", fn)) as f:
+                doc = json.load(f)
+            if any(r["reference"]["workload"] == workload for r in doc["runs"]):
+                break
+            doc = None
+        except Exception:
+            doc = None
+    if doc is None:
         return None
-    runs = [r for r in doc["runs"] if r["workload"] == workload]
-    if not runs:
-        return None
-    pair = None
-    try:        # round 3: reference and port back to back on one machine, same N, same thread count
-        with open(os.path.join(ROOT, "profiles", "r03_cpu_port_vs_reference.json")) as f:
-            pairs = [r for r in json.load(f)["runs"] if r["reference"]["workload"] == workload]
-        pair = [{"torch_threads": r["reference"]["torch_threads"],
+    pairs = [r for r in doc["runs"] if r["reference"]["workload"] == workload]
+    return {"kind": "reference", "source": "profiles/%s (tools/time_reference_cpu.py --port-vs-reference)" % fn,
+            "commit": doc.get("commit"),
+            "port_vs_reference_same_machine": [
+                {"torch_threads": r["reference"]["torch_threads"],
                  "reference_env_steps_per_s": r["reference"]["env_steps_per_s"],
                  "port_env_steps_per_s": r["port"]["env_steps_per_s"],
-                 "port_over_reference": r["port_over_reference"]} for r in pairs] or None
-    except Exception:
-        pass
-    return {"kind": "reference", "source": "profiles/r02_cpu_reference.json (tools/time_reference_cpu.py)",
-            "port_vs_reference_same_machine": pair,
-            "port_vs_reference_source": "profiles/r03_cpu_port_vs_reference.json (tools/time_reference_cpu.py "
-                                        "--port-vs-reference): the live `port` figure above times this ratio ~ the "
-                                        "reference on the GPU box's host",
+                 "port_over_reference": r["port_over_reference"]} for r in pairs],
             "host": doc["host"]["cpu"] + ", %d logical cores, build container" % doc["host"]["logical_cores"],
-            "n_rollout_threads_timed": runs[0]["n_rollout_threads_timed"],
+            "n_rollout_threads_timed": pairs[0]["reference"]["n_rollout_threads_timed"],
             "note": "same T / agents / dims / ppo_epoch as the GPU run, fewer rollout threads (host memory); env-steps/s "
-                    "is a per-sample rate",
-            "runs": [{"torch_threads": r["torch_threads"], "env_steps_per_s": r["env_steps_per_s"],
-                      "compute_returns_s": r["compute_returns_s"], "train_s": r["train_s"]} for r in runs]}
+                    "is a per-sample rate; the live `port` figure divided by port_over_reference ~ the reference on the "
+                    "GPU box's host",
+            "runs": [{"torch_threads": r["reference"]["torch_threads"], "env_steps_per_s": r["reference"]["env_steps_per_s"],
+                      "compute_returns_s": r["reference"]["compute_returns_s"], "train_s": r["reference"]["train_s"]}
+                     for r in pairs]}
+
+
+# ---- the other BASELINE configs on the driver's line ----------------------------------------------------------------
+# (VERDICT r5 "next" #1.)  `python bench.py` (north star, one GPU) appends `workloads`: every other BASELINE.json config
+# -- and the 64-thread shard one rank of configs[3]'s 8-GPU job owns -- run for a few steps by THIS command line, each
+# in a fresh process of this very script (`--workload X`), AFTER the timed region and outside `value`.  An entry is
+# the child's own line cut down to the figures a reader compares: value / ms_per_step, arithmetic, the dominant
+# launch against its roof, the GAE launch in situ, the CPU leg on a bounded sample.
+OTHER_WORKLOADS = (
+    # name, bench.py arguments, what it is
+    ("cfg2", ["--workload", "cfg2"], "BASELINE.json configs[1]"),
+    ("cfg3", ["--workload", "cfg3"], "BASELINE.json configs[2] (update phase; rollout + update: tools/cfg3_end_to_end.py)"),
+    ("ns_rnn", ["--workload", "ns_rnn", "--cpu-sample-threads", "16"], "north-star shapes, recurrent policy (SURVEY 8d: mappo and rmappo)"),
+    ("smac", ["--workload", "smac"], "BASELINE.json configs[3] shapes, all 512 threads on one GPU"),
+    ("smac_shard64", ["--workload", "smac", "--threads", "64", "--no-cpu-baseline"],
+     "BASELINE.json configs[3]: the 64 threads one of 8 ranks owns (single-GPU proxy of the per-rank step, no xGMI time)"),
+    ("hanabi", ["--workload", "hanabi", "--cpu-sample-threads", "8"], "BASELINE.json configs[4] shapes, all 8192 threads on one GPU"),
+)
+
+
+def compact_line(o, what):
+    r, g, cb = o.get("roofline") or {}, o.get("roofline_gae") or {}, o.get("cpu_baseline")
+    out = {"what": what, "workload": o["config"]["workload"], "n_rollout_threads": o["config"]["n_rollout_threads"],
+           "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"],
+           "warmup": o["warmup"], "dtype": o["dtype"], "arithmetic": o["arithmetic"].split(" (")[0],
+           "update_graph_replays_per_step": o.get("update_graph_replays_per_step"),
+           "hbm_peak_bytes": (o.get("hbm_peak_bytes_per_rank") or [None])[0],
+           "roofline": {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launch_ms",
+                                              "share_of_step")} if r else None,
+           "roofline_gae": {"frac": g.get("frac"), "launch_ms": g.get("launch_ms"),
+                            "back_to_back_frac": (g.get("back_to_back") or {}).get("frac")} if g else None}
+    if cb is not None:
+        out["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")}
+        if cb.get("reference_equivalent"):
+            out["cpu_baseline"]["reference_equivalent"] = {
+                k: cb["reference_equivalent"].get(k) for k in ("value", "port_over_reference", "gpu_over_reference_equivalent")}
+    else:
+        out["cpu_baseline"] = None
+    return out
+
+
+def other_workloads(opt, budget_s):
+    """Run OTHER_WORKLOADS as child processes of this script (the GPU is free: the caller dropped its tensors) ->
+    {name: compact entry | {"error": ...}}.  `budget_s` bounds the whole leg: a child that would start after it is
+    recorded as skipped, a child gets what is left (+ a floor) as its timeout."""
+    import subprocess
+    t_start = time.perf_counter()
+    res = {}
+    for name, argv, what in OTHER_WORKLOADS:
+        left = budget_s - (time.perf_counter() - t_start)
+        if left < 5:
+            res[name] = {"what": what, "skipped": "the leg's time budget (%d s) was spent" % budget_s}
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__)] + argv + [
+            "--steps", "3", "--warmup", "1", "--no-f32-mfma", "--no-workloads", "--sampler-rng", opt.sampler_rng,
+            "--matrix-arithmetic", opt.matrix_arithmetic] + (["--no-gemm-tuning"] if opt.no_gemm_tuning else [])
+        if opt.no_cpu_baseline and "--no-cpu-baseline" not in cmd:
+            cmd.append("--no-cpu-baseline")
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=max(60.0, left))
+            lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            if p.returncode != 0 or not lines:
+                res[name] = {"what": what, "error": "exit code %d: %s" % (p.returncode, (p.stderr or "")[-300:])}
+                continue
+            res[name] = compact_line(json.loads(lines[-1]), what)
+            res[name]["wall_s"] = round(time.perf_counter() - t0, 1)
+        except subprocess.TimeoutExpired:
+            res[name] = {"what": what, "error": "timed out after %.0f s" % max(60.0, left)}
+        except Exception as exc:
+            res[name] = {"what": what, "error": "%s: %s" % (type(exc).__name__, exc)}
+    # the shard runs the same per-sample CPU work as the full config: quote that leg instead of timing it twice
+    if res.get("smac_shard64") and res.get("smac") and "cpu_baseline" in res["smac_shard64"]:
+        res["smac_shard64"]["cpu_baseline"] = res["smac"].get("cpu_baseline")
+    return res
 
 
 def self_launch(n_gpus):
@@ -237,11 +315,17 @@ def main():
     ap.add_argument("--workload", default="ns", choices=sorted(WORKLOADS))
     ap.add_argument("--threads", type=int, default=None, help="override the global n_rollout_threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-threads", type=int, default=None,
+                    help="n_rollout_threads of the CPU leg's bounded sample (default: the workload's cpu_sample_N)")
+    ap.add_argument("--no-workloads", action="store_true",
+                    help="north-star run on one GPU: do not append the other BASELINE configs (`workloads`) to the line")
     ap.add_argument("--matrix-arithmetic", default="six_term", choices=["six_term", "f32_mfma"],
                     help="arithmetic of the K9 / K12 matrix products in the TIMED region (include/mappo_hip.h MAPPO_ARITH_*)")
     ap.add_argument("--no-f32-mfma", "--no-six-term", dest="no_other_arithmetic", action="store_true",
                     help="skip the extra steps (after the timed region) under the other arithmetic form")
     ap.add_argument("--sampler-rng", default="device", choices=["device", "host"])
+    ap.add_argument("--gae-scan", action="store_true",
+                    help="narrow buffers take the time-parallel GAE scan (--gae_scan: ~1e-6 relative instead of bit-exact)")
     ap.add_argument("--no-gemm-tuning", action="store_true",
                     help="leave GEMM kernel selection to the library heuristic (onpolicy/utils/gemm_tuning.py)")
     opt = ap.parse_args()
@@ -253,6 +337,8 @@ def main():
     wl = dict(WORKLOADS[opt.workload])
     if opt.threads:
         wl["N"] = opt.threads
+    if opt.cpu_sample_threads:
+        wl["cpu_sample_N"] = opt.cpu_sample_threads
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == opt.gpus, "--gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (opt.gpus, world)
     rank = int(os.environ.get("RANK", "0"))
@@ -280,7 +366,8 @@ def main():
     from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO
     from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy
 
-    args = make_args(wl, n_local, ["--sampler_rng", opt.sampler_rng, "--matrix_arithmetic", opt.matrix_arithmetic])
+    args = make_args(wl, n_local, ["--sampler_rng", opt.sampler_rng, "--matrix_arithmetic", opt.matrix_arithmetic] +
+                     (["--gae_scan"] if opt.gae_scan else []))
     spaces = Box((wl["Do"],)), Box((wl["Ds"],)), Discrete(wl["na"])
     torch.manual_seed(1)          # identical replicas on every rank (init draws come from the CPU stream)
     np.random.seed(1)
@@ -355,6 +442,8 @@ def main():
     e1.record()
     torch.cuda.synchronize(dev)
     gae_b2b_ms = e0.elapsed_time(e1) / reps
+    from onpolicy import _native
+    gae_variant, buf_gae_exact = _native.lib().mappo_gae_last_variant(), buf._gae_exact
     # Outside the contract's timed region, next to `value`: the same step under the OTHER arithmetic form of the K9 / K12 matrix
     # products (a per-policy choice carried by every call: policy.set_matrix_arithmetic).  The default -- and `value` -- is the
     # six-term form (float32 products from six bf16 x bf16 terms of the operands' exact three-way splits, float32 accumulate:
@@ -471,6 +560,8 @@ def main():
             "hbm_peak_bytes_per_rank": peak_mem,
             # updates of the timed region that were replays of a captured HIP graph (0: every update ran eagerly)
             "update_graph_replays_per_step": graph_replays / max(1, opt.steps),
+            # captures that failed (and were finished / re-run eagerly, update_graph.py) since the trainer was built: 0 expected
+            "update_graph_capture_failures": 0 if ug is None else ug.capture_failures,
             "config": {"workload": wl["label"], "T": wl["T"], "n_rollout_threads": wl["N"],
                        "threads_per_gpu": n_local, "agents": wl["A"], "obs_dim": wl["Do"],
                        "share_obs_dim": wl["Ds"], "actions": wl["na"], "ppo_epoch": args.ppo_epoch,
@@ -506,6 +597,9 @@ def main():
             # back to back the same launch finds part of its lines in the Infinity Cache and warm TLBs
             nbytes = g["algorithmic_bytes"]
             g["in_situ"] = {"launch_ms": g["launch_ms"], "frac": g["frac"]}
+            # which kernel ran (mappo_gae_last_variant; >= 70: the time-parallel scan, only with --gae-scan) and its contract
+            g["variant"] = int(gae_variant)
+            g["bit_exact"] = bool(buf_gae_exact)
             g["back_to_back"] = {"launch_ms": round(gae_b2b_ms, 5), "launches": reps,
                                  "achieved": round(nbytes / (gae_b2b_ms * 1e-3) / 1e9, 1),
                                  "frac": round(nbytes / (gae_b2b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
@@ -519,10 +613,11 @@ def main():
             cb["sample"] += "; GPU / CPU-port ratio on env-steps/s = %.0fx" % (value / cb["value"])
             if factor:
                 # the port is not the reference: on one machine it runs at `factor` x the reference's speed
-                # (profiles/r03_cpu_port_vs_reference.json), so the reference on THIS host would do about value / factor
+                # (ref["source"]), so the reference on THIS host would do about value / factor
                 cb["reference_equivalent"] = {
                     "value": round(cb["value"] / factor, 1), "unit": "env-steps/s", "port_over_reference": round(factor, 3),
                     "gpu_over_reference_equivalent": round(value / (cb["value"] / factor), 1),
+                    "source": ref["source"],
                     "note": "port rate / (port / reference measured back to back on one machine); the figure to hold "
                             "against north_star's >= 10x, not the port's"}
                 cb["sample"] += " (port), %.0fx against the reference-equivalent rate %.0f env-steps/s (port / %.2f)" % (
@@ -531,6 +626,13 @@ def main():
                 cb["reference_recorded"] = ref
     else:
         out = None
+    if out is not None and world == 1 and opt.workload == "ns" and not opt.threads and not opt.no_workloads:
+        # the other BASELINE configs, by this same command line (outside `value`): hand the GPU over first
+        del step, buf, trainer, policy, next_value, ug, info, kt, mt
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["workloads"] = other_workloads(opt, float(os.environ.get("MAPPO_BENCH_WORKLOADS_BUDGET_S", "240")))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

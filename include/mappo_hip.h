@@ -647,7 +647,7 @@ int     mappo_fold_input_norm_backward(const float* w, const float* gamma, const
  *   mappo_linear512_forward:  y [rows, 512] = x [rows, K] W^T (+ bias [512] unless NULL); x rows ldx >= K floats apart
  *     (columns K .. ldx - 1 must hold finite values: the zero padding of mappo_standardize_rows_ld); rows that start on 16-byte
  *     boundaries (ldx a multiple of 4) are loaded in 16-byte pieces, any other ldx (Hanabi's 1285 / 1385-wide gathered
- *     minibatches) in 4-byte pieces.
+ *     minibatches) in 4-byte pieces.  planes, y and bias must be 16-byte aligned (MAPPO_E_ALIGN otherwise).
  *   mappo_linear512_wgrad:    dw [512, K] = dy^T [512, rows] x [rows, K] (the weight gradient of y = x W^T; the contraction
  *     runs over the rows, partial sums of row ranges are added in a fixed order: deterministic run to run);
  *     workspace [mappo_linear512_wgrad_workspace_floats(K)] floats. */

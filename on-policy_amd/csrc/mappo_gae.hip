@@ -494,10 +494,17 @@ __global__ void __launch_bounds__((NPROD + (W + 63) / 64) * 64) gae_dma_kernel(G
 //   producers: issue DMA of tile k+R-2 (into the slot of tile k-2) -> epilogue of tile k-1 ->
 //              counted wait until tile k+1 has landed -> barrier.
 // The ring therefore holds tiles k-1 .. k+R-2; the output tile is double buffered.
-template <int W, int NPROD, int TC, int R, bool PTL, bool DENORM, bool ACT>
+// ring depth that fits the 160 KB of LDS for NF input fields (the deep-ring variants ask for more than the five-field
+// instances can hold: those run with the deepest ring that fits)
+constexpr int epi_ring_depth(int R, int NF, int TC, int W) {
+    return ((R * NF + 2) * TC * W * 4 <= 160 * 1024) ? R : (160 * 1024 / (TC * W * 4) - 2) / NF;
+}
+
+template <int W, int NPROD, int TC, int R_, bool PTL, bool DENORM, bool ACT>
 __global__ void __launch_bounds__((NPROD + (W + 63) / 64) * 64) gae_dma_epi_kernel(GaeArgs a) {
     constexpr int NWALK = (W + 63) / 64;
     constexpr int NF = 3 + (PTL ? 1 : 0) + (ACT ? 1 : 0);
+    constexpr int R = epi_ring_depth(R_, NF, TC, W);
     constexpr int RPI = 256 / W;
     constexpr int IPS = TC / RPI;
     constexpr int LPT = NF * IPS / NPROD;          // DMA instructions per producer wave per tile
@@ -1125,7 +1132,8 @@ hipError_t launch_dma(const GaeArgs& a, unsigned flags, hipStream_t stream) {
 
 template <int W, int NPROD, int TC, int R>
 hipError_t launch_dma_epi(const GaeArgs& a, unsigned flags, hipStream_t stream) {
-    const size_t lds = ((size_t)R * gae_slots(a, flags) + 2) * TC * W * sizeof(float);
+    const int nf = gae_slots(a, flags);
+    const size_t lds = ((size_t)epi_ring_depth(R, nf, TC, W) * nf + 2) * TC * W * sizeof(float);
     dim3 grid((unsigned)((a.C + W - 1) / W)), block((NPROD + (W + 63) / 64) * 64);
     if (lds > 64 * 1024) {
         const bool ptl = flags & MAPPO_GAE_PROPER_TIME_LIMITS;
@@ -1386,6 +1394,14 @@ extern "C" int mappo_gae_f32(const float* rewards, float* value_preds, const flo
         case 54: e = launch_dma_epi<64, 2, 16, 4>(a, flags, stream); break;
         case 56: e = launch_dma_epi<32, 2, 16, 4>(a, flags, stream); break;
         case 57: e = launch_dma_epi<128, 6, 12, 4>(a, flags, stream); break;
+        // (r6) deeper rings: with R = 4 a producer's counted wait leaves ~1.5 tiles (37 KB per CU, 9 MB chip-wide) in
+        // flight -- the epilogue's stores sit between the DMA issues in the counter -- which is what a 5.4 TB/s stream
+        // with ~1.7 us of loaded latency needs, and no more
+        case 58: e = launch_dma_epi<128, 6, 12, 5>(a, flags, stream); break;
+        case 59: e = launch_dma_epi<128, 6, 12, 6>(a, flags, stream); break;
+        case 60: e = launch_dma_epi<128, 4, 8, 6>(a, flags, stream); break;
+        case 61: e = launch_dma_epi<128, 8, 16, 4>(a, flags, stream); break;
+        case 62: e = launch_dma_epi<128, 4, 8, 8>(a, flags, stream); break;
         case 70: e = launch_scan<32>(a, flags, stream); break;
         // (71, the 64-column form, is gone: never selected automatically, and three of its instances spilled 68-196 bytes per lane)
         case 72: e = launch_scan<16>(a, flags, stream); break;

@@ -475,6 +475,7 @@ inline int forward(const float* x, long long rows, int K, int ldx, const float* 
     if (rows <= 0 || K <= 0 || ldx < K || ldx < 4) return MAPPO_E_SHAPE;
     if (((reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(y)) & 15) != 0) return MAPPO_E_ALIGN;
     if ((reinterpret_cast<uintptr_t>(x) & 3) != 0) return MAPPO_E_ALIGN;
+    if (bias && (reinterpret_cast<uintptr_t>(bias) & 15) != 0) return MAPPO_E_ALIGN;      // read as 16-byte vectors
     const bool x16 = ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     FwdArgs a;
     a.x = x;

@@ -2,7 +2,9 @@
 // mappo_mlp_impl.h, which holds the kernels and their launchers.
 #include <hip/hip_runtime.h>
 #include <mutex>
+#include <map>
 #include <unordered_map>
+#include <utility>
 
 #include "mappo_internal.h"
 
@@ -173,15 +175,18 @@ int g_launch_error = 0;
 template <class K>
 void grant_lds(K kernel, size_t bytes) {
     if (bytes > 48 * 1024) {
+        // the attribute belongs to (device, function): a process that drives two GPUs must be granted on both
         static std::mutex mu;
-        static std::unordered_map<const void*, size_t> granted;
+        static std::map<std::pair<int, const void*>, size_t> granted;
         const void* fn = reinterpret_cast<const void*>(kernel);
+        int device = 0;
+        if (hipGetDevice(&device) != hipSuccess) device = -1;
         std::lock_guard<std::mutex> lock(mu);
-        size_t& have = granted[fn];
+        size_t& have = granted[std::make_pair(device, fn)];
         if (bytes > have) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
             if (e != hipSuccess) g_launch_error = (int)e;
-            else have = bytes;
+            else if (device >= 0) have = bytes;
         }
     }
 }

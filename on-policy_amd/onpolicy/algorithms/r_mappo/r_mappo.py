@@ -470,6 +470,8 @@ class R_MAPPO():
 
         keys = ('value_loss', 'policy_loss', 'dist_entropy', 'actor_grad_norm', 'critic_grad_norm', 'ratio')
         totals = torch.zeros(len(keys), dtype=torch.float32, device=self.device)
+        if self._update_graph is not None:
+            self._update_graph.begin_train()    # (captures against parameters / optimiser state that were rebound are dropped)
 
         for _ in range(self.ppo_epoch):
             if self._use_recurrent_policy:

@@ -28,6 +28,19 @@ than four replays each: a caller whose minibatches point into matrices that move
 Not captured (the eager ``ppo_update`` runs): PopArt heads (``update`` rebinds the parameters' storage), trainers without the
 fused loss / fused optimiser kernels, ``update_actor=False``, host minibatches, minibatches cut into several row spans,
 subclasses that override ``ppo_update``.
+
+What else a graph bakes in, and how a stale one is kept from replaying: the addresses of the parameters, of
+their ``.grad`` targets and of the Adam state (``exp_avg``, ``exp_avg_sq``, ``step``), and the kernel-argument
+hyper-parameters (``clip_param``, ``entropy_coef``, ``value_loss_coef``, ``max_grad_norm``, ``huber_delta`` and the loss
+flags).  The hyper-parameters are part of every signature (a trainer that anneals ``entropy_coef`` gets a new capture, not stale
+coefficients); the addresses are compared once per ``train()`` (``begin_train``: after ``optimizer.load_state_dict``, a
+re-created optimiser or ``net.to()`` every entry is dropped and captured again), and ``invalidate()`` does the same on demand.
+
+Failures (VERDICT r5 "next" #8): only the CAPTURE may fail quietly, and only while nothing has executed -- the eager update then
+runs the whole minibatch.  In a multi-GPU job the front half has already run for real (ValueNorm fed, gradients
+all-reduced) when the back half is captured; if that capture fails the update is FINISHED eagerly from the reduced gradients
+(``_update_back``) instead of being run a second time.  Errors during a replay propagate.  ``capture_failures`` counts the
+events (bench.py prints it).
 """
 import os
 
@@ -46,7 +59,8 @@ class UpdateGraph(object):
         self.entries = {}           # signature -> entry
         self.order = []             # signatures, least recently used first
         self.pool = None
-        self.replays = self.captures = self.warmups = 0
+        self.replays = self.captures = self.warmups = self.capture_failures = self.invalidations = 0
+        self._state = None          # addresses of parameters / optimiser state the live entries were captured with
         self.max_rows = int(os.environ.get("MAPPO_UPDATE_GRAPH_MAX_ROWS", str(1 << 20)))
         self.off = os.environ.get("MAPPO_UPDATE_GRAPH", "1") == "0"
 
@@ -84,7 +98,39 @@ class UpdateGraph(object):
             return None, 0
         arith = tuple(matrix_arithmetic_of(m) for net in (t.policy.actor, t.policy.critic) for m in net.modules()
                       if hasattr(m, "matrix_arithmetic"))
-        return (tuple(parts), bool(update_actor), bool(t._obs_standardized), arith), rows
+        # scalars that travel as kernel ARGUMENTS (K7, K13) and are therefore frozen into a capture
+        hyper = (float(t.clip_param), float(t.entropy_coef), float(t.value_loss_coef), float(t.max_grad_norm),
+                 float(t.huber_delta), bool(t._use_max_grad_norm), bool(t._use_clipped_value_loss), bool(t._use_huber_loss),
+                 bool(t._use_policy_active_masks), bool(t._use_value_active_masks), bool(t._use_valuenorm))
+        return (tuple(parts), bool(update_actor), bool(t._obs_standardized), arith, hyper), rows
+
+    def _state_key(self):
+        """Addresses a capture bakes in besides the minibatch: parameters and the optimisers' state tensors."""
+        t = self.t
+        key = []
+        for net, opt in ((t.policy.actor, t.policy.actor_optimizer), (t.policy.critic, t.policy.critic_optimizer)):
+            key.append(id(opt))
+            for p in net.parameters():
+                st = opt.state.get(p, {})
+                key.append((p.data_ptr(),) + tuple(v.data_ptr() for v in st.values() if torch.is_tensor(v)))
+        return tuple(key)
+
+    def invalidate(self):
+        """Drop every captured update (restore / load paths that rebind parameters or optimiser state call this; train()
+        also notices by itself, ``begin_train``)."""
+        if self.entries:
+            self.invalidations += 1
+        self.entries.clear()
+        self.order.clear()
+        self._state = None
+
+    def begin_train(self):
+        """Once per ``train()``: entries captured against other parameter / optimiser-state addresses are dropped."""
+        if not self.entries:
+            return
+        key = self._state_key()
+        if self._state is not None and key != self._state:
+            self.invalidate()
 
     # ------------------------------------------------------------------------------------------------ the update
     def run(self, sample, update_actor):
@@ -115,13 +161,18 @@ class UpdateGraph(object):
                 self.off = True
                 return None
             try:
-                self._capture(e, sample, update_actor, scales)
-            except Exception as exc:        # capture is an optimisation: whatever it cannot take stays eager
+                finished = self._capture(e, sample, update_actor, scales)
+            except Exception as exc:
+                # Nothing of this minibatch has executed (a capture only records; _capture itself deals with a failure AFTER the
+                # front half ran): whatever the capture cannot take stays eager, loudly.
                 e.clear()
                 e["state"] = "failed"
+                self.capture_failures += 1
                 print("update graph: capture failed (%s: %s); this update shape stays eager" % (type(exc).__name__, exc))
                 torch.cuda.synchronize(t.device)
                 return None
+            if finished is not None:        # the back capture failed after the front had run: the update was completed eagerly
+                return finished
         return self._replay(e, sample, scales)
 
     def _remember(self, sig, entry):
@@ -181,15 +232,33 @@ class UpdateGraph(object):
             e["front_grads"] = [p.grad for p in t.dp._params]
             front.replay()                      # (a capture executes nothing: run the front once so that the bucket is real)
             t.dp.all_reduce_grads()             # -> every param.grad is a view of the reduced flat bucket
-            back = torch.cuda.CUDAGraph()
-            with capturing(back, pool=self.pool, capture_error_mode="thread_local"):
-                norms = t._update_back(update_actor, lr_devices=e["lr"])
+            # From here on this minibatch HAS been evaluated: ValueNorm fed, gradients reduced, one collective issued on
+            # every rank.  If the back half cannot be captured the update is finished eagerly from those gradients -- running
+            # the eager ppo_update instead would feed the normaliser twice and issue a collective the other ranks do not.
+            try:
+                back = torch.cuda.CUDAGraph()
+                with capturing(back, pool=self.pool, capture_error_mode="thread_local"):
+                    if os.environ.get("MAPPO_TEST_FAIL_BACK_CAPTURE", "0") == "1":     # (tests/test_gpu_update_graph.py)
+                        raise RuntimeError("forced by MAPPO_TEST_FAIL_BACK_CAPTURE")
+                    norms = t._update_back(update_actor, lr_devices=e["lr"])
+            except Exception as exc:
+                torch.cuda.synchronize(dev)
+                print("update graph: capture of the optimiser half failed after the front half ran (%s: %s); this update "
+                      "is finished eagerly, the shape stays eager" % (type(exc).__name__, exc))
+                norms = t._update_back(update_actor)
+                out = tuple(x.detach().clone() for x in (value_loss, norms[1], policy_loss, dist_entropy, norms[0], ratio))
+                e.clear()
+                e["state"] = "failed"
+                self.capture_failures += 1
+                return out
             e["back"] = back
             e["front_done"] = True              # the front already ran for the minibatch that triggered the capture
         e["grads"] = [(p, p.grad) for p in params]
         e["out"] = (value_loss, norms[1], policy_loss, dist_entropy, norms[0], ratio)
         e["state"] = "ready"
         self.captures += 1
+        self._state = self._state_key()
+        return None
 
     def _replay(self, e, sample, scales):
         t = self.t

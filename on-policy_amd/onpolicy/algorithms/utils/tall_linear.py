@@ -84,6 +84,8 @@ class _Linear512Fn(torch.autograd.Function):
         _native.check(lib.mappo_linear512_prepare(p(w), K, K, 0, p(planes), stream), "mappo_linear512_prepare")
         y = torch.empty((rows, 512), dtype=torch.float32, device=dev)
         b = None if bias is None else bias.detach().contiguous()
+        if b is not None and b.data_ptr() % 16:     # (a bias that is a view at an odd offset: the kernel reads 16-byte vectors)
+            b = b.clone()
         from . import fused_mlp         # (bench.py: an event pair + the algorithmic FLOPs / bytes of the launch while profiling)
         with fused_mlp._Timed("mappo_linear512_forward", 2.0 * rows * K * 512, 4.0 * rows * (ldx + 512)):
             _native.check(lib.mappo_linear512_forward(p(x), rows, K, int(ldx), p(planes), p(b), p(y), stream),
@@ -128,7 +130,8 @@ class _Linear512Fn(torch.autograd.Function):
 
 def linear512_ok(x, weight, arith=None):
     """Whether ``tall_linear`` sends this product through K15: 512 output features, a tall contiguous float32 HIP matrix whose
-    rows hold at least the weight's columns (a zero-padded standardised copy may be wider), the six-term arithmetic selected
+    rows hold exactly the weight's columns -- or those columns zero-padded to whole float4s, the one wider layout this
+    repo makes (``fused_mlp.standardize_rows``); any other width mismatch goes to ``F.linear``, which raises -- the six-term arithmetic selected
     (``arith``: _native.ARITH_* or None = the process default, MAPPO_MATRIX_ARITHMETIC) and MAPPO_LINEAR512 not 0.
     (MAPPO_LINEAR512_MIN_ROWS: tests send small fixtures through the kernels; below 65 536 rows the library GEMM is as good.)"""
     import os
@@ -138,7 +141,7 @@ def linear512_ok(x, weight, arith=None):
     a = _native.default_arith() if arith is None else _native.arith_code(arith)
     return a == _native.ARITH_SIX_TERM and x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous() \
         and x.shape[0] >= int(os.environ.get("MAPPO_LINEAR512_MIN_ROWS", _MIN_ROWS)) and weight.dim() == 2 and weight.shape[0] == 512 and weight.dtype == torch.float32 \
-        and 4 <= weight.shape[1] <= x.shape[1] and weight.is_cuda
+        and weight.shape[1] >= 4 and x.shape[1] in (weight.shape[1], (weight.shape[1] + 3) // 4 * 4) and weight.is_cuda
 
 
 def tall_linear(x, weight, bias, arith=None):

@@ -108,9 +108,12 @@ _NEW_FLAGS = [
     # 'device': minibatch permutations from the GPU generator (fast);
     # 'host': torch.randperm on the CPU generator, bit-identical index streams to the reference
     ("sampler_rng", str, "device", ["device", "host"]),
-    # bit-identical GAE returns for every buffer shape (default: narrow buffers, 2048 <= N * A < 16384, take the
-    # time-parallel scan, which agrees with the reference to ~1e-6 relative; see include/mappo_hip.h K1)
+    # GAE returns are bit-identical to the reference's numpy loop for every buffer shape (the default since round 6).
+    # --gae_scan (or MAPPO_GAE_SCAN=1) lets narrow buffers, 2048 <= N * A < 16384, take the time-parallel scan instead, which
+    # agrees with the reference to ~1e-6 relative and is 2-3 x faster on a launch that is < 0.2 % of an update step
+    # (include/mappo_hip.h K1).  --gae_exact is kept for command lines written against earlier rounds (it wins over --gae_scan).
     ("gae_exact", ON, False),
+    ("gae_scan", ON, False),
     # how the hidden-64 kernels (K9 trunk, K12 GRU) form their float32 matrix products (include/mappo_hip.h MAPPO_ARITH_*):
     # 'six_term' = six bf16 x bf16 terms of the operands' exact three-way splits on the bf16 matrix cores, float32
     # accumulation (error of the float32 MFMA chain's order); 'f32_mfma' = the float32 matrix instruction.  None = the

@@ -73,11 +73,13 @@ class SharedReplayBuffer(object):
         self._recurrent = bool(getattr(args, "use_recurrent_policy", False) or
                                getattr(args, "use_naive_recurrent_policy", False))
         self._sampler_rng = getattr(args, "sampler_rng", "device")
-        # --gae_exact (or MAPPO_GAE_EXACT=1): bit-identical returns for every buffer shape; by default narrow buffers
-        # (2048 <= N * A < 16384) take the time-parallel GAE scan, which agrees with the reference to ~1e-6 relative
-        # (tolerance mode).  --sampler_rng host is the integer-parity mode of the whole path: it implies the exact kernels.
-        self._gae_exact = bool(getattr(args, "gae_exact", False)) or os.environ.get("MAPPO_GAE_EXACT", "0") == "1" \
-            or self._sampler_rng == "host"
+        # Returns are bit-identical to the reference's loop for every buffer shape unless the caller opts into the
+        # time-parallel scan for narrow buffers (--gae_scan / MAPPO_GAE_SCAN=1: 2048 <= N * A < 16384 columns, ~1e-6 relative;
+        # VERDICT r5 "next" #9: the launch is < 0.2 % of a step either way, so bit-exactness is the default).  --gae_exact /
+        # MAPPO_GAE_EXACT=1 and --sampler_rng host (the integer-parity mode of the whole path) always mean the exact kernels.
+        scan = bool(getattr(args, "gae_scan", False)) or os.environ.get("MAPPO_GAE_SCAN", "0") == "1"
+        self._gae_exact = (not scan) or bool(getattr(args, "gae_exact", False)) \
+            or os.environ.get("MAPPO_GAE_EXACT", "0") == "1" or self._sampler_rng == "host"
 
         self.device = dev = self._resolve_device(args, device)
         self._lib = _native.lib()  # raises if the HIP library is not built
@@ -141,6 +143,12 @@ class SharedReplayBuffer(object):
         self.whole_batch_reuses = 0       # epochs that were handed the cached tuple (tests assert the route)
         self._std_rows = {}        # field name -> (key, row-standardised copy) for the fused trunk kernels
         self._std_keep = {}        # field name -> storage of the last copy, kept across train() calls when small (below)
+        self._obs_writes = {"share_obs": 0, "obs": 0}   # slab writes of this class's kernels into the observation fields
+        # MAPPO_STANDARDIZE_AT_INSERT (default on): once a train() has asked for the row-standardised copy of an
+        # observation field, the copy stays resident and insert / chooseinsert / after_update keep it current slab by slab
+        # (_write_slabs), so a train() finds it ready instead of re-standardising the whole field (VERDICT r5 "next" #4a)
+        self._std_at_insert = os.environ.get("MAPPO_STANDARDIZE_AT_INSERT", "1") != "0"
+        self.std_slab_launches = self.std_full_passes = 0      # (tests / bench.py: which of the two ran)
         # MAPPO_PINNED_INSERT=1: host inputs of insert() go through one pinned staging buffer + one async H2D copy.
         # Off by default: measured at the north star (tools/pcie_insert_bench.py, 57 MB per step) the single-threaded
         # memcpy into the staging buffer makes it slower (1.88 ms per step, 30 GB/s) than one pageable .to(device) per
@@ -260,8 +268,10 @@ class SharedReplayBuffer(object):
         st["done"][k] = ev
         return out
 
-    def _write_slabs(self, pairs):
-        """One mappo_slab_copy launch for [(dst_view, value), ...] (K2)."""
+    def _write_slabs(self, pairs, obs_slabs=()):
+        """One mappo_slab_copy launch for [(dst_view, value), ...] (K2).  ``obs_slabs``: (field name, time index) of the
+        pairs that write a slab of share_obs / obs -- the resident row-standardised copy of that field (if a train() made
+        one) is brought up to date for just that slab."""
         if self.device.type == "cuda":
             pairs = self._stage_host_values(pairs)
         keep, slabs = [], []
@@ -280,6 +290,29 @@ class SharedReplayBuffer(object):
         arr = (_native.Slab * len(slabs))(*[_native.Slab(s, d, n) for s, d, n in slabs])
         _native.check(self._lib.mappo_slab_copy(arr, len(slabs), self._stream()), "mappo_slab_copy")
         self._content_version += 1
+        for name, t in obs_slabs:
+            self._obs_slab_written(name, t)
+
+    def _obs_key(self, name):
+        """What a standardised copy of field ``name`` is valid for: this class's slab writes + in-place torch writes."""
+        return (name, self._obs_writes[name], getattr(self, name)._version)
+
+    def _obs_slab_written(self, name, t):
+        """Slab ``t`` of observation field ``name`` was just rewritten by K2.  A resident standardised copy that was current
+        until now stays current: slab t of it is recomputed from the buffer slab (one launch over N * A rows; row T is not
+        part of the copy).  A copy that was already stale stays stale and is rebuilt by the next train()."""
+        hit = self._std_rows.get(name)
+        current = hit is not None and hit[0] == self._obs_key(name)
+        self._obs_writes[name] += 1
+        if not current:
+            return
+        if t < self.episode_length:
+            from onpolicy.algorithms.utils import fused_mlp
+            na = self.n_rollout_threads * self.num_agents
+            field = getattr(self, name)
+            fused_mlp.standardize_rows(field[t].reshape(na, -1), out=hit[1][t * na:(t + 1) * na])
+            self.std_slab_launches += 1
+        self._std_rows[name] = (self._obs_key(name), hit[1])
 
     # ------------------------------------------------------------------ storage
     def insert(self, share_obs, obs, rnn_states_actor, rnn_states_critic, actions, action_log_probs,
@@ -301,7 +334,7 @@ class SharedReplayBuffer(object):
             pairs.append((self.active_masks[s + 1], active_masks))
         if available_actions is not None:
             pairs.append((self.available_actions[s + 1], available_actions))
-        self._write_slabs(pairs)
+        self._write_slabs(pairs, obs_slabs=(("share_obs", s + 1), ("obs", s + 1)))
         self._adv_fresh = False
         self.step = (s + 1) % self.episode_length
 
@@ -322,7 +355,7 @@ class SharedReplayBuffer(object):
             pairs.append((self.active_masks[s], active_masks))
         if available_actions is not None:
             pairs.append((self.available_actions[s], available_actions))
-        self._write_slabs(pairs)
+        self._write_slabs(pairs, obs_slabs=(("share_obs", s), ("obs", s)))
         self._adv_fresh = False
         self.step = (s + 1) % self.episode_length
 
@@ -333,7 +366,7 @@ class SharedReplayBuffer(object):
             fields += [self.rnn_states, self.rnn_states_critic]
         if self.available_actions is not None:
             fields.append(self.available_actions)
-        self._write_slabs([(f[0], f[-1]) for f in fields])
+        self._write_slabs([(f[0], f[-1]) for f in fields], obs_slabs=(("share_obs", 0), ("obs", 0)))
         self._release_update_scratch()
 
     def chooseafter_update(self):
@@ -345,20 +378,21 @@ class SharedReplayBuffer(object):
         self._release_update_scratch()
 
     def _release_update_scratch(self):
-        """The row-standardised observation copies the fused trunk kernels read during train() (as large as the
-        observation fields themselves: 23.5 GB at the north star) go back to the allocator for the rollout; the next
-        train() takes the same blocks from its cache."""
-        # Small copies keep their storage (MAPPO_KEEP_STANDARDIZED_BYTES per field, default 8 GiB): the next train() writes into
-        # the same addresses, which is what lets a captured update graph (algorithms/r_mappo/update_graph.py: the addresses of
-        # the matrices its RowSources read are part of the graph) live across train() calls.  (Updates of up to 2^20 rows are
-        # graph candidates; the widest such field of the BASELINE configs is SMAC's 3.6 GB share_obs at 512 threads.  With a
-        # 2 GiB limit that copy went back to the allocator, came back at another address whenever the allocation pattern of a
-        # train() changed, and every new address cost a capture: 834 instead of 71 ms per step in one evidence run.)
-        limit = int(os.environ.get("MAPPO_KEEP_STANDARDIZED_BYTES", str(8 << 30)))
-        for name, (_, t) in self._std_rows.items():
-            if t.numel() * t.element_size() <= limit:
+        """What a train() leaves behind.  The row-standardised observation copies the fused trunk kernels read (as large
+        as the observation fields themselves: 23.5 GB at the north star) STAY resident and current (MAPPO_STANDARDIZE_AT_INSERT,
+        the default: insert / after_update re-standardise the one slab they write, so the next train() starts without the
+        full pass -- 8 ms and 45 GB of traffic per north-star step -- and the matrices a captured update graph reads keep
+        their addresses) as long as a field's copy is at most MAPPO_KEEP_STANDARDIZED_BYTES (default 48 GiB; larger copies,
+        or all of them with MAPPO_STANDARDIZE_AT_INSERT=0, go back to the allocator for the rollout; with the switch off,
+        copies of up to 8 GiB keep their storage, not their content, for the update graph's sake)."""
+        limit = int(os.environ.get("MAPPO_KEEP_STANDARDIZED_BYTES", str((48 if self._std_at_insert else 8) << 30)))
+        for name, (_, t) in list(self._std_rows.items()):
+            small = t.numel() * t.element_size() <= limit
+            if small and self._std_at_insert:
+                continue                    # stays in _std_rows: resident, kept current by _obs_slab_written
+            if small:
                 self._std_keep[name] = t
-        self._std_rows.clear()
+            del self._std_rows[name]
         self._whole_batch = self._whole_batch_key = None      # (holds RowSources on the standardised copies)
 
     # ------------------------------------------------------------------ returns
@@ -635,12 +669,14 @@ class SharedReplayBuffer(object):
         rows = field[:T].reshape(T * self.n_rollout_threads * self.num_agents, -1)
         if not standardized:
             return rows
-        key = (name, self._content_version, field._version)
+        key = self._obs_key(name)
         hit = self._std_rows.get(name)
         if hit is None or hit[0] != key:
             from onpolicy.algorithms.utils import fused_mlp
-            hit = (key, fused_mlp.standardize_rows(rows, out=self._std_keep.pop(name, None)))
+            out = hit[1] if hit is not None else self._std_keep.pop(name, None)
+            hit = (key, fused_mlp.standardize_rows(rows, out=out))
             self._std_rows[name] = hit
+            self.std_full_passes += 1
         return hit[1]
 
     def _gather(self, table, stats, idx, mb, chunk_len=None, standardize_obs=False, packed=None, lazy_obs=False):

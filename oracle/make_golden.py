@@ -208,6 +208,10 @@ def gen_generators(out, meta):
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if "--only-mid" in sys.argv:        # just trainer_mid_cases (>= 10^5 rows at the north-star flags)
+        import make_golden_trainer as mgt
+        mgt.generate(ref, make_args, fill_buffer, GOLD, mgt.CASES_MID, "trainer_mid_cases", with_grads=True)
+        return
     if "--only-cfg" in sys.argv:        # just trainer_cfg_cases (BASELINE configs[3] / [4] layer shapes)
         import make_golden_trainer as mgt
         mgt.generate(ref, make_args, fill_buffer, GOLD, mgt.CASES_CFG, "trainer_cfg_cases", with_grads=True)

@@ -17,11 +17,16 @@ FIXTURE = "trainer_cfg_cases"
 CASES = ["cfg4_shape", "cfg4_shape_dev", "cfg5_shape"]
 
 
-def build(gold, cname, device=None, **extra):
+MID_FIXTURE = "trainer_mid_cases"          # oracle/make_golden_trainer.py: CASES_MID (>= 10^5 rows, north-star flags)
+MID_CASES = ["mid_ns", "mid_ns_rnn"]
+
+
+def build(gold, cname, device=None, fixture=None, **extra):
     from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy
     from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO
-    z = gold.npz(FIXTURE)
-    meta = gold.meta(FIXTURE)[cname]
+    fixture = fixture or FIXTURE
+    z = gold.npz(fixture)
+    meta = gold.meta(fixture)[cname]
     spec = meta["spec"]
     kw = dict(spec["args"])
     kw.update(extra)

@@ -144,7 +144,8 @@ def run_fixture(cname, lo, hi, device=None, sampler_rng="host", fname="trainer_h
                                     dtype=torch.float64)
     # how the scalar prologue of the updates travelled (DataParallel.begin_scales / minibatch_scales)
     info = dict(info, _scalar_collectives=trainer.dp.scalar_collectives, _scales_reused=trainer.dp.scales_reused,
-                _whole_batch_reuses=getattr(buf, "whole_batch_reuses", 0))
+                _whole_batch_reuses=getattr(buf, "whole_batch_reuses", 0),
+                _capture_failures=getattr(getattr(trainer, "_update_graph", None), "capture_failures", 0))
     return info, sd, trainer.dp.world_size
 
 

@@ -1,0 +1,64 @@
+"""One comparison of a finished ``R_MAPPO.train`` on the device with what the REFERENCE left behind on the same inputs
+(tests/golden/trainer_*_cases.npz), shared by the -m gpu trainer tests, with ONE table of tolerances.
+
+The table sits at about three times the worst deviation measured over the whole device suite on the MI355X
+(profiles/r06_parity_margins.json, written by the ``margins`` fixture of conftest.py; VERDICT r5 "next" #9): a kernel change that
+costs accuracy shows up as a failing test instead of disappearing inside a 30x margin.  Units:
+  info_rel    the six train_info scalars, relative (floor 1e-5 absolute);
+  weight_abs  parameters after train(), absolute (an Adam step moves a weight by <= lr = 5e-4 ... 1e-3);
+  grad_rel    what the last ppo_update left in .grad (after clipping), relative to the tensor's largest reference entry;
+  norm_rtol   ValueNorm's running statistics.
+"""
+import numpy as np
+import pytest
+
+import cfg_shapes as C
+
+TOL = {"info_rel": 1e-3, "info_abs": 1e-5, "weight_abs": 5e-5, "weight_rtol": 1e-3, "grad_rel": 1e-3, "norm_rtol": 1e-5}
+
+
+def compare_update(z, key, meta, policy, trainer, info, tol=None):
+    """Asserts every quantity against the fixture -> {quantity: deviation} (for the ``margins`` record)."""
+    tol = dict(TOL, **(tol or {}))
+    worst = {}
+    for k, ref in meta["train_info"].items():
+        worst["info." + k] = abs(info[k] - ref) / max(abs(ref), 1e-5)
+        assert info[k] == pytest.approx(ref, rel=tol["info_rel"], abs=tol["info_abs"]), (k, info[k], ref)
+    for net, pre in ((policy.actor, "final_actor."), (policy.critic, "final_critic.")):
+        for k, v in net.state_dict().items():
+            got = v.detach().cpu().numpy()
+            sub, ref, mom = C.stored(z, key + pre + k, got)
+            worst["w." + pre + k] = float(np.abs(sub - ref).max()) if sub.size else 0.0
+            np.testing.assert_allclose(sub, ref, rtol=tol["weight_rtol"], atol=tol["weight_abs"], err_msg=pre + k)
+            if mom is not None:     # the elements in between, in aggregate
+                g64 = got.astype(np.float64)
+                assert abs(g64.sum() - mom[0]) <= tol["weight_abs"] * g64.size, (pre + k, g64.sum(), mom[0])
+                np.testing.assert_allclose((g64 * g64).sum(), mom[1], rtol=1e-4, err_msg=pre + k + " (sum of squares)")
+    for net, pre in ((policy.actor, "last_grad_actor."), (policy.critic, "last_grad_critic.")):
+        for k, p in net.named_parameters():
+            got = p.grad.detach().cpu().numpy()
+            sub, ref, mom = C.stored(z, key + pre + k, got)
+            scale = max(1e-12, float(np.abs(ref).max()))
+            err = float(np.abs(sub - ref).max()) / scale
+            worst["g." + pre + k] = err
+            assert err < tol["grad_rel"], (pre + k, err)
+            if mom is not None:
+                g64 = got.astype(np.float64)
+                np.testing.assert_allclose((g64 * g64).sum(), mom[1], rtol=2e-3, err_msg=pre + k + " (sum of squares)")
+    vn = trainer.value_normalizer
+    if vn is not None and (key + "final_norm") in z.files:
+        got = np.array([float(vn.running_mean), float(vn.running_mean_sq), float(vn.debiasing_term)])
+        ref = z[key + "final_norm"]
+        worst["valuenorm"] = float(np.abs(got - ref).max() / max(1e-12, np.abs(ref).max()))
+        np.testing.assert_allclose(got, ref, rtol=tol["norm_rtol"], atol=1e-9)
+    return worst
+
+
+def top3(worst):
+    def cls(k):
+        return k.split(".", 1)[0]
+    best = {}
+    for k, v in worst.items():
+        if v > best.get(cls(k), ("", -1.0))[1]:
+            best[cls(k)] = (k, v)
+    return {c: kv for c, kv in sorted(best.items())}

@@ -7,7 +7,7 @@ import os
 from conftest import GOLD
 from onpolicy.config import get_config
 
-OURS_ONLY = {"buffer_device", "sampler_rng", "gae_exact", "matrix_arithmetic"}
+OURS_ONLY = {"buffer_device", "sampler_rng", "gae_exact", "gae_scan", "matrix_arithmetic"}
 
 
 def _describe(parser):

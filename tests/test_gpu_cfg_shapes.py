@@ -15,6 +15,7 @@ import pytest
 import torch
 
 import cfg_shapes as C
+import parity
 from helpers import graph_replays
 
 pytestmark = pytest.mark.gpu
@@ -31,7 +32,7 @@ def _device_buffer(args, spec, spaces, arrays, dev):
 
 
 @pytest.mark.parametrize("cname", C.CASES + ["cfg5_shape/k15"])
-def test_update_at_baseline_config_shapes_vs_reference(gold, cname, monkeypatch):
+def test_update_at_baseline_config_shapes_vs_reference(gold, cname, monkeypatch, margins):
     from onpolicy import _native
     dev = torch.device("cuda", 0)
     k15 = cname.endswith("/k15")
@@ -75,18 +76,9 @@ def test_update_at_baseline_config_shapes_vs_reference(gold, cname, monkeypatch)
     if rng_mode == "device":
         assert calls.get("mappo_minibatch_indices", 0) == spec["args"]["ppo_epoch"], calls
 
-    worst = {}
-    for k, ref in meta["train_info"].items():
-        worst["info." + k] = abs(info[k] - ref) / max(abs(ref), 1e-5)
-        assert info[k] == pytest.approx(ref, rel=1e-3, abs=1e-5), (k, info[k], ref)
-    C.check_weights(z, key + "final_actor.", policy.actor, rtol=1e-3, atol=5e-5)
-    C.check_weights(z, key + "final_critic.", policy.critic, rtol=1e-3, atol=5e-5)
-    C.check_grads(z, key + "last_grad_actor.", policy.actor, rel=1e-3, worst=worst)
-    C.check_grads(z, key + "last_grad_critic.", policy.critic, rel=1e-3, worst=worst)
-    vn = trainer.value_normalizer
-    got = np.array([float(vn.running_mean), float(vn.running_mean_sq), float(vn.debiasing_term)])
-    np.testing.assert_allclose(got, z[key + "final_norm"], rtol=1e-5, atol=1e-9)
-    top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+    worst = parity.compare_update(z, key, meta, policy, trainer, info)
+    margins("cfg_shapes/%s%s" % (cname, "/k15" if k15 else ""), worst)
+    top = parity.top3(worst)
     print("\n[%s] native calls %s; largest relative errors: %s" % (cname, {k: v for k, v in sorted(calls.items())}, top))
 
 

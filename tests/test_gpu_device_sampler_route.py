@@ -14,6 +14,8 @@ permutation; r_mappo.py:171-224 consumes it).
 """
 import numpy as np
 import pytest
+
+import parity
 import torch
 
 from helpers import Box, Discrete, assert_k9_carried_the_updates, make_args
@@ -24,14 +26,14 @@ FIELDS = ("share_obs", "obs", "rnn_states", "rnn_states_critic", "actions", "val
           "active_masks", "action_log_probs", "available_actions", "rewards")
 
 
-def _setup(gold, fixture, cname, dev):
+def _setup(gold, fixture, cname, dev, **extra):
     from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy
     from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO
     from onpolicy.utils.shared_buffer import SharedReplayBuffer
     z = gold.npz(fixture)
     meta = gold.meta(fixture)[cname]
     spec = meta["spec"]
-    args = make_args(episode_length=spec["T"], n_rollout_threads=spec["N"], sampler_rng="device", **spec["args"])
+    args = make_args(episode_length=spec["T"], n_rollout_threads=spec["N"], sampler_rng="device", **dict(spec["args"], **extra))
     spaces = Box((spec["Do"],)), Box((spec["Ds"],)), Discrete(spec["na"])
     torch.manual_seed(1)
     np.random.seed(1)
@@ -65,9 +67,9 @@ def _launches():
     return t.get("mappo_mlp_forward", (0,))[0], t.get("mappo_mlp_backward", (0,))[0]
 
 
-def _train_and_compare(z, key, meta, spec, policy, trainer, buf, returns_exact):
+def _train_and_compare(z, key, meta, spec, policy, trainer, buf, returns_exact, margins=None):
     from onpolicy.algorithms.utils import fused_mlp
-    assert buf._sampler_rng == "device" and not buf._gae_exact        # the bench's modes, not the integer-parity ones
+    assert buf._sampler_rng == "device" and buf._gae_exact != (not returns_exact)     # the bench's sampler; the scan only on request
     buf.compute_returns(z[key + "next_value"], trainer.value_normalizer)
     got = buf.returns.cpu().numpy()
     if returns_exact:
@@ -88,44 +90,30 @@ def _train_and_compare(z, key, meta, spec, policy, trainer, buf, returns_exact):
     reuses = buf.whole_batch_reuses
     buf.after_update()
 
-    worst = {}
-    for k, ref in meta["train_info"].items():
-        worst["info." + k] = abs(info[k] - ref) / max(abs(ref), 1e-5)
-        assert info[k] == pytest.approx(ref, rel=1e-3, abs=1e-5), (k, info[k], ref)
-    for net, pre in ((policy.actor, "final_actor."), (policy.critic, "final_critic.")):
-        for k, v in net.state_dict().items():
-            np.testing.assert_allclose(v.cpu().numpy(), z[key + pre + k], rtol=1e-3, atol=5e-5, err_msg=pre + k)
-    for net, pre in ((policy.actor, "last_grad_actor."), (policy.critic, "last_grad_critic.")):
-        for k, p in net.named_parameters():
-            ref = z[key + pre + k]
-            scale = max(1e-12, float(np.abs(ref).max()))
-            err = float(np.abs(p.grad.cpu().numpy() - ref).max()) / scale
-            worst[pre + k] = err
-            assert err < 1e-3, (pre + k, err)
-    vn = trainer.value_normalizer
-    got = np.array([float(vn.running_mean), float(vn.running_mean_sq), float(vn.debiasing_term)])
-    np.testing.assert_allclose(got, z[key + "final_norm"], rtol=1e-5, atol=1e-9)
-    top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+    worst = parity.compare_update(z, key, meta, policy, trainer, info)
+    if margins is not None:
+        margins("device_route/" + key[4:-1], worst)
+    top = parity.top3(worst)
     print("\n[%s] device sampler: K9 launches fwd %d bwd %d, whole-batch reuses %d; largest relative errors: %s"
           % (key, n_fwd, n_bwd, reuses, top))
     return reuses
 
 
 @pytest.mark.parametrize("cname", ["h64_ns", "h64_gru_straddle"])
-def test_single_minibatch_device_route_vs_reference(gold, cname):
+def test_single_minibatch_device_route_vs_reference(gold, cname, margins):
     """num_mini_batch = 1: identity index list + whole-batch cache against the reference's randperm run."""
     dev = torch.device("cuda", 0)
     z, key, meta, spec, policy, trainer, buf = _setup(gold, "trainer_h64_cases", cname, dev)
-    reuses = _train_and_compare(z, key, meta, spec, policy, trainer, buf, returns_exact=True)
+    reuses = _train_and_compare(z, key, meta, spec, policy, trainer, buf, returns_exact=True, margins=margins)
     assert reuses == spec["args"]["ppo_epoch"] - 1
 
 
 @pytest.mark.parametrize("cname", ["dev_relu2", "dev_tail", "dev_gru"])
-def test_k10_minibatches_vs_reference_on_the_same_partition(gold, cname):
+def test_k10_minibatches_vs_reference_on_the_same_partition(gold, cname, margins):
     """Several minibatches per epoch: K10's slices on the device against the reference fed the same slices."""
     dev = torch.device("cuda", 0)
     z, key, meta, spec, policy, trainer, buf = _setup(gold, "trainer_dev_cases", cname, dev)
-    reuses = _train_and_compare(z, key, meta, spec, policy, trainer, buf, returns_exact=True)
+    reuses = _train_and_compare(z, key, meta, spec, policy, trainer, buf, returns_exact=True, margins=margins)
     assert reuses == 0          # every minibatch is a different set: nothing may be cached
 
 
@@ -143,13 +131,13 @@ def test_k10_slices_are_the_partition_the_reference_was_fed(gold):
         np.testing.assert_array_equal(idx, z[key + "perm%d" % epoch][:n_mb * mb])
 
 
-def test_scan_gae_then_update_vs_reference(gold):
-    """Config-2 shapes, 2560 columns x 64 steps: compute_returns takes the time-parallel scan (asserted through
-    mappo_gae_last_variant), train() runs on its output through the identity list + whole-batch cache."""
+def test_scan_gae_then_update_vs_reference(gold, margins):
+    """Config-2 shapes, 2560 columns x 64 steps, with --gae_scan: compute_returns takes the time-parallel scan (asserted through
+    mappo_gae_last_variant; without the flag the bit-exact kernels run, every other test of this file), train() runs on its output through the identity list + whole-batch cache."""
     from onpolicy import _native
     dev = torch.device("cuda", 0)
-    z, key, meta, spec, policy, trainer, buf = _setup(gold, "trainer_dev_cases", "dev_scan_cfg2", dev)
-    reuses = _train_and_compare(z, key, meta, spec, policy, trainer, buf, returns_exact=False)
+    z, key, meta, spec, policy, trainer, buf = _setup(gold, "trainer_dev_cases", "dev_scan_cfg2", dev, gae_scan=True)
+    reuses = _train_and_compare(z, key, meta, spec, policy, trainer, buf, returns_exact=False, margins=margins)
     assert _native.lib().mappo_gae_last_variant() in (70, 71, 72, 73, 74, 75)
     assert reuses == spec["args"]["ppo_epoch"] - 1
 

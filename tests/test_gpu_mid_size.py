@@ -1,0 +1,60 @@
+"""-m gpu: compute_returns + R_MAPPO.train on the device at >= 10^5 rows against what the REFERENCE produced on the same
+seeded rollout at the north-star flags (tests/golden/trainer_mid_cases.npz; oracle/make_golden_trainer.py: CASES_MID;
+VERDICT r5 "weak" #1: every other reference-generated trainer fixture is <= 1 200 rows).
+
+* mid_ns      mappo, tanh, hidden 64, obs 48 / share_obs 384, 8 agents, T = 100 x N = 256 = 204 800 rows (2 048 buffer
+              columns): K9's persistent grids walk several tiles per wave, the critic's first-layer weight gradient is split
+              over workgroups and reduced, K7 / K13 / the record gather run multi-block;
+* mid_ns_rnn  the same shapes, rmappo with chunk 10, T = 100 x N = 128 = 102 400 rows = 10 240 chunks: K12 walks several
+              32-chunk tiles per wave, its weight gradients are a multi-workgroup launch.
+Routes: the default one (device sampler -- one minibatch per epoch, so its single slice is the reference's batch as a set --
+and the update replayed from a HIP graph) and the host-permutation route.  Tolerances: the device trainer tests'."""
+import numpy as np
+import pytest
+import torch
+
+import cfg_shapes as C
+import parity
+from helpers import graph_replays
+from test_gpu_cfg_shapes import _device_buffer
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("rng_mode", ["device", "host"])
+@pytest.mark.parametrize("cname", C.MID_CASES)
+def test_update_at_mid_size_vs_reference(gold, cname, rng_mode, margins):
+    from onpolicy import _native
+    dev = torch.device("cuda", 0)
+    z, key, meta, spec, args, spaces, policy, trainer = C.build(gold, cname, device=dev, fixture=C.MID_FIXTURE,
+                                                                sampler_rng=rng_mode)
+    C.start_from_reference_weights(policy, z, key)
+    arrays, nv = C.inputs(spec, z, key)
+    buf = _device_buffer(args, spec, spaces, arrays, dev)
+    buf.compute_returns(nv, trainer.value_normalizer)
+    got = buf.returns.cpu().numpy()
+    sub, ref, mom = C.stored(z, key + "returns", got)
+    np.testing.assert_array_equal(sub, ref)                 # bit-exact GAE at 2 048 / 1 024 columns x 100 steps
+    g64 = got.astype(np.float64)
+    np.testing.assert_allclose([g64.sum(), (g64 * g64).sum()], mom, rtol=1e-12)
+    trainer.prep_training()
+    torch.manual_seed(21)
+    _native.count_calls(True)
+    try:
+        info = trainer.train(buf)
+        torch.cuda.synchronize()
+        calls = _native.calls()
+    finally:
+        _native.count_calls(False)
+    buf.after_update()
+    updates = spec["args"]["ppo_epoch"]
+    called = updates - graph_replays(trainer) + (1 if graph_replays(trainer) else 0)
+    recurrent = bool(spec["args"].get("use_recurrent_policy"))
+    for name in ("mappo_mlp_forward", "mappo_mlp_backward") + (
+            ("mappo_gru_seq_forward", "mappo_gru_seq_backward") if recurrent else ()):
+        assert calls.get(name, 0) == 2 * called, (name, calls)
+
+    worst = parity.compare_update(z, key, meta, policy, trainer, info)
+    margins("mid_size/%s/%s" % (cname, rng_mode), worst)
+    top = parity.top3(worst)
+    print("\n[%s %s] native calls %s; largest relative errors: %s" % (cname, rng_mode, dict(sorted(calls.items())), top))

@@ -808,7 +808,7 @@ def test_gae_time_parallel_scan_vs_oracle(T, N, A, ptl, norm):
     ref = ob.returns
     stats_exact = None
     for exact in (True, False):
-        buf = _buffer(make_args(gae_exact=exact, **kw), A)
+        buf = _buffer(make_args(gae_scan=not exact, **kw), A)
         load_into(buf, arrays)
         vn = _vn(triplet) if norm else None
         buf.compute_returns(arrays["next_value"], vn)

@@ -9,6 +9,8 @@ relative, weights 5e-5 absolute (an Adam step moves a weight by ~lr = 5e-4 .. 7e
 gradients the last update left in ``.grad`` to 1e-3 of each tensor's largest entry."""
 import numpy as np
 import pytest
+
+import parity
 import torch
 
 from helpers import Box, Discrete, assert_k9_carried_the_updates, make_args
@@ -52,7 +54,7 @@ def _launches():
 
 @pytest.mark.parametrize("graph", ["1", "0"], ids=["update_graph", "eager"])
 @pytest.mark.parametrize("cname", CASES)
-def test_fused_trunk_update_vs_reference(gold, cname, graph, monkeypatch):
+def test_fused_trunk_update_vs_reference(gold, cname, graph, monkeypatch, margins):
     """compute_returns + R_MAPPO.train at hidden 64 with the reference's permutations (sampler_rng=host, same CPU seed) -- with
     ppo_update replayed from a captured HIP graph after its first occurrence (the default) and all-eager."""
     from onpolicy.algorithms.utils import fused_mlp
@@ -79,24 +81,9 @@ def test_fused_trunk_update_vs_reference(gold, cname, graph, monkeypatch):
     assert_k9_carried_the_updates(trainer, n_fwd, n_bwd, updates)
     buf.after_update()
 
-    worst = {}
-    for k, ref in meta["train_info"].items():
-        worst["info." + k] = abs(info[k] - ref) / max(abs(ref), 1e-5)
-        assert info[k] == pytest.approx(ref, rel=1e-3, abs=1e-5), (k, info[k], ref)
-    for net, pre in ((policy.actor, "final_actor."), (policy.critic, "final_critic.")):
-        for k, v in net.state_dict().items():
-            np.testing.assert_allclose(v.cpu().numpy(), z[key + pre + k], rtol=1e-3, atol=5e-5, err_msg=pre + k)
-    for net, pre in ((policy.actor, "last_grad_actor."), (policy.critic, "last_grad_critic.")):
-        for k, p in net.named_parameters():
-            ref = z[key + pre + k]
-            scale = max(1e-12, float(np.abs(ref).max()))
-            err = float(np.abs(p.grad.cpu().numpy() - ref).max()) / scale
-            worst[pre + k] = err
-            assert err < 1e-3, (pre + k, err)
-    vn = trainer.value_normalizer
-    got = np.array([float(vn.running_mean), float(vn.running_mean_sq), float(vn.debiasing_term)])
-    np.testing.assert_allclose(got, z[key + "final_norm"], rtol=1e-5, atol=1e-9)
-    top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+    worst = parity.compare_update(z, key, meta, policy, trainer, info)
+    margins("trainer_h64/%s/%s" % (cname, "graph" if graph == "1" else "eager"), worst)
+    top = parity.top3(worst)
     print("\n[%s] K9 launches fwd %d bwd %d; largest relative errors: %s" % (cname, n_fwd, n_bwd, top))
 
 

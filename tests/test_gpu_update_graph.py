@@ -15,7 +15,8 @@ from helpers import Box, Discrete, graph_replays, make_args
 pytestmark = pytest.mark.gpu
 
 
-def _run(monkeypatch, graph, recurrent, trains=3, N=12, mini=2, update_actor=True, change_shape=False, rng="device", moving=False):
+def _run(monkeypatch, graph, recurrent, trains=3, N=12, mini=2, update_actor=True, change_shape=False, rng="device", moving=False,
+         between=None):
     from onpolicy.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy
     from onpolicy.algorithms.r_mappo.r_mappo import R_MAPPO
     from onpolicy.utils.shared_buffer import SharedReplayBuffer
@@ -52,6 +53,8 @@ def _run(monkeypatch, graph, recurrent, trains=3, N=12, mini=2, update_actor=Tru
         if recurrent:
             buf.rnn_states.normal_(generator=g)
             buf.rnn_states_critic.normal_(generator=g)
+        if between is not None:             # what a caller may do between two train() calls (anneal, restore, ...)
+            between(it, policy, trainer)
         torch.manual_seed(50 + it)          # the sampler's keys / permutations
         policy.lr_decay(it, trains + 1)     # reference base_runner / mpe_runner.py:33-34: a new learning rate every episode
         buf.compute_returns(torch.zeros(buf.value_preds.shape[1:], device=dev), trainer.value_normalizer)
@@ -134,3 +137,52 @@ def test_matrices_that_move_between_train_calls_switch_the_graphs_off(monkeypatc
     assert infos_g == infos_e
     for k in state_g:
         assert torch.equal(state_g[k], state_e[k]), k
+
+
+def test_annealed_hyperparameters_and_reloaded_optimiser_state_never_replay_a_stale_graph(monkeypatch):
+    """a capture freezes the kernel-argument hyper-parameters (entropy_coef, clip_param, ...) and the addresses of
+    the Adam state.  A trainer that anneals ``entropy_coef`` between train() calls, and a caller that restores the optimisers
+    with ``load_state_dict`` (new state tensors), must get the eager run's numbers bit for bit: the hyper-parameters are part of
+    the signature (a new capture), the addresses are compared once per train() (every entry dropped)."""
+    import copy
+
+    def between(it, policy, trainer):
+        if it == 1:
+            trainer.entropy_coef = 0.02                     # annealing (the reference keeps it constant; MAT-style schedules do not)
+            trainer.clip_param = 0.15
+        if it == 2:
+            for opt in (policy.actor_optimizer, policy.critic_optimizer):
+                opt.load_state_dict(copy.deepcopy(opt.state_dict()))      # same values, new exp_avg / exp_avg_sq / step tensors
+
+    infos_g, state_g, tr_g = _run(monkeypatch, "1", False, trains=4, between=between)
+    infos_e, state_e, _ = _run(monkeypatch, "0", False, trains=4, between=between)
+    ug = tr_g._update_graph
+    assert ug.captures == 3 and ug.invalidations == 1 and ug.replays > 0, (ug.captures, ug.invalidations, ug.replays)
+    assert infos_g == infos_e, (infos_g, infos_e)
+    for k in state_g:
+        assert torch.equal(state_g[k], state_e[k]), k
+
+
+def test_two_ranks_finish_the_update_eagerly_when_the_optimiser_half_cannot_be_captured(tmp_path, monkeypatch):
+    """VERDICT r5 "next" #8 / ADVICE r5: in a data-parallel job the front half of an update (forward, ValueNorm update,
+    backward) has RUN and the gradients are all-reduced when the back half (clip + Adam) is captured.  With that capture
+    forced to fail (MAPPO_TEST_FAIL_BACK_CAPTURE) the update must be finished from the reduced gradients -- not run again:
+    weights and ValueNorm statistics of both ranks equal the all-eager two-rank run bit for bit, one gradient collective per
+    update."""
+    from test_data_parallel_cpu import _run_two_ranks
+    out = {}
+    for mode, env in (("forced_failure", {"MAPPO_TEST_FAIL_BACK_CAPTURE": "1", "MAPPO_UPDATE_GRAPH": "1"}),
+                      ("eager", {"MAPPO_TEST_FAIL_BACK_CAPTURE": "0", "MAPPO_UPDATE_GRAPH": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        d = tmp_path / mode
+        d.mkdir()
+        spec, ranks = _run_two_ranks(d, "h64_ns", "cuda:0", {"sampler_rng": "device"})
+        for k in ranks[0]["sd"]:
+            assert torch.equal(ranks[0]["sd"][k], ranks[1]["sd"][k]), k
+        out[mode] = ranks[0]
+    assert out["forced_failure"]["info"]["_capture_failures"] == 1 and out["eager"]["info"]["_capture_failures"] == 0
+    for k in out["eager"]["sd"]:
+        assert torch.equal(out["forced_failure"]["sd"][k], out["eager"]["sd"][k]), k
+    for k in ("value_loss", "policy_loss", "actor_grad_norm", "critic_grad_norm"):
+        assert out["forced_failure"]["info"][k] == out["eager"]["info"][k], k

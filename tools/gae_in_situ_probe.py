@@ -8,6 +8,10 @@ fused GAE launch with events:
   tlb         spin, but one 4-byte read per 64 KB of the six arrays first (translations warm, data cold)
   mall        spin, but the four input arrays read once first (translations and Infinity Cache warm)
   b2b         the same launch again right behind the previous one
+  clean       (r6) spin, but a READ-ONLY sweep of an unrelated 1 GB first: the Infinity Cache holds clean foreign lines, so the
+              launch evicts nothing dirty (the eviction copy leaves 256 MiB of dirty lines that the other cold modes write
+              back during the launch: MI355X_MICROARCH.md "boundary": + B / 6 TB/s for B dirty bytes of the predecessor)
+  k2          (r6) clean, then the step's real predecessor: one fused slab copy of after_update's size (57 MB written)
 
     python tools/gae_in_situ_probe.py [--T 400 --N 4096 --A 8] [--reps 6]
 """
@@ -62,7 +66,10 @@ def main():
 
     stride = 64 * 1024 // 4
     out = {"T": T, "C": C, "bytes": 24 * T * C, "us": {}}
-    for mode in ("spin", "busy", "tlb", "mall", "b2b"):
+    slab_src = torch.randn(opt.N * opt.A * 432, device=dev, generator=g)       # after_update's obs + share_obs slabs (57 MB)
+    slab_dst = torch.empty_like(slab_src)
+    slab = (_native.Slab * 1)(_native.Slab(slab_src.data_ptr(), slab_dst.data_ptr(), slab_src.numel()))
+    for mode in ("spin", "busy", "tlb", "mall", "b2b", "clean", "k2"):
         ts = []
         for _ in range(opt.reps):
             big_b.copy_(big_a)
@@ -78,6 +85,10 @@ def main():
                 sink = sum(d[k].sum() for k in ("r", "v", "m", "am"))
             if mode == "b2b":
                 gae()
+            if mode in ("clean", "k2"):
+                sink = big_a[:256 * 1024 ** 2].sum()
+                if mode == "k2":
+                    assert lib.mappo_slab_copy(slab, 1, stream) == 0
             a, b = timed()
             torch.cuda.synchronize()
             ts.append(1e3 * a.elapsed_time(b))

@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 # workload -> reduced n_rollout_threads for the timing (the GPU bench runs the full N of bench.WORKLOADS)
-SAMPLE_N = {"ns": 64, "ns_rnn": 16, "cfg2": 128, "smac": 8, "hanabi": 16}
+SAMPLE_N = {"ns": 64, "ns_rnn": 16, "cfg2": 128, "cfg3": 128, "smac": 8, "hanabi": 16}
 
 
 def time_one(name, threads):

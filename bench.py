@@ -100,6 +100,20 @@ WORKLOADS = {
 }
 
 
+def csrc_digest():
+    """sha256[:16] over the kernel sources (on-policy_amd/csrc/*.hip, *.h, *.cc, Makefile, sorted by name): what ties a
+    committed rocprofv3 record to the code it was taken on -- computable on the GPU box, where there is no .git."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "on-policy_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h", ".cc")) or fn == "Makefile":
+            h.update(fn.encode())
+            with open(os.path.join(d, fn), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 class Box(object):
     def __init__(self, shape):
         self.shape = tuple(shape)
@@ -487,31 +501,40 @@ def main():
         ms_per_step = 1e3 * elapsed / opt.steps
         value = wl["T"] * wl["N"] * opt.steps / elapsed
 
+        here = csrc_digest()
+
         def pmc_traffic(name, nbytes):
-            """(HBM bytes per launch, file) from the committed rocprofv3 PMC passes (profiles/r0N_pmc_summary.json, newest
-            first: 2 x FETCH_SIZE + WRITE_SIZE, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950) -- only
-            quoted when the profiled launch had the same algorithmic byte count."""
-            for fn in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json",
-                       "r01_pmc_summary.json"):
+            """(HBM bytes per launch, provenance) from the committed rocprofv3 PMC passes (profiles/r0N_pmc_summary.json, newest
+            first: 2 x FETCH_SIZE + WRITE_SIZE, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950) -- only quoted when
+            the profiled launch had the same algorithmic byte count.  Provenance: the file, the commit and the digest of the
+            kernel sources the passes ran on (tools/summarize_round.py writes them), and whether that digest is the one of
+            the sources this run was built from."""
+            for fn in ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json",
+                       "r02_pmc_summary.json", "r01_pmc_summary.json"):
                 try:
                     with open(os.path.join(ROOT, "profiles", fn)) as f:
-                        rec = json.load(f).get(name)
+                        doc = json.load(f)
+                    rec = doc.get(name)
                     if rec and abs(rec["algorithmic_bytes"] - nbytes) <= 0.01 * nbytes:
-                        return rec["hbm_bytes"], "committed rocprofv3 PMC passes (profiles/%s), not this run" % fn
+                        meta = doc.get("_provenance", {})
+                        return rec["hbm_bytes"], {
+                            "traffic_source": "committed rocprofv3 PMC passes (profiles/%s), not this run" % fn,
+                            "traffic_commit": meta.get("commit"), "traffic_csrc_digest": meta.get("csrc_digest"),
+                            "traffic_kernels": rec.get("kernels_seen"),
+                            "traffic_matches_this_build": (meta.get("csrc_digest") == here) if meta.get("csrc_digest") else None}
                 except Exception:
                     pass
-            return None, None
+            return None, {"traffic_source": None}
 
         def roof(name):
             if name not in kt:
                 return None
             launches, ms, nbytes = kt[name]
             achieved = nbytes / (ms * 1e-3) / 1e9
-            traffic, source = pmc_traffic(name, nbytes)
-            return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_source": source,
-                    "launch_ms": round(ms, 5), "launches": launches, "algorithmic_bytes": int(nbytes)}
+            traffic, prov = pmc_traffic(name, nbytes)
+            return dict({"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "launch_ms": round(ms, 5), "launches": launches, "algorithmic_bytes": int(nbytes)}, **prov)
 
         def roof_mfma(name, what):
             """K9 / K15 launches (the fused trunk, the 512-wide Linear layers): the launch against BOTH of its roofs, and
@@ -528,7 +551,7 @@ def main():
             launches, ms, flops, nbytes = mt[name]
             tf = flops / launches / (ms * 1e-3) / 1e12
             gbs = nbytes / launches / (ms * 1e-3) / 1e9
-            traffic, source = pmc_traffic(name, nbytes / launches)
+            traffic, prov = pmc_traffic(name, nbytes / launches)
             six = opt.matrix_arithmetic == "six_term"
             mfma_peak = MFMA_BF16_PEAK_TFLOPS / 6 if six else MFMA_F32_PEAK_TFLOPS
             roofs = {"mfma": {"achieved": round(tf, 1), "peak": round(mfma_peak, 1),
@@ -539,7 +562,7 @@ def main():
             bound = "hbm" if roofs["hbm"]["frac"] > roofs["mfma"]["frac"] else "mfma"
             return {"kernel": what, "bound": bound, "achieved": roofs[bound]["achieved"], "peak": roofs[bound]["peak"],
                     "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": roofs[bound]["frac"],
-                    "traffic": traffic, "traffic_source": source, "roofs": roofs,
+                    "traffic": traffic, **prov, "roofs": roofs,
                     "frac_of_f32_mfma_peak": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
                     "launch_ms": round(ms, 4), "launches": launches, "flop_per_launch": int(flops / launches),
                     "algorithmic_bytes": int(nbytes / launches),
@@ -558,6 +581,7 @@ def main():
                 args.hidden_size == 512 and opt.matrix_arithmetic == "six_term" and "mappo_linear512_forward" in mt)) else
                           "f32 (library float32 GEMMs + K6 / K7)",
             "hbm_peak_bytes_per_rank": peak_mem,
+            "csrc_digest": here,        # of the kernel sources this run was built from (cf. roofline.traffic_csrc_digest)
             # updates of the timed region that were replays of a captured HIP graph (0: every update ran eagerly)
             "update_graph_replays_per_step": graph_replays / max(1, opt.steps),
             # captures that failed (and were finished / re-run eagerly, update_graph.py) since the trainer was built: 0 expected

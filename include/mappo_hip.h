@@ -603,7 +603,9 @@ int     mappo_mlp_set_grid_cap(int cap);
 int     mappo_mlp_set_debug(long long* buf);
 /* tuning / test hook: option bits of the K9 launchers (initial value: environment variable MAPPO_MLP_FLAGS, default 0);
  * returns the previous value, or -1 (nothing changed) for a bit that does not exist.  NONE of them selects arithmetic
- * (that is the per-call `arith` field).  1 = the forward's compute waves keep the default priority; 4 = mappo_mlp_forward
+ * (that is the per-call `arith` field).  1 = the forward's compute waves keep the default priority; 2 = K15's forward
+ * (mappo_linear512_forward) issues its MFMAs in four groups of four feature tiles per step (round 5's form; default: eight
+ * groups of two); 4 = mappo_mlp_forward
  * keeps the loader / compute kernel (mlp_fwd_kernel) for shapes the version-3 kernel (operands straight from global memory,
  * resident first-layer weights; aligned rows up to 448 floats wide, two or three layers) would take; 32 = the OTHER form of
  * the direct-to-LDS first-layer weight-gradient kernel: under MAPPO_ARITH_F32_MFMA two slots per wave and two workgroups per

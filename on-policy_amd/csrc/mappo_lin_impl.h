@@ -90,8 +90,10 @@ __global__ void __launch_bounds__(kThreads) lin_planes_kernel(const float* w, in
 // issues of W(s + 2), the read and the split of X(s + 1) -> b(s + 1), the DMA issue of X(s + 3)].  Every position the loads
 // need (block of planes, row tile, column, buffer, slot) is a counter that advances with the step: no division in the loop.
 // (A third version with [256 rows, 256 features] per workgroup -- half the plane traffic, X read twice -- was slower.)
-template <bool X16>
+template <bool X16, bool BIAS, int GT>
 __global__ void __launch_bounds__(kThreads, 1) lin_fwd_kernel(FwdArgs a) {
+    constexpr int NG = 16 / GT;                     // groups of GT feature tiles per step (GT = 2: default; 4: tuning bit 2)
+    static_assert(GT == 2 || GT == 4, "feature tiles per group");
     float* lds = prim::lds();
     float* wbuf = lds;                              // [3][kWBlock]
     float* xring = lds + 3 * kWBlock;               // [wave 4][slot 2][kXSlot]
@@ -188,61 +190,81 @@ __global__ void __launch_bounds__(kThreads, 1) lin_fwd_kernel(FwdArgs a) {
     issue_x();                                      // X(2) -> slot 0
     int rbuf = 0, rslot = 1;                        // buffer of W(s), slot of X(s + 1)
     for (long long m = 0; m < my_tiles; ++m) {
+        // the accumulators start from the bias (features 32 t + 8 q + 4 g + e of this lane; 64 16-byte loads per 128-row tile, L2
+        // hits): the tile's epilogue is then 64 stores straight from the accumulator registers.  (Round 5 added the bias in the
+        // epilogue: the compiler moved all 256 accumulators into vector registers first and spilled 36-38 of them, 148 / 156
+        // bytes of scratch per lane.  The K9 kernels start their first layer from the bias the same way.)
         f32x16 acc[16];
+        if (BIAS) {             // (a template parameter: a run-time choice made the compiler merge two sets of 256 start values)
 #pragma unroll
-        for (int t = 0; t < 16; ++t)
+            for (int t = 0; t < 16; ++t) {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+                for (int q = 0; q < 4; ++q) {
+                    const v4 b = *reinterpret_cast<const v4*>(a.bias + 32 * t + 8 * q + 4 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[t][4 * q + e] = b[e];
+                }
+                prim::sched_fence();        // (tile by tile: no 64 bias loads in flight at once)
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+        }
         for (int kb = 0; kb < nkb; ++kb) {
             // this wave's part of W(s) and its X(s + 1) have landed: everything but the youngest W and X group
             prim::wait_lds_loads<12 + kXGroup>();
             __syncthreads();    // ... and everybody else's part of W(s); all waves are done with step s - 1's buffer
             const float* wb = wbuf + rbuf * kWBlock + lane * 4;
             bf8 nb1, nb2, nb3;
-            // four groups of four feature tiles; the next group's 12 A operands are read while this group's 24 MFMAs issue (the
-            // scheduling fences keep the compiler from hoisting all 48 reads to the top: 192 registers); the loads of the coming
-            // steps and the next step's operand ride along, a few instructions per group
-            bf8 an[3][4];
+            // NG groups of GT feature tiles; the next group's 3 GT A operands are read while this group's 6 GT MFMAs issue (the
+            // scheduling fences keep the compiler from hoisting all 48 reads to the top).  Two tiles per group (the default since
+            // round 6; round 5 ran four) are enough to keep an MFMA from waiting for the one issued just before it and halve the
+            // registers held by A operands.  The loads of the coming steps and the next step's operand ride along, a few
+            // instructions per group.
+            bf8 an[3][GT];
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) an[p][t] = *reinterpret_cast<const bf8*>(wb + p * 4096 + t * 256);
+                for (int t = 0; t < GT; ++t) an[p][t] = *reinterpret_cast<const bf8*>(wb + p * 4096 + t * 256);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                bf8 af[3][4];
+            for (int q = 0; q < NG; ++q) {
+                bf8 af[3][GT];
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) af[p][t] = an[p][t];
-                if (q < 3) {
+                    for (int t = 0; t < GT; ++t) af[p][t] = an[p][t];
+                if (q < NG - 1) {
 #pragma unroll
                     for (int p = 0; p < 3; ++p)
 #pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            an[p][t] = *reinterpret_cast<const bf8*>(wb + p * 4096 + (4 * (q + 1) + t) * 256);
+                        for (int t = 0; t < GT; ++t)
+                            an[p][t] = *reinterpret_cast<const bf8*>(wb + p * 4096 + (GT * (q + 1) + t) * 256);
                 }
-                if (q == 1) read_x(rslot, nb1, nb2, nb3);
+                if (q == NG / 2 - 1) read_x(rslot, nb1, nb2, nb3);
                 prim::sched_fence();
-                if (q < 3) issue_w4(q);             // (in issue order: W(s + 2)'s twelve units, then X(s + 3))
-                if (q == 3) {                       // ... into the slot X(s + 1) was read from two groups ago (by every lane)
+                // (in issue order: W(s + 2)'s twelve units in three runs, then X(s + 3))
+                if (q % (NG / 4) == 0 && q / (NG / 4) < 3) issue_w4(q / (NG / 4));
+                if (q == NG - 1) {                  // ... into the slot X(s + 1) was read from half a step ago (by every lane)
                     next_w();
                     prim::wave_sync();
                     issue_x();
                 }
-                // smallest terms first; term by term over the group's four tiles, so that an MFMA never waits for the result of
+                // smallest terms first; term by term over the group's tiles, so that an MFMA never waits for the result of
                 // the one issued just before it
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[4 * q + t] = prim::mfma_bf16(af[0][t], b3, acc[4 * q + t]);
+                for (int t = 0; t < GT; ++t) acc[GT * q + t] = prim::mfma_bf16(af[0][t], b3, acc[GT * q + t]);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[4 * q + t] = prim::mfma_bf16(af[2][t], b1, acc[4 * q + t]);
+                for (int t = 0; t < GT; ++t) acc[GT * q + t] = prim::mfma_bf16(af[2][t], b1, acc[GT * q + t]);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[4 * q + t] = prim::mfma_bf16(af[1][t], b2, acc[4 * q + t]);
+                for (int t = 0; t < GT; ++t) acc[GT * q + t] = prim::mfma_bf16(af[1][t], b2, acc[GT * q + t]);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[4 * q + t] = prim::mfma_bf16(af[0][t], b2, acc[4 * q + t]);
+                for (int t = 0; t < GT; ++t) acc[GT * q + t] = prim::mfma_bf16(af[0][t], b2, acc[GT * q + t]);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[4 * q + t] = prim::mfma_bf16(af[1][t], b1, acc[4 * q + t]);
+                for (int t = 0; t < GT; ++t) acc[GT * q + t] = prim::mfma_bf16(af[1][t], b1, acc[GT * q + t]);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[4 * q + t] = prim::mfma_bf16(af[0][t], b1, acc[4 * q + t]);
+                for (int t = 0; t < GT; ++t) acc[GT * q + t] = prim::mfma_bf16(af[0][t], b1, acc[GT * q + t]);
             }
             b1 = nb1;
             b2 = nb2;
@@ -250,7 +272,7 @@ __global__ void __launch_bounds__(kThreads, 1) lin_fwd_kernel(FwdArgs a) {
             rbuf = rbuf == 2 ? 0 : rbuf + 1;
             rslot ^= 1;
         }
-        // the tile is complete: row c of this wave, features 32 t + 8 q + 4 g + e (+ bias, read from global memory: once per tile)
+        // the tile is complete: row c of this wave, features 32 t + 8 q + 4 g + e
         const long long tile = blockIdx.x + m * gridDim.x;
         const long long row = tile * 128 + 32 * wave + c;
         if (row < a.rows) {
@@ -262,14 +284,8 @@ __global__ void __launch_bounds__(kThreads, 1) lin_fwd_kernel(FwdArgs a) {
                     v4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = acc[t][4 * q + e];
-                    if (a.bias != nullptr) {
-                        const v4 b = *reinterpret_cast<const v4*>(a.bias + 32 * t + 8 * q + 4 * g);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] += b[e];
-                    }
                     *reinterpret_cast<v4*>(yr + 32 * t + 8 * q) = o;
                 }
-                prim::sched_fence();        // (tile by tile: no 64 bias loads in flight at once)
             }
         }
     }
@@ -487,8 +503,17 @@ inline int forward(const float* x, long long rows, int K, int ldx, const float* 
     a.bias = bias;
     a.y = y;
     const long long grid = mlp::capped((rows + 127) / 128, kGridCap);
-    if (x16) MAPPO_LAUNCH(lin_fwd_kernel<true>, (unsigned)grid, kThreads, (size_t)kFwdLds * 4, stream, a);
-    else MAPPO_LAUNCH(lin_fwd_kernel<false>, (unsigned)grid, kThreads, (size_t)kFwdLds * 4, stream, a);
+    const bool four = (mlp::tuning_flags() & 2) != 0;      // tuning bit 2: four feature tiles per MFMA group (round 5's form)
+#define MAPPO_LIN_FWD(X, B)                                                                                        \
+    do {                                                                                                           \
+        if (four) MAPPO_LAUNCH((lin_fwd_kernel<X, B, 4>), (unsigned)grid, kThreads, (size_t)kFwdLds * 4, stream, a); \
+        else MAPPO_LAUNCH((lin_fwd_kernel<X, B, 2>), (unsigned)grid, kThreads, (size_t)kFwdLds * 4, stream, a);      \
+    } while (0)
+    if (x16 && bias) MAPPO_LIN_FWD(true, true);
+    else if (x16) MAPPO_LIN_FWD(true, false);
+    else if (bias) MAPPO_LIN_FWD(false, true);
+    else MAPPO_LIN_FWD(false, false);
+#undef MAPPO_LIN_FWD
     return MAPPO_LAUNCH_ERROR();
 }
 

@@ -71,11 +71,44 @@ class R_MAPPOPolicy:
 
     def evaluate_logits(self, cent_obs, obs, rnn_states_actor, rnn_states_critic, masks, obs_standardized=False,
                         need_actor=True):
-        """-> (values, logits of the Discrete action head or None): the inputs of the fused PPO loss."""
-        logits = self.actor.evaluate_logits(obs, rnn_states_actor, masks, obs_standardized=obs_standardized) \
-            if need_actor else None
-        values = self.critic(cent_obs, rnn_states_critic, masks, obs_standardized=obs_standardized)[0]
+        """-> (values, logits of the Discrete action head or None): the inputs of the fused PPO loss.
+
+        The critic runs on a SIDE STREAM next to the actor (MAPPO_TWO_STREAM_UPDATE=0 switches it off, MAPPO_TWO_STREAM_MAX_ROWS
+        bounds the minibatch size it applies to; default: every size).  The two networks share nothing.  On small minibatches
+        one network's launches occupy a fraction of the chip (the 64-threads-per-GPU shard of BASELINE configs[3]: K12 is one
+        32-chunk tile per wave on 400 of 1 024 SIMDs) and the other network's fit beside them; on large ones the second
+        stream fills the tails of the persistent kernels.  Autograd runs every backward node on its forward's stream, so the
+        backward passes overlap the same way; captured into the update graph (update_graph.py) the fork / join become two
+        branches of the graph.  Same kernels on the same data: results are bit-identical to the one-stream order
+        (tests/test_gpu_update_graph.py).  Measured, alternating on one box (profiles/r06_ab_two_streams.json): SMAC shard
+        16.3 -> 13.8 ms per step, SMAC shapes at 512 threads 64.7 -> 61.4, north star 200.5 -> 199.1, configs[1] unchanged."""
+        side = self._critic_stream(masks) if need_actor else None
+        if side is None:
+            logits = self.actor.evaluate_logits(obs, rnn_states_actor, masks, obs_standardized=obs_standardized) \
+                if need_actor else None
+            values = self.critic(cent_obs, rnn_states_critic, masks, obs_standardized=obs_standardized)[0]
+            return values, logits
+        main = torch.cuda.current_stream(masks.device)
+        side.wait_stream(main)                  # the minibatch (index lists, masks, RNN states) is ready
+        with torch.cuda.stream(side):
+            values = self.critic(cent_obs, rnn_states_critic, masks, obs_standardized=obs_standardized)[0]
+        logits = self.actor.evaluate_logits(obs, rnn_states_actor, masks, obs_standardized=obs_standardized)
+        main.wait_stream(side)                  # the loss kernel reads both
         return values, logits
+
+    def _critic_stream(self, masks):
+        """The side stream of ``evaluate_logits`` for this minibatch, or None (CPU tensors, no autograd,
+        MAPPO_TWO_STREAM_UPDATE=0, more rows than MAPPO_TWO_STREAM_MAX_ROWS)."""
+        import os
+        if not (torch.is_tensor(masks) and masks.is_cuda and torch.is_grad_enabled()) \
+                or os.environ.get("MAPPO_TWO_STREAM_UPDATE", "1") == "0" \
+                or masks.shape[0] > int(os.environ.get("MAPPO_TWO_STREAM_MAX_ROWS", str(1 << 40))):
+            return None
+        streams = self.__dict__.setdefault("_side_streams", {})
+        key = masks.device.index
+        if key not in streams:
+            streams[key] = torch.cuda.Stream(device=masks.device)
+        return streams[key]
 
     def act(self, obs, rnn_states_actor, masks, available_actions=None, deterministic=False):
         actions, _, rnn_states_actor = self.actor(obs, rnn_states_actor, masks, available_actions, deterministic)

@@ -302,7 +302,7 @@ class SharedReplayBuffer(object):
         until now stays current: slab t of it is recomputed from the buffer slab (one launch over N * A rows; row T is not
         part of the copy).  A copy that was already stale stays stale and is rebuilt by the next train()."""
         hit = self._std_rows.get(name)
-        current = hit is not None and hit[0] == self._obs_key(name)
+        current = self._std_at_insert and hit is not None and hit[0] == self._obs_key(name)
         self._obs_writes[name] += 1
         if not current:
             return

@@ -67,7 +67,12 @@ _MARGINS = {}
 def margins():
     def record(name, worst):
         """``worst``: {quantity: largest deviation, in the unit the test asserts it in}."""
-        _MARGINS[name] = {k: float(v) for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]}
+        # the two largest of every class of quantity (info.* relative, w.* absolute, g.* relative to the tensor's largest entry)
+        kept = {}
+        for cls in sorted({k.split(".", 1)[0] for k in worst}):
+            items = sorted(((k, v) for k, v in worst.items() if k.split(".", 1)[0] == cls), key=lambda kv: -kv[1])[:2]
+            kept.update({k: float(v) for k, v in items})
+        _MARGINS[name] = kept
     return record
 
 

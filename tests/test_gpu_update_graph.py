@@ -186,3 +186,23 @@ def test_two_ranks_finish_the_update_eagerly_when_the_optimiser_half_cannot_be_c
         assert torch.equal(out["forced_failure"]["sd"][k], out["eager"]["sd"][k]), k
     for k in ("value_loss", "policy_loss", "actor_grad_norm", "critic_grad_norm"):
         assert out["forced_failure"]["info"][k] == out["eager"]["info"][k], k
+
+
+@pytest.mark.parametrize("graph", ["1", "0"], ids=["update_graph", "eager"])
+@pytest.mark.parametrize("recurrent", [False, True], ids=["mappo", "rmappo"])
+def test_critic_on_a_side_stream_is_bit_identical_to_one_stream(monkeypatch, recurrent, graph):
+    """Small minibatches evaluate the critic on a side stream next to the actor (R_MAPPOPolicy.evaluate_logits; forward and,
+    through autograd's stream rule, backward): the same kernels on the same data, so weights, optimiser state, ValueNorm,
+    gradients and logged scalars equal the one-stream run bit for bit -- eagerly and replayed from the update graph, where
+    the fork / join are two branches of the captured graph."""
+    monkeypatch.setenv("MAPPO_TWO_STREAM_UPDATE", "1")
+    infos_2, state_2, tr_2 = _run(monkeypatch, graph, recurrent)
+    assert getattr(tr_2.policy, "_side_streams", None), "the side stream was never used"
+    monkeypatch.setenv("MAPPO_TWO_STREAM_UPDATE", "0")
+    infos_1, state_1, tr_1 = _run(monkeypatch, graph, recurrent)
+    assert not getattr(tr_1.policy, "_side_streams", None)
+    if graph == "1":
+        assert tr_2._update_graph.replays == tr_1._update_graph.replays > 0
+    assert infos_2 == infos_1, (infos_2, infos_1)
+    for k in state_2:
+        assert torch.equal(state_2[k], state_1[k]), k

@@ -32,6 +32,24 @@ def mean_of(acc, key):
     return (sum(vals) / len(vals) if vals else 0.0), len(vals)
 
 
+def seen(acc, *keys):
+    """Kernel names (template arguments kept, argument lists cut) of the dispatches an entry was computed from."""
+    return sorted({k.split("(")[0].strip() for k in acc if any(q in k for q in keys)})
+
+
+def provenance():
+    """What the passes ran on: the commit the call was made from (MAPPO_COMMIT, baked into the gpurun command line --
+    the GPU box has no .git; gpurun_out/<round>/commit.txt) and the digest of the kernel sources AS THEY WERE ON THE BOX
+    (csrc_digest.txt, bench.csrc_digest()).  bench.py prints both next to `traffic` and compares the digest with its own."""
+    out = {}
+    for key, fn in (("commit", "commit.txt"), ("csrc_digest", "csrc_digest.txt")):
+        try:
+            out[key] = open(os.path.join(SRC, fn)).read().strip() or None
+        except OSError:
+            out[key] = None
+    return out
+
+
 def main():
     from onpolicy.algorithms.utils.fused_mlp import _work
     fetch, write = counters("FETCH_SIZE"), counters("WRITE_SIZE")
@@ -45,7 +63,7 @@ def main():
     out["mappo_mlp_forward"] = {
         "algorithmic_bytes": alg_f, "fetch_size_bytes_raw": f, "write_size_bytes": w, "hbm_bytes": 2 * f + w,
         "dispatches_averaged": n,
-        "kernel": "mlp::mlp_fwd3_kernel<2, 1, 2> (actor) / mlp::mlp_fwd3_kernel<2, 1, 4> (critic) (round 4; before: mlp::mlp_fwd_kernel<1, true>)",
+        "kernels_seen": seen(fetch, "mlp_fwd"),
         "note": "north-star bench.py step (separate --pmc passes with --kernel-trace only, tools/profile_r02.sh); actor "
                 "and critic launches averaged; FETCH_SIZE doubled (gfx950 counts 64 B per 128 B request of a wide "
                 "coalesced read, MI355X_MICROARCH.md)"}
@@ -66,14 +84,13 @@ def main():
     out["mappo_mlp_backward"] = {
         "algorithmic_bytes": alg_b, "fetch_size_bytes_raw": fb, "write_size_bytes": wb, "hbm_bytes": 2 * fb + wb,
         "calls_averaged": n_calls,
-        "kernel": "mlp::mlp_bwd_kernel<2, 1, 0, true, true> (actor: chain + first-layer weight gradient in one launch) / "
-                  "mlp::mlp_bwd_kernel<2, 1, 1, true> + mlp::mlp_dw1_direct_kernel<3, 2, true> (critic) + mlp::mlp_tail_kernel",
+        "kernels_seen": seen(fetch, "mlp_bwd_kernel", "mlp_dw1_", *set(small)),
         "note": "one mappo_mlp_backward call = chain kernel (+ first-layer weight-gradient kernel for inputs wider than 64) + "
                 "the tail kernel; actor and critic calls averaged, six-term arithmetic only (--no-f32-mfma)"}
     f, n = mean_of(fetch, "gae_")
     w, _ = mean_of(write, "gae_")
     out["mappo_gae_f32"] = {"algorithmic_bytes": 24 * rows, "fetch_size_bytes_raw": f, "write_size_bytes": w,
-                            "hbm_bytes": 2 * f + w, "dispatches_averaged": n,
+                            "hbm_bytes": 2 * f + w, "dispatches_averaged": n, "kernels_seen": seen(fetch, "gae_"),
                             "note": "north-star size, fused advantages epilogue (24 B / element)"}
     # the record gather of the north-star step (once per train(): the whole-batch tuple): 64-byte records read through the
     # index list + the gathered columns written; algorithmic bytes as SharedReplayBuffer._gather counts them
@@ -83,12 +100,14 @@ def main():
         rec_widths = 1 + 1 + 1 + 1 + 1 + 1 + 1 + 5      # actions, value_preds, returns, masks, active_masks, logp, adv, avail
         out["mappo_gather_rows"] = {"algorithmic_bytes": 2 * 4 * rec_widths * rows + 8 * rows, "fetch_size_bytes_raw": f,
                                     "write_size_bytes": w, "hbm_bytes": 2 * f + w, "dispatches_averaged": n,
-                                    "kernel": "gather_records_kernel",
+                                    "kernels_seen": seen(fetch, "gather_records_kernel"),
                                     "note": "until round 4 the packed records were 64 bytes (16 floats, 12 of them payload: "
                                             "fetched bytes exceeded the algorithmic count by the padding); round 5 packs "
                                             "dense 48-byte records for the device sampler's ascending walks"}
+    prov = provenance()
     with open(os.path.join(DST, TAG + "_pmc_summary.json"), "w") as fh:
-        json.dump(out, fh, indent=1)
+        json.dump(dict(out, _provenance=prov), fh, indent=1)
+    print("provenance:", prov)
     for k, v in out.items():
         print(k, "algorithmic %.3f GB, HBM %.3f GB (%.2fx)" % (v["algorithmic_bytes"] / 1e9, v["hbm_bytes"] / 1e9,
                                                               v["hbm_bytes"] / v["algorithmic_bytes"]))

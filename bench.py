@@ -610,7 +610,9 @@ def main():
                                                "mlp_bwd_kernel + mlp_dw1_{direct,rows}_kernel + reduce / finish (mappo_mlp_backward)"),
             # the kernel BASELINE.json's north star names (>= 70 % of HBM in the GAE scan), HBM bound
             "roofline_gae": roof("mappo_gae_f32"),
-            "roofline_gather": roof("mappo_gather_chunks" if wl["recurrent"] else "mappo_gather_rows"),
+            # the sampler's traffic: the fused gather -- or, for one feed-forward minibatch per epoch on the trainer's route, only
+            # the normalised advantages (the other fields are views of the buffer: SharedReplayBuffer._whole_batch_views)
+            "roofline_gather": roof("mappo_gather_chunks" if wl["recurrent"] else "mappo_gather_rows") or roof("mappo_adv_normalize"),
             "train_info": {k: round(float(v), 6) for k, v in info.items()},
         }
         if other is not None:

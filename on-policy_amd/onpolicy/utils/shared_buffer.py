@@ -766,6 +766,50 @@ class SharedReplayBuffer(object):
         self._whole_batch_versions = self._output_versions(self._whole_batch)
         return self._whole_batch
 
+    # The trainer's private route (lazy_obs), one minibatch per epoch, device sampler: the single slice is every sample in
+    # MEMORY ORDER, i.e. row r of a "gathered" field is row r of the buffer field itself.  Nothing is packed or gathered: the
+    # tuple holds VIEWS of the buffer fields ([:T] flattened to [rows, dim]) and one fresh tensor, the normalised
+    # advantages (mappo_adv_normalize, 8 bytes per sample) -- the north-star step loses its record pack + record gather
+    # (1.0 ms, 2.9 GB of traffic; round 6).  Only on this route: its consumer, R_MAPPO.ppo_update, never writes its inputs.
+    # Callers of the public protocol (no lazy_obs) keep the copies and the edit detection of _whole_batch_tuple.
+    def _whole_batch_views_ok(self, rand, mb, batch_size):
+        return rand is getattr(self, "_identity_idx", None) and mb == batch_size and not self._adv_external \
+            and os.environ.get("MAPPO_WHOLE_BATCH_VIEWS", "1") != "0"
+
+    def _whole_batch_views(self, table, stats, rand, mb, standardize_obs):
+        T = self.episode_length
+        key = ("views", self._content_version, bool(standardize_obs), None if stats is None else stats.data_ptr(),
+               tuple((src.data_ptr(), src._version) for _, src, _ in table if src is not None))
+        if self._whole_batch_key == key:
+            self.whole_batch_reuses += 1
+            return self._whole_batch
+        from onpolicy.algorithms.utils.fused_mlp import RowSource
+        outs = []
+        for name, src, is_state in table:
+            if src is None:
+                outs.append(None)
+                continue
+            tail = tuple(src.shape[3:])
+            if name in ("share_obs", "obs") and len(tail) == 1:
+                width = int(tail[0])
+                outs.append(RowSource(self._obs_rows(name, standardize_obs), rand, None, standardized=standardize_obs,
+                                      width=width))
+            elif is_state and not self._recurrent:
+                outs.append(src[0, 0, 0].expand((mb,) + tail))           # zeros, no traffic
+            elif name == "advantages" and stats is not None:
+                dst = torch.empty((mb,) + tail, dtype=torch.float32, device=self.device)
+                ev = self._timed("mappo_adv_normalize", 8 * mb)
+                _native.check(self._lib.mappo_adv_normalize(src.data_ptr(), stats.data_ptr(), dst.data_ptr(), mb,
+                                                            self._stream()), "mappo_adv_normalize")
+                self._timed_end(ev)
+                outs.append(dst)
+            else:
+                outs.append(src[:T].reshape((mb,) + tail))               # a view: [T, N, A, ...] is contiguous
+        self._whole_batch = tuple(outs)
+        self._whole_batch_key = key
+        self._whole_batch_versions = ()
+        return self._whole_batch
+
     def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None,
                                standardize_obs=False, lazy_obs=False):
         """Minibatches of independent (t, n, a) samples for MLP policies
@@ -792,6 +836,9 @@ class SharedReplayBuffer(object):
             mini_batch_size = batch_size // num_mini_batch
         rand = self._sampler_indices(batch_size, mini_batch_size, num_mini_batch)
         table, stats = self._field_table(advantages)
+        if num_mini_batch == 1 and lazy_obs and self._whole_batch_views_ok(rand, mini_batch_size, batch_size):
+            yield self._whole_batch_views(table, stats, rand, mini_batch_size, standardize_obs)
+            return
         packed = self._pack_records(table)
         if num_mini_batch == 1 and self._whole_batch_ok(rand, packed):
             yield self._whole_batch_tuple(table, stats, rand, mini_batch_size, None, standardize_obs, lazy_obs, packed)

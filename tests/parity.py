@@ -1,21 +1,27 @@
 """One comparison of a finished ``R_MAPPO.train`` on the device with what the REFERENCE left behind on the same inputs
 (tests/golden/trainer_*_cases.npz), shared by the -m gpu trainer tests, with ONE table of tolerances.
 
-The table sits at about three times the worst deviation measured over the whole device suite on the MI355X
+The tables sit at about three times the worst deviation measured over the whole device suite on the MI355X
 (profiles/r06_parity_margins.json, written by the ``margins`` fixture of conftest.py; VERDICT r5 "next" #9): a kernel change that
 costs accuracy shows up as a failing test instead of disappearing inside a 30x margin.  Units:
   info_rel    the six train_info scalars, relative (floor 1e-5 absolute);
   weight_abs  parameters after train(), absolute (an Adam step moves a weight by <= lr = 5e-4 ... 1e-3);
   grad_rel    what the last ppo_update left in .grad (after clipping), relative to the tensor's largest reference entry;
-  norm_rtol   ValueNorm's running statistics.
+  norm_rtol   ValueNorm's running statistics, relative to the largest of the three.
 """
 import numpy as np
 import pytest
 
 import cfg_shapes as C
 
-TOL = {"info_rel": 1e-3, "info_abs": 1e-5, "weight_abs": 5e-5, "weight_rtol": 1e-3, "grad_rel": 1e-3, "norm_rtol": 1e-5}
-
+# Measured worst cases over the device suite (round 6, profiles/r06_parity_margins.json, 26 comparisons):
+#   hidden 64 (K9 / K12 routes: trainer_h64 x {graph, eager}, device_route, cfg4_shape, mid_size at 10^5 rows):
+#       train_info 3.9e-7 relative, weights 7.4e-7 absolute, last gradients 4.2e-5 of the tensor's largest entry, ValueNorm 1.2e-7
+#   hidden 512 (cfg5_shape through the library GEMMs and through K15): 4.6e-6, 1.6e-6, 2.1e-4, 1.1e-7
+# Until round 6 every trainer test asserted 1e-3 / 5e-5 / 1e-3 (30-2500 x the measured values).
+TOL = {"info_rel": 1.5e-6, "info_abs": 1e-7, "weight_abs": 2.5e-6, "weight_rtol": 1e-5, "grad_rel": 1.5e-4, "norm_rtol": 5e-7}
+# (hidden 512: the library route's GEMM kernels are picked per box by TunableOp, so the margin is 5 x, not 3 x)
+TOL_H512 = {"info_rel": 2.5e-5, "info_abs": 1e-7, "weight_abs": 8e-6, "weight_rtol": 1e-5, "grad_rel": 1e-3, "norm_rtol": 5e-7}
 
 def compare_update(z, key, meta, policy, trainer, info, tol=None):
     """Asserts every quantity against the fixture -> {quantity: deviation} (for the ``margins`` record)."""
@@ -50,7 +56,7 @@ def compare_update(z, key, meta, policy, trainer, info, tol=None):
         got = np.array([float(vn.running_mean), float(vn.running_mean_sq), float(vn.debiasing_term)])
         ref = z[key + "final_norm"]
         worst["valuenorm"] = float(np.abs(got - ref).max() / max(1e-12, np.abs(ref).max()))
-        np.testing.assert_allclose(got, ref, rtol=tol["norm_rtol"], atol=1e-9)
+        assert worst["valuenorm"] <= tol["norm_rtol"], (got, ref)        # (of the largest statistic: the three differ by 10^5)
     return worst
 
 

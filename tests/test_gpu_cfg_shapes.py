@@ -8,8 +8,9 @@ share_obs 435 / 18 actions / 10 agents, rmappo, chunk 10, 2 minibatches, gain 1)
 * cfg5_shape      hidden 512: library GEMMs + K6 (bias + ReLU + LayerNorm) + the LDS-staged K7 at 48 actions + K13;
   cfg5_shape/k15  the same with every 512-wide product through K15 (six-term bf16 arithmetic; the route real Hanabi
                   minibatches take -- the 160-row fixture is sent there with MAPPO_LINEAR512_MIN_ROWS=1).
-Every case asserts which entry points of libmappo_hip.so carried the update.  Tolerances: the device trainer tests' (losses
-1e-3 relative, weights 5e-5 absolute, last gradients 1e-3 of each tensor's largest entry)."""
+Every case asserts which entry points of libmappo_hip.so carried the update.  Tolerances: tests/parity.py (about three times the
+measured worst case: hidden 64 losses 1.5e-6 relative, weights 2.5e-6 absolute, last gradients 1.5e-4 of each tensor's largest
+entry; hidden 512 2.5e-5 / 8e-6 / 1e-3)."""
 import numpy as np
 import pytest
 import torch
@@ -76,7 +77,8 @@ def test_update_at_baseline_config_shapes_vs_reference(gold, cname, monkeypatch,
     if rng_mode == "device":
         assert calls.get("mappo_minibatch_indices", 0) == spec["args"]["ppo_epoch"], calls
 
-    worst = parity.compare_update(z, key, meta, policy, trainer, info)
+    worst = parity.compare_update(z, key, meta, policy, trainer, info,
+                                  tol=parity.TOL_H512 if spec["args"]["hidden_size"] == 512 else None)
     margins("cfg_shapes/%s%s" % (cname, "/k15" if k15 else ""), worst)
     top = parity.top3(worst)
     print("\n[%s] native calls %s; largest relative errors: %s" % (cname, {k: v for k, v in sorted(calls.items())}, top))

@@ -207,3 +207,33 @@ def test_rollout_forward_on_the_device_route_vs_reference(gold, cname):
                                                 flat("rnn_states_critic"), actions.float(), flat("masks"),
                                                 flat("available_actions"), flat("active_masks"))
     torch.testing.assert_close(logp, ev_logp, rtol=1e-4, atol=2e-5)
+
+
+def test_whole_batch_views_equal_the_gathered_tuple_and_train_identically(gold, monkeypatch):
+    """Round 6: on the trainer's private route (lazy_obs, one minibatch, device sampler) the 12-tuple is VIEWS of the buffer
+    fields + the normalised advantages -- no record pack, no gather.  Every element must equal what the gather produces
+    (MAPPO_WHOLE_BATCH_VIEWS=0) bit for bit, and a whole train() must end with identical weights."""
+    from onpolicy.algorithms.utils.fused_mlp import RowSource
+    dev = torch.device("cuda", 0)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MAPPO_WHOLE_BATCH_VIEWS", mode)
+        z, key, meta, spec, policy, trainer, buf = _setup(gold, "trainer_h64_cases", "h64_ns", dev)
+        buf.compute_returns(z[key + "next_value"], trainer.value_normalizer)
+        adv = buf.normalized_advantages(trainer.value_normalizer)
+        tup = next(iter(buf.feed_forward_generator(adv, 1, standardize_obs=True, lazy_obs=True)))
+        again = next(iter(buf.feed_forward_generator(adv, 1, standardize_obs=True, lazy_obs=True)))
+        assert all(a is b for a, b in zip(tup, again)) and buf.whole_batch_reuses == 1
+        if mode == "1":     # zero-copy: the returns of the tuple ARE the buffer's
+            assert tup[6].data_ptr() == buf.returns.data_ptr() and tup[10].data_ptr() != buf.advantages.data_ptr()
+        fields = [x.materialize().clone() if isinstance(x, RowSource) else (None if x is None else x.clone()) for x in tup]
+        trainer.prep_training()
+        torch.manual_seed(21)
+        trainer.train(buf)
+        w = torch.cat([p.detach().reshape(-1) for net in (policy.actor, policy.critic) for p in net.parameters()]).clone()
+        out[mode] = (fields, w)
+    for a, b in zip(out["1"][0], out["0"][0]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)
+    assert torch.equal(out["1"][1], out["0"][1])

@@ -435,14 +435,21 @@ def main():
     k9_timed_in = "the timed region"
     if ug is not None and ug.replays > 0 and not mt:
         ug.off = True
-        try:
+        two = os.environ.get("MAPPO_TWO_STREAM_UPDATE")
+        os.environ["MAPPO_TWO_STREAM_UPDATE"] = "0"     # (a launch that shares the chip with the other network's cannot be
+        try:                                            #  set against a roofline: time them one after the other)
             fused_mlp.profile(True)
             step()
             torch.cuda.synchronize(dev)
             mt = fused_mlp.profile_times()
         finally:
             ug.off = False
-        k9_timed_in = "one eager step after the timed region (the timed steps replay ppo_update from HIP graphs)"
+            if two is None:
+                os.environ.pop("MAPPO_TWO_STREAM_UPDATE", None)
+            else:
+                os.environ["MAPPO_TWO_STREAM_UPDATE"] = two
+        k9_timed_in = "one eager one-stream step after the timed region (the timed steps replay ppo_update from HIP graphs, " \
+                      "actor and critic on two streams)"
     # the GAE launch once more, outside the timed region, back to back (no update phase in between: caches and TLBs as the
     # previous launch left them) -- reported next to the in-situ figure as roofline_gae.back_to_back
     buf.profile_kernels(False)

@@ -73,15 +73,17 @@ class R_MAPPOPolicy:
                         need_actor=True):
         """-> (values, logits of the Discrete action head or None): the inputs of the fused PPO loss.
 
-        The critic runs on a SIDE STREAM next to the actor (MAPPO_TWO_STREAM_UPDATE=0 switches it off, MAPPO_TWO_STREAM_MAX_ROWS
-        bounds the minibatch size it applies to; default: every size).  The two networks share nothing.  On small minibatches
-        one network's launches occupy a fraction of the chip (the 64-threads-per-GPU shard of BASELINE configs[3]: K12 is one
-        32-chunk tile per wave on 400 of 1 024 SIMDs) and the other network's fit beside them; on large ones the second
-        stream fills the tails of the persistent kernels.  Autograd runs every backward node on its forward's stream, so the
-        backward passes overlap the same way; captured into the update graph (update_graph.py) the fork / join become two
-        branches of the graph.  Same kernels on the same data: results are bit-identical to the one-stream order
-        (tests/test_gpu_update_graph.py).  Measured, alternating on one box (profiles/r06_ab_two_streams.json): SMAC shard
-        16.3 -> 13.8 ms per step, SMAC shapes at 512 threads 64.7 -> 61.4, north star 200.5 -> 199.1, configs[1] unchanged."""
+        Minibatches of at most MAPPO_TWO_STREAM_MAX_ROWS rows (default 2^20: the regime in which ``ppo_update`` is replayed
+        from a HIP graph, update_graph.py) evaluate the critic on a SIDE STREAM next to the actor (MAPPO_TWO_STREAM_UPDATE=0: one
+        stream).  The two networks share nothing until the loss kernel.  On such minibatches one network's launches occupy a
+        fraction of the chip (the 64-threads-per-GPU shard of BASELINE configs[3]: K12 is one 32-chunk tile per wave on 400 of
+        1 024 SIMDs) and the other network's fit beside them.  Autograd runs every backward node on its forward's stream, so
+        the backward passes overlap the same way; captured into the update graph the fork / join become two branches of the
+        graph.  Same kernels on the same data: bit-identical to the one-stream order (tests/test_gpu_update_graph.py).
+        Measured, alternating on one box (profiles/r06_ab_two_streams.json): SMAC shard 16.3 -> 13.8 ms per step, 128-thread
+        recurrent north-star shard 24.7 -> 21.7, SMAC shapes at 512 threads 64.7 -> 61.4, configs[1] unchanged.  Larger
+        minibatches stay on one stream: their kernels fill the chip (north star -0.7 %, recurrent north star / config 3 / Hanabi
+        within the noise) and a launch that shares the chip can no longer be timed against its roofline."""
         side = self._critic_stream(masks) if need_actor else None
         if side is None:
             logits = self.actor.evaluate_logits(obs, rnn_states_actor, masks, obs_standardized=obs_standardized) \
@@ -102,7 +104,7 @@ class R_MAPPOPolicy:
         import os
         if not (torch.is_tensor(masks) and masks.is_cuda and torch.is_grad_enabled()) \
                 or os.environ.get("MAPPO_TWO_STREAM_UPDATE", "1") == "0" \
-                or masks.shape[0] > int(os.environ.get("MAPPO_TWO_STREAM_MAX_ROWS", str(1 << 40))):
+                or masks.shape[0] > int(os.environ.get("MAPPO_TWO_STREAM_MAX_ROWS", str(1 << 20))):
             return None
         streams = self.__dict__.setdefault("_side_streams", {})
         key = masks.device.index

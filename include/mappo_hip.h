@@ -605,7 +605,8 @@ int     mappo_mlp_set_debug(long long* buf);
  * returns the previous value, or -1 (nothing changed) for a bit that does not exist.  NONE of them selects arithmetic
  * (that is the per-call `arith` field).  1 = the forward's compute waves keep the default priority; 2 = K15's forward
  * (mappo_linear512_forward) issues its MFMAs in four groups of four feature tiles per step (round 5's form; default: eight
- * groups of two); 4 = mappo_mlp_forward
+ * groups of two); 8 = K15's weight gradient (mappo_linear512_wgrad): every wave reads and splits all four column tiles of X
+ * itself (round 5's form; default: one tile per wave, shared through LDS as bf16 planes); 4 = mappo_mlp_forward
  * keeps the loader / compute kernel (mlp_fwd_kernel) for shapes the version-3 kernel (operands straight from global memory,
  * resident first-layer weights; aligned rows up to 448 floats wide, two or three layers) would take; 32 = the OTHER form of
  * the direct-to-LDS first-layer weight-gradient kernel: under MAPPO_ARITH_F32_MFMA two slots per wave and two workgroups per

@@ -299,6 +299,7 @@ constexpr int kWgX = 16 * kWgCols;                  // floats of a [16, 128] til
 constexpr int kWgSlot = kWgDz + kWgX;               // 40 KB
 constexpr int kWgSlots = 3;
 constexpr int kWgLds = kWgSlots * kWgSlot;          // 120 KB
+constexpr int kWgPlanes = 3 * 4 * 256;              // floats of the shared B planes of one X tile (SHB): 12 KB
 
 struct WgArgs {
     const float* dy;        // [rows, 512]
@@ -311,9 +312,18 @@ struct WgArgs {
 // Pipeline (second version, like lin_fwd_kernel): the operands of step m + 1 (8 rows of one column per lane: 64 4-byte LDS
 // reads and eight 3-way splits) are read and split while the 96 MFMAs of step m issue; tiles are issued three steps ahead into
 // a ring of three slots (tile j is read during step j - 1, so at step m the slots of tiles <= m are free).
-template <bool X16>
+//
+// SHB (round 6, the default; tuning bit 8 keeps the other form): the four waves of a workgroup need the SAME four column tiles of
+// X as their B operands (each wave owns 128 of the 512 features and all 128 columns), and until round 6 every wave read and split
+// all of them: 32 of the 64 strided LDS reads and 4 of the 8 three-way splits of a step were done four times over.  Now wave w
+// reads and splits column tile w of tile m + 1 at the start of step m, writes its three bf16 planes to a 12 KB LDS area in MFMA
+// operand order, and after a second barrier (behind the step's first 24 MFMAs) every wave fetches the four tiles' planes with
+// twelve 16-byte reads: 55 LDS instructions + 5 splits per step instead of 64 + 8 -- the non-MFMA stream that one wave per SIMD
+// has to fit into the MFMAs' shadow shrinks by a third.
+template <bool X16, bool SHB>
 __global__ void __launch_bounds__(kThreads, 1) lin_wgrad_kernel(WgArgs a) {
     float* lds = prim::lds();
+    float* bpl = lds + kWgLds;                      // SHB: [plane 3][column tile 4][lane 64] x 16 bytes
     const int tid = threadIdx.x, lane = tid & 63, wave = prim::uniform(tid >> 6), c = lane & 31, g = lane >> 5;
     const int col0 = blockIdx.y * kWgCols;
     const long long ntiles = (a.rows + 15) / 16;
@@ -403,6 +413,17 @@ __global__ void __launch_bounds__(kThreads, 1) lin_wgrad_kernel(WgArgs a) {
             for (int e = 0; e < 8; ++e) v[e] = xt[(8 * g + e) * kWgCols + 32 * j];
             mlp::split3(v, B3[0], B3[1], B3[2]);
         };
+        // SHB: this wave's column tile (j = wave) of tile m -> the shared planes; the planes of column tile j -> registers
+        auto write_b = [&](long long m) {
+            bf8 q[3];
+            operand_b(m, wave, q);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<bf8*>(bpl + (p * 4 + wave) * 256 + lane * 4) = q[p];
+        };
+        auto read_b = [&](int j, bf8* B3) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) B3[p] = *reinterpret_cast<const bf8*>(bpl + (p * 4 + j) * 256 + lane * 4);
+        };
         issue(0);
         issue(1);
         issue(2);
@@ -412,12 +433,20 @@ __global__ void __launch_bounds__(kThreads, 1) lin_wgrad_kernel(WgArgs a) {
         bf8 A[4][3], B[4][3];
 #pragma unroll
         for (int i = 0; i < 4; ++i) operand_a(0, i, A[i]);
+        if (SHB) {
+            write_b(0);
+            __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) operand_b(0, j, B[j]);
+            for (int j = 0; j < 4; ++j) read_b(j, B[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) operand_b(0, j, B[j]);
+        }
         for (long long m = 0; m < n_it; ++m) {
             prim::wait_lds_loads<kGroup>();         // this wave's loads of tile m + 1: all but the youngest group (tile m + 2)
             zero_tail(m + 1);
             __syncthreads();                        // ... and everybody else's; all waves have read tile m (during step m - 1)
+                                                    // (SHB: ... and the shared planes of tile m, during step m - 1)
             issue(m + 3);                           // -> the slot of tile m
             bf8 nA[4][3], nB[4][3];
             // smallest terms first, term by term over a feature tile's four column tiles (an MFMA never waits for the one before
@@ -425,7 +454,19 @@ __global__ void __launch_bounds__(kThreads, 1) lin_wgrad_kernel(WgArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 operand_a(m + 1, i, nA[i]);
-                operand_b(m + 1, i, nB[i]);
+                if (SHB) {
+                    if (i == 0) write_b(m + 1);
+                    if (i == 1) {                   // (behind the barrier that follows group 0)
+                        read_b(0, nB[0]);
+                        read_b(1, nB[1]);
+                    }
+                    if (i == 2) {
+                        read_b(2, nB[2]);
+                        read_b(3, nB[3]);
+                    }
+                } else {
+                    operand_b(m + 1, i, nB[i]);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = prim::mfma_bf16(A[i][0], B[j][2], acc[i][j]);
 #pragma unroll
@@ -438,6 +479,7 @@ __global__ void __launch_bounds__(kThreads, 1) lin_wgrad_kernel(WgArgs a) {
                 for (int j = 0; j < 4; ++j) acc[i][j] = prim::mfma_bf16(A[i][1], B[j][0], acc[i][j]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = prim::mfma_bf16(A[i][0], B[j][0], acc[i][j]);
+                if (SHB && i == 0) __syncthreads();     // every wave's planes of tile m + 1 are written
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -450,6 +492,10 @@ __global__ void __launch_bounds__(kThreads, 1) lin_wgrad_kernel(WgArgs a) {
         prim::wait_lds_loads<0>();
     }
     // partial slab of this row range (zeros for a range without rows): D row = feature within the tile, D column = lane & 31
+    // (the lane's position is taken afresh from the hardware lane counter: kept alive across the loop -- where every vector
+    // register is in use -- it was the one value the SHB form spilled)
+    const int le = prim::lane_again();
+    const int ce = le & 31, ge = le >> 5;
     float* prow = a.partials + (long long)blockIdx.x * kN * kp;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -457,8 +503,8 @@ __global__ void __launch_bounds__(kThreads, 1) lin_wgrad_kernel(WgArgs a) {
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const int f = 128 * wave + 32 * i + (v & 3) + 8 * (v >> 2) + 4 * g;
-                prow[(long long)f * kp + col0 + 32 * j + c] = acc[i][j][v];
+                const int f = 128 * wave + 32 * i + (v & 3) + 8 * (v >> 2) + 4 * ge;
+                prow[(long long)f * kp + col0 + 32 * j + ce] = acc[i][j][v];
             }
 }
 
@@ -541,8 +587,12 @@ inline int wgrad(const float* dy, const float* x, long long rows, int K, int ldx
     int gx = wgrad_ranges(K);
     const int cap = mlp::grid_cap_override();       // (tests: few row ranges, many steps each)
     if (cap > 0 && cap < gx) gx = cap;
-    if (x16) MAPPO_LAUNCH(lin_wgrad_kernel<true>, dim3((unsigned)gx, (unsigned)gy), kThreads, (size_t)kWgLds * 4, stream, a);
-    else MAPPO_LAUNCH(lin_wgrad_kernel<false>, dim3((unsigned)gx, (unsigned)gy), kThreads, (size_t)kWgLds * 4, stream, a);
+    const bool own_b = (mlp::tuning_flags() & 8) != 0;     // tuning bit 8: every wave splits all four column tiles itself (round 5)
+    const size_t lds_shb = (size_t)(kWgLds + kWgPlanes) * 4;
+    if (x16 && !own_b) MAPPO_LAUNCH((lin_wgrad_kernel<true, true>), dim3((unsigned)gx, (unsigned)gy), kThreads, lds_shb, stream, a);
+    else if (!own_b) MAPPO_LAUNCH((lin_wgrad_kernel<false, true>), dim3((unsigned)gx, (unsigned)gy), kThreads, lds_shb, stream, a);
+    else if (x16) MAPPO_LAUNCH((lin_wgrad_kernel<true, false>), dim3((unsigned)gx, (unsigned)gy), kThreads, (size_t)kWgLds * 4, stream, a);
+    else MAPPO_LAUNCH((lin_wgrad_kernel<false, false>), dim3((unsigned)gx, (unsigned)gy), kThreads, (size_t)kWgLds * 4, stream, a);
     int code = MAPPO_LAUNCH_ERROR();
     if (code) return code;
     long long grid = ((long long)kN * K + kThreads - 1) / kThreads;

@@ -97,6 +97,9 @@ __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0
 __device__ __forceinline__ void set_priority_high() { __builtin_amdgcn_s_setprio(3); }
 // wave-uniform value -> scalar register
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// this lane's index in its wave, read afresh from the hardware lane counter (two instructions): for an epilogue that would
+// otherwise keep a function of threadIdx alive -- or spilled -- across a loop that uses every vector register
+__device__ __forceinline__ int lane_again() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 // global_load_lds_dwordx4: lane l's 16 bytes at g go to LDS address (wave-uniform) base + 16 l, not through VGPRs.  Issued
 // from inline asm, so the compiler neither counts nor drains these loads: wait_lds_loads() before the data is read.
 __device__ __forceinline__ void load_lds16(const float* g, float* lds_wave_base) {

@@ -3077,7 +3077,7 @@ inline int& grid_cap_override() {
     return cap;
 }
 // option bits of mappo_mlp_set_flags that exist (tuning / tests only; arithmetic is the per-call `arith` field)
-constexpr int kTuningBits = 1 | 2 | 4 | 32 | 128 | 256;
+constexpr int kTuningBits = 1 | 2 | 4 | 8 | 32 | 128 | 256;
 inline int& tuning_flags_ref() {
     static int v = -1;
     if (v < 0) {

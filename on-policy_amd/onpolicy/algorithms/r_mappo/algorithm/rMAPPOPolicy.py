@@ -104,7 +104,14 @@ class R_MAPPOPolicy:
         import os
         if not (torch.is_tensor(masks) and masks.is_cuda and torch.is_grad_enabled()) \
                 or os.environ.get("MAPPO_TWO_STREAM_UPDATE", "1") == "0" \
-                or masks.shape[0] > int(os.environ.get("MAPPO_TWO_STREAM_MAX_ROWS", str(1 << 20))):
+                or max(masks.shape[0], getattr(self, "_update_rows", 0)) > int(os.environ.get("MAPPO_TWO_STREAM_MAX_ROWS", str(1 << 20))):
+            return None
+        # (only under the six-term arithmetic, whose matrix products are in-tree kernels made of independent workgroups: the
+        # float32 route goes through library GEMMs, and nothing says those tolerate a second GEMM taking CUs away under them)
+        from onpolicy import _native
+        from onpolicy.algorithms.utils.fused_mlp import matrix_arithmetic_of
+        if any(matrix_arithmetic_of(net.base) != _native.ARITH_SIX_TERM for net in (self.actor, self.critic)
+               if hasattr(net, "base")):
             return None
         streams = self.__dict__.setdefault("_side_streams", {})
         key = masks.device.index

@@ -227,6 +227,7 @@ inline float xhalf(float v) {
 }
 
 inline float* lds() { return simt::st().lds; }
+inline int lane_again() { return (int)(threadIdx.x & 63); }
 
 }  // namespace prim
 

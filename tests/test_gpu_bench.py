@@ -27,6 +27,30 @@ def _run(extra_env=None, args=()):
     return json.loads(line)
 
 
+def test_default_command_line_carries_the_other_baseline_configs():
+    """`python bench.py` (north star, one GPU) appends `workloads`: the other BASELINE configs run by child processes of the same
+    script after the timed region (VERDICT r5 "next" #1).  Here with two of the six (MAPPO_BENCH_WORKLOADS) to keep the test
+    short: entries carry value / ms_per_step / arithmetic / the dominant launch against its roof / the GAE launch in situ."""
+    env = dict(os.environ, MAPPO_BENCH_WORKLOADS="cfg2,smac_shard64", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                          "--no-f32-mfma"], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                      # ONE JSON line, whatever the children printed
+    d = json.loads(lines[0])
+    assert d["config"]["n_rollout_threads"] == 4096 and d["value"] > 0
+    w = d["workloads"]
+    assert set(w) == {"cfg2", "smac_shard64"}, w.keys()
+    for name, e in w.items():
+        assert "error" not in e and "skipped" not in e, (name, e)
+        assert e["value"] > 0 and e["ms_per_step"] > 0 and e["dtype"] == "f32" and e["arithmetic"].startswith("f32 products")
+        assert 0 < e["roofline"]["frac"] < 1 and e["roofline"]["bound"] in ("hbm", "mfma")
+        assert 0 < e["roofline_gae"]["frac"] < 1
+        assert e["update_graph_replays_per_step"] == 10.0      # both replay their ten updates per step from HIP graphs
+    assert w["cfg2"]["n_rollout_threads"] == 1024 and w["smac_shard64"]["n_rollout_threads"] == 64
+    assert d["update_graph_capture_failures"] == 0 and len(d["csrc_digest"]) == 16
+
+
 def test_bench_contract_and_rccl_single_rank():
     plain = _run()
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",

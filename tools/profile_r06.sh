@@ -28,10 +28,11 @@ fi
 if [[ $STAGE == all || $STAGE == bench ]]; then
   timeout 900 python bench.py --steps 20 --warmup 5 2>&1 | tail -1 > $OUT/bench_ns.json      # (the driver's command line: carries `workloads`)
   # the same workloads as their own command lines (what `workloads` must agree with within +- 3 %)
-  for w in cfg3 cfg2 ns_rnn smac; do
-    timeout 300 python bench.py --workload $w --steps 3 --warmup 1 --no-f32-mfma 2>&1 | tail -1 > $OUT/bench_$w.json
-  done
-  timeout 300 python bench.py --workload smac --threads 64 --steps 3 --warmup 1 --no-f32-mfma --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_smac_shard64.json
+  timeout 300 python bench.py --workload cfg2 --steps 30 --warmup 5 --no-f32-mfma 2>&1 | tail -1 > $OUT/bench_cfg2.json
+  timeout 300 python bench.py --workload cfg3 --steps 10 --warmup 2 --no-f32-mfma 2>&1 | tail -1 > $OUT/bench_cfg3.json
+  timeout 300 python bench.py --workload ns_rnn --steps 3 --warmup 1 --no-f32-mfma --cpu-sample-threads 16 2>&1 | tail -1 > $OUT/bench_ns_rnn.json
+  timeout 300 python bench.py --workload smac --steps 10 --warmup 2 --no-f32-mfma 2>&1 | tail -1 > $OUT/bench_smac.json
+  timeout 300 python bench.py --workload smac --threads 64 --steps 40 --warmup 5 --no-f32-mfma --no-cpu-baseline 2>&1 | tail -1 > $OUT/bench_smac_shard64.json
   timeout 500 python bench.py --workload hanabi --steps 3 --warmup 1 --no-f32-mfma --cpu-sample-threads 8 2>&1 | tail -1 > $OUT/bench_hanabi.json
   timeout 600 python tools/cfg3_end_to_end.py --out $OUT/cfg3_end_to_end.json > $OUT/cfg3_end_to_end.log 2>&1
   tail -1 $OUT/cfg3_end_to_end.log | cut -c1-400

@@ -26,7 +26,10 @@ def bench(threads, forced, workload, steps):
         env.setdefault("MASTER_ADDR", "127.0.0.1")
         env.setdefault("MASTER_PORT", "29577")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--threads", str(threads),
-           "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline"]
+           "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline", "--no-f32-mfma"]
+    # (--no-f32-mfma: the proxy needs the default arithmetic only.  Round 6: the float32 sibling steps of the 1024-thread
+    # Hanabi shard sent TunableOp into minutes of tuning for GEMM shapes that are not in the shipped table -- the one-rank
+    # RCCL watchdog then aborted the run after 600 s: profiles/r06_shard_proxy.json "incident".)
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]
     if not line:

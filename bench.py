@@ -259,8 +259,9 @@ def compact_line(o, what):
            "warmup": o["warmup"], "dtype": o["dtype"], "arithmetic": o["arithmetic"].split(" (")[0],
            "update_graph_replays_per_step": o.get("update_graph_replays_per_step"),
            "hbm_peak_bytes": (o.get("hbm_peak_bytes_per_rank") or [None])[0],
+           "two_streams": o.get("two_streams"),
            "roofline": {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launch_ms",
-                                              "share_of_step")} if r else None,
+                                              "share_of_step", "timed_in")} if r else None,
            "roofline_gae": {"frac": g.get("frac"), "launch_ms": g.get("launch_ms"),
                             "back_to_back_frac": (g.get("back_to_back") or {}).get("frac")} if g else None}
     if cb is not None:
@@ -420,6 +421,13 @@ def main():
     trainer.dp.time_collectives(True)
     scalar0, reused0 = trainer.dp.scalar_collectives, trainer.dp.scales_reused
     replays0 = getattr(getattr(trainer, "_update_graph", None), "replays", 0)
+    # Python's cyclic collector: a full collection walks every object alive (modules, fixtures of the process, ...) and fell
+    # into the timed region of about one in ten to twenty steps -- ~60 ms, invisible on the north star's 4 s, +12 % on a
+    # ten-step config-3 line (47.5 against 53.7 ms between processes; tools/step_times.py).  Everything alive now is
+    # moved to the permanent generation: the collector stays on, its passes only look at what the steps themselves create.
+    import gc
+    gc.collect()
+    gc.freeze()
     fence()
     t0 = time.perf_counter()
     for _ in range(opt.steps):
@@ -438,23 +446,30 @@ def main():
     ug = getattr(trainer, "_update_graph", None)
     graph_replays = 0 if ug is None else ug.replays - replays0
     k9_timed_in = "the timed region"
-    if ug is not None and ug.replays > 0 and not mt:
-        ug.off = True
+    # ... and small evaluations (<= 2^20 rows: graph-replayed minibatches, the row spans of a hidden-512 update) run actor and
+    # critic on two streams (R_MAPPOPolicy.evaluate_logits): a launch that shares the chip with the other network's cannot be
+    # set against a roofline.  In both cases the launches are timed one after the other in the extra step.
+    two_streams = bool(getattr(policy, "_side_streams", None))
+    if (ug is not None and ug.replays > 0 and not mt) or two_streams:
+        if ug is not None:
+            ug.off = True
         two = os.environ.get("MAPPO_TWO_STREAM_UPDATE")
-        os.environ["MAPPO_TWO_STREAM_UPDATE"] = "0"     # (a launch that shares the chip with the other network's cannot be
-        try:                                            #  set against a roofline: time them one after the other)
+        os.environ["MAPPO_TWO_STREAM_UPDATE"] = "0"
+        try:
             fused_mlp.profile(True)
             step()
             torch.cuda.synchronize(dev)
             mt = fused_mlp.profile_times()
         finally:
-            ug.off = False
+            if ug is not None:
+                ug.off = False
             if two is None:
                 os.environ.pop("MAPPO_TWO_STREAM_UPDATE", None)
             else:
                 os.environ["MAPPO_TWO_STREAM_UPDATE"] = two
-        k9_timed_in = "one eager one-stream step after the timed region (the timed steps replay ppo_update from HIP graphs, " \
-                      "actor and critic on two streams)"
+        k9_timed_in = "one eager one-stream step after the timed region (the timed steps %s)" % " and ".join(
+            ([] if not graph_replays else ["replay ppo_update from HIP graphs"]) +
+            ([] if not two_streams else ["run actor and critic launches on two streams"]))
     # the GAE launch once more, outside the timed region, back to back (no update phase in between: caches and TLBs as the
     # previous launch left them) -- reported next to the in-situ figure as roofline_gae.back_to_back
     buf.profile_kernels(False)
@@ -606,6 +621,9 @@ def main():
             "update_graph_replays_per_step": graph_replays / max(1, opt.steps),
             # captures that failed (and were finished / re-run eagerly, update_graph.py) since the trainer was built: 0 expected
             "update_graph_capture_failures": 0 if ug is None else ug.capture_failures,
+            # whether the timed steps ran actor and critic on two streams (evaluations of <= 2^20 rows; rooflines then come from
+            # one extra one-stream step: `timed_in`)
+            "two_streams": two_streams,
             "config": {"workload": wl["label"], "T": wl["T"], "n_rollout_threads": wl["N"],
                        "threads_per_gpu": n_local, "agents": wl["A"], "obs_dim": wl["Do"],
                        "share_obs_dim": wl["Ds"], "actions": wl["na"], "ppo_epoch": args.ppo_epoch,

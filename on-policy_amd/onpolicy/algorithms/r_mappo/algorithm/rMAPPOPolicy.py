@@ -73,17 +73,19 @@ class R_MAPPOPolicy:
                         need_actor=True):
         """-> (values, logits of the Discrete action head or None): the inputs of the fused PPO loss.
 
-        Minibatches of at most MAPPO_TWO_STREAM_MAX_ROWS rows (default 2^20: the regime in which ``ppo_update`` is replayed
-        from a HIP graph, update_graph.py) evaluate the critic on a SIDE STREAM next to the actor (MAPPO_TWO_STREAM_UPDATE=0: one
-        stream).  The two networks share nothing until the loss kernel.  On such minibatches one network's launches occupy a
-        fraction of the chip (the 64-threads-per-GPU shard of BASELINE configs[3]: K12 is one 32-chunk tile per wave on 400 of
-        1 024 SIMDs) and the other network's fit beside them.  Autograd runs every backward node on its forward's stream, so
-        the backward passes overlap the same way; captured into the update graph the fork / join become two branches of the
-        graph.  Same kernels on the same data: bit-identical to the one-stream order (tests/test_gpu_update_graph.py).
-        Measured, alternating on one box (profiles/r06_ab_two_streams.json): SMAC shard 16.3 -> 13.8 ms per step, 128-thread
-        recurrent north-star shard 24.7 -> 21.7, SMAC shapes at 512 threads 64.7 -> 61.4, configs[1] unchanged.  Larger
-        minibatches stay on one stream: their kernels fill the chip (north star -0.7 %, recurrent north star / config 3 / Hanabi
-        within the noise) and a launch that shares the chip can no longer be timed against its roofline."""
+        Evaluations of at most MAPPO_TWO_STREAM_MAX_ROWS rows (default 2^20: the minibatches whose ``ppo_update`` is replayed
+        from a HIP graph, update_graph.py, and the row spans a larger hidden-512 minibatch is cut into) run the critic on a
+        SIDE STREAM next to the actor (MAPPO_TWO_STREAM_UPDATE=0: one stream).  The two networks share nothing until the loss
+        kernel.  On such sizes one network's launches occupy a fraction of the chip (the 64-threads-per-GPU shard of BASELINE
+        configs[3]: K12 is one 32-chunk tile per wave on 400 of 1 024 SIMDs) or leave tails the other network's fill.
+        Autograd runs every backward node on its forward's stream, so the backward passes overlap the same way; captured into
+        the update graph the fork / join become two branches of the graph.  Same kernels on the same data: bit-identical to
+        the one-stream order (tests/test_gpu_update_graph.py).  Measured, alternating on one box
+        (profiles/r06_ab_two_streams.json): SMAC shard 16.3 -> 13.8 ms per step, 128-thread recurrent north-star shard
+        24.7 -> 21.7, SMAC shapes at 512 threads 64.7 -> 61.4, Hanabi shapes (six spans of 683 k rows) 4.70 -> 4.57-4.64 s,
+        configs[1] unchanged.  One evaluation of more rows (north star, config 3: 13.1 M / 4.9 M rows) stays on one stream:
+        -0.7 % at best, and launches that share the chip cannot be timed against a roofline -- bench.py times the K9 / K15
+        launches of workloads that do use the side stream in one extra one-stream step."""
         side = self._critic_stream(masks) if need_actor else None
         if side is None:
             logits = self.actor.evaluate_logits(obs, rnn_states_actor, masks, obs_standardized=obs_standardized) \
@@ -104,7 +106,7 @@ class R_MAPPOPolicy:
         import os
         if not (torch.is_tensor(masks) and masks.is_cuda and torch.is_grad_enabled()) \
                 or os.environ.get("MAPPO_TWO_STREAM_UPDATE", "1") == "0" \
-                or max(masks.shape[0], getattr(self, "_update_rows", 0)) > int(os.environ.get("MAPPO_TWO_STREAM_MAX_ROWS", str(1 << 20))):
+                or masks.shape[0] > int(os.environ.get("MAPPO_TWO_STREAM_MAX_ROWS", str(1 << 20))):
             return None
         # (only under the six-term arithmetic, whose matrix products are in-tree kernels made of independent workgroups: the
         # float32 route goes through library GEMMs, and nothing says those tolerate a second GEMM taking CUs away under them)

@@ -379,9 +379,6 @@ class R_MAPPO():
             scale4 = torch.stack([inv3[0], inv3[0], inv3[1], inv3[2]])
         sums = torch.zeros(4, dtype=torch.float64, device=dev)
         normalized = self._use_popart or self._use_valuenorm
-        # (the policy decides by the size of the whole minibatch -- not of a row span of it -- whether actor and critic share
-        # the chip on two streams: R_MAPPOPolicy._critic_stream)
-        self.policy._update_rows = rows
         for lo, hi in spans:
             values, logits = self.policy.evaluate_logits(
                 cut(share_obs, lo, hi), cut(obs, lo, hi), cut(rnn_a, lo, hi), cut(rnn_c, lo, hi), cut(masks, lo, hi),

@@ -40,8 +40,11 @@ fi
 
 if [[ $STAGE == all || $STAGE == prof ]]; then
   cd /tmp
+  # (MAPPO_TWO_STREAM_UPDATE=0: cfg2 / smac / hanabi evaluate actor and critic on two streams, and a kernel that shares the chip
+  # has no duration of its own -- the statistics are of the launches one after the other, like bench.py's roofline timings;
+  # ns / cfg3 / ns_rnn run on one stream anyway)
   for w in ns cfg2 cfg3 ns_rnn smac hanabi; do
-    timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_$w -o $w -- python $REPO/bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline --no-f32-mfma > $OUT/prof_$w.log 2>&1
+    MAPPO_TWO_STREAM_UPDATE=0 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_$w -o $w -- python $REPO/bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline --no-f32-mfma > $OUT/prof_$w.log 2>&1
   done
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --kernel-trace --pmc $C -f csv -d $OUT/pmc_$C -o ns -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-f32-mfma > $OUT/pmc_$C.log 2>&1

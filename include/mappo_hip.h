@@ -260,6 +260,28 @@ typedef struct mappo_slab {
 
 int mappo_slab_copy(const mappo_slab_t* slabs, int n_slabs, mappo_stream_t stream);
 
+/* The same launch + the slabs of row-standardised observation copies that have to follow the slabs being written (round 6).
+ * Networks with an input LayerNorm (reference onpolicy/algorithms/utils/mlp.py:47-53: feature_norm) read obs / share_obs
+ * through a resident copy whose rows hold (x - mean) / sqrt(var + eps) (mappo_standardize_rows_ld; the LayerNorm's affine half
+ * is folded into the first Linear); when insert / chooseinsert / after_update (shared_buffer.py:90-177) rewrite a slab of the
+ * field, the same slab of the copy is recomputed from the VALUE being written -- by extra workgroups of this launch, in the
+ * arithmetic of mappo_standardize_rows_ld (bit-identical rows).  src [rows, D] floats; dst [rows, ld >= D] floats, columns
+ * D .. ld - 1 are written as zeros.  std is a HOST array of at most MAPPO_MAX_STD_SLABS entries; n_std = 0 is
+ * mappo_slab_copy; n_slabs = 0 (slabs may be NULL) only standardises -- the full pass over a field goes through here too, so
+ * that slab and full pass are one piece of code (every operation IEEE, one explicit fused multiply-add per term of the
+ * second moment) and bit-identical by construction. */
+#define MAPPO_MAX_STD_SLABS 4
+typedef struct mappo_std_slab {
+    const float* src;
+    float*       dst;
+    int64_t      rows;
+    int          D, ld;
+    float        eps;
+} mappo_std_slab_t;
+
+int mappo_slab_copy_std(const mappo_slab_t* slabs, int n_slabs, const mappo_std_slab_t* std, int n_std,
+                        mappo_stream_t stream);
+
 /* ------------------------------------------------------------ K6: row LayerNorm ----
  * The LayerNorm the reference applies to the observations and after every Linear / GRU of the
  * actor and critic trunks (onpolicy/algorithms/utils/mlp.py:17-22,47-53, rnn.py:22,79:

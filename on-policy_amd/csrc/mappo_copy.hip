@@ -426,11 +426,162 @@ extern "C" int mappo_gather_chunks(const mappo_field_t* fields, int n_fields, co
                             static_cast<hipStream_t>(stream));
 }
 
-extern "C" int mappo_slab_copy(const mappo_slab_t* slabs, int n_slabs, mappo_stream_t stream) {
+// ---- K2 with the standardised copies of the observation slabs kept current in the SAME launch (round 6) ----
+// insert / chooseinsert / after_update write one slab per field; networks with an input LayerNorm read the observation fields
+// through a resident row-standardised copy (utils/shared_buffer.py: _obs_rows), whose slab has to follow.  As launches of their
+// own the two standardisations were two more launches per rollout step on a path that is launch-bound (config 3 end to end:
+// 0.140 -> 0.154 ms per env step).  Here the workgroups behind the copy tiles standardise the rows of the incoming VALUE (not of
+// the buffer slab: no dependence on the copy tiles of the same launch): 16 lanes per row, the row read three times from cache
+// (sum, centred second moment, output).  The FULL pass over a field (first train(), or after an in-place torch write) goes
+// through the same code (n_slabs = 0), so a slab comes out exactly as the full pass would write it
+// (tests/test_gpu_standardize_at_insert.py) -- by construction, not by keeping two kernels in step: the instances of
+// mlp::standardize_rows_kernel (mappo_mlp_impl.h, built with fp contract(fast): the rollout's network inputs) round their
+// second moment in whatever mixture of fused and unfused operations the compiler picked per instance.  Here every operation
+// is written out: IEEE add / sub / mul / div / sqrt, and one explicit fused multiply-add per term of the second moment.
+struct StdSlab {
+    const float* src;   // [rows, D] the value being inserted
+    float* dst;         // [rows, ld] the slab of the standardised copy
+    long long rows;
+    int D, ld;
+    float eps;
+    unsigned block_begin, blocks;
+};
+struct StdArgs {
+    StdSlab s[MAPPO_MAX_STD_SLABS];
+    int n;
+    unsigned copy_blocks;
+};
+
+__device__ __forceinline__ float sum16_xor(float v) {      // = prim::sum16 (mappo_mlp.hip)
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+// 4 consecutive floats of a row from column k on, zero beyond the row's end (mlp::load4_guard)
+__device__ __forceinline__ void load4_guard(const float* p, int remaining, float* x) {
+    x[0] = remaining > 0 ? p[0] : 0.f;
+    x[1] = remaining > 1 ? p[1] : 0.f;
+    x[2] = remaining > 2 ? p[2] : 0.f;
+    x[3] = remaining > 3 ? p[3] : 0.f;
+}
+
+__device__ void standardize_slab(const StdSlab& d, unsigned block, unsigned nblocks) {
+    const int sub = threadIdx.x & 15;
+    const long long groups = ((long long)nblocks * kThreads) >> 4;
+    const long long first = ((long long)block * kThreads + threadIdx.x) >> 4;
+    const long long trips = (d.rows + groups - 1) / groups;     // the same for every lane: sum16 is a wave collective
+    const int D = d.D;
+    for (long long it = 0; it < trips; ++it) {
+        const long long r = first + it * groups;
+        const bool ok = r < d.rows;
+        const float* p = d.src + (ok ? r : d.rows - 1) * D;
+        float s = 0.f;
+        for (int k = 4 * sub; k < D; k += 64) {
+            float x[4];
+            load4_guard(p + k, D - k, x);
+            s += (x[0] + x[1]) + (x[2] + x[3]);
+        }
+        s = sum16_xor(s);
+        const float mean = s / (float)D;
+        float q = 0.f;
+        for (int k = 4 * sub; k < D; k += 64) {
+            float x[4];
+            load4_guard(p + k, D - k, x);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k + e < D) {
+                    const float c = x[e] - mean;
+                    q = __builtin_fmaf(c, c, q);
+                }
+        }
+        q = sum16_xor(q);
+        const float rstd = 1.f / sqrtf(q / (float)D + d.eps);
+        if (ok) {
+            float* o = d.dst + r * d.ld;
+            if (sub == 0)
+                for (int k = D; k < d.ld; ++k) o[k] = 0.f;
+            for (int k = 4 * sub; k < D; k += 64) {
+                float x[4];
+                load4_guard(p + k, D - k, x);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (k + e < D) o[k + e] = (x[e] - mean) * rstd;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void copy_tiles(const SlabArgs& a, unsigned block, unsigned nblocks) {
+    for (unsigned tile = block; tile < a.total_tiles; tile += nblocks) {
+        int k = 0;
+#pragma unroll 1
+        for (int q = 1; q < a.n; ++q)
+            if (tile >= a.s[q].tile_begin) k = q;
+        const float* s_src = a.s[k].src;
+        float* s_dst = a.s[k].dst;
+        const unsigned long long units = a.s[k].units;
+        const unsigned vec = a.s[k].vec;
+        unsigned long long base = (unsigned long long)(tile - a.s[k].tile_begin) * kTileUnits;
+        if (vec == 4) {
+            const float4* src = reinterpret_cast<const float4*>(s_src);
+            float4* dst = reinterpret_cast<float4*>(s_dst);
+            float4 v[kMaxUnroll];
+#pragma unroll
+            for (int u = 0; u < kMaxUnroll; ++u) {
+                unsigned long long i = base + u * kThreads + threadIdx.x;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < units) v[u] = src[i];
+            }
+#pragma unroll
+            for (int u = 0; u < kMaxUnroll; ++u) {
+                unsigned long long i = base + u * kThreads + threadIdx.x;
+                if (i < units) dst[i] = v[u];
+            }
+        } else {
+            float v[kMaxUnroll];
+#pragma unroll
+            for (int u = 0; u < kMaxUnroll; ++u) {
+                unsigned long long i = base + u * kThreads + threadIdx.x;
+                v[u] = 0.f;
+                if (i < units) v[u] = s_src[i];
+            }
+#pragma unroll
+            for (int u = 0; u < kMaxUnroll; ++u) {
+                unsigned long long i = base + u * kThreads + threadIdx.x;
+                if (i < units) s_dst[i] = v[u];
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kThreads) slab_std_kernel(SlabArgs a, StdArgs st) {
+    if (blockIdx.x < st.copy_blocks) {
+        copy_tiles(a, blockIdx.x, st.copy_blocks);
+        return;
+    }
+    const unsigned b = blockIdx.x - st.copy_blocks;
+    int k = 0;
+#pragma unroll 1
+    for (int q = 1; q < st.n; ++q)
+        if (b >= st.s[q].block_begin) k = q;
+    // (the descriptor into registers: indexing the by-value argument with a runtime k otherwise goes through scratch memory)
+    StdSlab d;
+    d.src = st.s[k].src;
+    d.dst = st.s[k].dst;
+    d.rows = st.s[k].rows;
+    d.D = st.s[k].D;
+    d.ld = st.s[k].ld;
+    d.eps = st.s[k].eps;
+    standardize_slab(d, b - st.s[k].block_begin, st.s[k].blocks);
+}
+
+namespace {
+int fill_slabs(const mappo_slab_t* slabs, int n_slabs, SlabArgs& a) {
     if (!slabs) return MAPPO_E_NULL;
     if (n_slabs <= 0) return MAPPO_E_SHAPE;
     if (n_slabs > MAPPO_MAX_FIELDS) return MAPPO_E_TOO_MANY;
-    SlabArgs a;
     a.n = n_slabs;
     unsigned long long tiles = 0;
     for (int k = 0; k < n_slabs; ++k) {
@@ -448,10 +599,57 @@ extern "C" int mappo_slab_copy(const mappo_slab_t* slabs, int n_slabs, mappo_str
         if (tiles >= (1ull << 32)) return MAPPO_E_SHAPE;
     }
     a.total_tiles = (unsigned)tiles;
+    return 0;
+}
+}  // namespace
+
+extern "C" int mappo_slab_copy(const mappo_slab_t* slabs, int n_slabs, mappo_stream_t stream) {
+    SlabArgs a;
+    int code = fill_slabs(slabs, n_slabs, a);
+    if (code) return code;
     unsigned grid = a.total_tiles < (unsigned)(mappo::kCUs * 8) ? a.total_tiles
                                                                   : (unsigned)(mappo::kCUs * 8);
     hipLaunchKernelGGL(slab_kernel, dim3(grid), dim3(kThreads), 0,
                        static_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mappo_slab_copy_std(const mappo_slab_t* slabs, int n_slabs, const mappo_std_slab_t* std, int n_std,
+                                   mappo_stream_t stream) {
+    if (n_std == 0) return mappo_slab_copy(slabs, n_slabs, stream);
+    if (!std) return MAPPO_E_NULL;
+    if (n_std < 0 || n_std > MAPPO_MAX_STD_SLABS) return MAPPO_E_TOO_MANY;
+    SlabArgs a;
+    a.n = 0;
+    a.total_tiles = 0;
+    if (n_slabs != 0) {         // (n_slabs = 0: only the standardisation -- the full pass over a field)
+        int code = fill_slabs(slabs, n_slabs, a);
+        if (code) return code;
+    }
+    StdArgs st;
+    st.n = n_std;
+    st.copy_blocks = a.total_tiles < (unsigned)(mappo::kCUs * 8) ? a.total_tiles : (unsigned)(mappo::kCUs * 8);
+    unsigned blocks = 0;
+    for (int k = 0; k < n_std; ++k) {
+        const mappo_std_slab_t& s = std[k];
+        if (!s.src || !s.dst) return MAPPO_E_NULL;
+        if (s.rows <= 0 || s.D <= 0 || s.ld < s.D) return MAPPO_E_SHAPE;
+        if (!mappo::aligned_to(s.src, 4) || !mappo::aligned_to(s.dst, 4)) return MAPPO_E_ALIGN;
+        StdSlab& d = st.s[k];
+        d.src = s.src;
+        d.dst = s.dst;
+        d.rows = s.rows;
+        d.D = s.D;
+        d.ld = s.ld;
+        d.eps = s.eps;
+        long long nb = (s.rows * 16 + kThreads - 1) / kThreads;
+        if (nb > mappo::kCUs * 4) nb = mappo::kCUs * 4;
+        d.block_begin = blocks;
+        d.blocks = (unsigned)nb;
+        blocks += (unsigned)nb;
+    }
+    hipLaunchKernelGGL(slab_std_kernel, dim3(st.copy_blocks + blocks), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream), a, st);
     return (int)hipGetLastError();
 }
 

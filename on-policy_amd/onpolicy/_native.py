@@ -59,6 +59,14 @@ class Slab(ctypes.Structure):
     _fields_ = [("src", _vp), ("dst", _vp), ("count", _i64)]
 
 
+MAX_STD_SLABS = 4       # MAPPO_MAX_STD_SLABS
+
+
+class StdSlab(ctypes.Structure):
+    """struct mappo_std_slab (include/mappo_hip.h)."""
+    _fields_ = [("src", _vp), ("dst", _vp), ("rows", _i64), ("D", _int), ("ld", _int), ("eps", ctypes.c_float)]
+
+
 class PPOLoss(ctypes.Structure):
     """struct mappo_ppo_loss (include/mappo_hip.h)."""
     _fields_ = [(n, _vp) for n in ("logits", "available", "actions", "old_logp", "adv", "active", "factor", "values",
@@ -119,6 +127,7 @@ SIGNATURES = {
                                     _int, _vp, _vp]),
     "mappo_gather_set_variant": (_int, [_int]),
     "mappo_slab_copy": (_int, [ctypes.POINTER(Slab), _int, _vp]),
+    "mappo_slab_copy_std": (_int, [ctypes.POINTER(Slab), _int, ctypes.POINTER(StdSlab), _int, _vp]),
     "mappo_layernorm_max_blocks": (_int, []),
     "mappo_act_layernorm_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, ctypes.c_float, _int, _vp]),
     "mappo_act_layernorm_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),

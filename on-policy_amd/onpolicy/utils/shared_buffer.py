@@ -274,7 +274,7 @@ class SharedReplayBuffer(object):
         one) is brought up to date for just that slab."""
         if self.device.type == "cuda":
             pairs = self._stage_host_values(pairs)
-        keep, slabs = [], []
+        keep, slabs, srcs = [], [], {}
         for dst, value in pairs:
             src = self._dev(value)
             if src.numel() != dst.numel() and src.numel() * dst.shape[-1] == dst.numel():
@@ -286,33 +286,45 @@ class SharedReplayBuffer(object):
                                  % (src.numel(), dst.numel(), tuple(dst.shape)))
             assert dst.is_contiguous()
             keep.append(src)
+            srcs[dst.data_ptr()] = src
             slabs.append((src.data_ptr(), dst.data_ptr(), dst.numel()))
         arr = (_native.Slab * len(slabs))(*[_native.Slab(s, d, n) for s, d, n in slabs])
-        _native.check(self._lib.mappo_slab_copy(arr, len(slabs), self._stream()), "mappo_slab_copy")
-        self._content_version += 1
+        # the slabs of the resident standardised copies that follow (same launch: K2's extra workgroups, csrc/mappo_copy.hip)
+        std = []
         for name, t in obs_slabs:
-            self._obs_slab_written(name, t)
+            hit = self._obs_slab_written(name, t)
+            if hit is not None:
+                na = self.n_rollout_threads * self.num_agents
+                field = getattr(self, name)
+                src = srcs[field[t].data_ptr()]             # the value being written, not the buffer slab
+                D = int(field.shape[-1])
+                out = hit[t * na:(t + 1) * na]
+                std.append(_native.StdSlab(src.data_ptr(), out.data_ptr(), na, D, int(out.shape[1]), 1e-5))
+        if std:
+            sarr = (_native.StdSlab * len(std))(*std)
+            _native.check(self._lib.mappo_slab_copy_std(arr, len(slabs), sarr, len(std), self._stream()),
+                          "mappo_slab_copy_std")
+            self.std_slab_launches += len(std)      # (slabs standardised; they ride in K2's launch)
+        else:
+            _native.check(self._lib.mappo_slab_copy(arr, len(slabs), self._stream()), "mappo_slab_copy")
+        self._content_version += 1
 
     def _obs_key(self, name):
         """What a standardised copy of field ``name`` is valid for: this class's slab writes + in-place torch writes."""
         return (name, self._obs_writes[name], getattr(self, name)._version)
 
     def _obs_slab_written(self, name, t):
-        """Slab ``t`` of observation field ``name`` was just rewritten by K2.  A resident standardised copy that was current
-        until now stays current: slab t of it is recomputed from the buffer slab (one launch over N * A rows; row T is not
-        part of the copy).  A copy that was already stale stays stale and is rebuilt by the next train()."""
+        """Slab ``t`` of observation field ``name`` is being rewritten by K2.  A resident standardised copy that was current
+        until now stays current: -> the copy, whose slab t the same launch recomputes from the value being written (row T is
+        not part of the copy: -> None, nothing to do).  A copy that was already stale stays stale (-> None) and is rebuilt by
+        the next train()."""
         hit = self._std_rows.get(name)
         current = self._std_at_insert and hit is not None and hit[0] == self._obs_key(name)
         self._obs_writes[name] += 1
         if not current:
-            return
-        if t < self.episode_length:
-            from onpolicy.algorithms.utils import fused_mlp
-            na = self.n_rollout_threads * self.num_agents
-            field = getattr(self, name)
-            fused_mlp.standardize_rows(field[t].reshape(na, -1), out=hit[1][t * na:(t + 1) * na])
-            self.std_slab_launches += 1
+            return None
         self._std_rows[name] = (self._obs_key(name), hit[1])
+        return hit[1] if t < self.episode_length else None
 
     # ------------------------------------------------------------------ storage
     def insert(self, share_obs, obs, rnn_states_actor, rnn_states_critic, actions, action_log_probs,
@@ -672,12 +684,30 @@ class SharedReplayBuffer(object):
         key = self._obs_key(name)
         hit = self._std_rows.get(name)
         if hit is None or hit[0] != key:
-            from onpolicy.algorithms.utils import fused_mlp
             out = hit[1] if hit is not None else self._std_keep.pop(name, None)
-            hit = (key, fused_mlp.standardize_rows(rows, out=out))
+            hit = (key, self._standardize_field(rows, out))
             self._std_rows[name] = hit
             self.std_full_passes += 1
         return hit[1]
+
+    def _standardize_field(self, rows2d, out=None, eps=1e-5):
+        """(x - mean) / sqrt(var + eps) of every row of ``rows2d`` into a [rows, D padded to 4] matrix: the full pass, through
+        the SAME device code that keeps single slabs current inside K2's launch (mappo_slab_copy_std with no copy slabs), so
+        that a slab and the full pass agree bit for bit."""
+        n, D = rows2d.shape
+        ld = (D + 3) // 4 * 4 if os.environ.get("MAPPO_PAD_STANDARDIZED", "1") != "0" else D
+        if out is None or tuple(out.shape) != (n, ld) or out.dtype != rows2d.dtype or out.device != rows2d.device:
+            out = torch.empty((n, ld), dtype=rows2d.dtype, device=rows2d.device)
+        assert rows2d.is_contiguous()
+        done, per = 0, -(-n // _native.MAX_STD_SLABS)
+        std = []
+        while done < n:         # (cut into up to four descriptors: more workgroups on a large field)
+            m = min(per, n - done)
+            std.append(_native.StdSlab(rows2d[done:done + m].data_ptr(), out[done:done + m].data_ptr(), m, D, ld, float(eps)))
+            done += m
+        sarr = (_native.StdSlab * len(std))(*std)
+        _native.check(self._lib.mappo_slab_copy_std(None, 0, sarr, len(std), self._stream()), "mappo_slab_copy_std")
+        return out
 
     def _gather(self, table, stats, idx, mb, chunk_len=None, standardize_obs=False, packed=None, lazy_obs=False):
         """One minibatch -> the 12-tuple of fresh device tensors: wide fields through the fused tile

@@ -19,7 +19,10 @@ import cfg_shapes as C
 #       train_info 3.9e-7 relative, weights 7.4e-7 absolute, last gradients 4.2e-5 of the tensor's largest entry, ValueNorm 1.2e-7
 #   hidden 512 (cfg5_shape through the library GEMMs and through K15): 4.6e-6, 1.6e-6, 2.1e-4, 1.1e-7
 # Until round 6 every trainer test asserted 1e-3 / 5e-5 / 1e-3 (30-2500 x the measured values).
-TOL = {"info_rel": 1.5e-6, "info_abs": 1e-7, "weight_abs": 2.5e-6, "weight_rtol": 1e-5, "grad_rel": 1.5e-4, "norm_rtol": 5e-7}
+# (Second measurement, same round: the standardised observation copies moved to another kernel with the same accuracy against
+# float64 -- inputs that differ in the last bit of 4 % of their elements.  train_info's worst case went from 3.9e-7 to 2.2e-6
+# (critic_grad_norm of mid_ns after two epochs): that sensitivity, not the first run's luck, is what the margin has to cover.)
+TOL = {"info_rel": 7e-6, "info_abs": 1e-7, "weight_abs": 2.5e-6, "weight_rtol": 1e-5, "grad_rel": 1.5e-4, "norm_rtol": 5e-7}
 # (hidden 512: the library route's GEMM kernels are picked per box by TunableOp, so the margin is 5 x, not 3 x)
 TOL_H512 = {"info_rel": 2.5e-5, "info_abs": 1e-7, "weight_abs": 8e-6, "weight_rtol": 1e-5, "grad_rel": 1e-3, "norm_rtol": 5e-7}
 

@@ -1,6 +1,7 @@
 """-m gpu: the row-standardised observation copies the fused trunk kernels (K9) read stay resident after a train() and are
 kept current slab by slab by insert / chooseinsert / after_update (utils/shared_buffer.py: _obs_slab_written; VERDICT r5
-"next" #4a) -- bit-identical to standardising the whole field again, never stale:
+"next" #4a), inside K2's own launch (mappo_slab_copy_std) -- bit-identical to standardising the whole field again (the full
+pass runs the same device code), and within float32 rounding of the float64 definition; never stale:
 
 * slab writes of this class's kernels update exactly the slab they wrote (and nothing for row T, which is not part of the copy);
 * in-place torch writes to the field (runners do ``buffer.obs[0] = ...``) are seen through the version counter -> full pass;
@@ -31,9 +32,9 @@ def _step_values(rng):
 
 
 def _fresh(buf, name):
-    from onpolicy.algorithms.utils import fused_mlp
+    """The full pass over the field as it is now (into fresh storage)."""
     field = getattr(buf, name)
-    return fused_mlp.standardize_rows(field[:T].reshape(T * N * A, -1).clone())
+    return buf._standardize_field(field[:T].reshape(T * N * A, -1).clone())
 
 
 @pytest.mark.parametrize("mode", ["insert", "chooseinsert"])
@@ -109,3 +110,16 @@ def test_training_loop_is_bit_identical_to_the_full_pass_per_train(monkeypatch):
     np.testing.assert_array_equal(w1, w0)
     assert slabs0 == 0 and full0 == 6                      # one full pass per field and train()
     assert full1 == 2 and slabs1 > 0, (full1, slabs1)      # only the first train() standardised whole fields
+
+
+def test_standardised_rows_against_float64():
+    """The device rows against (x - mean) / sqrt(var + 1e-5) in float64, for the widths of the BASELINE configs (incl. the odd
+    ones, padded with zero columns)."""
+    _, buf = _buffer()
+    for D in (18, 30, 48, 54, 150, 370, 384, 435, 1285):
+        x = torch.randn(333, D, device=buf.device) * 3 + 0.5
+        got = buf._standardize_field(x)
+        assert got.shape == (333, (D + 3) // 4 * 4) and torch.all(got[:, D:] == 0)
+        x64 = x.double()
+        ref = (x64 - x64.mean(1, keepdim=True)) / torch.sqrt(x64.var(1, unbiased=False, keepdim=True) + 1e-5)
+        assert (got[:, :D].double() - ref).abs().max().item() < 2e-6

@@ -21,10 +21,13 @@ import cfg_shapes as C
 # Until round 6 every trainer test asserted 1e-3 / 5e-5 / 1e-3 (30-2500 x the measured values).
 # (Second measurement, same round: the standardised observation copies moved to another kernel with the same accuracy against
 # float64 -- inputs that differ in the last bit of 4 % of their elements.  train_info's worst case went from 3.9e-7 to 2.2e-6
-# (critic_grad_norm of mid_ns after two epochs): that sensitivity, not the first run's luck, is what the margin has to cover.)
-TOL = {"info_rel": 7e-6, "info_abs": 1e-7, "weight_abs": 2.5e-6, "weight_rtol": 1e-5, "grad_rel": 1.5e-4, "norm_rtol": 5e-7}
+# (critic_grad_norm of mid_ns after two epochs), and twelve of the 384 entries of the critic's feature_norm.bias of mid_ns moved
+# by up to 1.0e-5: their gradients are at noise level, and Adam divides a gradient by its own running magnitude -- a parameter
+# whose gradient is noise takes a step of noise / |noise| x lr.  That sensitivity, not the first run's luck, is what the margins
+# have to cover: weights 3e-5 absolute (4 % of an Adam step; the 5e-5 of rounds 1-5 was not as loose as it looked).)
+TOL = {"info_rel": 7e-6, "info_abs": 1e-7, "weight_abs": 3e-5, "weight_rtol": 1e-5, "grad_rel": 1.5e-4, "norm_rtol": 5e-7}
 # (hidden 512: the library route's GEMM kernels are picked per box by TunableOp, so the margin is 5 x, not 3 x)
-TOL_H512 = {"info_rel": 2.5e-5, "info_abs": 1e-7, "weight_abs": 8e-6, "weight_rtol": 1e-5, "grad_rel": 1e-3, "norm_rtol": 5e-7}
+TOL_H512 = {"info_rel": 2.5e-5, "info_abs": 1e-7, "weight_abs": 3e-5, "weight_rtol": 1e-5, "grad_rel": 1e-3, "norm_rtol": 5e-7}
 
 def compare_update(z, key, meta, policy, trainer, info, tol=None):
     """Asserts every quantity against the fixture -> {quantity: deviation} (for the ``margins`` record)."""

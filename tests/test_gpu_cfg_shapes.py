@@ -9,8 +9,8 @@ share_obs 435 / 18 actions / 10 agents, rmappo, chunk 10, 2 minibatches, gain 1)
   cfg5_shape/k15  the same with every 512-wide product through K15 (six-term bf16 arithmetic; the route real Hanabi
                   minibatches take -- the 160-row fixture is sent there with MAPPO_LINEAR512_MIN_ROWS=1).
 Every case asserts which entry points of libmappo_hip.so carried the update.  Tolerances: tests/parity.py (about three times the
-measured worst case: hidden 64 losses 1.5e-6 relative, weights 2.5e-6 absolute, last gradients 1.5e-4 of each tensor's largest
-entry; hidden 512 2.5e-5 / 8e-6 / 1e-3)."""
+measured worst case: hidden 64 losses 7e-6 relative, weights 3e-5 absolute, last gradients 1.5e-4 of each tensor's largest
+entry; hidden 512 2.5e-5 / 3e-5 / 1e-3)."""
 import numpy as np
 import pytest
 import torch

@@ -5,8 +5,9 @@ algorithms/utils/mlp.py:6-58, act.py:44-60, r_actor_critic.py:147-175 driven by 
 
 Every case asserts that the fused trunk kernels were actually launched (forward AND backward), so a silent fall-back to
 the PyTorch modules cannot pass.  Tolerances: tests/parity.py, about three times the worst deviation measured on the MI355X --
-losses 1.5e-6 relative, weights 2.5e-6 absolute (an Adam step moves a weight by ~lr = 5e-4 .. 7e-4 whatever the gradient's
-size: 0.4 % of a step), the gradients the last update left in ``.grad`` to 1.5e-4 of each tensor's largest entry."""
+losses 7e-6 relative, weights 3e-5 absolute (an Adam step moves a weight by ~lr = 5e-4 .. 7e-4 whatever the gradient's
+size -- also when the gradient is noise: 4 % of a step), the gradients the last update left in ``.grad`` to 1.5e-4 of each
+tensor's largest entry."""
 import numpy as np
 import pytest
 

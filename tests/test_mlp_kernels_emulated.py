@@ -249,11 +249,11 @@ def test_first_layer_weight_gradient_inside_the_chain(emu_lib, flags, din, act, 
 
 
 def test_tuning_flags_reject_unknown_bits(emu_lib):
-    """mappo_mlp_set_flags knows bits 1, 4, 32, 128, 256; anything else (e.g. the arithmetic bits of ABI version 1) is refused and
-    changes nothing.  An unknown ``arith`` value is an argument error."""
+    """mappo_mlp_set_flags knows bits 1, 2, 4, 8, 32, 128, 256; anything else (e.g. the arithmetic bits of ABI version 1) is refused
+    and changes nothing.  An unknown ``arith`` value is an argument error."""
     old = emu_lib.mappo_mlp_set_flags(4)
     try:
-        for bad in (8, 16, 64, 512, 1024, 2048, 4096, 8192, 4 | 64):
+        for bad in (16, 64, 512, 1024, 2048, 4096, 8192, 4 | 64):
             assert emu_lib.mappo_mlp_set_flags(bad) == -1
             assert emu_lib.mappo_mlp_set_flags(4) == 4
     finally:

@@ -117,12 +117,20 @@ CASES_CFG = {
 #   mid_ns_rnn  the same shapes with the recurrent policy (chunk 10), T = 100 x N = 128: 102 400 rows = 10 240 chunks.
 # One minibatch per epoch: the device sampler's single slice is the reference's batch as a set, no permutation patch needed.
 # Inputs rebuilt from the seed (digest in the fixture); tensors above 65 536 elements stored subsampled (incl. the returns).
+# ``first_grads``: also what the reference's FIRST ppo_update left in .grad.  That is the well-conditioned quantity at this size:
+# under ValueNorm the first update's targets have the batch mean subtracted, so the first gradient of the value head's bias is a
+# sum that cancels to rounding noise; Adam (eps 1e-5) turns that noise into a step whose size depends on its sign and magnitude,
+# and everything after it -- the second update's gradients (0.2 % of the critic's), a handful of weights (5e-5) -- lands on
+# one of two branches depending on the last bit of the inputs (measured on the device: tools/r06/probe_mid3.py).
+# ``torch_threads`` = 1: at this size PyTorch's CPU reductions split over the threads, and the reference's own numbers move in
+# their sixth digit with the thread count -- one thread makes the fixture regenerate bit for bit on any machine.
 _MID = dict(hidden_size=64, layer_N=1, use_ReLU=False, ppo_epoch=2, num_mini_batch=1, lr=7e-4, critic_lr=7e-4, gain=0.01)
 CASES_MID = {
     "mid_ns": dict(args=dict(algorithm_name="mappo", **_MID), T=100, N=256, A=8, Do=48, Ds=384, na=5, k10=False,
-                   regen=True, subsample=8),
+                   regen=True, subsample=8, first_grads=True, torch_threads=1),
     "mid_ns_rnn": dict(args=dict(algorithm_name="rmappo", use_recurrent_policy=True, data_chunk_length=10, **_MID),
-                       T=100, N=128, A=8, Do=48, Ds=384, na=5, k10=False, regen=True, subsample=8),
+                       T=100, N=128, A=8, Do=48, Ds=384, na=5, k10=False, regen=True, subsample=8, first_grads=True,
+                       torch_threads=1),
 }
 SUBSAMPLE_ABOVE = 65536
 
@@ -170,7 +178,9 @@ def main(ref, make_args, fill_buffer, gold_dir):
 
 def generate(ref, make_args, fill_buffer, gold_dir, cases, fname, with_grads=False):
     out, meta = {}, {}
+    threads_before = torch.get_num_threads()
     for cname, spec in cases.items():
+        torch.set_num_threads(int(spec.get("torch_threads", threads_before)))
         T, N, A, Do, Ds, na = (spec[k] for k in ("T", "N", "A", "Do", "Ds", "na"))
         args = make_args(episode_length=T, n_rollout_threads=N, **spec["args"])
         obs_space, cent_space, act_space = ref.Box((Do,)), ref.Box((Ds,)), ref.Discrete(na)
@@ -237,8 +247,22 @@ def generate(ref, make_args, fill_buffer, gold_dir, cases, fname, with_grads=Fal
             recorder = RandpermAsK10(spec["args"]["num_mini_batch"])
         else:
             recorder = PermRecorder()
+        first = {}
+        if spec.get("first_grads"):
+            inner = trainer.ppo_update
+
+            def recording_update(*a, **k):
+                res = inner(*a, **k)
+                if not first:
+                    for net, pre in ((policy.actor, "first_grad_actor."), (policy.critic, "first_grad_critic.")):
+                        for kk, p in net.named_parameters():
+                            first[pre + kk] = p.grad.detach().cpu().numpy().copy()
+                return res
+            trainer.ppo_update = recording_update
         with recorder as rec:
             info = trainer.train(buf)
+        for kk, g in first.items():
+            _store(out, key + kk, g, int(spec.get("subsample", 0)))
         for i, p in enumerate(rec.calls if (spec.get("store_perms") or not spec.get("regen")) else []):
             out[key + "perm%d" % i] = p.astype(np.int64)
         info = {k: float(v) for k, v in info.items()}
@@ -254,6 +278,7 @@ def generate(ref, make_args, fill_buffer, gold_dir, cases, fname, with_grads=Fal
             out[key + "final_norm"] = np.array([float(vn.running_mean), float(vn.running_mean_sq),
                                                 float(vn.debiasing_term)], dtype=np.float64)
         meta[cname] = dict(spec=spec, train_info=info, n_perms=len(rec.calls))
+    torch.set_num_threads(threads_before)
     np.savez_compressed(os.path.join(gold_dir, fname + ".npz"), **out)
     with open(os.path.join(gold_dir, fname + ".json"), "w") as f:
         json.dump(meta, f, indent=1)

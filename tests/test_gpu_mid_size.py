@@ -7,6 +7,7 @@ VERDICT r5 "weak" #1: every other reference-generated trainer fixture is <= 1 20
               over workgroups and reduced, K7 / K13 / the record gather run multi-block;
 * mid_ns_rnn  the same shapes, rmappo with chunk 10, T = 100 x N = 128 = 102 400 rows = 10 240 chunks: K12 walks several
               32-chunk tiles per wave, its weight gradients are a multi-workgroup launch.
+Asserted tightly: the gradients of the FIRST update (``first_grad_*`` of the fixture), train_info, the bulk of the weights.
 Routes: the default one (device sampler -- one minibatch per epoch, so its single slice is the reference's batch as a set --
 and the update replayed from a HIP graph) and the host-permutation route.  Tolerances: tests/parity.py (3 x the measured worst)."""
 import numpy as np
@@ -39,6 +40,17 @@ def test_update_at_mid_size_vs_reference(gold, cname, rng_mode, margins):
     np.testing.assert_allclose([g64.sum(), (g64 * g64).sum()], mom, rtol=1e-12)
     trainer.prep_training()
     torch.manual_seed(21)
+    # what the FIRST update leaves in .grad: the well-conditioned quantity at this size (see below)
+    first, inner = {}, trainer._run_update
+
+    def recording_update(sample, update_actor):
+        out = inner(sample, update_actor)
+        if not first:
+            for net, pre in ((policy.actor, "first_grad_actor."), (policy.critic, "first_grad_critic.")):
+                for k, p in net.named_parameters():
+                    first[pre + k] = p.grad.detach().clone()
+        return out
+    trainer._run_update = recording_update
     _native.count_calls(True)
     try:
         info = trainer.train(buf)
@@ -54,7 +66,20 @@ def test_update_at_mid_size_vs_reference(gold, cname, rng_mode, margins):
             ("mappo_gru_seq_forward", "mappo_gru_seq_backward") if recurrent else ()):
         assert calls.get(name, 0) == 2 * called, (name, calls)
 
-    worst = parity.compare_update(z, key, meta, policy, trainer, info)
+    # (1) the first update's gradients against the reference's, tight: 2 x 10^5 rows through the persistent grids, split
+    # reductions and multi-workgroup weight gradients, before any optimiser step has touched anything
+    worst = {}
+    for name, got in first.items():
+        sub, ref, mom = C.stored(z, key + name, got.cpu().numpy())
+        err = float(np.abs(sub - ref).max()) / max(1e-12, float(np.abs(ref).max()))
+        worst["g1." + name] = err
+        assert err < parity.TOL["grad_rel"], (name, err)
+    # (2) everything after the first Adam step, loose where Adam makes it ill-conditioned: under ValueNorm the first update's
+    # targets have the batch mean subtracted, so the first gradient of the value head's bias is a sum that cancels to rounding
+    # noise; Adam (eps 1e-5) turns its sign and size into a step, and the second update's critic gradients land on one of two
+    # branches 0.2 % apart (tools/r06/probe_mid3.py: random one-ulp perturbations of the inputs pick either).  train_info and the
+    # bulk of the weights do not care.
+    worst.update(parity.compare_update(z, key, meta, policy, trainer, info, tol={"grad_rel": 5e-3}))
     margins("mid_size/%s/%s" % (cname, rng_mode), worst)
     top = parity.top3(worst)
     print("\n[%s %s] native calls %s; largest relative errors: %s" % (cname, rng_mode, dict(sorted(calls.items())), top))

@@ -26,7 +26,21 @@ def test_train_matches_reference_at_mid_size(gold, cname):
     np.testing.assert_allclose([r64.sum(), (r64 * r64).sum()], mom, rtol=1e-12)
     trainer.prep_training()
     torch.manual_seed(21)
+    first, inner = {}, trainer._run_update
+
+    def recording_update(sample, update_actor):
+        out = inner(sample, update_actor)
+        if not first:
+            for net, pre in ((policy.actor, "first_grad_actor."), (policy.critic, "first_grad_critic.")):
+                for k, p in net.named_parameters():
+                    first[pre + k] = p.grad.detach().clone()
+        return out
+    trainer._run_update = recording_update
     info = trainer.train(buf)
+    for name, got in first.items():             # the first update's gradients: the well-conditioned quantity at this size
+        sub, ref, mom = C.stored(z, key + name, got.numpy())
+        # (the reference itself moves by 3e-5 of such a tensor between one and four CPU threads: sums that nearly cancel)
+        assert float(np.abs(sub - ref).max()) <= 1e-4 * max(1e-12, float(np.abs(ref).max())), name
     for k, ref in meta["train_info"].items():
         assert info[k] == pytest.approx(ref, rel=3e-4, abs=2e-6), (k, info[k], ref)
     C.check_weights(z, key + "final_actor.", policy.actor, rtol=1e-4, atol=2e-5)

@@ -30,10 +30,10 @@ import cfg_shapes as C
 # (Third measurement -- the same perturbation, one kernel rebuild later: three of the 24 576 entries of mid_ns's first critic
 # layer off by 4.7e-5.  The MAXIMUM over the weights is the statistic Adam makes ill-conditioned, so it only guards against gross
 # errors (a wrong sign is 1.4e-3): 1.5e-4.  The bulk is the tight check: the 99.5th percentile of |difference| per tensor.)
-TOL = {"info_rel": 7e-6, "info_abs": 1e-7, "weight_abs": 1.5e-4, "weight_bulk": 1e-5, "weight_rtol": 1e-5, "grad_rel": 1.5e-4,
+TOL = {"info_rel": 7e-6, "info_abs": 1e-7, "weight_abs": 1.5e-4, "weight_bulk": 3e-6, "weight_rtol": 1e-5, "grad_rel": 1.5e-4,
        "norm_rtol": 5e-7}
 # (hidden 512: the library route's GEMM kernels are picked per box by TunableOp, so the margin is 5 x, not 3 x)
-TOL_H512 = {"info_rel": 2.5e-5, "info_abs": 1e-7, "weight_abs": 1.5e-4, "weight_bulk": 1e-5, "weight_rtol": 1e-5, "grad_rel": 1e-3,
+TOL_H512 = {"info_rel": 2.5e-5, "info_abs": 1e-7, "weight_abs": 1.5e-4, "weight_bulk": 3e-6, "weight_rtol": 1e-5, "grad_rel": 1e-3,
             "norm_rtol": 5e-7}
 
 def compare_update(z, key, meta, policy, trainer, info, tol=None):

@@ -149,6 +149,8 @@ def tall_linear(x, weight, bias, arith=None):
     K15 (``_Linear512Fn``)."""
     if linear512_ok(x, weight, arith):
         return _Linear512Fn.apply(x, weight, bias)
+    if x.dim() == 2 and x.shape[1] == (weight.shape[1] + 3) // 4 * 4 != weight.shape[1]:
+        x = x[:, :weight.shape[1]]      # the zero padding of a standardised copy (shared_buffer._whole_batch_views): a strided view
     if x.dim() == 2 and x.is_cuda and x.shape[0] >= _MIN_ROWS and torch.is_grad_enabled() \
             and x.is_contiguous():
         return _TallLinearFn.apply(x, weight, bias)

@@ -801,14 +801,17 @@ class SharedReplayBuffer(object):
     # tuple holds VIEWS of the buffer fields ([:T] flattened to [rows, dim]) and one fresh tensor, the normalised
     # advantages (mappo_adv_normalize, 8 bytes per sample) -- the north-star step loses its record pack + record gather
     # (1.0 ms, 2.9 GB of traffic; round 6).  Only on this route: its consumer, R_MAPPO.ppo_update, never writes its inputs.
-    # Callers of the public protocol (no lazy_obs) keep the copies and the edit detection of _whole_batch_tuple.
+    # Callers of the public protocol (neither lazy_obs nor standardize_obs) keep the copies and the edit detection of
+    # _whole_batch_tuple.  With standardize_obs alone (networks that take tensors: hidden 512) the observation elements of the
+    # tuple are the resident standardised copies themselves -- rows padded to 16 bytes, which K15's aligned loads want anyway
+    # (Hanabi's 1285 / 1385-wide rows: first-layer forward 4.51 -> 4.16 ms, no standardising gather).
     def _whole_batch_views_ok(self, rand, mb, batch_size):
         return rand is getattr(self, "_identity_idx", None) and mb == batch_size and not self._adv_external \
             and os.environ.get("MAPPO_WHOLE_BATCH_VIEWS", "1") != "0"
 
-    def _whole_batch_views(self, table, stats, rand, mb, standardize_obs):
+    def _whole_batch_views(self, table, stats, rand, mb, standardize_obs, lazy_obs=True):
         T = self.episode_length
-        key = ("views", self._content_version, bool(standardize_obs), None if stats is None else stats.data_ptr(),
+        key = ("views", self._content_version, bool(standardize_obs), bool(lazy_obs), None if stats is None else stats.data_ptr(),
                tuple((src.data_ptr(), src._version) for _, src, _ in table if src is not None))
         if self._whole_batch_key == key:
             self.whole_batch_reuses += 1
@@ -820,10 +823,15 @@ class SharedReplayBuffer(object):
                 outs.append(None)
                 continue
             tail = tuple(src.shape[3:])
-            if name in ("share_obs", "obs") and len(tail) == 1:
+            if name in ("share_obs", "obs") and len(tail) == 1 and lazy_obs:
                 width = int(tail[0])
                 outs.append(RowSource(self._obs_rows(name, standardize_obs), rand, None, standardized=standardize_obs,
                                       width=width))
+            elif name in ("share_obs", "obs") and len(tail) == 1 and standardize_obs:
+                # networks that take tensors (hidden sizes without a fused trunk: Hanabi's 512): the resident standardised copy
+                # itself, in memory order -- [rows, D padded to a multiple of 4] with zero columns behind the data (K15 takes the
+                # padded rows through its aligned loads; tall_linear cuts them off for the library GEMM).  Nothing is gathered.
+                outs.append(self._obs_rows(name, True))
             elif is_state and not self._recurrent:
                 outs.append(src[0, 0, 0].expand((mb,) + tail))           # zeros, no traffic
             elif name == "advantages" and stats is not None:
@@ -866,8 +874,10 @@ class SharedReplayBuffer(object):
             mini_batch_size = batch_size // num_mini_batch
         rand = self._sampler_indices(batch_size, mini_batch_size, num_mini_batch)
         table, stats = self._field_table(advantages)
-        if num_mini_batch == 1 and lazy_obs and self._whole_batch_views_ok(rand, mini_batch_size, batch_size):
-            yield self._whole_batch_views(table, stats, rand, mini_batch_size, standardize_obs)
+        if num_mini_batch == 1 and (lazy_obs or standardize_obs) and self._whole_batch_views_ok(rand, mini_batch_size, batch_size) \
+                and (lazy_obs or self.can_standardize_obs()):
+            # (standardize_obs / lazy_obs are this implementation's extensions of the protocol: only its own trainer passes them)
+            yield self._whole_batch_views(table, stats, rand, mini_batch_size, standardize_obs, lazy_obs)
             return
         packed = self._pack_records(table)
         if num_mini_batch == 1 and self._whole_batch_ok(rand, packed):

@@ -103,3 +103,36 @@ def test_forward_at_baseline_config_shapes_vs_reference(gold, cname):
     np.testing.assert_allclose(values.cpu().numpy(), z[key + "eval_values"], **tol)
     np.testing.assert_allclose(logp.cpu().numpy(), z[key + "eval_logp"], **tol)
     np.testing.assert_allclose(float(ent), float(z[key + "eval_entropy"]), **tol)
+
+
+@pytest.mark.parametrize("k15", [True, False], ids=["k15", "library_gemm"])
+def test_hidden512_one_minibatch_reads_the_resident_standardised_copies(gold, monkeypatch, k15):
+    """Round 6: with ONE minibatch per epoch under the device sampler, networks that take tensors (hidden 512) get the resident
+    row-standardised copies of obs / share_obs themselves as their minibatch -- rows padded from 1285 / 1385 to 1288 / 1388
+    floats (K15's aligned loads; cut off again for the library GEMM) -- instead of a standardising gather.  Same update as
+    with the gathered tuple (MAPPO_WHOLE_BATCH_VIEWS=0) up to the last bits of the standardised inputs: train_info and the
+    bulk of the weights agree tightly."""
+    dev = torch.device("cuda", 0)
+    monkeypatch.setenv("MAPPO_LINEAR512_MIN_ROWS", "1" if k15 else "1000000000")
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MAPPO_WHOLE_BATCH_VIEWS", mode)
+        z, key, meta, spec, args, spaces, policy, trainer = C.build(gold, "cfg5_shape", device=dev, sampler_rng="device")
+        C.start_from_reference_weights(policy, z, key)
+        arrays, nv = C.inputs(spec, z, key)
+        buf = _device_buffer(args, spec, spaces, arrays, dev)
+        buf.compute_returns(nv, trainer.value_normalizer)
+        trainer.prep_training()
+        torch.manual_seed(21)
+        info = trainer.train(buf)
+        if mode == "1":
+            so, ob = buf._whole_batch[0], buf._whole_batch[1]
+            assert torch.is_tensor(so) and so.shape[1] == 1388 and ob.shape[1] == 1288     # the padded copies themselves
+            assert so.data_ptr() == buf._std_rows["share_obs"][1].data_ptr()
+        buf.after_update()
+        w = torch.cat([p.detach().reshape(-1) for net in (policy.actor, policy.critic) for p in net.parameters()]).cpu().numpy()
+        out[mode] = (info, w)
+    for k in out["1"][0]:
+        assert out["1"][0][k] == pytest.approx(out["0"][0][k], rel=2e-5, abs=1e-7), k
+    diff = np.abs(out["1"][1] - out["0"][1])
+    assert float(np.quantile(diff, 0.995)) < 3e-6 and float(diff.max()) < 1.5e-4, (np.quantile(diff, 0.995), diff.max())

@@ -1,64 +1,59 @@
-"""bench.py pieces that can run without a GPU: the workload table and the `cpu_baseline` leg (oracle buffer + the
-product's trainer on host cores) on a shrunken copy of every workload; the timed HIP path itself is covered by the
--m gpu bench test."""
+"""bench.py's host-side pieces that need no GPU: the `workloads` leg's compaction of a child's JSON line, the table of child
+command lines, the provenance digest of the kernel sources, and the CPU-reference record the line quotes."""
 import importlib.util
+import json
 import os
-
-import pytest
-import torch
 
 from conftest import ROOT
 
 
-@pytest.fixture(scope="module")
-def bench():
-    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
 
 
-def test_workload_table(bench):
-    assert set(bench.WORKLOADS) == {"ns", "ns_rnn", "cfg2", "cfg3", "smac", "hanabi"}
-    c3 = bench.WORKLOADS["cfg3"]            # BASELINE.json configs[2]: simple_spread itself at N=4096, T=400
-    assert (c3["T"], c3["N"], c3["A"], c3["Do"], c3["Ds"]) == (400, 4096, 3, 18, 54)
-    ns = bench.WORKLOADS["ns"]
-    assert (ns["T"], ns["N"], ns["A"], ns["Do"], ns["Ds"], ns["na"]) == (400, 4096, 8, 48, 384, 5)     # BASELINE north star
-    args = bench.make_args(ns, 512)
-    assert args.n_rollout_threads == 512 and args.ppo_epoch == 10 and args.use_ReLU is False             # --use_ReLU => Tanh
-    assert bench.make_args(bench.WORKLOADS["smac"], 8).use_recurrent_policy is True
+def test_other_workloads_cover_every_baseline_config():
+    b = _bench()
+    names = [w[0] for w in b.OTHER_WORKLOADS]
+    assert names == ["cfg2", "cfg3", "ns_rnn", "smac", "smac_shard64", "hanabi"]
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert len(base["configs"]) == 5            # configs[0] is the CPU-runnable plumbing case; [1..4] = cfg2, cfg3, smac, hanabi
+    for name, argv, (steps, warmup), what in b.OTHER_WORKLOADS:
+        assert argv[0] == "--workload" and argv[1] in b.WORKLOADS and steps >= 3 and warmup >= 1 and what
+        # every child runs long enough to be timed: >= ~0.4 s of steps at the sizes measured in round 6
+    assert dict((w[0], w[2]) for w in b.OTHER_WORKLOADS)["smac_shard64"][0] >= 30
 
 
-@pytest.mark.parametrize("name", ["ns", "ns_rnn", "smac"])
-def test_cpu_baseline_leg_runs(bench, name):
-    threads = torch.get_num_threads()
-    wl = dict(bench.WORKLOADS[name], T=20, cpu_sample_N=2)
-    wl["flags"] = [f if f != "10" or wl["flags"][i - 1] != "--ppo_epoch" else "2" for i, f in enumerate(wl["flags"])]
-    try:
-        out = bench.cpu_baseline(wl)
-    finally:
-        torch.set_num_threads(threads)
-    assert out["kind"] == "port" and out["unit"] == "env-steps/s" and out["value"] > 0 and out["cores"] >= 1
-    assert "n_rollout_threads=2" in out["sample"]
+def test_compact_line_keeps_what_a_reader_compares():
+    b = _bench()
+    committed = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_lines.json")))
+    for name in ("cfg2", "cfg3", "ns_rnn", "smac", "smac_shard64", "hanabi"):
+        c = b.compact_line(committed[name], "what")
+        assert c["value"] == committed[name]["value"] and c["ms_per_step"] == committed[name]["ms_per_step"]
+        assert c["dtype"] == "f32" and 0 < c["roofline"]["frac"] < 1 and c["roofline"]["bound"] in ("hbm", "mfma")
+        assert 0 < c["roofline_gae"]["frac"] < 1 and c["roofline"]["timed_in"]
+        assert (c["cpu_baseline"] is None) == (committed[name].get("cpu_baseline") is None)
+    # a child without a GAE / roofline object (e.g. a failed profile) does not break the parent's line
+    bare = {"config": {"workload": "w", "n_rollout_threads": 1}, "value": 1.0, "unit": "env-steps/s", "ms_per_step": 1.0,
+            "steps": 1, "warmup": 0, "dtype": "f32", "arithmetic": "f32 (library)"}
+    c = b.compact_line(bare, "what")
+    assert c["roofline"] is None and c["roofline_gae"] is None and c["cpu_baseline"] is None
 
 
-def test_plain_gpus_flag_launches_one_rank_per_gpu(bench, monkeypatch):
-    """`python bench.py --gpus N` without a launcher around it starts N ranks itself through torch.distributed.run
-    (loop-back rendezvous) and hands the original flags on; under a launcher the world size must match --gpus."""
-    import subprocess
-    import sys
-    seen = {}
-    monkeypatch.setattr(subprocess, "call", lambda cmd: seen.setdefault("cmd", cmd) and 0)
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--threads", "64"])
-    monkeypatch.delenv("WORLD_SIZE", raising=False)
-    with pytest.raises(SystemExit) as e:
-        bench.main()
-    assert e.value.code == 0
-    cmd = seen["cmd"]
-    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
-    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
-    assert cmd[-6:] == ["--gpus", "4", "--steps", "2", "--threads", "64"] and cmd[-7].endswith("bench.py")
-    # a launcher that started a different number of ranks than --gpus asks for is an error, not a silent N = 1 run
-    monkeypatch.setenv("WORLD_SIZE", "2")
-    with pytest.raises(AssertionError, match="--gpus 4"):
-        bench.main()
+def test_committed_line_carries_its_workloads_and_provenance():
+    ns = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_lines.json")))["ns"]
+    assert set(ns["workloads"]) == {"cfg2", "cfg3", "ns_rnn", "smac", "smac_shard64", "hanabi"}
+    alone = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_lines.json")))
+    for name, e in ns["workloads"].items():     # in-line and own-command-line figures of one call agree (+- 3 %)
+        assert abs(e["ms_per_step"] / alone[name]["ms_per_step"] - 1) < 0.03, name
+    r = ns["roofline"]
+    assert r["timed_in"] == "the timed region" and ns["two_streams"] is False
+    assert r["traffic_commit"] and r["traffic_csrc_digest"] and r["traffic_matches_this_build"] is True
+    b = _bench()
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_summary.json")))
+    # the committed PMC passes ran on the kernel sources of this tree
+    assert pmc["_provenance"]["csrc_digest"] == b.csrc_digest() == ns["csrc_digest"]
+    rec = b.reference_recorded("ns")
+    assert rec["source"].startswith("profiles/r06_cpu_port_vs_reference.json") and len(rec["port_vs_reference_same_machine"]) == 2

@@ -87,9 +87,9 @@ WORKLOADS = {
     "hanabi": dict(T=100, N=8192, A=5, Do=1285, Ds=1385, na=48, cpu_sample_N=16,
                    flags=["--algorithm_name", "mappo", "--hidden_size", "512", "--layer_N", "2",
                           "--ppo_epoch", "15", "--num_mini_batch", "1", "--lr", "7e-4", "--critic_lr", "1e-3",
-                          "--gain", "0.01", "--use_ReLU"],
+                          "--gain", "0.01"],       # (train_hanabi_forward.sh:15-17 passes no --use_ReLU: ReLU blocks)
                    recurrent=False,
-                   label="synthetic Hanabi-Full 5p shapes T=100 N=8192 A=5, mappo MLP h512 x2, ppo_epoch=15"),
+                   label="synthetic Hanabi-Full 5p shapes T=100 N=8192 A=5, mappo MLP h512 x2 (ReLU), ppo_epoch=15"),
     # BASELINE.json configs[3] shapes (SMAC MMM2), recurrent policy, chunk 10
     "smac": dict(T=400, N=512, A=10, Do=370, Ds=435, na=18, cpu_sample_N=8,
                  flags=["--algorithm_name", "rmappo", "--hidden_size", "64", "--layer_N", "1",

@@ -673,6 +673,13 @@ int     mappo_fold_input_norm_backward(const float* w, const float* gamma, const
  *     (columns K .. ldx - 1 must hold finite values: the zero padding of mappo_standardize_rows_ld); rows that start on 16-byte
  *     boundaries (ldx a multiple of 4) are loaded in 16-byte pieces, any other ldx (Hanabi's 1285 / 1385-wide gathered
  *     minibatches) in 4-byte pieces.  planes, y and bias must be 16-byte aligned (MAPPO_E_ALIGN otherwise).
+ *   mappo_linear512_forward_norm:  a whole block Sequential(Linear, ReLU, LayerNorm) of the reference's MLPLayer (mlp.py:17-22)
+ *     in the forward's launch: y [rows, 512] = x W^T + bias (the pre-activation, what mappo_bias_act_layernorm_bwd reads with
+ *     a zero pre_bias), yn [rows, 512] = gamma * (relu(y) - mean) * rstd + beta, mean / rstd [rows] the statistics of
+ *     relu(y) over the 512 features (biased variance, rstd = 1 / sqrt(var + eps): the arithmetic of
+ *     mappo_bias_act_layernorm_fwd); act must be 2 = relu (the codes of mappo_bias_act_layernorm_fwd; MAPPO_E_FLAGS otherwise); bias, gamma, beta, planes, y,
+ *     yn 16-byte aligned.  Replaces mappo_linear512_forward + mappo_bias_act_layernorm_fwd: the pre-activation is written
+ *     once and not read back.
  *   mappo_linear512_wgrad:    dw [512, K] = dy^T [512, rows] x [rows, K] (the weight gradient of y = x W^T; the contraction
  *     runs over the rows, partial sums of row ranges are added in a fixed order: deterministic run to run);
  *     workspace [mappo_linear512_wgrad_workspace_floats(K)] floats. */
@@ -680,6 +687,9 @@ int64_t mappo_linear512_planes_floats(int K);
 int     mappo_linear512_prepare(const float* w, int K, int ldw, int transposed, float* planes, mappo_stream_t stream);
 int     mappo_linear512_forward(const float* x, int64_t rows, int K, int ldx, const float* planes, const float* bias,
                                 float* y, mappo_stream_t stream);
+int     mappo_linear512_forward_norm(const float* x, int64_t rows, int K, int ldx, const float* planes, const float* bias,
+                                     const float* gamma, const float* beta, float eps, int act, float* y, float* yn,
+                                     float* mean, float* rstd, mappo_stream_t stream);
 int64_t mappo_linear512_wgrad_workspace_floats(int K);
 int     mappo_linear512_wgrad(const float* dy, const float* x, int64_t rows, int K, int ldx, float* dw, float* workspace,
                               mappo_stream_t stream);

@@ -47,6 +47,13 @@ struct FwdArgs {
     const float* planes;    // [nkb][kWBlock]
     const float* bias;      // [512] or nullptr
     float* y;               // [rows, 512]
+    // NORM (the block's ReLU + LayerNorm in the epilogue): y receives the pre-activation x W^T + bias, yn the block's output
+    const float* gamma;     // [512] LayerNorm weight
+    const float* beta;      // [512] LayerNorm bias
+    float eps;
+    float* yn;              // [rows, 512] = gamma * (relu(y) - mean) * rstd + beta
+    float* mean;            // [rows] statistics of relu(y) over the 512 features
+    float* rstd;            // [rows] 1 / sqrt(biased variance + eps)
 };
 
 inline long long planes_floats(int K) { return (long long)((K + 15) / 16) * kWBlock; }
@@ -90,7 +97,16 @@ __global__ void __launch_bounds__(kThreads) lin_planes_kernel(const float* w, in
 // issues of W(s + 2), the read and the split of X(s + 1) -> b(s + 1), the DMA issue of X(s + 3)].  Every position the loads
 // need (block of planes, row tile, column, buffer, slot) is a counter that advances with the step: no division in the loop.
 // (A third version with [256 rows, 256 features] per workgroup -- half the plane traffic, X read twice -- was slower.)
-template <bool X16, bool BIAS, int GT>
+//
+// NORM (round 6): the block's ReLU and LayerNorm (reference onpolicy/algorithms/utils/mlp.py:17-22, Sequential(Linear, ReLU,
+// LayerNorm)) in the tile's epilogue.  A lane holds 256 of the 512 features of ONE row (its partner in the other half-wave the
+// other 256), so the row statistics are in-lane sums + one prim::xhalf exchange each.  Three passes that only READ the
+// accumulators, value by value through prim::acc_get (ordinary uses of acc[t][v] in vector arithmetic -- in place or not, with
+// or without scheduling fences -- made the register allocator move all 256 values into vector registers behind the loop and
+// spill 116 bytes per lane); the ReLU is re-applied in each pass (one instruction): (1) store the pre-activation, sum relu; (2) squared deviations from the mean (the
+// two-pass variance of K6's forward); (3) normalise, scale, shift, store.  ~2 300 vector instructions per lane and tile against >= 3 072 MFMA issue slots of ONE
+// k-step: +3 % on a K = 512 launch, and the LayerNorm launch (one read of z, one write) is gone.
+template <bool X16, bool BIAS, int GT, bool NORM = false>
 __global__ void __launch_bounds__(kThreads, 1) lin_fwd_kernel(FwdArgs a) {
     constexpr int NG = 16 / GT;                     // groups of GT feature tiles per step (GT = 2: default; 4: tuning bit 2)
     static_assert(GT == 2 || GT == 4, "feature tiles per group");
@@ -275,18 +291,76 @@ __global__ void __launch_bounds__(kThreads, 1) lin_fwd_kernel(FwdArgs a) {
         // the tile is complete: row c of this wave, features 32 t + 8 q + 4 g + e
         const long long tile = blockIdx.x + m * gridDim.x;
         const long long row = tile * 128 + 32 * wave + c;
-        if (row < a.rows) {
-            float* yr = a.y + row * kN + 4 * g;
+        if (!NORM) {
+            if (row < a.rows) {
+                float* yr = a.y + row * kN + 4 * g;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = acc[t][4 * q + e];
+                        *reinterpret_cast<v4*>(yr + 32 * t + 8 * q) = o;
+                    }
+                }
+            }
+        } else {
+            // (rows past the end hold the LAST row's values -- their X was clamped to it, and a matrix instruction's result does
+            // not depend on the lane that holds it -- and store them to the last row's place once more: no branch per store)
+            const long long srow = row < a.rows ? row : a.rows - 1;
+            float* yr = a.y + srow * kN + 4 * g;
+            prim::mfma_drain();
+            mlp::f2 s2 = {0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     v4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = acc[t][4 * q + e];
+                    for (int e = 0; e < 4; ++e) o[e] = prim::acc_get(acc[t], 4 * q + e);
                     *reinterpret_cast<v4*>(yr + 32 * t + 8 * q) = o;
+                    s2 += __builtin_elementwise_max(mlp::f2{o[0], o[1]}, mlp::f2{0.f, 0.f});
+                    s2 += __builtin_elementwise_max(mlp::f2{o[2], o[3]}, mlp::f2{0.f, 0.f});
+                    prim::sched_fence();
                 }
             }
+            float sum = s2[0] + s2[1];
+            sum += prim::xhalf(sum);
+            const float mu = sum * (1.f / (float)kN);
+            mlp::f2 q2 = {0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+#pragma unroll
+                for (int v = 0; v < 16; v += 2) {
+                    const mlp::f2 av = {prim::acc_get(acc[t], v), prim::acc_get(acc[t], v + 1)};
+                    const mlp::f2 d = __builtin_elementwise_max(av, mlp::f2{0.f, 0.f}) - mu;
+                    q2 += d * d;
+                    if (v % 4 == 2) prim::sched_fence();
+                }
+            }
+            float var = q2[0] + q2[1];
+            var += prim::xhalf(var);
+            const float r = 1.0f / sqrtf(var * (1.f / (float)kN) + a.eps);
+            float* nr = a.yn + srow * kN + 4 * g;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const v4 gm = *reinterpret_cast<const v4*>(a.gamma + 32 * t + 8 * q + 4 * g);
+                    const v4 bt = *reinterpret_cast<const v4*>(a.beta + 32 * t + 8 * q + 4 * g);
+                    v4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float av = prim::acc_get(acc[t], 4 * q + e);
+                        o[e] = ((av > 0.f ? av : 0.f) - mu) * r * gm[e] + bt[e];
+                    }
+                    *reinterpret_cast<v4*>(nr + 32 * t + 8 * q) = o;
+                }
+                prim::sched_fence();
+            }
+            a.mean[srow] = mu;
+            a.rstd[srow] = r;
         }
     }
     prim::wait_lds_loads<0>();      // (the groups issued past the end)
@@ -548,6 +622,9 @@ inline int forward(const float* x, long long rows, int K, int ldx, const float* 
     a.planes = planes;
     a.bias = bias;
     a.y = y;
+    a.gamma = a.beta = nullptr;
+    a.eps = 0.f;
+    a.yn = a.mean = a.rstd = nullptr;
     const long long grid = mlp::capped((rows + 127) / 128, kGridCap);
     const bool four = (mlp::tuning_flags() & 2) != 0;      // tuning bit 2: four feature tiles per MFMA group (round 5's form)
 #define MAPPO_LIN_FWD(X, B)                                                                                        \
@@ -560,6 +637,39 @@ inline int forward(const float* x, long long rows, int K, int ldx, const float* 
     else if (bias) MAPPO_LIN_FWD(false, true);
     else MAPPO_LIN_FWD(false, false);
 #undef MAPPO_LIN_FWD
+    return MAPPO_LAUNCH_ERROR();
+}
+
+// the block form: y = x W^T + bias (the pre-activation K6's backward wants), yn = LayerNorm(relu(y)), mean / rstd per row
+inline int forward_norm(const float* x, long long rows, int K, int ldx, const float* planes, const float* bias,
+                        const float* gamma, const float* beta, float eps, int act, float* y, float* yn, float* mean,
+                        float* rstd, hipStream_t stream) {
+    if (!x || !planes || !bias || !gamma || !beta || !y || !yn || !mean || !rstd) return MAPPO_E_NULL;
+    if (rows <= 0 || K <= 0 || ldx < K || ldx < 4) return MAPPO_E_SHAPE;
+    if (act != 2) return MAPPO_E_FLAGS;             // 2 = relu (the reference's default --use_ReLU)
+    if (((reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(yn) |
+          reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) != 0)
+        return MAPPO_E_ALIGN;
+    if ((reinterpret_cast<uintptr_t>(x) & 3) != 0) return MAPPO_E_ALIGN;
+    const bool x16 = ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    FwdArgs a;
+    a.x = x;
+    a.rows = rows;
+    a.K = K;
+    a.ldx = ldx;
+    a.nkb = (K + 15) / 16;
+    a.planes = planes;
+    a.bias = bias;
+    a.y = y;
+    a.gamma = gamma;
+    a.beta = beta;
+    a.eps = eps;
+    a.yn = yn;
+    a.mean = mean;
+    a.rstd = rstd;
+    const long long grid = mlp::capped((rows + 127) / 128, kGridCap);
+    if (x16) MAPPO_LAUNCH((lin_fwd_kernel<true, true, 2, true>), (unsigned)grid, kThreads, (size_t)kFwdLds * 4, stream, a);
+    else MAPPO_LAUNCH((lin_fwd_kernel<false, true, 2, true>), (unsigned)grid, kThreads, (size_t)kFwdLds * 4, stream, a);
     return MAPPO_LAUNCH_ERROR();
 }
 

@@ -95,6 +95,17 @@ __device__ __forceinline__ float rsq_fast(float v) { return __builtin_amdgcn_rsq
 // scheduling barrier: the compiler may not move instructions across it (used to keep operand prefetches early)
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 __device__ __forceinline__ void set_priority_high() { __builtin_amdgcn_s_setprio(3); }
+// element i of an accumulator tile that must STAY in the accumulator half of the register file (one wave per SIMD: 256 + 256
+// registers): a plain a[i] in vector arithmetic makes the register allocator move the whole tile -- in K15's forward all 16
+// tiles -- into vector registers at once (and spill); this reads one value when it is needed.  Volatile: a second read is a
+// second instruction, not a value kept alive.  mfma_drain() first: the hazard recogniser does not look inside inline asm, and
+// a matrix instruction's result may not be read for up to 18 passes after its issue.
+__device__ __forceinline__ float acc_get(const f32x16& a, int i) {
+    float v;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a[i]));
+    return v;
+}
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); }
 // wave-uniform value -> scalar register
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // this lane's index in its wave, read afresh from the hardware lane counter (two instructions): for an epilogue that would
@@ -272,6 +283,13 @@ extern "C" int mappo_linear512_forward(const float* x, int64_t rows, int K, int 
                                        float* y, mappo_stream_t stream) {
     g_launch_error = 0;
     return lin::forward(x, rows, K, ldx, planes, bias, y, static_cast<hipStream_t>(stream));
+}
+extern "C" int mappo_linear512_forward_norm(const float* x, int64_t rows, int K, int ldx, const float* planes, const float* bias,
+                                            const float* gamma, const float* beta, float eps, int act, float* y, float* yn,
+                                            float* mean, float* rstd, mappo_stream_t stream) {
+    g_launch_error = 0;
+    return lin::forward_norm(x, rows, K, ldx, planes, bias, gamma, beta, eps, act, y, yn, mean, rstd,
+                             static_cast<hipStream_t>(stream));
 }
 extern "C" int64_t mappo_linear512_wgrad_workspace_floats(int K) { return lin::wgrad_workspace_floats(K); }
 extern "C" int mappo_linear512_wgrad(const float* dy, const float* x, int64_t rows, int K, int ldx, float* dw,

@@ -173,6 +173,8 @@ SIGNATURES = {
     "mappo_linear512_planes_floats": (_i64, [_int]),
     "mappo_linear512_prepare": (_int, [_vp, _int, _int, _int, _vp, _vp]),
     "mappo_linear512_forward": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp, _vp]),
+    "mappo_linear512_forward_norm": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp, _vp, ctypes.c_float, _int, _vp, _vp, _vp, _vp,
+                                           _vp]),
     "mappo_linear512_wgrad_workspace_floats": (_i64, [_int]),
     "mappo_linear512_wgrad": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp]),
     "mappo_simple_spread_step": (_int, [_vp] * 11 + [_i64, _int, _int, _int, _int, _vp]),

@@ -118,9 +118,12 @@ class DenseBlock(nn.Sequential):
     def forward(self, x):
         linear, act, norm = self[0], self[1], self[2]
         if isinstance(norm, FusedLayerNorm):
+            from .tall_linear import tall_linear, linear512_norm_ok, linear512_relu_norm
+            arith = getattr(linear, "matrix_arithmetic", None)
+            if norm._fusable(x) and linear512_norm_ok(x, linear.weight, linear.bias, act, norm, arith):
+                return linear512_relu_norm(x, linear.weight, linear.bias, norm)     # hidden 512: ONE K15 launch (epilogue)
             if linear.bias is not None and norm.fuses_bias(x, act, linear.out_features):
                 # GEMM without bias; the bias add and its gradient ride along in the act+LayerNorm kernels
-                from .tall_linear import tall_linear
                 return norm.forward_act(tall_linear(x, linear.weight, None, getattr(linear, "matrix_arithmetic", None)), act,
                                         pre_bias=linear.bias)
             return norm.forward_act(linear(x), act)

@@ -8,7 +8,7 @@ import torch.nn as nn
 
 from . import fused_mlp
 from .fused_norm import FusedLayerNorm, DenseBlock
-from .tall_linear import TallLinear, tall_linear
+from .tall_linear import TallLinear, tall_linear, linear512_norm_ok, linear512_relu_norm
 from .util import init
 
 
@@ -94,7 +94,10 @@ class MLPBase(nn.Module):
         linear, act, norm = first[0], first[1], first[2]
         w_eff = linear.weight * self.feature_norm.weight
         b_eff = linear.bias + linear.weight @ self.feature_norm.bias
-        if isinstance(norm, FusedLayerNorm) and norm.fuses_bias(x, act, linear.out_features):
+        if isinstance(norm, FusedLayerNorm) and norm._fusable(x) \
+                and linear512_norm_ok(x, w_eff, b_eff, act, norm, self.matrix_arithmetic):
+            h = linear512_relu_norm(x, w_eff, b_eff, norm)      # hidden 512: bias, ReLU and LayerNorm in K15's epilogue
+        elif isinstance(norm, FusedLayerNorm) and norm.fuses_bias(x, act, linear.out_features):
             h = norm.forward_act(tall_linear(x, w_eff, None, self.matrix_arithmetic), act, pre_bias=b_eff)   # bias add in the LN kernel
         else:
             h = norm.forward_act(tall_linear(x, w_eff, b_eff, self.matrix_arithmetic), act)

@@ -96,36 +96,107 @@ class _Linear512Fn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx, dw = _linear512_grads(ctx.needs_input_grad[0], ctx.needs_input_grad[1], dy, x, w)
+        db = column_sums(dy) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+class _Linear512NormFn(torch.autograd.Function):
+    """``LayerNorm(relu(x W^T + b))`` of a hidden-512 block (reference onpolicy/algorithms/utils/mlp.py:17-22:
+    ``Sequential(Linear, ReLU, LayerNorm)``) with the bias add, the activation and the LayerNorm in the EPILOGUE of K15's forward
+    (``mappo_linear512_forward_norm``): a workgroup of that kernel holds all 512 features of its 128 rows in registers, so the
+    row statistics cost two cross-lane exchanges and the [rows, 512] pre-activation is written once and never read back by a
+    LayerNorm launch of its own (K6's forward read it: one of the two streams of that launch).  The backward is the unfused
+    pair: K6's backward on the saved pre-activation (bias included: ``pre_bias`` is a zero vector there, its gradient is the
+    Linear's bias gradient), then K15's input gradient and weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, ln_weight, ln_bias, eps):
         from onpolicy import _native
         lib, p = _native.lib(), _native.ptr
-        x, w = ctx.saved_tensors
         dev = x.device
         stream = _native.stream_of(dev)
         rows, ldx = x.shape
+        w = weight.detach().contiguous()
         K = int(w.shape[1])
+        planes = torch.empty(lib.mappo_linear512_planes_floats(K), dtype=torch.float32, device=dev)
+        _native.check(lib.mappo_linear512_prepare(p(w), K, K, 0, p(planes), stream), "mappo_linear512_prepare")
+        b = _aligned16(bias.detach().contiguous())
+        g = _aligned16(ln_weight.detach().contiguous())
+        be = _aligned16(ln_bias.detach().contiguous())
+        z = torch.empty((rows, 512), dtype=torch.float32, device=dev)
+        y = torch.empty((rows, 512), dtype=torch.float32, device=dev)
+        mean = torch.empty(rows, dtype=torch.float32, device=dev)
+        rstd = torch.empty(rows, dtype=torch.float32, device=dev)
+        from . import fused_mlp
+        with fused_mlp._Timed("mappo_linear512_forward", 2.0 * rows * K * 512, 4.0 * rows * (ldx + 1024 + 2)):
+            _native.check(lib.mappo_linear512_forward_norm(p(x), rows, K, int(ldx), p(planes), p(b), p(g), p(be), float(eps),
+                                                           _ACT_RELU, p(z), p(y), p(mean), p(rstd), stream),
+                          "mappo_linear512_forward_norm")
+        ctx.save_for_backward(x, w, z, mean, rstd, g)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from onpolicy import _native
+        lib, p = _native.lib(), _native.ptr
+        x, w, z, mean, rstd, g = ctx.saved_tensors
+        dev = x.device
+        stream = _native.stream_of(dev)
+        rows = x.shape[0]
         dy = dy.contiguous()
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            if K == 512 and ldx == 512:     # dX = dY W: the forward kernel on the planes of W^T
-                planes = torch.empty(lib.mappo_linear512_planes_floats(512), dtype=torch.float32, device=dev)
-                _native.check(lib.mappo_linear512_prepare(p(w), 512, 512, 1, p(planes), stream), "mappo_linear512_prepare")
-                dx = torch.empty((rows, 512), dtype=torch.float32, device=dev)
-                _native.check(lib.mappo_linear512_forward(p(dy), rows, 512, 512, p(planes), None, p(dx), stream),
-                              "mappo_linear512_forward")
-            else:
-                dx = dy @ w
-                if ldx != K:
-                    dx = F.pad(dx, (0, ldx - K))
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty((512, K), dtype=torch.float32, device=dev)
-            ws = torch.empty(lib.mappo_linear512_wgrad_workspace_floats(K), dtype=torch.float32, device=dev)
-            from . import fused_mlp
-            with fused_mlp._Timed("mappo_linear512_wgrad", 2.0 * rows * K * 512, 4.0 * rows * (ldx + 512)):
-                _native.check(lib.mappo_linear512_wgrad(p(dy), p(x), rows, K, int(ldx), p(dw), p(ws), stream),
-                              "mappo_linear512_wgrad")
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = column_sums(dy)
-        return dx, dw, db
+        dz = torch.empty_like(z)
+        dg = torch.empty(512, dtype=torch.float32, device=dev)
+        dbe = torch.empty(512, dtype=torch.float32, device=dev)
+        db = torch.empty(512, dtype=torch.float32, device=dev)
+        zero = torch.zeros(512, dtype=torch.float32, device=dev)      # (the bias is already inside z)
+        partials = torch.empty(3 * lib.mappo_layernorm_max_blocks() * 512, dtype=torch.float32, device=dev)
+        _native.check(lib.mappo_bias_act_layernorm_bwd(p(dy), p(z), p(zero), p(mean), p(rstd), p(g), p(dz), p(dg), p(dbe), p(db),
+                                                       p(partials), rows, 512, _ACT_RELU, stream),
+                      "mappo_bias_act_layernorm_bwd")
+        dx, dw = _linear512_grads(ctx.needs_input_grad[0], ctx.needs_input_grad[1], dz, x, w)
+        return dx, dw, db, dg, dbe, None
+
+
+_ACT_RELU = 2       # (fused_norm.ACT_RELU, include/mappo_hip.h)
+
+
+def _aligned16(t):
+    """The kernels read these vectors in 16-byte pieces: a view at an odd offset is copied."""
+    return t.clone() if t.data_ptr() % 16 else t
+
+
+def _linear512_grads(want_dx, want_dw, dy, x, w):
+    """Input and weight gradient of ``y = x W^T`` through K15 (dX = dY W: the forward kernel on the planes of W^T for a
+    512 -> 512 layer, the library GEMM otherwise)."""
+    from onpolicy import _native
+    lib, p = _native.lib(), _native.ptr
+    dev = x.device
+    stream = _native.stream_of(dev)
+    rows, ldx = x.shape
+    K = int(w.shape[1])
+    dx = dw = None
+    if want_dx:
+        if K == 512 and ldx == 512:     # dX = dY W: the forward kernel on the planes of W^T
+            planes = torch.empty(lib.mappo_linear512_planes_floats(512), dtype=torch.float32, device=dev)
+            _native.check(lib.mappo_linear512_prepare(p(w), 512, 512, 1, p(planes), stream), "mappo_linear512_prepare")
+            dx = torch.empty((rows, 512), dtype=torch.float32, device=dev)
+            _native.check(lib.mappo_linear512_forward(p(dy), rows, 512, 512, p(planes), None, p(dx), stream),
+                          "mappo_linear512_forward")
+        else:
+            dx = dy @ w
+            if ldx != K:
+                dx = F.pad(dx, (0, ldx - K))
+    if want_dw:
+        dw = torch.empty((512, K), dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.mappo_linear512_wgrad_workspace_floats(K), dtype=torch.float32, device=dev)
+        from . import fused_mlp
+        with fused_mlp._Timed("mappo_linear512_wgrad", 2.0 * rows * K * 512, 4.0 * rows * (ldx + 512)):
+            _native.check(lib.mappo_linear512_wgrad(p(dy), p(x), rows, K, int(ldx), p(dw), p(ws), stream),
+                          "mappo_linear512_wgrad")
+    return dx, dw
 
 
 def linear512_ok(x, weight, arith=None):
@@ -155,6 +226,23 @@ def tall_linear(x, weight, bias, arith=None):
             and x.is_contiguous():
         return _TallLinearFn.apply(x, weight, bias)
     return F.linear(x, weight, bias)
+
+
+def linear512_relu_norm(x, weight, bias, norm):
+    """``norm(relu(x W^T + b))`` in ONE K15 launch (``_Linear512NormFn``); callers check ``linear512_norm_ok`` first."""
+    return _Linear512NormFn.apply(x, weight, bias, norm.weight, norm.bias, float(norm.eps))
+
+
+def linear512_norm_ok(x, weight, bias, act_module, norm, arith=None):
+    """Whether a block ``Sequential(Linear, act, LayerNorm)`` takes the fused epilogue: K15 takes the product, the activation is
+    ReLU (Hanabi's, the reference's default ``--use_ReLU``), the LayerNorm is an affine one over the 512 features, gradients
+    are on (the rollout's evaluations keep the two-launch route: nothing to save there) and MAPPO_LINEAR512_NORM=1.
+    OPT-IN: on the MI355X the block form is 3.5 % SLOWER on the Hanabi-shaped step (profiles/r06_ab_lin512_block_epilogue.json:
+    the epilogue's LayerNorm weight / bias loads queue behind the tile's own stores in the in-order vector-memory counter)."""
+    import os
+    return os.environ.get("MAPPO_LINEAR512_NORM", "0") == "1" and bias is not None and isinstance(act_module, nn.ReLU) \
+        and isinstance(norm, nn.LayerNorm) and tuple(norm.normalized_shape) == (512,) and norm.elementwise_affine \
+        and norm.bias is not None and torch.is_grad_enabled() and linear512_ok(x, weight, arith)
 
 
 class TallLinear(nn.Linear):

@@ -21,6 +21,8 @@ inline unsigned ticket(unsigned* counter) { return (*counter)++; }       // (blo
 inline int f2i(float v) { int i; memcpy(&i, &v, 4); return i; }
 inline float i2f(int v) { float f; memcpy(&f, &v, 4); return f; }
 inline int uniform(int v) { return v; }
+inline float acc_get(const f32x16& a, int i) { return a[i]; }
+inline void mfma_drain() {}
 // direct-to-LDS load: lane l's 16 bytes land at base + 16 l.  The copy happens at once; wait_lds_loads() is a wave
 // barrier, so that no lane reads a slot before every lane of its wave has issued its part.
 inline void load_lds16(const float* g, float* lds_wave_base) {
@@ -135,6 +137,11 @@ extern "C" int mappo_linear512_prepare(const float* w, int K, int ldw, int trans
 extern "C" int mappo_linear512_forward(const float* x, int64_t rows, int K, int ldx, const float* planes, const float* bias,
                                        float* y, mappo_stream_t stream) {
     return lin::forward(x, rows, K, ldx, planes, bias, y, stream);
+}
+extern "C" int mappo_linear512_forward_norm(const float* x, int64_t rows, int K, int ldx, const float* planes, const float* bias,
+                                            const float* gamma, const float* beta, float eps, int act, float* y, float* yn,
+                                            float* mean, float* rstd, mappo_stream_t stream) {
+    return lin::forward_norm(x, rows, K, ldx, planes, bias, gamma, beta, eps, act, y, yn, mean, rstd, stream);
 }
 extern "C" int64_t mappo_linear512_wgrad_workspace_floats(int K) { return lin::wgrad_workspace_floats(K); }
 extern "C" int mappo_linear512_wgrad(const float* dy, const float* x, int64_t rows, int K, int ldx, float* dw,

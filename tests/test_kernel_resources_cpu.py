@@ -37,8 +37,11 @@ def test_snapshot_has_no_spills_and_expected_occupancy():
     # aligned or not x bias or not x two / four feature tiles per MFMA group), the default (two tiles) within 128 vector registers;
     # the weight gradient in 4 (rows aligned or not x the X tile's bf16 planes shared through LDS or split by every wave)
     k15 = {k: v for k, v in table.items() if "lin::lin_fwd_kernel" in k or "lin::lin_wgrad_kernel" in k}
-    assert len(k15) == 12 and all(v["agprs"] == 256 and v["occupancy"] == 1 and v["scratch_bytes"] == 0 for v in k15.values())
-    assert all(v["vgprs"] <= 128 for k, v in k15.items() if "lin_fwd_kernel" in k and ", 2>" in k)
+    # (+ 2 forward instances with the block's ReLU + LayerNorm in the epilogue, round 6: the accumulators are read value by value
+    # through prim::acc_get -- ordinary vector arithmetic on them moved all 256 into vector registers and spilled 116-208 bytes)
+    assert len(k15) == 14 and all(v["agprs"] == 256 and v["occupancy"] == 1 and v["scratch_bytes"] == 0 for v in k15.values())
+    assert all(v["vgprs"] <= 128 for k, v in k15.items() if "lin_fwd_kernel" in k and ", 2, " in k)
+    assert sum(1 for k in k15 if "lin_fwd_kernel" in k and k.rstrip(")").endswith("true>(lin::FwdArgs")) == 2, sorted(k15)
     # round 4: the version-3 forward -- 15 instances (layers x activation x groups of 8 columns in a row's last chunk), two
     # waves per SIMD (<= 256 registers), no scratch
     f3 = {k: v for k, v in table.items() if "mlp_fwd3_kernel<" in k}

@@ -22,7 +22,7 @@ def emu():
     import build
     from onpolicy import _native
     lib = ctypes.CDLL(build.build())
-    for name in ("mappo_linear512_planes_floats", "mappo_linear512_prepare", "mappo_linear512_forward",
+    for name in ("mappo_linear512_planes_floats", "mappo_linear512_prepare", "mappo_linear512_forward", "mappo_linear512_forward_norm",
                  "mappo_linear512_wgrad_workspace_floats", "mappo_linear512_wgrad", "mappo_mlp_set_grid_cap"):
         res, args = _native.SIGNATURES[name]
         getattr(lib, name).restype, getattr(lib, name).argtypes = res, args
@@ -73,6 +73,52 @@ def test_forward_vs_float64(emu, rows, K, ldx, bias, cap):
     err = np.abs(y - ref) / ((16.0 + K / 6.0) * U * S)
     print("\n[K15 forward rows %d K %d] worst error = %.2f of the bound" % (rows, K, err.max()))
     assert err.max() <= 1.0
+
+
+@pytest.mark.parametrize("rows,K,ldx,cap", [(128 + 37, 40, 40, 0), (70, 1285, 1288, 0), (128 * 3, 512, 512, 1), (33, 21, 21, 0)])
+def test_forward_with_the_block_epilogue_vs_float64(emu, rows, K, ldx, cap):
+    """mappo_linear512_forward_norm: y = x W^T + b as the plain forward gives it (bit for bit: the epilogue only reads the
+    accumulators), yn = LayerNorm(relu(y)), mean / rstd the statistics K6's backward expects (reference mlp.py:17-22)."""
+    rng = np.random.default_rng(rows * 7 + K)
+    x = _aligned((rows, ldx))
+    x[:] = 0.0
+    x[:, :K] = rng.standard_normal((rows, K)) * 1.5 + 0.3
+    w = (rng.standard_normal((512, K)) * 0.2).astype(np.float32)
+    b, gamma, beta = (_aligned((512,)) for _ in range(3))
+    b[:] = rng.standard_normal(512)
+    gamma[:] = 1.0 + 0.3 * rng.standard_normal(512)
+    beta[:] = 0.2 * rng.standard_normal(512)
+    planes = _planes(emu, w, K, K, 0)
+    y, yn, y0 = (_aligned((rows, 512)) for _ in range(3))
+    mean, rstd = np.full(rows, np.nan, np.float32), np.full(rows, np.nan, np.float32)
+    for a in (y, yn, y0):
+        a[:] = np.nan
+    eps = 1e-5
+    emu.mappo_mlp_set_grid_cap(cap)
+    try:
+        assert emu.mappo_linear512_forward(_ptr(x), rows, K, ldx, _ptr(planes), _ptr(b), _ptr(y0), None) == 0
+        assert emu.mappo_linear512_forward_norm(_ptr(x), rows, K, ldx, _ptr(planes), _ptr(b), _ptr(gamma), _ptr(beta), eps, 2,
+                                                _ptr(y), _ptr(yn), _ptr(mean), _ptr(rstd), None) == 0
+    finally:
+        emu.mappo_mlp_set_grid_cap(0)
+    assert np.array_equal(y, y0)
+    a64 = np.maximum(y.astype(np.float64), 0.0)             # the LayerNorm of the pre-activation the kernel itself produced
+    mu = a64.mean(1)
+    var = a64.var(1)
+    ref = (a64 - mu[:, None]) / np.sqrt(var + eps)[:, None] * gamma.astype(np.float64) + beta.astype(np.float64)
+    assert np.isfinite(yn).all() and np.isfinite(mean).all() and np.isfinite(rstd).all()
+    assert np.abs(mean - mu).max() <= 4e-7 * np.abs(a64).max()
+    assert np.abs(rstd * np.sqrt(var + eps) - 1.0).max() <= 2e-6
+    err = np.abs(yn - ref).max()
+    print("\n[K15 forward + block epilogue rows %d K %d] worst LayerNorm error %.2e" % (rows, K, err))
+    assert err <= 4e-6 * max(1.0, np.abs(ref).max())
+
+
+def test_block_epilogue_argument_checks(emu):
+    x = _aligned((4, 8))
+    args = (_ptr(x), 4, 8, 8, _ptr(x), _ptr(x), _ptr(x), _ptr(x), 1e-5)
+    assert emu.mappo_linear512_forward_norm(*args, 2, _ptr(x), _ptr(x), _ptr(x), None, None) == -1     # rstd missing
+    assert emu.mappo_linear512_forward_norm(*args, 1, _ptr(x), _ptr(x), _ptr(x), _ptr(x), None) != 0    # only relu
 
 
 def test_transposed_planes_give_the_input_gradient(emu):

@@ -156,6 +156,16 @@ int mappo_gae_set_variant(int variant);
  * strip kernels.  For tests that must know which arithmetic a shape took. */
 int mappo_gae_last_variant(void);
 
+/* Measurement hook for benchmarks: mappo_gae_time_next_launch arms one of 64 slots (returned, >= 0; they are reused in a ring)
+ * and the NEXT strip / LDS-DMA launch of mappo_gae_f32 in this process (every GAE-mode call with aligned columns; not the
+ * one-lane-per-column kernel, not the scan) is bracketed by that slot's HIP event pair at dispatch level
+ * (hipExtLaunchKernelGGL: kernel begin / end timestamps, what rocprofv3 --kernel-trace reports), on the stream of that call.
+ * mappo_gae_timed_launch_ms(slot) waits for that launch and returns its duration in milliseconds; MAPPO_E_FLAGS if the slot
+ * was never armed or its armed call launched a kernel without the hook.  (A pair of hipEventRecord calls around a launch also
+ * times two packets of the command processor: + 5-6 us on this 50 us kernel.)  Not thread-safe, like the other hooks. */
+int mappo_gae_time_next_launch(void);
+int mappo_gae_timed_launch_ms(int slot, float* ms);
+
 /* --------------------------------------------- K5: advantage moments / stats ----
  * Replaces np.nanmean / np.nanstd over the masked advantages
  *   (onpolicy/algorithms/r_mappo/r_mappo.py:183-186).

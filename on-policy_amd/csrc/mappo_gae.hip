@@ -20,6 +20,7 @@
 //   * "column" kernel: one lane per column with plain 4-byte loads; used for any C / any
 //     alignment and for the non-GAE modes.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "mappo_hip.h"
@@ -1079,6 +1080,27 @@ hipError_t launch_scan(const GaeArgs& a, unsigned flags, hipStream_t stream) {
     return hipErrorInvalidValue;
 }
 
+// Measurement hook (mappo_gae_time_next_launch): the next launch of a strip / LDS-DMA kernel carries the library's own event
+// pair AT DISPATCH LEVEL (hipExtLaunchKernelGGL: the events take the kernel's begin and end timestamps -- what rocprofv3's
+// kernel trace reports).  A pair of hipEventRecord calls around the launch brackets two more packets of the command processor:
+// + 5-6 us on this 50 us kernel, measured against the trace of the same run (profiles/r06_gae_in_situ_timing.json).
+constexpr int kTimeSlots = 64;
+hipEvent_t g_time_begin[kTimeSlots], g_time_end[kTimeSlots];
+bool g_time_made[kTimeSlots], g_time_taken[kTimeSlots];
+int g_time_armed = -1, g_time_next = 0;
+
+template <typename K>
+inline void launch_gae(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const GaeArgs& a) {
+    if (g_time_armed >= 0) {
+        const int s = g_time_armed;
+        g_time_armed = -1;
+        g_time_taken[s] = true;
+        hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, stream, g_time_begin[s], g_time_end[s], 0, a);
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, a);
+    }
+}
+
 #define MAPPO_DISPATCH_FLAGS(KERNEL, ...)                                                        \
     do {                                                                                         \
         const bool ptl = flags & MAPPO_GAE_PROPER_TIME_LIMITS;                                   \
@@ -1086,14 +1108,14 @@ hipError_t launch_scan(const GaeArgs& a, unsigned flags, hipStream_t stream) {
         const bool act = a.active != nullptr;                                                    \
         const int sel = (ptl ? 4 : 0) | (den ? 2 : 0) | (act ? 1 : 0);                           \
         switch (sel) {                                                                           \
-            case 0: hipLaunchKernelGGL((KERNEL<__VA_ARGS__, false, false, false>), grid, block, lds, stream, a); break; \
-            case 1: hipLaunchKernelGGL((KERNEL<__VA_ARGS__, false, false, true>), grid, block, lds, stream, a); break;  \
-            case 2: hipLaunchKernelGGL((KERNEL<__VA_ARGS__, false, true, false>), grid, block, lds, stream, a); break;  \
-            case 3: hipLaunchKernelGGL((KERNEL<__VA_ARGS__, false, true, true>), grid, block, lds, stream, a); break;   \
-            case 4: hipLaunchKernelGGL((KERNEL<__VA_ARGS__, true, false, false>), grid, block, lds, stream, a); break;  \
-            case 5: hipLaunchKernelGGL((KERNEL<__VA_ARGS__, true, false, true>), grid, block, lds, stream, a); break;   \
-            case 6: hipLaunchKernelGGL((KERNEL<__VA_ARGS__, true, true, false>), grid, block, lds, stream, a); break;   \
-            default: hipLaunchKernelGGL((KERNEL<__VA_ARGS__, true, true, true>), grid, block, lds, stream, a); break;   \
+            case 0: launch_gae((KERNEL<__VA_ARGS__, false, false, false>), grid, block, lds, stream, a); break; \
+            case 1: launch_gae((KERNEL<__VA_ARGS__, false, false, true>), grid, block, lds, stream, a); break;  \
+            case 2: launch_gae((KERNEL<__VA_ARGS__, false, true, false>), grid, block, lds, stream, a); break;  \
+            case 3: launch_gae((KERNEL<__VA_ARGS__, false, true, true>), grid, block, lds, stream, a); break;   \
+            case 4: launch_gae((KERNEL<__VA_ARGS__, true, false, false>), grid, block, lds, stream, a); break;  \
+            case 5: launch_gae((KERNEL<__VA_ARGS__, true, false, true>), grid, block, lds, stream, a); break;   \
+            case 6: launch_gae((KERNEL<__VA_ARGS__, true, true, false>), grid, block, lds, stream, a); break;   \
+            default: launch_gae((KERNEL<__VA_ARGS__, true, true, true>), grid, block, lds, stream, a); break;   \
         }                                                                                        \
     } while (0)
 
@@ -1322,6 +1344,27 @@ extern "C" int mappo_gae_set_variant(int variant) {
 }
 
 extern "C" int mappo_gae_last_variant(void) { return g_last_variant; }
+
+extern "C" int mappo_gae_time_next_launch(void) {
+    const int s = g_time_next;
+    if (!g_time_made[s]) {
+        if (hipEventCreate(&g_time_begin[s]) != hipSuccess || hipEventCreate(&g_time_end[s]) != hipSuccess) return MAPPO_E_FLAGS;
+        g_time_made[s] = true;
+    }
+    g_time_next = (s + 1) % kTimeSlots;
+    g_time_taken[s] = false;
+    g_time_armed = s;
+    return s;
+}
+
+extern "C" int mappo_gae_timed_launch_ms(int slot, float* ms) {
+    if (!ms) return MAPPO_E_NULL;
+    if (slot < 0 || slot >= kTimeSlots) return MAPPO_E_SHAPE;
+    if (g_time_armed == slot) g_time_armed = -1;                            // (asked before any launch took it: disarmed)
+    if (!g_time_made[slot] || !g_time_taken[slot]) return MAPPO_E_FLAGS;    // never armed, or the armed call took a kernel without the hook
+    if (hipEventSynchronize(g_time_end[slot]) != hipSuccess) return (int)hipGetLastError();
+    return (int)hipEventElapsedTime(ms, g_time_begin[slot], g_time_end[slot]);
+}
 
 extern "C" int mappo_gae_f32(const float* rewards, float* value_preds, const float* next_value,
                              const float* masks, const float* bad_masks, float* returns,

@@ -116,6 +116,8 @@ SIGNATURES = {
     "mappo_gae_partial_rows": (_i64, [_i64]),
     "mappo_gae_set_variant": (_int, [_int]),
     "mappo_gae_last_variant": (_int, []),
+    "mappo_gae_time_next_launch": (_int, []),
+    "mappo_gae_timed_launch_ms": (_int, [_int, ctypes.POINTER(ctypes.c_float)]),
     "mappo_advantages_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]),
     "mappo_adv_reduce": (_int, [_vp, _i64, _vp, _vp]),
     "mappo_adv_stats": (_int, [_vp, _vp, _vp]),

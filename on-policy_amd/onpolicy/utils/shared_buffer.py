@@ -214,8 +214,18 @@ class SharedReplayBuffer(object):
             if evs:
                 ms = [a.elapsed_time(b) for a, b, _ in evs]
                 out[name] = (len(evs), sum(ms) / len(ms), sum(n for _, _, n in evs) / len(evs))
+        import ctypes
+        ms, nb = [], []
+        for slot, nbytes in getattr(self, "_gae_dispatch", []):
+            v = ctypes.c_float(0.0)
+            if self._lib.mappo_gae_timed_launch_ms(slot, ctypes.byref(v)) == 0:     # (a launch without the hook: skipped)
+                ms.append(float(v.value))
+                nb.append(nbytes)
+        if ms:      # the GAE launches once more, by the kernel's own begin / end timestamps
+            out["mappo_gae_f32/dispatch"] = (len(ms), sum(ms) / len(ms), sum(nb) / len(nb))
         if reset and self._events is not None:
             self._events = {}
+            self._gae_dispatch = []
         return out
 
     def _dev(self, x):
@@ -473,7 +483,22 @@ class SharedReplayBuffer(object):
         self._adv_is_gae = False
         # algorithmic bytes: r, v, m reads + returns write (16 B) + advantages write + active read
         # (+8 B) [+ bad_masks read 4 B] per (t, n, a) element  
-        ev = self._timed("mappo_gae_f32", (24 + (4 if self._use_proper_time_limits else 0)) * T * N * A, settle=True)
+        # while profiling (bench.py), the launches are timed ALTERNATELY by an event pair recorded around the launch (what
+        # every round quoted) and by the kernel's own begin / end timestamps (events attached to the dispatch:
+        # mappo_gae_time_next_launch).  Not both on one launch: the dispatch-level events lengthen what the pair around them
+        # sees (65 us against 58 us), and the pair itself also times two packets of the command processor -- 5-6 us on this
+        # 50 us kernel against rocprofv3's trace of the same run.
+        nbytes = (24 + (4 if self._use_proper_time_limits else 0)) * T * N * A
+        ev = None
+        if self._events is not None and not torch.cuda.is_current_stream_capturing():
+            self._gae_profiled = getattr(self, "_gae_profiled", 0) + 1
+            if self._gae_profiled % 2 == 0:
+                torch.cuda._sleep(250000)           # (as in _timed: the kernel starts from a filled queue)
+                slot = self._lib.mappo_gae_time_next_launch()
+                if slot >= 0:
+                    self._gae_dispatch = (getattr(self, "_gae_dispatch", []) + [(slot, nbytes)])[-64:]
+            else:
+                ev = self._timed("mappo_gae_f32", nbytes, settle=True)
         code = self._lib.mappo_gae_f32(
             p(self.rewards), p(self.value_preds), p(nv), p(self.masks),
             p(self.bad_masks) if self._use_proper_time_limits else None, p(self.returns), p(denorm),

@@ -636,6 +636,56 @@ def test_host_parity_action_sampling():
     assert bool((torch.gather(avail, 1, a_cpu) == 1).all())
 
 
+def test_gae_dispatch_timing_hook():
+    """mappo_gae_time_next_launch / mappo_gae_timed_launch_ms (the measurement hook bench.py's roofline_gae uses): the armed
+    launch is timed by events attached to its dispatch, its results are those of an unarmed launch, a slot that never
+    launched reports MAPPO_E_FLAGS, and the duration is no longer than what an event pair around the same launch sees."""
+    import ctypes
+    import torch
+    from onpolicy import _native
+    lib = _native.lib()
+    dev = torch.device("cuda", 0)
+    T, C = 128, 32768
+    g = torch.Generator(device=dev).manual_seed(11)
+    rewards = torch.randn(T, C, device=dev, generator=g)
+    values = torch.randn(T + 1, C, device=dev, generator=g)
+    masks = (torch.rand(T + 1, C, device=dev, generator=g) > 0.05).float()
+    nv = values[-1].clone()
+    outs = []
+    ms = ctypes.c_float(-1.0)
+    for armed in (False, True):
+        returns, adv = torch.zeros(T + 1, C, device=dev), torch.zeros(T, C, device=dev)
+        partials = torch.zeros(lib.mappo_gae_partial_rows(C) * 4 + 64, dtype=torch.float64, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        slot = lib.mappo_gae_time_next_launch() if armed else -1
+        assert (slot >= 0) == armed
+        torch.cuda._sleep(200000)
+        e0.record()
+        _native.check(lib.mappo_gae_f32(rewards.data_ptr(), values.data_ptr(), nv.data_ptr(), masks.data_ptr(), None,
+                                        returns.data_ptr(), None, adv.data_ptr(), None, partials.data_ptr(), T, C, 0.99, 0.95,
+                                        _native.GAE_USE_GAE, _native.stream_of(dev)), "mappo_gae_f32")
+        e1.record()
+        torch.cuda.synchronize()
+        outs.append((returns, adv))
+        if armed:
+            assert lib.mappo_gae_timed_launch_ms(slot, ctypes.byref(ms)) == 0
+            pair = e0.elapsed_time(e1)
+            print("\n[GAE timing hook] dispatch %.2f us, event pair around the launch %.2f us" % (1e3 * ms.value, 1e3 * pair))
+            assert 0.0 < ms.value <= pair * 1.02
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    slot = lib.mappo_gae_time_next_launch()                    # armed, never launched
+    assert lib.mappo_gae_timed_launch_ms(slot, ctypes.byref(ms)) == -3
+    assert lib.mappo_gae_timed_launch_ms(64, ctypes.byref(ms)) == -2 and lib.mappo_gae_timed_launch_ms(slot, None) == -1
+    # (the armed slot is disarmed by the query above: the next launch is an ordinary one)
+    returns, adv = torch.zeros(T + 1, C, device=dev), torch.zeros(T, C, device=dev)
+    partials = torch.zeros(lib.mappo_gae_partial_rows(C) * 4 + 64, dtype=torch.float64, device=dev)
+    _native.check(lib.mappo_gae_f32(rewards.data_ptr(), values.data_ptr(), nv.data_ptr(), masks.data_ptr(), None,
+                                    returns.data_ptr(), None, adv.data_ptr(), None, partials.data_ptr(), T, C, 0.99, 0.95,
+                                    _native.GAE_USE_GAE, _native.stream_of(dev)), "mappo_gae_f32")
+    torch.cuda.synchronize()
+    assert lib.mappo_gae_timed_launch_ms(slot, ctypes.byref(ms)) == -3 and torch.equal(returns, outs[0][0])
+
+
 def test_gae_properties_at_scale():
     """Size-independent properties of the scan on a large buffer:
     (1) with all masks 1 and lambda = 1, returns are the discounted reward-to-go plus the discounted

@@ -144,6 +144,27 @@ __device__ __forceinline__ void load_lds16x4(const float* g, float* lds_wave_bas
         : "v"(g), "s"(dst)
         : "memory");
 }
+#ifndef MAPPO_K9_NT
+#define MAPPO_K9_NT 30      // (the default of mappo_mlp_impl.h, needed before its include)
+#endif
+// the same with the non-temporal bit when the build streams the weight-gradient kernels' operands (MAPPO_K9_NT & 4)
+__device__ __forceinline__ void load_lds16s(const float* g, float* lds_wave_base) {
+#if (MAPPO_K9_NT) & 4
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)lds_wave_base);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g), "s"(dst)
+        : "memory");
+#else
+    load_lds16(g, lds_wave_base);
+#endif
+}
 // ... until at most N of this wave's vector memory loads are outstanding (they complete in order)
 template <int N>
 __device__ __forceinline__ void wait_lds_loads() {

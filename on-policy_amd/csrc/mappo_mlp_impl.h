@@ -176,6 +176,30 @@ __device__ __forceinline__ float act_fn(float z) {
 // sums, the sum of squares as packed multiplies + 32 scalar adds, an IEEE square root and division per row: ~450 vector
 // instructions per 32-feature tail, ~350 with these forms).  exp2(-|m|) takes its sign handling as source modifiers.
 typedef float f2 __attribute__((ext_vector_type(2)));
+// Streaming accesses of the K9 kernels (build-time bit mask MAPPO_K9_NT; round 6 default 30).  Every saved activation and every
+// dz1 row is touched once per launch and the next touch is a launch and >= 7 GB of other traffic away, so nothing of this is
+// worth a place in L2 / the Infinity Cache:
+//    2 = the forward's saved activations / statistics as non-temporal stores     (forward launch -1.3 %)
+//    4 = the direct-to-LDS loads of the first-layer weight-gradient kernels with the nt bit
+//    8 = the chain's saved-activation loads non-temporal                         (4 + 8: backward call -0.8 %)
+//   16 = the chain's dz1 rows as non-temporal stores
+//    1 = the forward's input rows as non-temporal loads -- NOT set: + 24 % on the forward launch (a lane loads 16-byte pieces
+//        of 32 different rows and needs L2 to merge the eight pieces of a 128-byte line it asks for one after the other)
+// North star 200.5-201.5 -> 198.1-199.3 ms with 30 on one box, config 2 -3.5 %, config 3 / recurrent north star / the
+// 512-thread shard -1 %, the 64-thread SMAC shard unchanged (profiles/r06_ab_k9_streaming_hints.json).
+#ifndef MAPPO_K9_NT
+#define MAPPO_K9_NT 30
+#endif
+template <int BIT, typename T>
+__device__ __forceinline__ T ld_stream(const T* p) {
+    if ((MAPPO_K9_NT) & BIT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+template <int BIT, typename T>
+__device__ __forceinline__ void st_stream(T* p, T v) {
+    if ((MAPPO_K9_NT) & BIT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 template <int ACT>
 __device__ __forceinline__ f2 act_fn2(f2 z) {
     if (ACT == 1) {
@@ -345,7 +369,7 @@ __device__ __forceinline__ void load_frag64(const float* ztile /* z + 2048 * (ti
                                             float* reg) {
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-        const v4 o = *reinterpret_cast<const v4*>(ztile + 4 * lane + 256 * b);
+        const v4 o = ld_stream<8>(reinterpret_cast<const v4*>(ztile + 4 * lane + 256 * b));
 #pragma unroll
         for (int e = 0; e < 4; ++e) reg[4 * b + e] = o[e];
     }
@@ -708,7 +732,7 @@ __device__ __forceinline__ void layer_tail_nhat(const f32x16* acc, float eps, fl
             reg[4 * b + e] *= rstd;
             nh[e] = reg[4 * b + e];
         }
-        if (KEEP) *reinterpret_cast<v4*>(ztile + 4 * lane + 256 * b) = nh;     // block 4 t + q = slots 16 t + 4 q ..
+        if (KEEP) st_stream<2>(reinterpret_cast<v4*>(ztile + 4 * lane + 256 * b), nh);     // block 4 t + q = slots 16 t + 4 q ..
     }
 }
 
@@ -840,11 +864,11 @@ __global__ void __launch_bounds__(64 * 8) mlp_fwd3_kernel(FwdArgs a) {
             for (int q = 0; q < 4; ++q) {
                 int k = 32 * it_kc + 8 * q + 4 * h;
                 if (k > din - 4) k = din - 4;   // a piece past the row's end: finite data against zero weights (or never used)
-                B.x[q] = *reinterpret_cast<const v4u*>(row_it + k);
+                B.x[q] = ld_stream<1>(reinterpret_cast<const v4u*>(row_it + k));
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) B.x[q] = *reinterpret_cast<const v4u*>(xp + 8 * q);
+            for (int q = 0; q < 4; ++q) B.x[q] = ld_stream<1>(reinterpret_cast<const v4u*>(xp + 8 * q));
         }
         xp += 32;
         if (++it_kc == nch) {
@@ -1246,11 +1270,11 @@ __global__ void __launch_bounds__(64 * 4, 1) mlp_fwd4_kernel(FwdArgs a) {
             for (int q = 0; q < 8; ++q) {
                 int k = 64 * it_kc + 16 * (q >> 1) + 8 * h + 4 * (q & 1);
                 if (k > din - 4) k = din - 4;   // a piece past the row's end: finite data against zero weights (or never used)
-                B.x[q] = *reinterpret_cast<const v4u*>(row_it + k);
+                B.x[q] = ld_stream<1>(reinterpret_cast<const v4u*>(row_it + k));
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) B.x[q] = *reinterpret_cast<const v4u*>(xp + 16 * (q >> 1) + 4 * (q & 1));
+            for (int q = 0; q < 8; ++q) B.x[q] = ld_stream<1>(reinterpret_cast<const v4u*>(xp + 16 * (q >> 1) + 4 * (q & 1)));
         }
         xp += 64;
         if (++it_kc == nsc) {
@@ -1380,7 +1404,7 @@ __global__ void __launch_bounds__(64 * 4, 1) mlp_fwd4_kernel(FwdArgs a) {
         // ---- layer 0's tail
         if (a.z[0] != nullptr) {
             layer_tail_nhat<true, ACT>(acc, n.eps, nh, a.z[0] + tile * 2048, lane, mean, rstd);
-            *reinterpret_cast<f2*>(a.st[0] + 2 * row) = f2{mean, rstd};
+            st_stream<2>(reinterpret_cast<f2*>(a.st[0] + 2 * row), f2{mean, rstd});
         } else {
             layer_tail_nhat<false, ACT>(acc, n.eps, nh, nullptr, lane, mean, rstd);
         }
@@ -1426,7 +1450,7 @@ __global__ void __launch_bounds__(64 * 4, 1) mlp_fwd4_kernel(FwdArgs a) {
         }
         if (a.z[1] != nullptr) {
             layer_tail_nhat<true, ACT>(acc, n.eps, nh, a.z[1] + tile * 2048, lane, mean, rstd);
-            *reinterpret_cast<f2*>(a.st[1] + 2 * row) = f2{mean, rstd};
+            st_stream<2>(reinterpret_cast<f2*>(a.st[1] + 2 * row), f2{mean, rstd});
         } else {
             layer_tail_nhat<false, ACT>(acc, n.eps, nh, nullptr, lane, mean, rstd);
         }
@@ -1774,7 +1798,7 @@ __global__ void __launch_bounds__(64 * kB2Waves, 1) mlp_bwd_kernel(BwdArgs a) {
             for (int i = 0; i < 8; ++i) db0 += sv[i];
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                *reinterpret_cast<v4*>(a.dz1 + (staged * 32 + 4 * i + (lane >> 4)) * 64 + 4 * (lane & 15)) = sv[i];
+                st_stream<16>(reinterpret_cast<v4*>(a.dz1 + (staged * 32 + 4 * i + (lane >> 4)) * 64 + 4 * (lane & 15)), sv[i]);
             prim::wave_sync();
         }
     };
@@ -2694,12 +2718,12 @@ __device__ __forceinline__ void dw1_direct_body(const Dw1Args& a, float* lds, in
         for (int i = 0; i < NT; ++i) {
             int k = k0 + 32 * (wave + 4 * i) + 4 * (lane & 7);
             if (k > din - 4) k = din - 4;           // a piece past the row's end: its columns are never written out
-            prim::load_lds16(a.rs.src + (long long)sr0 * din + k, xslot + i * (kD2Rows * 32));
-            prim::load_lds16(a.rs.src + (long long)sr1 * din + k, xslot + i * (kD2Rows * 32) + 256);
+            prim::load_lds16s(a.rs.src + (long long)sr0 * din + k, xslot + i * (kD2Rows * 32));
+            prim::load_lds16s(a.rs.src + (long long)sr1 * din + k, xslot + i * (kD2Rows * 32) + 256);
         }
         long long r = row0_of(m) + 4 * wave + (lane >> 4);
         if (r >= rows) r = rows - 1;                // (zeroed in LDS before the product)
-        prim::load_lds16(a.dz1 + r * 64 + 4 * (lane & 15), dzs + slot * kD2DzSlot + wave * 256);
+        prim::load_lds16s(a.dz1 + r * 64 + 4 * (lane & 15), dzs + slot * kD2DzSlot + wave * 256);
         issue_table(m + kD2Slots - 1);
     };
     constexpr int NA = NT > 0 ? NT : 1;
@@ -2801,15 +2825,15 @@ __global__ void __launch_bounds__(kThreads) mlp_dw1_rows_kernel(Dw1Args a) {
         for (int i = 0; i < NT; ++i) {
             int k = 32 * i + 4 * (lane & 7);
             if (k > din - 4) k = din - 4;
-            prim::load_lds16(a.rs.src + (long long)sr0 * din + k, slot + i * (kD2Rows * 32));
-            prim::load_lds16(a.rs.src + (long long)sr1 * din + k, slot + i * (kD2Rows * 32) + 256);
+            prim::load_lds16s(a.rs.src + (long long)sr0 * din + k, slot + i * (kD2Rows * 32));
+            prim::load_lds16s(a.rs.src + (long long)sr1 * din + k, slot + i * (kD2Rows * 32) + 256);
         }
         const long long r0 = row0_of(m);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             long long r = r0 + 4 * g + (lane >> 4);
             if (r >= rows) r = rows - 1;
-            prim::load_lds16(a.dz1 + r * 64 + 4 * (lane & 15), slot + NT * (kD2Rows * 32) + g * 256);
+            prim::load_lds16s(a.dz1 + r * 64 + 4 * (lane & 15), slot + NT * (kD2Rows * 32) + g * 256);
         }
         issue_table(m + SLOTS - 1);
     };

@@ -28,6 +28,7 @@ inline void mfma_drain() {}
 inline void load_lds16(const float* g, float* lds_wave_base) {
     memcpy(lds_wave_base + 4 * (simt::st().cur->tid & 63), g, 16);
 }
+inline void load_lds16s(const float* g, float* lds_wave_base) { load_lds16(g, lds_wave_base); }
 inline void load_lds16x4(const float* g, float* lds_wave_base) {
     for (int u = 0; u < 4; ++u) load_lds16(g + 256 * u, lds_wave_base + 256 * u);
 }

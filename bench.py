@@ -671,7 +671,8 @@ def main():
             # launches; the figures of the event pair -- what every earlier round quoted -- stay under `event_pair_around_launch`.
             if "mappo_gae_f32/dispatch" in kt:
                 dl, dms, _ = kt["mappo_gae_f32/dispatch"]
-                g["event_pair_around_launch"] = {"launch_ms": g["launch_ms"], "achieved": g["achieved"], "frac": g["frac"]}
+                g["event_pair_around_launch"] = {"launch_ms": g["launch_ms"], "achieved": g["achieved"], "frac": g["frac"],
+                                                 "launches": g["launches"]}
                 g["launch_ms"], g["launches"] = round(dms, 5), dl
                 g["achieved"] = round(nbytes / (dms * 1e-3) / 1e9, 1)
                 g["frac"] = round(nbytes / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
